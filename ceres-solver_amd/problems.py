@@ -1,0 +1,297 @@
+"""Host-side problem builders: the reference's hand-written known-answer problems
+and synthetic BAL-shaped block-sparse Jacobians.
+
+* `linear_least_squares_problem(i)`: the data of the reference's
+  LinearLeastSquaresProblem0..6 (internal/ceres/linear_least_squares_problems.cc:78-965)
+  re-entered as plain arrays, with the hand-computed answers its comments carry.
+* `random_schur_problem`: random block sizes with an E|F partition, rows without an
+  E block and rows with several F cells (the structure cases of problems 2, 4, 6).
+* `synthetic_bal`: the generator SURVEY.md §8(d) specifies — BAL block counts
+  (`BAL_SHAPES`), every point seen by >= 2 distinct cameras, rows grouped by point,
+  E|F-split or row-sequential value layout, values/b ~ N(0,1),
+  D = sqrt(clamp(diag(J^T J), 1e-6, 1e32) / 1e4)
+  (internal/ceres/levenberg_marquardt_strategy.cc:84-96), seed 38401
+  (examples/bundle_adjuster.cc:138).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from .block_structure import BlockStructure
+
+# cameras, points, observations  (SURVEY.md §8 header / BASELINE.md §2)
+BAL_SHAPES = {
+    "dubrovnik16": (16, 22106, 83718),
+    "ladybug1723": (1723, 156502, 678718),
+    "venice1778": (1778, 993923, 5001946),
+    "synthetic10M": (50000, 10_000_000, 30_000_000),
+}
+
+
+@dataclass
+class LinearProblem:
+    bs: BlockStructure
+    values: np.ndarray
+    b: np.ndarray
+    D: Optional[np.ndarray]
+    num_eliminate_blocks: int
+    known: dict = field(default_factory=dict)  # hand-computed answers from the reference
+    # BAL-shaped problems only: per-row (observation) block ids
+    camera_of_row: Optional[np.ndarray] = None
+    point_of_row: Optional[np.ndarray] = None
+
+    @property
+    def num_rows(self):
+        return self.bs.num_rows
+
+    @property
+    def num_cols(self):
+        return self.bs.num_cols
+
+
+def _scalar_problem(num_cols, rows, values, nelim, D, known):
+    bs = BlockStructure.from_rows([1] * num_cols, [(1, cells) for cells in rows])
+    n_rows = len(rows)
+    return LinearProblem(bs, np.asarray(values, dtype=np.float64), np.arange(n_rows, dtype=np.float64),
+                         np.asarray(D, dtype=np.float64), nelim, known)
+
+
+def linear_least_squares_problem(problem_id: int) -> LinearProblem:
+    if problem_id == 0:
+        # dense 3x2, one row block / one column block; x and x_D from the reference comment :64-77
+        bs = BlockStructure.from_rows([2], [(3, [(0, 0)])])
+        return LinearProblem(bs, np.array([1., 2., 3., 4., 6., -10.]), np.array([8., 18., -18.]),
+                             np.array([1., 2.]), 0,
+                             {"x": np.array([2., 3.]), "x_D": np.array([1.78448275, 2.82327586])})
+    if problem_id == 2:  # :301-439, answers :135-185 (computed with D = 0)
+        rows = [[(0, 0), (2, 1)], [(0, 2), (3, 3)], [(1, 4), (4, 5)], [(1, 6), (2, 7)], [(1, 8), (2, 9)],
+                [(2, 10), (3, 11), (4, 12)]]
+        vals = [1, 2, 3, 4, 5, 6, 7, 8, 9, 1, 1, 1, 1]
+        known = {
+            "AtA": np.array([[10, 0, 2, 12, 0], [0, 155, 65, 0, 30], [2, 65, 70, 1, 1], [12, 0, 1, 17, 1],
+                             [0, 30, 1, 1, 37]], dtype=np.float64),
+            "Atb": np.array([3., 67., 33., 9., 17.]),
+            "S": np.array([[42.3419, -1.4000, -11.5806], [-1.4000, 2.6000, 1.0000], [-11.5806, 1.0000, 31.1935]]),
+            "r": np.array([4.3032, 5.4000, 4.0323]),
+            "S_solve_r": np.array([0.2102, 2.1367, 0.1388]),
+            "x": np.array([-2.3061, 0.3172, 0.2102, 2.1367, 0.1388]),
+        }
+        return _scalar_problem(5, rows, vals, 2, [1] * 5, known)
+    if problem_id == 3:  # :441-525, no F blocks
+        rows = [[(0, 0)], [(0, 1)], [(1, 2)], [(1, 3)], [(1, 4)]]
+        return _scalar_problem(2, rows, [1, 3, 5, 7, 9], 2, [1] * 2, {})
+    if problem_id == 4:  # :548-617
+        bs = BlockStructure.from_rows([2, 3, 2], [(2, [(0, 0), (2, 4)]), (1, [(1, 8), (2, 11)])])
+        vals = [1, 2, 1, 4, 1, 1, 5, 6, 9, 0, 0, 3, 1]
+        return LinearProblem(bs, np.array(vals, dtype=np.float64), np.arange(3, dtype=np.float64),
+                             np.arange(1, 8, dtype=np.float64) * 100, 1, {})
+    if problem_id == 5:  # :678-800, answers :620-675 (D = 0)
+        rows = [[(0, 0), (4, 1)], [(0, 2), (4, 3)], [(1, 4), (3, 5)], [(1, 6), (3, 7)], [(1, 8), (2, 9)],
+                [(1, 10), (2, 11)]]
+        vals = [-1, 2, 3, 4, -1, 1, -3, 1, -1, 3, -2, 1]
+        known = {
+            "S": np.array([[8.3333, -1.3333, 0], [-1.3333, 0.9333, 0], [0, 0, 10.0000]]),
+            "r": np.array([8.6667, -1.6667, 1.0000]),
+            "S_solve_r": np.array([0.9778, -0.3889, 0.1000]),
+            "x": np.array([0.2, -1.4444, 0.9777, -0.3888, 0.1]),
+        }
+        return _scalar_problem(5, rows, vals, 2, [1] * 5, known)
+    if problem_id == 6:  # :829-925
+        bs = BlockStructure.from_rows([2, 3, 2], [(2, [(0, 0), (2, 4)]), (2, [(0, 8), (2, 12)]),
+                                                  (1, [(1, 16), (2, 19)])])
+        vals = [1, 2, 1, 4, 1, 1, 5, 6, 3, 4, 5, 6, 7, 8, 9, 0, 9, 0, 0, 3, 1]
+        return LinearProblem(bs, np.array(vals, dtype=np.float64), np.arange(5, dtype=np.float64),
+                             np.arange(1, 8, dtype=np.float64) * 100, 1, {})
+    raise ValueError(f"no block-sparse problem with id {problem_id}")
+
+
+def random_schur_problem(num_e_blocks=7, num_f_blocks=5, max_rows_per_e=4, num_no_e_rows=3,
+                         block_sizes=(1, 2, 3, 4), static_sizes=None, seed=0, shuffle_values=True,
+                         with_D=True) -> LinearProblem:
+    """Random E|F-partitioned Jacobian.  static_sizes=(row, e, f) forces one size
+    triple on every E row (BAL is (2, 3, 9)); otherwise sizes vary per block."""
+    rng = np.random.default_rng(seed)
+    pick = lambda: int(rng.choice(block_sizes))
+    if static_sizes:
+        rs0, es0, fs0 = static_sizes
+        col_sizes = [es0] * num_e_blocks + [fs0] * num_f_blocks
+    else:
+        col_sizes = [pick() for _ in range(num_e_blocks + num_f_blocks)]
+    shapes = []  # (row_size, [col blocks])
+    for e in range(num_e_blocks):
+        for _ in range(int(rng.integers(1, max_rows_per_e + 1))):
+            nf = int(rng.integers(0 if not static_sizes else 1, min(3, num_f_blocks) + 1))
+            if static_sizes:
+                nf = 1 if static_sizes == (2, 3, 9) else max(nf, 1)
+            fs = sorted(rng.choice(num_f_blocks, size=nf, replace=False).tolist())
+            shapes.append((static_sizes[0] if static_sizes else pick(), [e] + [num_e_blocks + f for f in fs]))
+    for _ in range(num_no_e_rows):
+        nf = int(rng.integers(1, min(3, num_f_blocks) + 1))
+        fs = sorted(rng.choice(num_f_blocks, size=nf, replace=False).tolist())
+        shapes.append((pick(), [num_e_blocks + f for f in fs]))
+    # value positions: sequential, optionally in a shuffled cell order (arbitrary cell.position)
+    cells = [(i, j) for i, (_, cols) in enumerate(shapes) for j in cols]
+    order = rng.permutation(len(cells)) if shuffle_values else np.arange(len(cells))
+    pos = {}
+    cursor = 0
+    for idx in order:
+        i, j = cells[idx]
+        pos[(i, j)] = cursor
+        cursor += shapes[i][0] * col_sizes[j]
+    rows = [(rs, [(j, pos[(i, j)]) for j in cols]) for i, (rs, cols) in enumerate(shapes)]
+    bs = BlockStructure.from_rows(col_sizes, rows)
+    values = rng.standard_normal(cursor)
+    b = rng.standard_normal(bs.num_rows)
+    D = (0.5 + rng.random(bs.num_cols)) if with_D else None
+    return LinearProblem(bs, values, b, D, num_e_blocks)
+
+
+def random_block_sparse(num_row_blocks=40, num_col_blocks=12, density=0.3, block_sizes=(1, 2, 3, 5), seed=0):
+    """Unpartitioned random matrix in the spirit of BlockSparseMatrix::CreateRandomMatrix
+    (internal/ceres/block_sparse_matrix.cc:712-782): every row block gets >= 1 cell."""
+    rng = np.random.default_rng(seed)
+    col_sizes = [int(rng.choice(block_sizes)) for _ in range(num_col_blocks)]
+    rows, cursor = [], 0
+    for _ in range(num_row_blocks):
+        rs = int(rng.choice(block_sizes))
+        cols = np.flatnonzero(rng.random(num_col_blocks) < density)
+        if len(cols) == 0:
+            cols = np.array([int(rng.integers(num_col_blocks))])
+        cells = []
+        for j in cols:
+            cells.append((int(j), cursor))
+            cursor += rs * col_sizes[j]
+        rows.append((rs, cells))
+    bs = BlockStructure.from_rows(col_sizes, rows)
+    return LinearProblem(bs, rng.standard_normal(cursor), rng.standard_normal(bs.num_rows),
+                         0.5 + rng.random(bs.num_cols), 0)
+
+
+# --------------------------------------------------------------------------
+# Synthetic BAL-shaped Jacobians
+# --------------------------------------------------------------------------
+def _track_lengths(rng, n_cams, n_points, n_obs):
+    kmin = min(2, n_cams)
+    if n_obs < kmin * n_points:
+        raise ValueError("need at least 2 observations per point (reference precondition, "
+                         "internal/ceres/reorder_program.cc:313-317)")
+    mean_extra = n_obs / n_points - kmin
+    k = np.full(n_points, kmin, dtype=np.int64)
+    if mean_extra > 0:
+        k += np.minimum(rng.geometric(1.0 / (1.0 + mean_extra), size=n_points) - 1, n_cams - kmin)
+    diff = int(n_obs - k.sum())
+    while diff != 0:  # nudge random points until the total is exact
+        idx = rng.integers(0, n_points, size=abs(diff))
+        if diff > 0:
+            ok = idx[k[idx] < n_cams]
+            ok = np.unique(ok)
+            k[ok] += 1
+            diff -= len(ok)
+        else:
+            ok = np.unique(idx[k[idx] > kmin])
+            k[ok] -= 1
+            diff += len(ok)
+    return k
+
+
+def _distinct_cameras(rng, n_cams, point_of_obs, weights):
+    n_obs = point_of_obs.shape[0]
+    draw = (lambda n: rng.choice(n_cams, size=n, p=weights)) if weights is not None else (
+        lambda n: rng.integers(0, n_cams, size=n))
+    cam = draw(n_obs).astype(np.int64)
+    for _ in range(200):
+        key = point_of_obs * n_cams + cam
+        order = np.argsort(key, kind="stable")
+        dup = np.zeros(n_obs, dtype=bool)
+        dup[order[1:]] = key[order[1:]] == key[order[:-1]]
+        n_dup = int(dup.sum())
+        if n_dup == 0:
+            break
+        cam[dup] = draw(n_dup)
+    else:  # pathological (track length close to n_cams): fix the stragglers point by point
+        for p in np.unique(point_of_obs[dup]):
+            sel = np.flatnonzero(point_of_obs == p)
+            cam[sel] = rng.permutation(n_cams)[: len(sel)]
+    return cam
+
+
+def synthetic_bal(shape="dubrovnik16", layout="schur", seed=38401, skew=0.0, num_cameras=None,
+                  num_points=None, num_observations=None, with_values=True) -> LinearProblem:
+    """BAL-shaped <2,3,9> Jacobian.  layout="schur": column blocks = points then cameras,
+    values E|F-split (ITERATIVE_SCHUR, internal/ceres/block_jacobian_writer.cc:68-167);
+    layout="cgnr": column blocks in order of first use (camera, point interleaved), cells
+    sorted by column block, values row-sequential (internal/ceres/block_jacobian_writer.cc:59-64)."""
+    n_cams, n_points, n_obs = BAL_SHAPES[shape] if shape else (num_cameras, num_points, num_observations)
+    if num_cameras is not None:
+        n_cams, n_points, n_obs = num_cameras, num_points, num_observations
+    rng = np.random.default_rng(seed)
+    k = _track_lengths(rng, n_cams, n_points, n_obs)
+    point_of_obs = np.repeat(np.arange(n_points, dtype=np.int64), k)
+    weights = None
+    if skew > 0:
+        weights = np.arange(1, n_cams + 1, dtype=np.float64) ** (-skew)
+        weights /= weights.sum()
+    cam_of_obs = _distinct_cameras(rng, n_cams, point_of_obs, weights)
+    # sort cameras inside each point so that rows look like a real BAL file
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    cam_of_obs = cam_of_obs[order]
+    r = np.arange(n_obs, dtype=np.int64)
+    if layout == "schur":
+        col_sizes = np.concatenate([np.full(n_points, 3, np.int32), np.full(n_cams, 9, np.int32)])
+        point_block = point_of_obs
+        cam_block = n_points + cam_of_obs
+        cell_col = np.stack([point_block, cam_block], axis=1).reshape(-1)
+        cell_pos = np.stack([6 * r, 6 * n_obs + 18 * r], axis=1).reshape(-1)
+        nelim = n_points
+    elif layout == "cgnr":
+        # program order: first use in (camera, point) argument order over the observation list
+        first_cam = np.full(n_cams, 2 * n_obs, dtype=np.int64)
+        np.minimum.at(first_cam, cam_of_obs, 2 * r)
+        first_pt = np.full(n_points, 2 * n_obs, dtype=np.int64)
+        np.minimum.at(first_pt, point_of_obs, 2 * r + 1)
+        keys = np.concatenate([first_cam, first_pt])
+        rank = np.empty(n_cams + n_points, dtype=np.int64)
+        rank[np.argsort(keys, kind="stable")] = np.arange(n_cams + n_points)
+        cam_block = rank[cam_of_obs]
+        point_block = rank[n_cams + point_of_obs]
+        col_sizes = np.empty(n_cams + n_points, dtype=np.int32)
+        col_sizes[rank[:n_cams]] = 9
+        col_sizes[rank[n_cams:]] = 3
+        cam_first = cam_block < point_block
+        cell_col = np.where(cam_first[:, None], np.stack([cam_block, point_block], 1),
+                            np.stack([point_block, cam_block], 1)).reshape(-1)
+        cell_pos = np.where(cam_first[:, None], np.stack([24 * r, 24 * r + 18], 1),
+                            np.stack([24 * r, 24 * r + 6], 1)).reshape(-1)
+        nelim = 0
+    else:
+        raise ValueError(layout)
+    if cell_pos.max(initial=0) + 18 >= 2 ** 31:
+        raise ValueError("value offsets exceed int32 (reference limit, internal/ceres/block_sparse_matrix.h:171-172)")
+    col_pos = np.concatenate([[0], np.cumsum(col_sizes.astype(np.int64))[:-1]])
+    bs = BlockStructure(np.full(n_obs, 2, np.int32), 2 * r, col_sizes, col_pos, 2 * np.arange(n_obs + 1, dtype=np.int64),
+                        cell_col, cell_pos)
+    if not with_values:
+        return LinearProblem(bs, np.zeros(0), np.zeros(0), None, nelim, {}, cam_block, point_block)
+    values = rng.standard_normal(24 * n_obs)
+    b = rng.standard_normal(2 * n_obs)
+    # D = sqrt(clamp(diag(J^T J)) / radius), radius = initial_trust_region_radius = 1e4
+    diag = np.zeros(bs.num_cols)
+    if layout == "schur":
+        E = values[: 6 * n_obs].reshape(n_obs, 2, 3)
+        F = values[6 * n_obs:].reshape(n_obs, 2, 9)
+    else:
+        v = values.reshape(n_obs, 24)
+        cam_first = (cam_block < point_block)[:, None]
+        F = np.where(cam_first, v[:, :18], v[:, 6:]).reshape(n_obs, 2, 9)
+        E = np.where(cam_first, v[:, 18:], v[:, :6]).reshape(n_obs, 2, 3)
+    e2 = (E * E).sum(axis=1)
+    f2 = (F * F).sum(axis=1)
+    for c in range(3):
+        diag += np.bincount(col_pos[point_block] + c, weights=e2[:, c], minlength=bs.num_cols)
+    for c in range(9):
+        diag += np.bincount(col_pos[cam_block] + c, weights=f2[:, c], minlength=bs.num_cols)
+    D = np.sqrt(np.clip(diag, 1e-6, 1e32) / 1e4)
+    return LinearProblem(bs, values, b, D, nelim, {}, cam_block, point_block)

@@ -1,0 +1,274 @@
+/*
+ * ceres_hip.h — C ABI of the MI355X-native Levenberg–Marquardt linear-solve path.
+ *
+ * This is the drop-in boundary.  Everything behind it is hand-written HIP for
+ * gfx950; everything in front of it is host code (the Ceres-side adapter shown
+ * in INTEGRATION.md, the C++ mirror in ceres-solver_amd/host/, or the ctypes
+ * binding in ceres-solver_amd/__init__.py).  Plain C types only: pointers,
+ * sizes, POD structs.  No torch types, no C++ types, no exceptions.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the
+ * ceres-solver tree, "I/" = internal/ceres/):
+ *
+ *   ceres_hip_create / _destroy      LinearSolver::Create(options)              I/linear_solver.cc:75-126
+ *                                    (cases CGNR :80-88, ITERATIVE_SCHUR :111-116)
+ *   ceres_hip_set_structure          the CompressedRowBlockStructure a solver   I/block_structure.h:52-182
+ *                                    reads through A->block_structure(); one
+ *                                    instance sees constant sparsity            I/linear_solver.h:137-142
+ *   ceres_hip_solve                  LinearSolver::Solve(A, b, per_solve, x)    I/linear_solver.h:339-342
+ *                                    = CgnrSolver::SolveImpl                    I/cgnr_solver.cc:146-207
+ *                                    = IterativeSchurComplementSolver::SolveImpl I/iterative_schur_complement_solver.cc:64-157
+ *   ceres_hip_op_*                   the individual operators of SURVEY.md §8(a), exported so
+ *                                    that parity tests and roofline runs can address them one
+ *                                    at a time (file:line given next to each declaration).
+ *
+ * Conventions
+ *   - every function returning int returns CERES_HIP_OK (0) or a negative
+ *     CERES_HIP_E_* code; on error ceres_hip_last_error() holds a message.  A
+ *     non-zero return from ceres_hip_solve maps to
+ *     LinearSolverTerminationType::FATAL_ERROR on the Ceres side.
+ *   - "host" pointers are ordinary (or pinned) host memory owned by the caller
+ *     and not retained past the call; "dev" pointers are HIP device pointers on
+ *     the solver's device, also caller-owned.
+ *   - all scalars on this path are IEEE fp64, all indices int32, exactly as in
+ *     the reference (SURVEY.md §8 header).
+ *   - a solver handle is not thread-safe (same contract as the reference,
+ *     I/implicit_schur_complement.h:88-91); distinct handles are independent.
+ */
+#ifndef CERES_HIP_H_
+#define CERES_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CERES_HIP_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define CERES_HIP_OK 0
+#define CERES_HIP_E_INVALID (-1)     /* bad argument / call order               */
+#define CERES_HIP_E_UNSUPPORTED (-2) /* structure or option not implemented     */
+#define CERES_HIP_E_HIP (-3)         /* a HIP runtime call failed               */
+#define CERES_HIP_E_COMM (-4)        /* an RCCL call failed                     */
+#define CERES_HIP_E_NODEVICE (-5)    /* no usable gfx950 device                 */
+
+/* ---- enums: numeric values equal the reference's -------------------------
+ * solver_type         ceres::LinearSolverType          include/ceres/types.h:57-91
+ * preconditioner_type ceres::PreconditionerType        include/ceres/types.h:93-141
+ * termination_type    LinearSolverTerminationType      I/linear_solver.h:57-74     */
+#define CERES_HIP_ITERATIVE_SCHUR 5
+#define CERES_HIP_CGNR 6
+
+#define CERES_HIP_IDENTITY 0
+#define CERES_HIP_JACOBI 1
+#define CERES_HIP_SCHUR_JACOBI 2
+
+#define CERES_HIP_SUCCESS 0
+#define CERES_HIP_NO_CONVERGENCE 1
+#define CERES_HIP_FAILURE 2
+#define CERES_HIP_FATAL_ERROR 3
+
+/* Which device code path set_structure selected (ceres_hip_info.kernel_path). */
+#define CERES_HIP_PATH_GENERIC 0 /* any block sizes, multi-pass kernels          */
+#define CERES_HIP_PATH_BAL 1     /* static <2,3,9>, fused single-pass kernels    */
+
+/* ---- flattened CompressedRowBlockStructure (I/block_structure.h:52-182) ---
+ * cols[j] = {col_block_size[j], col_block_pos[j]}
+ * rows[i].block = {row_block_size[i], row_block_pos[i]}
+ * rows[i].cells = cells[row_cell_ptr[i] .. row_cell_ptr[i+1])
+ * cells[k] = {cell_col_block[k] (Cell::block_id), cell_value_pos[k] (Cell::position)}
+ * Cell values are row-major row_size x col_size at values + position
+ * (I/block_sparse_matrix.cc:239-274).  Nothing about the value layout is
+ * assumed: E|F-split (I/block_jacobian_writer.cc:68-167), row-sequential and
+ * interleaved layouts are all accepted because every access goes through
+ * cell_value_pos.                                                           */
+typedef struct ceres_hip_block_structure {
+  int32_t num_row_blocks;
+  int32_t num_col_blocks;
+  const int32_t* row_block_size; /* [num_row_blocks]   */
+  const int32_t* row_block_pos;  /* [num_row_blocks]   */
+  const int32_t* col_block_size; /* [num_col_blocks]   */
+  const int32_t* col_block_pos;  /* [num_col_blocks]   */
+  const int32_t* row_cell_ptr;   /* [num_row_blocks+1] */
+  const int32_t* cell_col_block; /* [num_cells]        */
+  const int32_t* cell_value_pos; /* [num_cells]        */
+} ceres_hip_block_structure;
+
+/* ---- LinearSolver::Options subset that this path reads --------------------
+ * I/linear_solver.h:148-230; defaults as there (max_num_iterations = 1!).   */
+typedef struct ceres_hip_options {
+  int32_t solver_type;           /* CERES_HIP_CGNR | CERES_HIP_ITERATIVE_SCHUR             */
+  int32_t preconditioner_type;   /* IDENTITY | JACOBI | SCHUR_JACOBI                       */
+  int32_t min_num_iterations;    /* LinearSolver::Options::min_num_iterations              */
+  int32_t max_num_iterations;    /* LinearSolver::Options::max_num_iterations              */
+  int32_t residual_reset_period; /* LinearSolver::Options::residual_reset_period (10)      */
+  int32_t num_eliminate_blocks;  /* elimination_groups[0]; 0 for CGNR                      */
+  int32_t device;                /* HIP device ordinal                                     */
+  int32_t force_generic_path;    /* 1: never select the fused BAL kernels (testing)        */
+  int32_t cg_check_interval;     /* CG iterations enqueued between host polls of the
+                                    device-side termination flag; <=0 -> default (8)       */
+  int32_t reserved[7];
+} ceres_hip_options;
+
+/* ---- LinearSolver::Summary (I/linear_solver.h:320-326) ------------------- */
+typedef struct ceres_hip_summary {
+  double residual_norm;     /* -1, as the reference's iterative solvers leave it */
+  int32_t num_iterations;
+  int32_t termination_type; /* CERES_HIP_SUCCESS ... CERES_HIP_FATAL_ERROR      */
+  char message[256];
+} ceres_hip_summary;
+
+/* What set_structure derived; all counts in scalars unless noted. */
+typedef struct ceres_hip_info {
+  int32_t kernel_path;      /* CERES_HIP_PATH_*                                        */
+  int32_t num_rows, num_cols;
+  int32_t num_cols_e, num_cols_f;
+  int32_t num_row_blocks_e; /* rows whose first cell is an E block (PMV ctor :60-66)   */
+  int32_t num_e_blocks, num_f_blocks;
+  int32_t row_block_size, e_block_size, f_block_size; /* DetectStructure; -1 = dynamic */
+  int64_t num_nonzeros;
+  int64_t num_observations; /* BAL path: rows with one E and one F cell; else 0        */
+  int64_t num_tiles;        /* BAL path: 64-slot tiles after packing                   */
+  int64_t device_bytes;     /* HBM held by this handle                                 */
+  int32_t camera_accum_in_lds; /* BAL path: 1 if the F-space accumulators fit in LDS   */
+  int32_t world_size, rank;
+} ceres_hip_info;
+
+typedef struct ceres_hip_solver ceres_hip_solver; /* opaque */
+
+/* ---- lifetime ------------------------------------------------------------ */
+int ceres_hip_abi_version(void);
+/* Number of visible HIP devices whose arch is gfx950 (0 => nothing will run). */
+int ceres_hip_device_count(void);
+/* Create a solver; returns NULL on failure (see ceres_hip_last_error(NULL)). */
+ceres_hip_solver* ceres_hip_create(const ceres_hip_options* options);
+void ceres_hip_destroy(ceres_hip_solver* s);
+/* Message for the most recent error on s (or, with s == NULL, of create). */
+const char* ceres_hip_last_error(const ceres_hip_solver* s);
+
+/* Upload the (constant) sparsity once per solver instance.  For a sharded run
+ * each rank passes the structure of ITS rows only: E (point) column blocks are
+ * disjoint across ranks, F (camera) column blocks are the same on every rank
+ * (SURVEY.md §8e).                                                           */
+int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure* bs);
+int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ----------------------
+ * Rank 0 obtains an id, the host distributes the 128 bytes by any means
+ * (torch.distributed broadcast in bench.py), every rank calls comm_init.
+ * After that ceres_hip_solve / the op_* entry points sum F-space (camera)
+ * quantities over ranks with ncclAllReduce on the solver's stream, and the
+ * CGNR inner products over the E-space (point) part likewise.               */
+#define CERES_HIP_UNIQUE_ID_BYTES 128
+int ceres_hip_comm_get_unique_id(uint8_t id[CERES_HIP_UNIQUE_ID_BYTES]);
+int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_ID_BYTES],
+                        int32_t rank, int32_t world_size);
+
+/* ---- the boundary call ----------------------------------------------------
+ * LinearSolver::Solve (I/linear_solver.h:339-342).  values: num_nonzeros
+ * doubles in the caller's layout; b: num_rows; D: num_cols or NULL
+ * (PerSolveOptions::D, :237-257); x: num_cols, fully overwritten unless the
+ * termination type is FAILURE/FATAL_ERROR
+ * (I/iterative_schur_complement_solver.cc:150-154).                          */
+int ceres_hip_solve(ceres_hip_solver* s, const double* host_values, const double* host_b,
+                    const double* host_D, double q_tolerance, double r_tolerance,
+                    double* host_x, ceres_hip_summary* summary);
+/* Same, all four arrays already resident in HBM (used by bench.py so that the
+ * timed region holds no PCIe traffic; also the form a device evaluator uses). */
+int ceres_hip_solve_device(ceres_hip_solver* s, const double* dev_values, const double* dev_b,
+                           const double* dev_D, double q_tolerance, double r_tolerance,
+                           double* dev_x, ceres_hip_summary* summary);
+
+/* ---- operator-level entry points (parity tests, roofline runs) ------------
+ * All of them act on the state loaded by ceres_hip_load.  Vector arguments are
+ * HOST pointers; results are copied back synchronously.                      */
+
+/* Upload values/b/D (b, D may be NULL) and run the per-step re-layout kernel. */
+int ceres_hip_load(ceres_hip_solver* s, const double* host_values, const double* host_b,
+                   const double* host_D);
+int ceres_hip_load_device(ceres_hip_solver* s, const double* dev_values, const double* dev_b,
+                          const double* dev_D);
+
+/* y += A x      BlockSparseMatrix::RightMultiplyAndAccumulate  I/block_sparse_matrix.cc:239-274 */
+int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y);
+/* y += A^T x    BlockSparseMatrix::LeftMultiplyAndAccumulate   I/block_sparse_matrix.cc:278-349 */
+int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y);
+/* x[j] = |A_j|^2  BlockSparseMatrix::SquaredColumnNorm           I/block_sparse_matrix.cc:351-401 */
+int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x);
+/* y = (A^T A + D^2) x, one fused pass.  CgnrLinearOperator::RightMultiplyAndAccumulate
+ * with y zeroed first, as CG calls it                           I/cgnr_solver.cc:98-114        */
+int ceres_hip_op_jtjx(ceres_hip_solver* s, const double* x, double* y);
+/* y = A^T b     CgnrSolver::SolveImpl rhs                        I/cgnr_solver.cc:188-191       */
+int ceres_hip_op_jtb(ceres_hip_solver* s, double* y);
+
+/* ImplicitSchurComplement::Init: block_diagonal (E^T E + D_e^2)^-1 and
+ * rhs = F^T (b - E (E^T E)^-1 E^T b)                             I/implicit_schur_complement.cc:49-97,179-204,251-276 */
+int ceres_hip_op_schur_init(ceres_hip_solver* s);
+/* rhs of the reduced system: num_cols_f doubles. */
+int ceres_hip_get_schur_rhs(ceres_hip_solver* s, double* rhs);
+/* Inverse E^T E blocks, dense row-major e x e each, in E-block order. */
+int ceres_hip_get_ete_inverse(ceres_hip_solver* s, double* blocks, int64_t capacity);
+/* y = S x       ImplicitSchurComplement::RightMultiplyAndAccumulate (assigns y)
+ *                                                                I/implicit_schur_complement.cc:106-144 */
+int ceres_hip_op_schur_sx(ceres_hip_solver* s, const double* x, double* y);
+/* ImplicitSchurComplement::BackSubstitute: z (num_cols_f) -> x (num_cols)
+ *                                                                I/implicit_schur_complement.cc:208-243 */
+int ceres_hip_op_back_substitute(ceres_hip_solver* s, const double* z, double* x);
+
+/* BlockSparseJacobiPreconditioner::UpdateImpl                    I/block_jacobi_preconditioner.cc:59-115 */
+int ceres_hip_op_block_jacobi_update(ceres_hip_solver* s);
+/* SchurJacobiPreconditioner::UpdateImpl = SchurEliminator::Eliminate into a
+ * block-diagonal lhs + Invert     I/schur_jacobi_preconditioner.cc:87-97, I/schur_eliminator_impl.h:184-311 */
+int ceres_hip_op_schur_jacobi_update(ceres_hip_solver* s);
+/* The preconditioner's inverted diagonal blocks, dense row-major, block order.
+ * If not_inverted != 0 the blocks as they were BEFORE Invert() are returned
+ * (i.e. the diagonal blocks of J^T J + D^2, or of S).                        */
+int ceres_hip_get_preconditioner_blocks(ceres_hip_solver* s, int32_t not_inverted,
+                                        double* blocks, int64_t capacity);
+/* y += M^-1 x   BlockRandomAccessDiagonalMatrix::RightMultiplyAndAccumulate
+ *                                                                I/block_random_access_diagonal_matrix.cc:102-116 */
+int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y);
+
+/* SchurEliminator::Eliminate with a DENSE lhs (all S(i,j) cells present) and
+ * rhs; lhs is num_cols_f x num_cols_f row-major, upper block triangle filled
+ * like the reference (I/schur_eliminator_impl.h:184-311,548-565).  Generic
+ * kernels; meant for the small/explicit-S callers.         */
+int ceres_hip_op_schur_eliminate_dense(ceres_hip_solver* s, double* lhs, double* rhs);
+/* SchurEliminator::BackSubstitute                                I/schur_eliminator_impl.h:314-380 */
+int ceres_hip_op_eliminator_back_substitute(ceres_hip_solver* s, const double* z, double* x);
+
+/* BLAS-1 used by CG: Dot / Norm / Axpby   I/eigen_vector_ops.h:47-101.  n <= num_cols. */
+int ceres_hip_op_dot(ceres_hip_solver* s, const double* x, const double* y, int64_t n,
+                     double* result);
+int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b, const double* y,
+                       int64_t n, double* z);
+
+/* ---- timing for the roofline numbers --------------------------------------
+ * Runs `iters` back-to-back launches of one operator on the solver's stream
+ * with device-resident operands and brackets them with HIP events recorded on
+ * that same stream; returns the average milliseconds per application.        */
+#define CERES_HIP_TIMED_JTJX 1
+#define CERES_HIP_TIMED_SX 2
+#define CERES_HIP_TIMED_SCHUR_INIT 3
+#define CERES_HIP_TIMED_SCHUR_JACOBI 4
+#define CERES_HIP_TIMED_BACK_SUBSTITUTE 5
+#define CERES_HIP_TIMED_PACK 6
+#define CERES_HIP_TIMED_BLOCK_JACOBI 7
+#define CERES_HIP_TIMED_COPY 8 /* plain device copy of the values array: HBM ceiling probe */
+int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms);
+/* Per-phase event timings (ms) of the most recent ceres_hip_solve*. */
+typedef struct ceres_hip_solve_timing {
+  double upload_ms, pack_ms, setup_ms, preconditioner_ms, cg_ms, back_substitute_ms,
+      download_ms, total_ms;
+  int32_t operator_applications; /* lhs applications inside CG (incl. residual resets) */
+  int32_t reserved;
+} ceres_hip_solve_timing;
+int ceres_hip_get_last_timing(const ceres_hip_solver* s, ceres_hip_solve_timing* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CERES_HIP_H_ */

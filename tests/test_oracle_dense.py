@@ -1,0 +1,157 @@
+"""KA-7: the dense-algebra constructions of the reference's unit tests re-expressed with
+numpy on random inputs (schur_eliminator_test.cc:80-222, implicit_schur_complement_test.cc:126-217,
+partitioned_matrix_view_test.cc:103-262, block_jacobi_preconditioner_test.cc:45-95,
+block_sparse_matrix_test.cc:196-247).  CPU only."""
+import numpy as np
+import pytest
+
+
+def dense_schur(A, b, D, ne):
+    """H = A'A + D^2, eliminate the leading ne columns with dense algebra."""
+    H = A.T @ A + (np.diag(D ** 2) if D is not None else 0)
+    g = A.T @ b
+    P, Q, R = H[:ne, :ne], H[:ne, ne:], H[ne:, ne:]
+    # P is block diagonal in the E blocks, so inv(P) is what the eliminator applies blockwise
+    Pinv = np.linalg.inv(P)
+    S = R - Q.T @ Pinv @ Q
+    r = g[ne:] - Q.T @ Pinv @ g[:ne]
+    return H, g, S, r
+
+
+CASES = [dict(seed=s, static_sizes=ss, with_D=wd) for s, ss, wd in
+         [(1, None, True), (2, None, False), (3, (2, 3, 9), True), (4, (2, 3, 6), True), (5, (1, 1, 1), True), (6, (2, 3, 9), False)]]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_operators_against_dense(oracle, problems, case):
+    p = problems.random_schur_problem(num_e_blocks=9, num_f_blocks=4, **case)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    A = p.bs.to_dense(p.values)
+    rng = np.random.default_rng(0)
+    x, yr = rng.standard_normal(m.num_cols), rng.standard_normal(m.num_rows)
+    ne = m.num_cols_e
+    tol = dict(rtol=0, atol=1e-13 * np.abs(A).max() * A.shape[1])
+    np.testing.assert_allclose(m.right_multiply(p.values, x), A @ x, **tol)
+    np.testing.assert_allclose(m.left_multiply(p.values, yr), A.T @ yr, **tol)
+    np.testing.assert_allclose(m.squared_column_norm(p.values), (A * A).sum(0), **tol)
+    np.testing.assert_allclose(m.right_multiply_e(p.values, x[:ne]), A[:, :ne] @ x[:ne], **tol)
+    np.testing.assert_allclose(m.right_multiply_f(p.values, x[ne:]), A[:, ne:] @ x[ne:], **tol)
+    np.testing.assert_allclose(m.left_multiply_e(p.values, yr), A[:, :ne].T @ yr, **tol)
+    np.testing.assert_allclose(m.left_multiply_f(p.values, yr), A[:, ne:].T @ yr, **tol)
+    scale = 0.5 + rng.random(m.num_cols)
+    np.testing.assert_allclose(p.bs.to_dense(m.scale_columns(p.values, scale)), A * scale, rtol=1e-15)
+    # accumulate semantics: y += A x
+    y0 = rng.standard_normal(m.num_rows)
+    np.testing.assert_allclose(m.right_multiply(p.values, x, y0), y0 + A @ x, **tol)
+    # block diagonals
+    ete = m.block_diagonal_ete(p.values)
+    ftf = m.block_diagonal_ftf(p.values)
+    H = A.T @ A
+    off = 0
+    for j in range(p.bs.num_col_blocks):
+        s, c = int(p.bs.col_block_size[j]), int(p.bs.col_block_pos[j])
+        src = ete if j < p.num_eliminate_blocks else ftf
+        if j == p.num_eliminate_blocks:
+            off = 0
+        np.testing.assert_allclose(src[off:off + s * s].reshape(s, s), H[c:c + s, c:c + s], **tol)
+        off += s * s
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eliminator_and_implicit_complement(oracle, problems, case):
+    p = problems.random_schur_problem(num_e_blocks=8, num_f_blocks=5, **case)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    A = p.bs.to_dense(p.values)
+    D = p.D if p.D is not None else None
+    if D is None:  # keep E'E invertible without regularisation: only use cases where it is
+        if np.linalg.matrix_rank(A[:, :m.num_cols_e]) < m.num_cols_e:
+            pytest.skip("rank-deficient E without D")
+    H, g, S, r = dense_schur(A, p.b, D, m.num_cols_e)
+    lhs, rhs = m.schur_eliminate(p.values, p.b, D)
+    Sfull = np.triu(lhs) + np.triu(lhs, 1).T
+    # only cells with block1 <= block2 are written; the strictly-lower blocks stay zero, but inside a
+    # diagonal block both triangles are written
+    scale = np.abs(S).max()
+    bpos = p.bs.col_block_pos[p.num_eliminate_blocks:] - m.num_cols_e
+    bsz = p.bs.col_block_size[p.num_eliminate_blocks:]
+    for i in range(len(bsz)):
+        for j in range(len(bsz)):
+            blk = lhs[bpos[i]:bpos[i] + bsz[i], bpos[j]:bpos[j] + bsz[j]]
+            ref = S[bpos[i]:bpos[i] + bsz[i], bpos[j]:bpos[j] + bsz[j]]
+            if i <= j:
+                np.testing.assert_allclose(blk, ref, rtol=0, atol=1e-13 * scale)
+            else:
+                assert not blk.any()
+    np.testing.assert_allclose(rhs, r, rtol=0, atol=1e-13 * max(1, np.abs(r).max()) * 10)
+    # diagonal-only lhs (SCHUR_JACOBI) = the diagonal blocks of S
+    dl, _ = m.schur_eliminate(p.values, None, D, diagonal_only=True, want_rhs=False)
+    off = 0
+    for i in range(len(bsz)):
+        n = int(bsz[i])
+        np.testing.assert_allclose(dl[off:off + n * n].reshape(n, n), S[bpos[i]:bpos[i] + n, bpos[i]:bpos[i] + n],
+                                   rtol=0, atol=1e-13 * scale)
+        off += n * n
+    # back substitution reproduces the dense solve
+    sol = np.linalg.solve(H, g)
+    z = np.linalg.solve(S, r)
+    np.testing.assert_allclose(m.schur_back_substitute(p.values, p.b, D, z), sol, rtol=0, atol=1e-11 * max(1, np.abs(sol).max()))
+    # implicit complement: every column of S, rhs, back substitution (kEpsilon = 1e-14 in the reference)
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, D, p.b)
+    cols = np.stack([isc.sx(e) for e in np.eye(m.num_cols_f)], axis=1)
+    np.testing.assert_allclose(cols, S, rtol=0, atol=1e-13 * scale)
+    np.testing.assert_allclose(isc.rhs(), r, rtol=0, atol=1e-12 * max(1, np.abs(r).max()))
+    np.testing.assert_allclose(isc.back_substitute(z), sol, rtol=0, atol=1e-11 * max(1, np.abs(sol).max()))
+    # preconditioners: M^-1 * block = I
+    inv, raw = m.schur_jacobi(p.values, D)
+    off = 0
+    for i in range(len(bsz)):
+        n = int(bsz[i])
+        Sb = S[bpos[i]:bpos[i] + n, bpos[i]:bpos[i] + n]
+        np.testing.assert_allclose(inv[off:off + n * n].reshape(n, n) @ Sb, np.eye(n), atol=1e-10)
+        np.testing.assert_allclose(np.triu(raw[off:off + n * n].reshape(n, n)), np.triu(Sb), atol=1e-13 * scale)
+        off += n * n
+    inv, raw = m.block_jacobi(p.values, D)
+    off = 0
+    for j in range(p.bs.num_col_blocks):
+        n, c = int(p.bs.col_block_size[j]), int(p.bs.col_block_pos[j])
+        np.testing.assert_allclose(inv[off:off + n * n].reshape(n, n) @ H[c:c + n, c:c + n], np.eye(n), atol=1e-10)
+        off += n * n
+
+
+def test_threads_agree(oracle, problems):
+    # reference: parallel right-multiply bit-exact, parallel left-multiply 1e-12
+    # (internal/ceres/block_sparse_matrix_test.cc:208-247)
+    p = problems.synthetic_bal(None, num_cameras=12, num_points=400, num_observations=1700, seed=3)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(m.num_cols), rng.standard_normal(m.num_rows)
+    oracle.set_num_threads(1)
+    r1, l1 = m.right_multiply(p.values, x), m.left_multiply(p.values, y)
+    s1, sum1 = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, max_it=30, r_tol=1e-12)
+    oracle.set_num_threads(4)
+    try:
+        r4, l4 = m.right_multiply(p.values, x), m.left_multiply(p.values, y)
+        s4, sum4 = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, max_it=30, r_tol=1e-12)
+    finally:
+        oracle.set_num_threads(1)
+    np.testing.assert_array_equal(r1, r4)
+    np.testing.assert_allclose(l1, l4, rtol=0, atol=1e-12 * np.abs(l1).max())
+    np.testing.assert_allclose(s1, s4, rtol=0, atol=1e-9 * np.abs(s1).max())
+
+
+@pytest.mark.parametrize("layout", ["schur", "cgnr"])
+def test_bal_shaped_solvers_match_dense(oracle, problems, layout):
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=6, num_points=40, num_observations=150, seed=11)
+    nelim = p.num_eliminate_blocks
+    m = oracle.Matrix(p.bs, nelim)
+    assert m.detect_structure() == ((2, 3, 9) if layout == "schur" else (0, 0, 0))
+    A = p.bs.to_dense(p.values)
+    ref = np.linalg.solve(A.T @ A + np.diag(p.D ** 2), A.T @ p.b)
+    if layout == "schur":
+        x, s = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, max_it=200, r_tol=1e-13)
+        assert s.termination_type == 0
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    x, s = m.cgnr_solve(p.values, p.b, p.D, preconditioner=1, max_it=500, r_tol=1e-13)
+    assert s.termination_type == 0
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
