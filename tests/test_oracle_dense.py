@@ -152,6 +152,7 @@ def test_bal_shaped_solvers_match_dense(oracle, problems, layout):
         x, s = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, max_it=200, r_tol=1e-13)
         assert s.termination_type == 0
         np.testing.assert_allclose(x, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    # CGNR works on the normal equations: error ~ cond(J'J + D^2) * r_tol, cond ~ 1e4..1e6 here
     x, s = m.cgnr_solve(p.values, p.b, p.D, preconditioner=1, max_it=500, r_tol=1e-13)
     assert s.termination_type == 0
-    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
