@@ -16,7 +16,7 @@ import numpy as np
 
 
 class CBlockStructure(ctypes.Structure):
-    """ctypes image of ceres_hip_block_structure / oracle_block_structure."""
+    """ctypes image of ceres_hip_block_structure."""
 
     _fields_ = [
         ("num_row_blocks", ctypes.c_int32),

@@ -1,0 +1,73 @@
+"""Builds csrc/ into csrc/libceres_hip.so with hipcc for gfx950 (in-tree, so that the
+built library travels to the GPU box with the repository snapshot)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libceres_hip.so")
+SOURCES = ["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal.hip", "solver.hip"]
+HEADERS = ["common.h", "device.h", os.path.join("..", "..", "include", "ceres_hip.h")]
+HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")
+HOST_DRIVER = os.path.join(HERE, "host", "host_driver")
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in srcs:
+        obj = os.path.splitext(src)[0] + ".o"
+        objs.append(obj)
+        if force or _stale(obj, [src] + [os.path.join(CSRC, h) for h in HEADERS]):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+                   "-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    if force or _stale(OUT, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+def build_host_driver(force=False, verbose=False):
+    """The C++ host-side mirror of ceres::internal::LinearSolver + a small driver (g++, links the C ABI)."""
+    if not os.path.exists(HOST_DRIVER_SRC):
+        return None
+    deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), OUT]
+    if force or _stale(HOST_DRIVER, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"), "-I", os.path.join(HERE, "host"),
+               HOST_DRIVER_SRC, "-o", HOST_DRIVER, "-L", CSRC, "-lceres_hip", "-Wl,-rpath," + CSRC,
+               "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_DRIVER
+
+
+def build_all(force=False, verbose=False):
+    build_library(force, verbose)
+    build_host_driver(force, verbose)
+    return OUT
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

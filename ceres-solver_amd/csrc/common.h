@@ -1,0 +1,81 @@
+// common.h — shared declarations of the gfx950 LM linear-solve library.
+//
+// Layering inside csrc/:
+//   plan.cc            host analysis of the block structure (no HIP): flattening,
+//                      transpose, chunks, BAL detection, tile packing plan
+//   kernels_generic.hip any block sizes; multi-pass kernels that mirror the
+//                      reference's operator decomposition
+//   kernels_bal.hip    static <2,3,9>; fused single-pass kernels over packed tiles
+//   kernels_cg.hip     device-resident preconditioned CG (vector kernels)
+//   solver.hip         the C ABI of include/ceres_hip.h
+//   comm.hip           RCCL communicator (multi-GPU sharding by point)
+#ifndef CERES_HIP_COMMON_H_
+#define CERES_HIP_COMMON_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ceres_hip.h"
+
+namespace chip {
+
+constexpr int kTile = 64;           // observation slots per tile = one wavefront
+constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
+constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
+
+// ---------------------------------------------------------------------------
+// Host-side analysis (plan.cc).  Pure C++, unit-testable without a GPU through
+// the ceres_hip_debug_* exports.
+// ---------------------------------------------------------------------------
+struct HostStructure {
+  int nrb = 0, ncb = 0, nelim = 0, ncells = 0;
+  std::vector<int32_t> rsz, rpos, csz, cpos, rptr, ccol, cval;
+  int num_rows = 0, num_cols = 0, num_cols_e = 0, num_cols_f = 0, num_row_blocks_e = 0;
+  int64_t nnz = 0;
+  int64_t values_extent = 0;  // 1 + largest value index any cell touches
+  int max_block = 0;
+  int det_row = 0, det_e = 0, det_f = 0;  // DetectStructure; -1 dynamic, 0 none
+  // transpose (column block -> cells, in row order)
+  std::vector<int32_t> tptr, trow, tcell;
+  // scalar row/col -> owning block (for thread-per-scalar generic kernels)
+  std::vector<int32_t> row_block_of, col_block_of;
+  // diagonal block stores
+  std::vector<int64_t> diag_off_all;  // ncb+1, offsets of csz^2 blocks over all column blocks
+  std::vector<int64_t> diag_off_f;    // nf+1
+  std::vector<int64_t> diag_off_e;    // nelim+1
+  // E block of each row (-1 if the row has no E cell)
+  std::vector<int32_t> row_e_block;
+  // chunk = rows of one E block (contiguous): start/size per E block; size 0 if none
+  std::vector<int32_t> chunk_start, chunk_size;
+  bool chunks_contiguous = true;
+};
+
+struct BalPlan {
+  bool eligible = false;
+  std::string why_not;         // reason the fused path was not selected
+  int n_points = 0, n_cameras = 0;
+  int64_t n_obs = 0, n_tiles = 0;
+  bool contiguous_layout = false;  // pt_pos = 3p, cam_pos(F-relative) = 9c
+  std::vector<int32_t> pt_block, cam_block;   // column block of each point / camera
+  std::vector<int32_t> pt_pos, cam_pos;       // scalar offset in x (camera: minus num_cols_e)
+  // per slot (n_tiles * 64)
+  std::vector<int32_t> slot_epos, slot_fpos, slot_bpos;  // value / residual offsets, -1 = padding
+  std::vector<int32_t> slot_cam, slot_pt;                // ids, -1 = padding
+  std::vector<uint32_t> slot_seg;  // first | last<<8 | flags<<16 ; flags bit0 valid
+  // per tile: 0 normal, 1 head of a long point (tile_aux = #tiles), 2 continuation
+  std::vector<int32_t> tile_kind, tile_aux;
+  // camera-major lists
+  std::vector<int32_t> cam_ptr;    // n_cameras+1
+  std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major
+  std::vector<int32_t> cam_slot;   // slot of each observation, camera-major
+  int max_track = 0, max_camera_degree = 0;
+};
+
+// Fills hs from the ABI structure; returns "" or an error message.
+std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs);
+// Decides whether the fused <2,3,9> path applies and, if so, builds the packing plan.
+void BuildBalPlan(const HostStructure& hs, bool allow_e_free_layout, BalPlan* plan);
+
+}  // namespace chip
+#endif

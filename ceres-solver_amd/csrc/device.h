@@ -1,0 +1,179 @@
+// device.h — kernel argument structs and launcher declarations shared by the .hip files.
+#ifndef CERES_HIP_DEVICE_H_
+#define CERES_HIP_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace chip {
+
+constexpr int kBalBlock = 512;               // threads per workgroup of the fused kernels (8 waves)
+constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
+constexpr int kVecBlock = 256;
+constexpr int kMaxVecGrid = 512;             // partial sums per inner product
+
+// ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
+enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5 };
+
+struct BalArgs {
+  // packed problem
+  const double2* J = nullptr;   // [n_tiles][12][64]
+  const double2* b = nullptr;   // [n_tiles][64]
+  const int32_t* slot_cam = nullptr;
+  const int32_t* slot_pt = nullptr;
+  const uint32_t* slot_seg = nullptr;
+  const int32_t* tile_kind = nullptr;
+  const int32_t* tile_aux = nullptr;
+  int64_t n_tiles = 0, n_slots = 0;
+  const int32_t* pt_pos = nullptr;   // nullptr => 3*p
+  const int32_t* cam_pos = nullptr;  // nullptr => 9*c   (relative to the F base pointer)
+  // vectors: *_e indexed by pt_pos, *_f by cam_pos
+  const double* x_e = nullptr;
+  const double* x_f = nullptr;
+  double* y_e = nullptr;
+  const double* D_e = nullptr;  // nullptr => no regularisation on the point part
+  // per-point 3x3 inverses, packed symmetric 6 doubles / point
+  double* etei = nullptr;
+  double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
+  const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => 9*p
+  double* Mo = nullptr;                   // [3][n_slots] symmetric 2x2 per observation (kInit)
+  int have_b = 0;
+  // camera accumulation
+  double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
+  double* global_acc = nullptr;  // [n_f9]         (global-atomic mode)
+  int n_f9 = 0;                  // 9 * n_cameras
+  const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
+};
+
+hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
+hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
+                                   const double* D_f, const double* x_f, double* y_f, const int* status,
+                                   hipStream_t stream);
+hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
+                                 const int* status, hipStream_t stream);
+hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
+                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, double2* bt, hipStream_t stream);
+hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const int32_t* cam_ptr, const int32_t* cam_fpos,
+                                 const int32_t* cam_slot, const double* Mo, int64_t n_slots, const double* D_f,
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, int n_cameras,
+                                 hipStream_t stream);
+
+hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream);
+
+// ---- generic kernels (kernels_generic.hip) --------------------------------
+struct GenStructure {
+  int nrb = 0, ncb = 0, nelim = 0, nrbe = 0, num_rows = 0, num_cols = 0, nce = 0, ncf = 0;
+  const int32_t *rsz = nullptr, *rpos = nullptr, *rptr = nullptr, *ccol = nullptr, *cval = nullptr;
+  const int32_t *csz = nullptr, *cpos = nullptr;
+  const int32_t *tptr = nullptr, *trow = nullptr, *tcell = nullptr;
+  const int32_t *row_block_of = nullptr, *col_block_of = nullptr, *row_e_block = nullptr;
+  const int64_t *diag_off_all = nullptr, *diag_off_e = nullptr, *diag_off_f = nullptr;
+};
+enum GenPart { kAll = 0, kE = 1, kF = 2 };
+
+// y += A_part x   (x, y are the base pointers of the part's own index space)
+hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
+                                  const int* status, hipStream_t stream);
+// y += A_part^T x
+hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
+                                 const int* status, hipStream_t stream);
+// blocks = blockdiag(A_part^T A_part) (+ D^2 if D != nullptr; D is the FULL num_cols vector)
+hipError_t LaunchGenBlockDiagonal(const GenStructure& G, const double* values, int part, const double* D,
+                                  double* blocks, int64_t total_entries, hipStream_t stream);
+// x[j] = |A_j|^2
+hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* values, double* x, hipStream_t stream);
+// In-place SPD inverse (upper triangle authoritative) of nblocks dense blocks; blocks
+// [first_block, first_block + nblocks) of the column-block list, offsets relative to off[0].
+hipError_t LaunchGenInvertBlocks(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
+                                 double* blocks, int* fail_flag, hipStream_t stream);
+// y += blockdiag x over column blocks [first_block, first_block+nblocks); vectors start at that block.
+hipError_t LaunchGenBlockDiagonalApply(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
+                                       const double* blocks, const double* x, double* y, const int* status,
+                                       hipStream_t stream);
+// blocks(j)(a,a) += D[col]^2 over column blocks [first_block, first_block+nblocks); D is the FULL vector.
+hipError_t LaunchAddBlockDiagonalSquares(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
+                                         const double* D, double* blocks, hipStream_t stream);
+// Diagonal blocks of the Schur complement (SchurEliminator::Eliminate into a
+// block-diagonal lhs): needs the inverted E^T E blocks.  D may be nullptr; add_f_diag
+// controls whether D_f^2 is added (sharded runs add it after the all-reduce).
+hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
+                                int add_f_diag, double* blocks, int64_t total_entries, hipStream_t stream);
+// Dense S (upper block triangle) and nothing else; rhs comes from the ISC path.
+hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
+                               double* lhs, hipStream_t stream);
+
+// ---- vector kernels + device-resident CG (kernels_cg.hip) ------------------
+hipError_t LaunchSet(double* x, double v, int64_t n, hipStream_t stream);
+hipError_t LaunchAxpby(double a, const double* x, double b, const double* y, double* z, int64_t n, hipStream_t stream);
+// y = D^2 .* x  (D may be nullptr => y = 0)
+hipError_t LaunchSquareScale(const double* D, const double* x, double* y, int64_t n, const int* status, hipStream_t stream);
+// y += D^2 .* x
+hipError_t LaunchAddSquareScale(const double* D, const double* x, double* y, int64_t n, const int* status, hipStream_t stream);
+// out[0] = x . y  (two-stage, deterministic); partials has kMaxVecGrid doubles
+hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partials, double* out, hipStream_t stream);
+hipError_t LaunchExpandSym3(const double* packed6, double* dense9, const int64_t* pt_diag_off, int n_points, hipStream_t stream);
+
+// Status word values (device side) — 0 means "keep iterating".
+enum CgStatus {
+  kCgRunning = 0,
+  kCgConvergedZeta = 1,
+  kCgConvergedResidual = 2,
+  kCgMaxIterations = 3,
+  kCgFailRho = 4,
+  kCgFailBeta = 5,
+  kCgIndefinite = 6,
+  kCgFailAlpha = 7,
+  kCgZeroRhs = 8,          // |b| = 0: x = 0, SUCCESS
+  kCgInitialResidual = 9,  // min_num_iterations == 0 and |r0| <= tol
+};
+
+struct CgScalars {
+  double norm_rhs, tol_r, q_tol;
+  double rho, rho_new, beta, pq, alpha, Q0, Q1, zeta, norm_r, norm_p, norm_q;
+  int iter, status, min_it, max_it;
+  int fail_dir, fail_step;  // failures staged by direction / step, committed by finalize
+};
+
+struct CgBuffers {
+  int64_t n = 0;
+  // Sharded CGNR: the first n_local elements (this rank's points) are a shard, the rest
+  // (cameras) are replicated.  Workgroups [0, grid_e) cover the shard, [grid_e, grid) the
+  // rest; the shard's share of every inner product is collapsed into comm[slot], summed
+  // over ranks by the host (ncclAllReduce) and added by the consumers.  Unsharded:
+  // n_local = 0, grid_e = 0 and comm is ignored.
+  int64_t n_local = 0;
+  int grid = 1, grid_e = 0;
+  double *x = nullptr, *r = nullptr, *p = nullptr, *z = nullptr;
+  const double* rhs = nullptr;
+  double* partials = nullptr;  // 4 slots * kMaxVecGrid doubles
+  double* comm = nullptr;      // 4 doubles
+  CgScalars* S = nullptr;      // device
+};
+
+// z = M^-1 r (block-diagonal, or copy when blocks == nullptr) and partial r.z
+// slot 0 <- partial |rhs|^2
+hipError_t LaunchCgRhsNorm(const CgBuffers& B, hipStream_t stream);
+// x = 0, r = rhs, scalars initialised from slot 0 (I/conjugate_gradients_solver.h:130-159 with x0 = 0)
+hipError_t LaunchCgInit(const CgBuffers& B, double q_tol, double r_tol, int min_it, int max_it, hipStream_t stream);
+// z = M^-1 r (block diagonal over column blocks [first_block, ..), vectors start at scalar
+// column col_begin; blocks == nullptr => identity) and slot 0 <- partial r.z
+hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin,
+                                const int64_t* diag_off, const double* blocks, hipStream_t stream);
+// rho = sum(slot 0); beta; p = z + beta p
+hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t stream);
+// slot 1 <- partial p.q  (q lives in z)
+hipError_t LaunchCgDotPq(const CgBuffers& B, hipStream_t stream);
+// pq = sum(slot 1); alpha; x += alpha p; unless reset: r -= alpha q, slots 2,3 <- partial Q1, |r|^2
+hipError_t LaunchCgStep(const CgBuffers& B, int reset, hipStream_t stream);
+// r = rhs - tmp; slots 2,3
+hipError_t LaunchCgResidualReset(const CgBuffers& B, const double* tmp, hipStream_t stream);
+// termination tests in the reference's order (:273-302); iter++
+hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
+// comm[slot] = sum over the shard's workgroups of partials[slot] for slot in [first, first+count)
+hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t stream);
+
+}  // namespace chip
+#endif

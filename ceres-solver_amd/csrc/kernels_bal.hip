@@ -1,0 +1,703 @@
+// kernels_bal.hip — fused single-pass kernels for the static <2,3,9> (BAL) structure.
+//
+// Data layout in HBM (built once per LM step by bal_pack_kernel from the caller's
+// values, whatever their layout):
+//   tiles of 64 observation slots, one wavefront per tile;
+//   J   [tile][12][64] double2   pair j of slot l holds Jacobian doubles (2j, 2j+1) of the
+//                                24 = 6 (E, 2x3 row-major) + 18 (F, 2x9 row-major)
+//   b   [tile][64]     double2   the two residuals of the slot
+//   cam [tile][64] int32, pt [tile][64] int32, seg [tile][64] uint32 (first|last<<8|valid<<16)
+// so that every global load of the hot kernels is a 16-byte-per-lane, 1 KiB-per-wave
+// contiguous access and the algorithmic traffic is 192 + 8 (+4) bytes per observation.
+//
+// All per-point reductions (E^T·, (E^T E)^-1) are segmented wavefront scans over
+// __shfl_up — observations of a point are adjacent lanes by construction of the
+// plan (plan.cc); points longer than 64 observations own whole tiles and are
+// handled by the same wave in two sweeps.  Per-camera sums (F^T·) go to a
+// workgroup-private accumulator in LDS (9 doubles per camera: 128 KB for Venice's
+// 1778 cameras, LDS is 160 KB) with ds_add_f64, flushed once per workgroup and
+// combined by bal_reduce_partials_kernel; when the cameras do not fit in LDS the
+// same code accumulates into a zeroed global array with global_atomic_add_f64.
+//
+// Reference operators restated by each MODE (file:line in include/ceres_hip.h):
+//   kSx        ImplicitSchurComplement::RightMultiplyAndAccumulate (4 passes there, 1 here)
+//   kJtJx      CgnrLinearOperator::RightMultiplyAndAccumulate      (2 passes there, 1 here)
+//   kJtb       A^T b
+//   kInit      ImplicitSchurComplement::Init: (E^T E + D^2)^-1, rhs; also the 2x2 blocks
+//              M_o = I - E_o (E^T E)^-1 E_o^T that SCHUR_JACOBI needs
+//   kEte       block diagonal (E^T E + D^2)^-1 only (CGNR JACOBI point blocks)
+//   kBackSub   ImplicitSchurComplement::BackSubstitute
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+
+namespace chip {
+
+namespace {
+
+__device__ __forceinline__ double shfl_up(double v, int d) { return __shfl_up(v, (unsigned)d, 64); }
+__device__ __forceinline__ double shfl_idx(double v, int l) { return __shfl(v, l, 64); }
+__device__ __forceinline__ double shfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// Inclusive segmented scan (segments = runs of lanes [first,last]); afterwards the
+// last lane of each segment holds the segment sum.  `span` bounds the longest
+// segment in the tile (wave-uniform) so that short tracks take fewer steps.
+template <int N>
+__device__ __forceinline__ void seg_scan(double (&v)[N], int lane, int first, int span) {
+  for (int d = 1; d < span; d <<= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double t = shfl_up(v[i], d);
+      if (lane - d >= first) v[i] += t;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void seg_allreduce(double (&v)[N], int lane, int first, int last, int span) {
+  seg_scan<N>(v, lane, first, span);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = shfl_idx(v[i], last);
+}
+template <int N>
+__device__ __forceinline__ void wave_allreduce(double (&v)[N]) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += shfl_xor(v[i], m);
+  }
+}
+
+// Inverse of the SPD 3x3 matrix [a0 a1 a2; a1 a3 a4; a2 a4 a5] through its Cholesky
+// factor (the reference: selfadjointView<Upper>().llt().solve(I),
+// I/implicit_schur_complement.cc:179-204).  Output in the same packed order.
+__device__ __forceinline__ void invert_spd3(const double (&a)[6], double (&o)[6]) {
+  const double l00 = sqrt(a[0]);
+  const double i00 = 1.0 / l00;
+  const double l10 = a[1] * i00, l20 = a[2] * i00;
+  const double l11 = sqrt(a[3] - l10 * l10);
+  const double i11 = 1.0 / l11;
+  const double l21 = (a[4] - l20 * l10) * i11;
+  const double l22 = sqrt(a[5] - l20 * l20 - l21 * l21);
+  const double i22 = 1.0 / l22;
+  // W = L^-1 (lower): w00 w10 w11 w20 w21 w22
+  const double w10 = -l10 * i00 * i11;
+  const double w21 = -l21 * i11 * i22;
+  const double w20 = -(l20 * i00 + l21 * w10) * i22;
+  // A^-1 = W^T W
+  o[0] = i00 * i00 + w10 * w10 + w20 * w20;
+  o[1] = w10 * i11 + w20 * w21;
+  o[2] = w20 * i22;
+  o[3] = i11 * i11 + w21 * w21;
+  o[4] = w21 * i22;
+  o[5] = i22 * i22;
+}
+
+template <bool LDS>
+__device__ __forceinline__ void acc_add(double* acc, int idx, double v) {
+  if constexpr (LDS) atomicAdd(&acc[idx], v);   // ds_add_f64
+  else unsafeAtomicAdd(&acc[idx], v);           // global_atomic_add_f64
+}
+
+struct Slot {
+  double e[6], f[18];
+  int cam, pt, first, last;
+  bool valid;
+};
+
+__device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int lane, Slot& s) {
+  const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
+  double2 p[kPairsPerSlot];
+#pragma unroll
+  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
+  s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
+  const int64_t sl = tile * kTile + lane;
+  s.cam = A.slot_cam[sl];
+  s.pt = A.slot_pt[sl];
+  const uint32_t sg = A.slot_seg[sl];
+  s.first = sg & 0xff;
+  s.last = (sg >> 8) & 0xff;
+  s.valid = (sg >> 16) & 1;
+  if (!s.valid) { s.cam = 0; s.pt = 0; }
+}
+
+__device__ __forceinline__ int pt_off(const BalArgs& A, int p) { return A.pt_pos ? A.pt_pos[p] : 3 * p; }
+__device__ __forceinline__ int cam_off(const BalArgs& A, int c) { return A.cam_pos ? A.cam_pos[c] : 9 * c; }
+
+__device__ __forceinline__ void load_ete_inverse(const BalArgs& A, int pt, double (&ei)[6]) {
+  const double2* q = reinterpret_cast<const double2*>(A.etei + int64_t(pt) * 6);
+  const double2 a = q[0], b = q[1], c = q[2];
+  ei[0] = a.x; ei[1] = a.y; ei[2] = b.x; ei[3] = b.y; ei[4] = c.x; ei[5] = c.y;
+}
+__device__ __forceinline__ void sym3_mul(const double (&m)[6], const double (&u)[3], double (&v)[3]) {
+  v[0] = m[0] * u[0] + m[1] * u[1] + m[2] * u[2];
+  v[1] = m[1] * u[0] + m[3] * u[1] + m[4] * u[2];
+  v[2] = m[2] * u[0] + m[4] * u[1] + m[5] * u[2];
+}
+
+// t = F * xc
+__device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], double& t0, double& t1) {
+  t0 = 0; t1 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { t0 += s.f[k] * xc[k]; t1 += s.f[9 + k] * xc[k]; }
+}
+template <bool LDS>
+__device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
+  if (!s.valid) return;
+  const int base = 9 * s.cam;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc_add<LDS>(acc, base + k, s.f[k] * z0 + s.f[9 + k] * z1);
+}
+
+enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5 };
+
+// E^T E (packed symmetric) of one slot.
+__device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
+  a[0] = s.e[0] * s.e[0] + s.e[3] * s.e[3];
+  a[1] = s.e[0] * s.e[1] + s.e[3] * s.e[4];
+  a[2] = s.e[0] * s.e[2] + s.e[3] * s.e[5];
+  a[3] = s.e[1] * s.e[1] + s.e[4] * s.e[4];
+  a[4] = s.e[1] * s.e[2] + s.e[4] * s.e[5];
+  a[5] = s.e[2] * s.e[2] + s.e[5] * s.e[5];
+}
+
+__device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int po, double (&a)[6]) {
+  if (A.D_e) {
+    const double d0 = A.D_e[po], d1 = A.D_e[po + 1], d2 = A.D_e[po + 2];
+    a[0] += d0 * d0; a[3] += d1 * d1; a[5] += d2 * d2;
+  }
+}
+
+__device__ __forceinline__ void store_ete_inverse(const BalArgs& A, int pt, const double (&ei)[6]) {
+  if (A.etei) {
+    double2* q = reinterpret_cast<double2*>(A.etei + int64_t(pt) * 6);
+    q[0] = make_double2(ei[0], ei[1]); q[1] = make_double2(ei[2], ei[3]); q[2] = make_double2(ei[4], ei[5]);
+  }
+  if (A.point_blocks) {  // dense 3x3 in the all-blocks diagonal store (CGNR JACOBI)
+    double* o = A.point_blocks + (A.pt_diag_off ? A.pt_diag_off[pt] : int64_t(9) * pt);
+    o[0] = ei[0]; o[1] = ei[1]; o[2] = ei[2]; o[3] = ei[1]; o[4] = ei[3]; o[5] = ei[4]; o[6] = ei[2]; o[7] = ei[4]; o[8] = ei[5];
+  }
+}
+
+// Everything after the per-point quantities are known, for kInit.
+template <bool LDS>
+__device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int64_t sl, double b0, double b1,
+                                           const double (&ei)[6], const double (&g)[3], double* acc) {
+  double h[3];
+  sym3_mul(ei, g, h);
+  const double w0 = b0 - (s.e[0] * h[0] + s.e[1] * h[1] + s.e[2] * h[2]);
+  const double w1 = b1 - (s.e[3] * h[0] + s.e[4] * h[1] + s.e[5] * h[2]);
+  if (A.have_b) scatter_ft<LDS>(s, acc, w0, w1);
+  if (A.Mo && s.valid) {  // M = I - E Ei E^T, symmetric 2x2
+    const double r0[3] = {s.e[0], s.e[1], s.e[2]}, r1[3] = {s.e[3], s.e[4], s.e[5]};
+    double q0[3], q1[3];
+    sym3_mul(ei, r0, q0);
+    sym3_mul(ei, r1, q1);
+    A.Mo[sl] = 1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]);
+    A.Mo[A.n_slots + sl] = -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]);
+    A.Mo[2 * A.n_slots + sl] = 1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]);
+  }
+}
+
+template <int MODE, bool LDS>
+__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, double* acc) {
+  Slot s;
+  load_slot(A, tile, lane, s);
+  const int64_t sl = tile * kTile + lane;
+  const int po = pt_off(A, s.pt);
+  if constexpr (MODE == kSx) {
+    double xc[9];
+    const int co = cam_off(A, s.cam);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+    double t0, t1;
+    f_times(s, xc, t0, t1);
+    double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
+    if (!s.valid) { u[0] = u[1] = u[2] = 0; }
+    seg_allreduce<3>(u, lane, s.first, s.last, span);
+    double ei[6], v[3];
+    load_ete_inverse(A, s.pt, ei);
+    sym3_mul(ei, u, v);
+    const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
+    const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
+    scatter_ft<LDS>(s, acc, z0, z1);
+  } else if constexpr (MODE == kJtJx || MODE == kJtb) {
+    double z0, z1, xp[3] = {0, 0, 0};
+    if constexpr (MODE == kJtJx) {
+      double xc[9];
+      const int co = cam_off(A, s.cam);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+      xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
+      f_times(s, xc, z0, z1);
+      z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
+      z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
+    } else {
+      const double2 bb = A.b[sl];
+      z0 = bb.x; z1 = bb.y;
+    }
+    scatter_ft<LDS>(s, acc, z0, z1);
+    double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
+    if (!s.valid) { w[0] = w[1] = w[2] = 0; }
+    seg_scan<3>(w, lane, s.first, span);
+    if (s.valid && lane == s.last) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double d = 0;
+        if (MODE == kJtJx && A.D_e) { d = A.D_e[po + j]; d = d * d * xp[j]; }
+        A.y_e[po + j] = w[j] + d;
+      }
+    }
+  } else if constexpr (MODE == kInit || MODE == kEte) {
+    double r[9];
+    {
+      double a[6];
+      ete_of(s, a);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = s.valid ? a[i] : 0.0;
+    }
+    double b0 = 0, b1 = 0;
+    if (MODE == kInit && A.have_b) { const double2 bb = A.b[sl]; b0 = bb.x; b1 = bb.y; }
+    r[6] = s.valid ? s.e[0] * b0 + s.e[3] * b1 : 0.0;
+    r[7] = s.valid ? s.e[1] * b0 + s.e[4] * b1 : 0.0;
+    r[8] = s.valid ? s.e[2] * b0 + s.e[5] * b1 : 0.0;
+    if constexpr (MODE == kInit) {
+      seg_allreduce<9>(r, lane, s.first, s.last, span);
+    } else {
+      double a6[6] = {r[0], r[1], r[2], r[3], r[4], r[5]};
+      seg_allreduce<6>(a6, lane, s.first, s.last, span);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = a6[i];
+    }
+    double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
+    add_e_diagonal(A, po, a);
+    if (!s.valid) { a[0] = a[3] = a[5] = 1.0; a[1] = a[2] = a[4] = 0.0; }
+    invert_spd3(a, ei);
+    if (s.valid && lane == s.last) store_ete_inverse(A, s.pt, ei);
+    if constexpr (MODE == kInit) {
+      const double g[3] = {r[6], r[7], r[8]};
+      init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
+    }
+  } else if constexpr (MODE == kBackSub) {
+    double zc[9];
+    const int co = cam_off(A, s.cam);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) zc[k] = A.x_f[co + k];
+    double t0, t1;
+    f_times(s, zc, t0, t1);
+    const double2 bb = A.b[sl];
+    t0 = bb.x - t0; t1 = bb.y - t1;
+    double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
+    if (!s.valid) { u[0] = u[1] = u[2] = 0; }
+    seg_scan<3>(u, lane, s.first, span);
+    if (s.valid && lane == s.last) {
+      double ei[6], v[3];
+      load_ete_inverse(A, s.pt, ei);
+      sym3_mul(ei, u, v);
+      A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2];
+    }
+  }
+}
+
+// A point with more than 64 observations: tiles [tile, tile+nt) belong to it alone.
+// Sweep 1 accumulates the per-point sums over all its tiles, sweep 2 (only where the
+// per-observation result depends on them) re-reads the tiles, which are L2-warm.
+template <int MODE, bool LDS>
+__device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t tile, int nt, int lane, double* acc) {
+  Slot s;
+  if constexpr (MODE == kSx || MODE == kBackSub) {
+    double u[3] = {0, 0, 0};
+    int pt = 0;
+    for (int t = 0; t < nt; ++t) {
+      load_slot(A, tile + t, lane, s);
+      if (t == 0) pt = __shfl(s.pt, 0, 64);
+      double xc[9];
+      const int co = cam_off(A, s.cam);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+      double t0, t1;
+      f_times(s, xc, t0, t1);
+      if constexpr (MODE == kBackSub) { const double2 bb = A.b[(tile + t) * kTile + lane]; t0 = bb.x - t0; t1 = bb.y - t1; }
+      if (s.valid) { u[0] += s.e[0] * t0 + s.e[3] * t1; u[1] += s.e[1] * t0 + s.e[4] * t1; u[2] += s.e[2] * t0 + s.e[5] * t1; }
+    }
+    wave_allreduce<3>(u);
+    double ei[6], v[3];
+    load_ete_inverse(A, pt, ei);
+    sym3_mul(ei, u, v);
+    if constexpr (MODE == kBackSub) {
+      if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
+    } else {
+      for (int t = 0; t < nt; ++t) {
+        load_slot(A, tile + t, lane, s);
+        double xc[9];
+        const int co = cam_off(A, s.cam);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+        double t0, t1;
+        f_times(s, xc, t0, t1);
+        const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
+        const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
+        scatter_ft<LDS>(s, acc, z0, z1);
+      }
+    }
+  } else if constexpr (MODE == kJtJx || MODE == kJtb) {
+    double w[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
+    int pt = 0, po = 0;
+    for (int t = 0; t < nt; ++t) {
+      load_slot(A, tile + t, lane, s);
+      if (t == 0) {
+        pt = __shfl(s.pt, 0, 64);
+        po = pt_off(A, pt);
+        if constexpr (MODE == kJtJx) { xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2]; }
+      }
+      double z0, z1;
+      if constexpr (MODE == kJtJx) {
+        double xc[9];
+        const int co = cam_off(A, s.cam);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+        f_times(s, xc, z0, z1);
+        z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
+        z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
+      } else {
+        const double2 bb = A.b[(tile + t) * kTile + lane];
+        z0 = bb.x; z1 = bb.y;
+      }
+      scatter_ft<LDS>(s, acc, z0, z1);
+      if (s.valid) { w[0] += s.e[0] * z0 + s.e[3] * z1; w[1] += s.e[1] * z0 + s.e[4] * z1; w[2] += s.e[2] * z0 + s.e[5] * z1; }
+    }
+    wave_allreduce<3>(w);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double d = 0;
+        if (MODE == kJtJx && A.D_e) { d = A.D_e[po + j]; d = d * d * xp[j]; }
+        A.y_e[po + j] = w[j] + d;
+      }
+    }
+  } else if constexpr (MODE == kInit || MODE == kEte) {
+    double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int pt = 0;
+    for (int t = 0; t < nt; ++t) {
+      load_slot(A, tile + t, lane, s);
+      if (t == 0) pt = __shfl(s.pt, 0, 64);
+      if (s.valid) {
+        double a[6];
+        ete_of(s, a);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] += a[i];
+        if (MODE == kInit && A.have_b) {
+          const double2 bb = A.b[(tile + t) * kTile + lane];
+          r[6] += s.e[0] * bb.x + s.e[3] * bb.y; r[7] += s.e[1] * bb.x + s.e[4] * bb.y; r[8] += s.e[2] * bb.x + s.e[5] * bb.y;
+        }
+      }
+    }
+    wave_allreduce<9>(r);
+    double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
+    add_e_diagonal(A, pt_off(A, pt), a);
+    invert_spd3(a, ei);
+    if (lane == 0) store_ete_inverse(A, pt, ei);
+    if constexpr (MODE == kInit) {
+      const double g[3] = {r[6], r[7], r[8]};
+      for (int t = 0; t < nt; ++t) {
+        load_slot(A, tile + t, lane, s);
+        double b0 = 0, b1 = 0;
+        const int64_t sl = (tile + t) * kTile + lane;
+        if (A.have_b) { const double2 bb = A.b[sl]; b0 = bb.x; b1 = bb.y; }
+        init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
+      }
+    }
+  }
+}
+
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(kBalBlock) void bal_fused_kernel(BalArgs A) {
+  extern __shared__ double lds_acc[];
+  if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
+  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit);
+  double* acc = nullptr;
+  if constexpr (kScatters) {
+    if constexpr (LDS) {
+      acc = lds_acc;
+      for (int i = threadIdx.x; i < A.n_f9; i += kBalBlock) acc[i] = 0.0;
+      __syncthreads();
+    } else {
+      acc = A.global_acc;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = int64_t(blockIdx.x) * (kBalBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = int64_t(gridDim.x) * (kBalBlock / 64);
+  for (int64_t tile = wave; tile < A.n_tiles; tile += nwaves) {
+    const int kind = A.tile_kind[tile];
+    if (kind == 2) continue;
+    const int aux = A.tile_aux[tile];
+    if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux, acc);
+    else process_long_point<MODE, LDS>(A, tile, aux, lane, acc);
+  }
+  if constexpr (kScatters && LDS) {
+    __syncthreads();
+    double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
+    for (int i = threadIdx.x; i < A.n_f9; i += kBalBlock) out[i] = acc[i];
+  }
+}
+
+// y_f[pos(i)] = sum over workgroup partials (+ D_f^2 x_f).  One thread per F scalar.
+__global__ void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
+                                           const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
+                                           const double* __restrict__ x_f, double* __restrict__ y_f,
+                                           const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_f9) return;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int w = 0;
+  for (; w + 4 <= nparts; w += 4) {
+    s0 += partials[int64_t(w) * n_f9 + i];
+    s1 += partials[int64_t(w + 1) * n_f9 + i];
+    s2 += partials[int64_t(w + 2) * n_f9 + i];
+    s3 += partials[int64_t(w + 3) * n_f9 + i];
+  }
+  for (; w < nparts; ++w) s0 += partials[int64_t(w) * n_f9 + i];
+  double s = (s0 + s1) + (s2 + s3);
+  const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
+  if (D_f) { const double d = D_f[o]; s += d * d * x_f[o]; }
+  y_f[o] = s;
+}
+
+// y_f += D_f^2 x_f over the camera scalars (after an all-reduce of the raw sums).
+__global__ void bal_add_f_diagonal_kernel(int n_f9, const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
+                                          const double* __restrict__ x_f, double* __restrict__ y_f,
+                                          const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_f9) return;
+  const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
+  const double d = D_f[o];
+  y_f[o] += d * d * x_f[o];
+}
+
+// Re-layout: caller's values (any cell.position) -> tiles.  One wavefront per tile.
+__global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict__ values, const double* __restrict__ b,
+                                                       const int32_t* __restrict__ slot_epos,
+                                                       const int32_t* __restrict__ slot_fpos,
+                                                       const int32_t* __restrict__ slot_bpos, int64_t n_tiles,
+                                                       double2* __restrict__ J, double2* __restrict__ bt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
+  const int64_t sl = tile * kTile + lane;
+  const int ep = slot_epos[sl], fp = slot_fpos[sl], bp = slot_bpos[sl];
+  double v[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) v[i] = 0.0;
+  double b0 = 0, b1 = 0;
+  if (ep >= 0) {
+    const double* e = values + ep;
+    const double* f = values + fp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = e[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) v[6 + i] = f[i];
+    if (b) { b0 = b[bp]; b1 = b[bp + 1]; }
+  }
+  double2* o = J + tile * (kPairsPerSlot * kTile) + lane;
+#pragma unroll
+  for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+  if (b) bt[sl] = make_double2(b0, b1);
+}
+
+// Per-camera 9x9 blocks: sum over the camera's observations of F^T M F (+ D^2), with
+// M = I (JACOBI: block diagonal of F^T F) or M = I - E (E^T E)^-1 E^T (SCHUR_JACOBI:
+// the diagonal blocks SchurEliminator::Eliminate writes into a block-diagonal lhs).
+// One workgroup per camera, observations gathered through the camera-major lists;
+// F is read from the caller-layout values (contiguous 144 B per observation).
+template <bool SCHUR>
+__global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __restrict__ values,
+                                                                const int32_t* __restrict__ cam_ptr,
+                                                                const int32_t* __restrict__ cam_fpos,
+                                                                const int32_t* __restrict__ cam_slot,
+                                                                const double* __restrict__ Mo, int64_t n_slots,
+                                                                const double* __restrict__ D_f,
+                                                                const int32_t* __restrict__ cam_pos,
+                                                                const int64_t* __restrict__ cam_diag_off,
+                                                                double* __restrict__ blocks) {
+  __shared__ double red[4][45];
+  const int c = blockIdx.x;
+  const int beg = cam_ptr[c], end = cam_ptr[c + 1];
+  double acc[45];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) acc[i] = 0.0;
+  for (int q = beg + threadIdx.x; q < end; q += 256) {
+    const double* f = values + cam_fpos[q];
+    double f0[9], f1[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { f0[k] = f[k]; f1[k] = f[9 + k]; }
+    double m00 = 1.0, m01 = 0.0, m11 = 1.0;
+    if constexpr (SCHUR) {
+      const int64_t sl = cam_slot[q];
+      m00 = Mo[sl]; m01 = Mo[n_slots + sl]; m11 = Mo[2 * n_slots + sl];
+    }
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      const double g0 = m00 * f0[a] + m01 * f1[a];  // row a of (F^T M): [g0 g1]
+      const double g1 = m01 * f0[a] + m11 * f1[a];
+#pragma unroll
+      for (int bb = a; bb < 9; ++bb) acc[idx++] += g0 * f0[bb] + g1 * f1[bb];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 45; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    acc[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 45; ++i) red[wv][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 81) {
+    const int a = threadIdx.x / 9, bb = threadIdx.x % 9;
+    const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
+    const int idx = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);
+    double v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+    if (a == bb && D_f) { const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + a]; v += d * d; }
+    blocks[(cam_diag_off ? cam_diag_off[c] : int64_t(81) * c) + threadIdx.x] = v;
+  }
+}
+
+// In-place inverse of the 9x9 SPD camera blocks from their upper triangle (Cholesky +
+// solves against I, like BlockRandomAccessDiagonalMatrix::Invert,
+// I/block_random_access_diagonal_matrix.cc:90-100).  One thread per camera.
+__global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
+                                                         int n_cameras, int* fail_flag) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= n_cameras) return;
+  double* a = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c);
+  double L[81], col[9];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double d = a[j * 9 + j];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) if (k < j) d -= L[j * 9 + k] * L[j * 9 + k];
+    if (!(d > 0.0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    L[j * 9 + j] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (i > j) {
+        double s = a[j * 9 + i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if (k < j) s -= L[i * 9 + k] * L[j * 9 + k];
+        L[i * 9 + j] = s * inv;
+      }
+    }
+  }
+  if (!ok && fail_flag) atomicExch(fail_flag, 1);
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double s = (i == e) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (k < i) s -= L[i * 9 + k] * col[k];
+      col[i] = s / L[i * 9 + i];
+    }
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+      double s = col[i];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (k > i) s -= L[k * 9 + i] * col[k];
+      col[i] = s / L[i * 9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i * 9 + e] = col[i];
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+template <int MODE>
+static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  if (lds) {
+    const size_t bytes = size_t(A.n_f9) * sizeof(double);
+    auto k = bal_fused_kernel<MODE, true>;
+    static bool attr_set = false;
+    static size_t attr_bytes = 0;
+    if (!attr_set || bytes > attr_bytes) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
+      if (e != hipSuccess) return e;
+      attr_set = true;
+      attr_bytes = kMaxLdsBytes;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBalBlock), bytes, stream, A);
+  } else {
+    hipLaunchKernelGGL((bal_fused_kernel<MODE, false>), dim3(grid), dim3(kBalBlock), 0, stream, A);
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  switch (mode) {
+    case kSx: return launch_fused<kSx>(A, lds, grid, stream);
+    case kJtJx: return launch_fused<kJtJx>(A, lds, grid, stream);
+    case kJtb: return launch_fused<kJtb>(A, lds, grid, stream);
+    case kInit: return launch_fused<kInit>(A, lds, grid, stream);
+    case kEte: return launch_fused<kEte>(A, false, grid, stream);
+    case kBackSub: return launch_fused<kBackSub>(A, false, grid, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
+                                   const double* D_f, const double* x_f, double* y_f, const int* status,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 255) / 256), dim3(256), 0, stream, partials, nparts,
+                     n_f9, cam_pos, D_f, x_f, y_f, status);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
+                                 const int* status, hipStream_t stream) {
+  hipLaunchKernelGGL(bal_add_f_diagonal_kernel, dim3((n_f9 + 255) / 256), dim3(256), 0, stream, n_f9, cam_pos, D_f,
+                     x_f, y_f, status);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
+                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, double2* bt, hipStream_t stream) {
+  if (n_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(bal_pack_kernel, dim3(unsigned((n_tiles + 3) / 4)), dim3(256), 0, stream, values, b, slot_epos,
+                     slot_fpos, slot_bpos, n_tiles, J, bt);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream) {
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 63) / 64), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const int32_t* cam_ptr, const int32_t* cam_fpos,
+                                 const int32_t* cam_slot, const double* Mo, int64_t n_slots, const double* D_f,
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, int n_cameras,
+                                 hipStream_t stream) {
+  if (schur)
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), dim3(n_cameras), dim3(256), 0, stream, values, cam_ptr,
+                       cam_fpos, cam_slot, Mo, n_slots, D_f, cam_pos, cam_diag_off, blocks);
+  else
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), dim3(n_cameras), dim3(256), 0, stream, values, cam_ptr,
+                       cam_fpos, cam_slot, Mo, n_slots, D_f, cam_pos, cam_diag_off, blocks);
+  return hipGetLastError();
+}
+
+}  // namespace chip

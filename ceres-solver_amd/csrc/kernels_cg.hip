@@ -1,0 +1,365 @@
+// kernels_cg.hip — device-resident preconditioned conjugate gradients.
+//
+// Restates ConjugateGradientsSolver<V> (I/conjugate_gradients_solver.h:108-306) and the
+// BLAS-1 it is written against (Norm/Dot/Axpby/SetZero/Copy, I/eigen_vector_ops.h:47-101)
+// as a fixed sequence of stream-ordered kernels that never need the host inside an
+// iteration:
+//
+//   precondition   z = M^-1 r ; partial r.z                     (:162-167)
+//   direction      rho, beta ; p = z + beta p                    (:167-191)
+//   <operator>     q = A p            (q lives in z, as in the reference :193-195)
+//   dot_pq         partial p.q                                   (:196)
+//   step           pq, alpha ; x += alpha p ; r -= alpha q ; partial Q1, |r|^2   (:208-249)
+//                  (every residual_reset_period-th iteration instead: <operator> tmp = A x,
+//                   residual_reset r = rhs - tmp, :235-239)
+//   finalize       zeta / |r| / max-iteration tests in the reference's order, iter++ (:273-302)
+//
+// All scalars (rho, alpha, beta, Q0, Q1, the status word) stay in HBM in CgScalars; every
+// inner product is a two-stage reduction — wavefront shuffles (__shfl_xor over 64 lanes),
+// one partial per workgroup, and the CONSUMER kernel re-sums the <= 512 partials in a
+// fixed order, so results are deterministic and no atomics or grid barriers are needed.
+// Once the status word is non-zero every kernel returns at once, which lets the host
+// enqueue a batch of iterations and poll the word only every few iterations.
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+
+namespace chip {
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Sum over the workgroup; every thread gets the result.  kVecBlock = 256 = 4 waves.
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 */) {
+  v = wave_sum(v);
+  __syncthreads();  // protect sh from a previous use
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+struct Span { int64_t i, end, step; };
+
+// Element range of this thread: workgroups [0, grid_e) stride over the shard
+// [0, n_local), the others over [n_local, n).
+__device__ __forceinline__ Span my_span(const CgBuffers& B) {
+  Span s;
+  if (int(blockIdx.x) < B.grid_e) {
+    s.i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x;
+    s.end = B.n_local;
+    s.step = int64_t(B.grid_e) * kVecBlock;
+  } else {
+    s.i = B.n_local + int64_t(blockIdx.x - B.grid_e) * kVecBlock + threadIdx.x;
+    s.end = B.n;
+    s.step = int64_t(B.grid - B.grid_e) * kVecBlock;
+  }
+  return s;
+}
+
+// Full inner product from a slot of workgroup partials (+ the all-reduced shard share).
+__device__ __forceinline__ double total_of(const CgBuffers& B, int slot, double* sh) {
+  const double* p = B.partials + slot * kMaxVecGrid;
+  double v = 0;
+  for (int k = B.grid_e + threadIdx.x; k < B.grid; k += kVecBlock) v += p[k];
+  double t = block_sum(v, sh);
+  if (B.grid_e > 0) t += B.comm[slot];
+  return t;
+}
+
+__device__ __forceinline__ bool zero_or_inf(double v) { return v == 0.0 || isinf(v); }
+
+__global__ __launch_bounds__(kVecBlock) void set_kernel(double* x, double v, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) x[i] = v;
+}
+__global__ __launch_bounds__(kVecBlock) void axpby_kernel(double a, const double* x, double b, const double* y, double* z, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) z[i] = a * x[i] + b * y[i];
+}
+template <bool ADD>
+__global__ __launch_bounds__(kVecBlock) void square_scale_kernel(const double* D, const double* x, double* y, int64_t n, const int* status) {
+  if (status && *status != 0) return;
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) {
+    const double d = D ? D[i] : 0.0;
+    if (ADD) y[i] += d * d * x[i]; else y[i] = d * d * x[i];
+  }
+}
+__global__ __launch_bounds__(kVecBlock) void dot_partial_kernel(const double* x, const double* y, int64_t n, double* partials) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) v += x[i] * y[i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(kVecBlock) void dot_final_kernel(const double* partials, int n, double* out) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (int k = threadIdx.x; k < n; k += kVecBlock) v += partials[k];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) out[0] = v;
+}
+__global__ void expand_sym3_kernel(const double* p6, double* d9, const int64_t* off, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double* a = p6 + int64_t(p) * 6;
+  double* o = d9 + (off ? off[p] : int64_t(9) * p);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
+}
+
+// ---- CG ---------------------------------------------------------------------
+__global__ __launch_bounds__(kVecBlock) void cg_rhs_norm_kernel(CgBuffers B) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) v += B.rhs[s.i] * B.rhs[s.i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) B.partials[blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_init_kernel(CgBuffers B, double q_tol, double r_tol, int min_it, int max_it) {
+  __shared__ double sh[4];
+  const double nn = total_of(B, 0, sh);
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) { B.x[s.i] = 0.0; B.r[s.i] = B.rhs[s.i]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    CgScalars& S = *B.S;
+    S.norm_rhs = sqrt(nn);
+    S.tol_r = r_tol * S.norm_rhs;
+    S.q_tol = q_tol;
+    S.rho = 1.0; S.rho_new = 1.0; S.beta = 0; S.pq = 0; S.alpha = 0;
+    S.Q0 = 0.0;  // -x.(rhs + r) with x = 0
+    S.Q1 = 0; S.zeta = 0; S.norm_r = S.norm_rhs; S.norm_p = 0; S.norm_q = 0;
+    S.iter = 1; S.min_it = min_it; S.max_it = max_it;
+    S.status = kCgRunning;
+    S.fail_dir = 0; S.fail_step = 0;
+    if (S.norm_rhs == 0.0) S.status = kCgZeroRhs;
+    else if (min_it == 0 && S.norm_r <= S.tol_r) S.status = kCgInitialResidual;
+  }
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_precondition_kernel(CgBuffers B, GenStructure G, int first_block, int col_begin,
+                                                                    const int64_t* diag_off, const double* blocks) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  double v = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) {
+    double z;
+    if (blocks) {
+      const int j = G.col_block_of[col_begin + s.i];
+      const int n = G.csz[j];
+      const int64_t pos = G.cpos[j] - col_begin;
+      const double* m = blocks + (diag_off[j - first_block] - diag_off[0]) + int64_t(s.i - pos) * n;
+      z = 0;
+      for (int c = 0; c < n; ++c) z += m[c] * B.r[pos + c];
+    } else {
+      z = B.r[s.i];
+    }
+    B.z[s.i] = z;
+    v += B.r[s.i] * z;
+  }
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) B.partials[0 * kMaxVecGrid + blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_direction_kernel(CgBuffers B) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  const double rho = total_of(B, 0, sh);
+  const double last_rho = B.S->rho;
+  const int iter = B.S->iter;
+  int fail = 0;
+  double beta = 0.0;
+  if (zero_or_inf(rho)) fail = kCgFailRho;
+  else if (iter > 1) { beta = rho / last_rho; if (zero_or_inf(beta)) fail = kCgFailBeta; }
+  if (!fail) {
+    if (iter == 1) { for (Span s = my_span(B); s.i < s.end; s.i += s.step) B.p[s.i] = B.z[s.i]; }
+    else { for (Span s = my_span(B); s.i < s.end; s.i += s.step) B.p[s.i] = B.z[s.i] + beta * B.p[s.i]; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    B.S->rho_new = rho;
+    B.S->beta = beta;
+    // The status word itself is written only by cg_finalize (one workgroup): a
+    // workgroup of THIS launch that starts late must not see it change.  Failures are
+    // staged in fail_dir / fail_step and committed there.
+    B.S->fail_dir = fail;
+  }
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_dot_pq_kernel(CgBuffers B) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  if (B.S->fail_dir != 0) return;  // direction failed: cg_step forwards it, cg_finalize commits it
+  double v = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) v += B.p[s.i] * B.z[s.i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) B.partials[1 * kMaxVecGrid + blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_step_kernel(CgBuffers B, int reset) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  const int staged = B.S->fail_dir;
+  const double pq = staged ? 1.0 : total_of(B, 1, sh);
+  const double rho = B.S->rho_new;
+  int fail = staged;
+  double alpha = 0;
+  if (!fail) {
+    if (pq <= 0 || isinf(pq)) fail = kCgIndefinite;
+    else { alpha = rho / pq; if (isinf(alpha)) fail = kCgFailAlpha; }
+  }
+  double q1 = 0, rr = 0;
+  if (!fail) {
+    if (reset) {
+      for (Span s = my_span(B); s.i < s.end; s.i += s.step) B.x[s.i] += alpha * B.p[s.i];
+    } else {
+      for (Span s = my_span(B); s.i < s.end; s.i += s.step) {
+        const double x = B.x[s.i] + alpha * B.p[s.i];
+        const double r = B.r[s.i] - alpha * B.z[s.i];
+        B.x[s.i] = x;
+        B.r[s.i] = r;
+        q1 -= x * (B.rhs[s.i] + r);
+        rr += r * r;
+      }
+    }
+  }
+  if (!reset) {
+    q1 = block_sum(q1, sh);
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) { B.partials[2 * kMaxVecGrid + blockIdx.x] = q1; B.partials[3 * kMaxVecGrid + blockIdx.x] = rr; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    B.S->pq = pq;
+    B.S->alpha = alpha;
+    B.S->fail_step = fail;
+  }
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_residual_reset_kernel(CgBuffers B, const double* tmp) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  if (B.S->fail_step != 0) return;
+  double q1 = 0, rr = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) {
+    const double r = B.rhs[s.i] - tmp[s.i];
+    B.r[s.i] = r;
+    q1 -= B.x[s.i] * (B.rhs[s.i] + r);
+    rr += r * r;
+  }
+  q1 = block_sum(q1, sh);
+  rr = block_sum(rr, sh);
+  if (threadIdx.x == 0) { B.partials[2 * kMaxVecGrid + blockIdx.x] = q1; B.partials[3 * kMaxVecGrid + blockIdx.x] = rr; }
+}
+
+// One workgroup.  The only writer of the status word while iterating.
+__global__ __launch_bounds__(kVecBlock) void cg_finalize_kernel(CgBuffers B) {
+  __shared__ double sh[4];
+  CgScalars& S = *B.S;
+  if (S.status != 0) return;
+  const int fail = S.fail_step;
+  if (fail != 0) {
+    if (threadIdx.x == 0) S.status = fail;
+    return;
+  }
+  const double Q1 = total_of(B, 2, sh);
+  const double rr = total_of(B, 3, sh);
+  if (threadIdx.x != 0) return;
+  const double norm_r = sqrt(rr);
+  const double zeta = S.iter * (Q1 - S.Q0) / Q1;
+  S.Q1 = Q1;
+  S.zeta = zeta;
+  S.norm_r = norm_r;
+  S.rho = S.rho_new;
+  if (zeta < S.q_tol && S.iter >= S.min_it) { S.status = kCgConvergedZeta; return; }
+  S.Q0 = Q1;
+  if (norm_r <= S.tol_r && S.iter >= S.min_it) { S.status = kCgConvergedResidual; return; }
+  if (S.iter >= S.max_it) { S.status = kCgMaxIterations; return; }
+  S.iter += 1;
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_collapse_kernel(CgBuffers B, int first_slot, int count) {
+  __shared__ double sh[4];
+  for (int k = 0; k < count; ++k) {
+    const double* p = B.partials + (first_slot + k) * kMaxVecGrid;
+    double v = 0;
+    for (int b = threadIdx.x; b < B.grid_e; b += kVecBlock) v += p[b];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) B.comm[first_slot + k] = v;
+  }
+}
+
+inline int vec_grid(int64_t n) {
+  int64_t g = (n + kVecBlock * 4 - 1) / (kVecBlock * 4);
+  if (g < 1) g = 1;
+  if (g > kMaxVecGrid) g = kMaxVecGrid;
+  return int(g);
+}
+
+}  // namespace
+
+hipError_t LaunchSet(double* x, double v, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(set_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, x, v, n);
+  return hipGetLastError();
+}
+hipError_t LaunchAxpby(double a, const double* x, double b, const double* y, double* z, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(axpby_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, a, x, b, y, z, n);
+  return hipGetLastError();
+}
+hipError_t LaunchSquareScale(const double* D, const double* x, double* y, int64_t n, const int* status, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL((square_scale_kernel<false>), dim3(vec_grid(n)), dim3(kVecBlock), 0, s, D, x, y, n, status);
+  return hipGetLastError();
+}
+hipError_t LaunchAddSquareScale(const double* D, const double* x, double* y, int64_t n, const int* status, hipStream_t s) {
+  if (n > 0 && D) hipLaunchKernelGGL((square_scale_kernel<true>), dim3(vec_grid(n)), dim3(kVecBlock), 0, s, D, x, y, n, status);
+  return hipGetLastError();
+}
+hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partials, double* out, hipStream_t s) {
+  const int g = vec_grid(n);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(g), dim3(kVecBlock), 0, s, x, y, n, partials);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kVecBlock), 0, s, partials, g, out);
+  return hipGetLastError();
+}
+hipError_t LaunchExpandSym3(const double* p6, double* d9, const int64_t* off, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(expand_sym3_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p6, d9, off, n);
+  return hipGetLastError();
+}
+
+hipError_t LaunchCgRhsNorm(const CgBuffers& B, hipStream_t s) {
+  hipLaunchKernelGGL(cg_rhs_norm_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B);
+  return hipGetLastError();
+}
+hipError_t LaunchCgInit(const CgBuffers& B, double q_tol, double r_tol, int min_it, int max_it, hipStream_t s) {
+  hipLaunchKernelGGL(cg_init_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, q_tol, r_tol, min_it, max_it);
+  return hipGetLastError();
+}
+hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin,
+                                const int64_t* diag_off, const double* blocks, hipStream_t s) {
+  hipLaunchKernelGGL(cg_precondition_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, diag_off, blocks);
+  return hipGetLastError();
+}
+hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t s) {
+  hipLaunchKernelGGL(cg_direction_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B);
+  return hipGetLastError();
+}
+hipError_t LaunchCgDotPq(const CgBuffers& B, hipStream_t s) {
+  hipLaunchKernelGGL(cg_dot_pq_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B);
+  return hipGetLastError();
+}
+hipError_t LaunchCgStep(const CgBuffers& B, int reset, hipStream_t s) {
+  hipLaunchKernelGGL(cg_step_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, reset);
+  return hipGetLastError();
+}
+hipError_t LaunchCgResidualReset(const CgBuffers& B, const double* tmp, hipStream_t s) {
+  hipLaunchKernelGGL(cg_residual_reset_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, tmp);
+  return hipGetLastError();
+}
+hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t s) {
+  hipLaunchKernelGGL(cg_finalize_kernel, dim3(1), dim3(kVecBlock), 0, s, B);
+  return hipGetLastError();
+}
+hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t s) {
+  hipLaunchKernelGGL(cg_collapse_kernel, dim3(1), dim3(kVecBlock), 0, s, B, first_slot, count);
+  return hipGetLastError();
+}
+
+}  // namespace chip

@@ -1,0 +1,373 @@
+// kernels_generic.hip — block-sparse kernels for ARBITRARY block sizes and cell layouts.
+//
+// These mirror the reference's operator decomposition one pass at a time (they are the
+// correctness path for every structure that is not the static <2,3,9> case, and the
+// path the known-answer problems of linear_least_squares_problems.cc run through):
+//   BlockSparseMatrix::Right/LeftMultiplyAndAccumulate   I/block_sparse_matrix.cc:239-349
+//   PartitionedMatrixView E/F products                   I/partitioned_matrix_view_impl.h:112-375
+//   UpdateBlockDiagonalEtE / FtF, BlockJacobi blocks     :446-658, I/block_jacobi_preconditioner.cc:59-115
+//   BlockRandomAccessDiagonalMatrix::Invert / apply      I/block_random_access_diagonal_matrix.cc:90-116
+//   SchurEliminator::Eliminate (diagonal or dense lhs)   I/schur_eliminator_impl.h:184-311
+// Parallelisation: one thread per OUTPUT scalar (row, column, or block entry), reading
+// through the row structure or the transpose structure, so there are no atomics and every
+// result is deterministic.  `cell_value_pos` is honoured everywhere: nothing assumes a
+// value layout.
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+
+namespace chip {
+
+namespace {
+
+constexpr int kB = 256;
+
+// Which cells of row block i belong to `part` (kAll / kE / kF): [k0, k1)
+__device__ __forceinline__ void row_cells(const GenStructure& G, int i, int part, int& k0, int& k1) {
+  k0 = G.rptr[i];
+  k1 = G.rptr[i + 1];
+  if (part == kE) { if (i < G.nrbe) k1 = k0 + 1; else k1 = k0; }
+  else if (part == kF) { if (i < G.nrbe) k0 += 1; }
+}
+// Is cell k of row i (reached through the transpose of column block j) in `part`?
+__device__ __forceinline__ bool cell_in_part(const GenStructure& G, int i, int k, int part) {
+  if (part == kAll) return true;
+  const bool is_e = (i < G.nrbe) && (k == G.rptr[i]);
+  return part == kE ? is_e : !is_e;
+}
+
+__global__ __launch_bounds__(kB) void gen_right_multiply_kernel(GenStructure G, const double* __restrict__ v, int part,
+                                                                const double* __restrict__ x, double* __restrict__ y,
+                                                                const int* status) {
+  if (status && *status != 0) return;
+  const int row = blockIdx.x * kB + threadIdx.x;
+  if (row >= G.num_rows) return;
+  const int i = G.row_block_of[row];
+  const int r = row - G.rpos[i];
+  int k0, k1;
+  row_cells(G, i, part, k0, k1);
+  const int xoff = (part == kF) ? G.nce : 0;
+  double s = 0;
+  for (int k = k0; k < k1; ++k) {
+    const int j = G.ccol[k];
+    const int cs = G.csz[j];
+    const double* a = v + G.cval[k] + int64_t(r) * cs;
+    const double* xx = x + G.cpos[j] - xoff;
+    for (int c = 0; c < cs; ++c) s += a[c] * xx[c];
+  }
+  y[row] += s;
+}
+
+__global__ __launch_bounds__(kB) void gen_left_multiply_kernel(GenStructure G, const double* __restrict__ v, int part,
+                                                               const double* __restrict__ x, double* __restrict__ y,
+                                                               const int* status) {
+  if (status && *status != 0) return;
+  const int begin = (part == kF) ? G.nce : 0;
+  const int end = (part == kE) ? G.nce : G.num_cols;
+  const int col = begin + blockIdx.x * kB + threadIdx.x;
+  if (col >= end) return;
+  const int j = G.col_block_of[col];
+  const int c = col - G.cpos[j];
+  const int cs = G.csz[j];
+  double s = 0;
+  for (int t = G.tptr[j]; t < G.tptr[j + 1]; ++t) {
+    const int i = G.trow[t], k = G.tcell[t];
+    if (!cell_in_part(G, i, k, part)) continue;
+    const double* a = v + G.cval[k] + c;
+    const double* xx = x + G.rpos[i];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) s += a[int64_t(r) * cs] * xx[r];
+  }
+  y[col - begin] += s;
+}
+
+// Locate the block that owns diagonal-store entry e: largest q with off[q] <= e.
+__device__ __forceinline__ int find_block(const int64_t* off, int n, int64_t e) {
+  int lo = 0, hi = n;  // off has n+1 entries
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kB) void gen_block_diagonal_kernel(GenStructure G, const double* __restrict__ v, int part,
+                                                                const double* __restrict__ D, double* __restrict__ blocks) {
+  const int64_t* off = part == kAll ? G.diag_off_all : (part == kE ? G.diag_off_e : G.diag_off_f);
+  const int nb = part == kAll ? G.ncb : (part == kE ? G.nelim : G.ncb - G.nelim);
+  const int first = part == kF ? G.nelim : 0;
+  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
+  if (e >= off[nb]) return;
+  const int q = find_block(off, nb, e);
+  const int j = first + q;
+  const int n = G.csz[j];
+  const int a = int((e - off[q]) / n), b = int((e - off[q]) % n);
+  double s = 0;
+  for (int t = G.tptr[j]; t < G.tptr[j + 1]; ++t) {
+    const int i = G.trow[t], k = G.tcell[t];
+    if (!cell_in_part(G, i, k, part)) continue;
+    const double* m = v + G.cval[k];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) s += m[int64_t(r) * n + a] * m[int64_t(r) * n + b];
+  }
+  if (D && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+  blocks[e] = s;
+}
+
+__global__ __launch_bounds__(kB) void gen_squared_column_norm_kernel(GenStructure G, const double* __restrict__ v, double* __restrict__ x) {
+  const int col = blockIdx.x * kB + threadIdx.x;
+  if (col >= G.num_cols) return;
+  const int j = G.col_block_of[col];
+  const int c = col - G.cpos[j];
+  const int cs = G.csz[j];
+  double s = 0;
+  for (int t = G.tptr[j]; t < G.tptr[j + 1]; ++t) {
+    const int i = G.trow[t], k = G.tcell[t];
+    const double* a = v + G.cval[k] + c;
+    for (int r = 0; r < G.rsz[i]; ++r) s += a[int64_t(r) * cs] * a[int64_t(r) * cs];
+  }
+  x[col] = s;
+}
+
+// In-place inverse of SPD block from its upper triangle: Cholesky + solves against I.
+// One thread per block; n <= kMaxGenericBlock.
+__global__ __launch_bounds__(64) void gen_invert_blocks_kernel(GenStructure G, int first_block, int nblocks,
+                                                               const int64_t* __restrict__ off, double* __restrict__ blocks,
+                                                               int* fail_flag) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= nblocks) return;
+  const int n = G.csz[first_block + q];
+  double* a = blocks + (off[q] - off[0]);
+  double L[kMaxGenericBlock * kMaxGenericBlock];
+  double col[kMaxGenericBlock];
+  bool ok = true;
+  for (int j = 0; j < n; ++j) {
+    double d = a[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0.0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    L[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = a[j * n + i];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s / d;
+    }
+  }
+  if (!ok && fail_flag) atomicExch(fail_flag, 1);
+  for (int e = 0; e < n; ++e) {
+    for (int i = 0; i < n; ++i) {
+      double s = (i == e) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= L[i * n + k] * col[k];
+      col[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = col[i];
+      for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * col[k];
+      col[i] = s / L[i * n + i];
+    }
+    for (int i = 0; i < n; ++i) a[i * n + e] = col[i];
+  }
+}
+
+__global__ __launch_bounds__(kB) void gen_block_diagonal_apply_kernel(GenStructure G, int first_block, int col_begin, int ncols,
+                                                                      const int64_t* __restrict__ off, const double* __restrict__ blocks,
+                                                                      const double* __restrict__ x, double* __restrict__ y,
+                                                                      const int* status) {
+  if (status && *status != 0) return;
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= ncols) return;
+  const int j = G.col_block_of[col_begin + i];
+  const int n = G.csz[j];
+  const int pos = G.cpos[j] - col_begin;
+  const double* m = blocks + (off[j - first_block] - off[0]) + int64_t(i - pos) * n;
+  double s = 0;
+  for (int c = 0; c < n; ++c) s += m[c] * x[pos + c];
+  y[i] += s;
+}
+
+// Entry (a,b) of S(q1,q2), q1 <= q2, of the Schur complement (without the D_f^2 term):
+//   sum over rows holding both blocks of F1[:,a] . F2[:,b]                (E rows and E-free rows alike)
+// - sum over chunks holding both of (E^T F1)[:,a]^T (E^T E)^-1 (E^T F2)[:,b]
+// which is what ChunkDiagonalBlockAndGradient + ChunkOuterProduct + NoEBlockRowsUpdate
+// accumulate (I/schur_eliminator_impl.h:449-721).  Walks the cells of column block q1 in
+// row order (rows of one chunk are contiguous) and, once per chunk, the rows of that chunk
+// (= the cells of the E column block in the transpose structure).
+__device__ double schur_entry(const GenStructure& G, const double* __restrict__ v, const double* __restrict__ ete_inv,
+                              int j1, int a, int j2, int b) {
+  const int n1 = G.csz[j1], n2 = G.csz[j2];
+  double s = 0;
+  double u1[kMaxGenericBlock], u2[kMaxGenericBlock];
+  int last_e = -1;
+  for (int t = G.tptr[j1]; t < G.tptr[j1 + 1]; ++t) {
+    const int i = G.trow[t], k1 = G.tcell[t];
+    const int rs = G.rsz[i];
+    const double* f1 = v + G.cval[k1];
+    // (1) F1^T F2 over rows holding both blocks
+    int k2 = -1;
+    if (j1 == j2) k2 = k1;
+    else for (int k = G.rptr[i]; k < G.rptr[i + 1]; ++k) if (G.ccol[k] == j2) { k2 = k; break; }
+    if (k2 >= 0) {
+      const double* f2 = v + G.cval[k2];
+      for (int r = 0; r < rs; ++r) s += f1[int64_t(r) * n1 + a] * f2[int64_t(r) * n2 + b];
+    }
+    // (2) once per chunk that holds j1: -(E^T F1)[:,a]^T (E^T E)^-1 (E^T F2)[:,b]
+    const int e = G.row_e_block[i];
+    if (e < 0 || e == last_e) continue;
+    last_e = e;
+    const int es = G.csz[e];
+    for (int p = 0; p < es; ++p) { u1[p] = 0; u2[p] = 0; }
+    bool any2 = false;
+    for (int tt = G.tptr[e]; tt < G.tptr[e + 1]; ++tt) {  // the rows of the chunk, in order
+      const int ii = G.trow[tt];
+      if (G.tcell[tt] != G.rptr[ii]) continue;
+      const int rsi = G.rsz[ii];
+      const double* E = v + G.cval[G.rptr[ii]];
+      for (int k = G.rptr[ii] + 1; k < G.rptr[ii + 1]; ++k) {
+        const int jj = G.ccol[k];
+        if (jj != j1 && jj != j2) continue;
+        const double* f = v + G.cval[k];
+        if (jj == j1) {
+          for (int p = 0; p < es; ++p) {
+            double w = 0;
+            for (int r = 0; r < rsi; ++r) w += E[int64_t(r) * es + p] * f[int64_t(r) * n1 + a];
+            u1[p] += w;
+          }
+        }
+        if (jj == j2) {
+          any2 = true;
+          for (int p = 0; p < es; ++p) {
+            double w = 0;
+            for (int r = 0; r < rsi; ++r) w += E[int64_t(r) * es + p] * f[int64_t(r) * n2 + b];
+            u2[p] += w;
+          }
+        }
+      }
+    }
+    if (any2) {
+      const double* inv = ete_inv + G.diag_off_e[e];
+      double tsum = 0;
+      for (int p = 0; p < es; ++p) {
+        double w = 0;
+        for (int q = 0; q < es; ++q) w += inv[p * es + q] * u2[q];
+        tsum += u1[p] * w;
+      }
+      s -= tsum;
+    }
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(kB) void gen_schur_jacobi_kernel(GenStructure G, const double* __restrict__ v,
+                                                              const double* __restrict__ ete_inv, const double* __restrict__ D,
+                                                              int add_f_diag, double* __restrict__ blocks) {
+  const int nf = G.ncb - G.nelim;
+  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
+  if (e >= G.diag_off_f[nf]) return;
+  const int q = find_block(G.diag_off_f, nf, e);
+  const int j = G.nelim + q;
+  const int n = G.csz[j];
+  const int a = int((e - G.diag_off_f[q]) / n), b = int((e - G.diag_off_f[q]) % n);
+  double s = schur_entry(G, v, ete_inv, j, a, j, b);
+  if (D && add_f_diag && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+  blocks[e] = s;
+}
+
+// Dense lhs, num_cols_f x num_cols_f row-major; only block1 <= block2 is written, the
+// rest is zeroed (the reference leaves those cells untouched after SetZero).
+__global__ __launch_bounds__(kB) void gen_schur_dense_kernel(GenStructure G, const double* __restrict__ v,
+                                                             const double* __restrict__ ete_inv, const double* __restrict__ D,
+                                                             double* __restrict__ lhs) {
+  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
+  const int64_t n = G.ncf;
+  if (e >= n * n) return;
+  const int row = int(e / n), col = int(e % n);
+  const int j1 = G.col_block_of[G.nce + row], j2 = G.col_block_of[G.nce + col];
+  if (j1 > j2) { lhs[e] = 0.0; return; }
+  const int a = G.nce + row - G.cpos[j1], b = G.nce + col - G.cpos[j2];
+  double s = schur_entry(G, v, ete_inv, j1, a, j2, b);
+  if (D && row == col) { const double d = D[G.nce + row]; s += d * d; }
+  lhs[e] = s;
+}
+
+// blocks[j](a,a) += D[cpos[j] + a]^2 for column blocks [first_block, first_block + nblocks)
+__global__ __launch_bounds__(kB) void gen_add_diag_squares_kernel(GenStructure G, int first_block, int nblocks,
+                                                                  const int64_t* __restrict__ off, const double* __restrict__ D,
+                                                                  double* __restrict__ blocks) {
+  const int col0 = G.cpos[first_block];
+  const int last = first_block + nblocks - 1;
+  const int ncols = G.cpos[last] + G.csz[last] - col0;
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= ncols) return;
+  const int j = G.col_block_of[col0 + i];
+  const int n = G.csz[j];
+  const int a = col0 + i - G.cpos[j];
+  const double d = D[col0 + i];
+  blocks[(off[j - first_block] - off[0]) + int64_t(a) * n + a] += d * d;
+}
+
+inline unsigned blocks_for(int64_t n) { return unsigned((n + kB - 1) / kB); }
+
+}  // namespace
+
+hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
+                                  const int* status, hipStream_t s) {
+  if (G.num_rows > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, part, x, y, status);
+  return hipGetLastError();
+}
+hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
+                                 const int* status, hipStream_t s) {
+  const int n = part == kAll ? G.num_cols : (part == kE ? G.nce : G.ncf);
+  if (n > 0) hipLaunchKernelGGL(gen_left_multiply_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, part, x, y, status);
+  return hipGetLastError();
+}
+hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* values, double* x, hipStream_t s) {
+  if (G.num_cols > 0) hipLaunchKernelGGL(gen_squared_column_norm_kernel, dim3(blocks_for(G.num_cols)), dim3(kB), 0, s, G, values, x);
+  return hipGetLastError();
+}
+hipError_t LaunchGenInvertBlocks(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off, double* blocks,
+                                 int* fail_flag, hipStream_t s) {
+  if (nblocks > 0) hipLaunchKernelGGL(gen_invert_blocks_kernel, dim3((nblocks + 63) / 64), dim3(64), 0, s, G, first_block, nblocks, diag_off, blocks, fail_flag);
+  return hipGetLastError();
+}
+hipError_t LaunchGenBlockDiagonalApply(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
+                                       const double* blocks, const double* x, double* y, const int* status, hipStream_t s) {
+  (void)nblocks;
+  // scalar range covered by the blocks: from cpos[first_block] to the end of the E part
+  // (first_block == 0 with the E list), of the F part, or of everything.
+  int col_begin, ncols;
+  if (first_block == 0 && diag_off == G.diag_off_e) { col_begin = 0; ncols = G.nce; }
+  else if (first_block == G.nelim && diag_off == G.diag_off_f) { col_begin = G.nce; ncols = G.ncf; }
+  else { col_begin = 0; ncols = G.num_cols; }
+  if (ncols > 0) hipLaunchKernelGGL(gen_block_diagonal_apply_kernel, dim3(blocks_for(ncols)), dim3(kB), 0, s, G, first_block, col_begin, ncols, diag_off, blocks, x, y, status);
+  return hipGetLastError();
+}
+hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D, double* lhs,
+                               hipStream_t s) {
+  const int64_t n = int64_t(G.ncf) * G.ncf;
+  if (n > 0) hipLaunchKernelGGL(gen_schur_dense_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, ete_inv, D, lhs);
+  return hipGetLastError();
+}
+
+hipError_t LaunchAddBlockDiagonalSquares(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
+                                         const double* D, double* blocks, hipStream_t s) {
+  if (nblocks > 0) {
+    const int ncols = first_block == 0 && nblocks == G.ncb ? G.num_cols : (first_block == G.nelim ? G.ncf : G.nce);
+    hipLaunchKernelGGL(gen_add_diag_squares_kernel, dim3(blocks_for(ncols)), dim3(kB), 0, s, G, first_block, nblocks, diag_off, D, blocks);
+  }
+  return hipGetLastError();
+}
+
+// The two launchers below need the total entry count, which lives on the host side of
+// the structure; solver.hip passes it.
+hipError_t LaunchGenBlockDiagonal(const GenStructure& G, const double* values, int part, const double* D, double* blocks,
+                                   int64_t total, hipStream_t s) {
+  if (total > 0) hipLaunchKernelGGL(gen_block_diagonal_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, part, D, blocks);
+  return hipGetLastError();
+}
+hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
+                                 int add_f_diag, double* blocks, int64_t total, hipStream_t s) {
+  if (total > 0) hipLaunchKernelGGL(gen_schur_jacobi_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, ete_inv, D, add_f_diag, blocks);
+  return hipGetLastError();
+}
+
+}  // namespace chip

@@ -1,0 +1,293 @@
+// plan.cc — host analysis of the block structure (no HIP in this file).
+//
+// What the reference spreads over BlockSparseMatrix's ctor (transpose structure,
+// I/block_sparse_matrix.cc:178-216,784-808), PartitionedMatrixView's ctor
+// (num_row_blocks_e, I/partitioned_matrix_view_impl.h:47-105), DetectStructure
+// (I/detect_structure.cc:39-121) and SchurEliminator::Init (chunks,
+// I/schur_eliminator_impl.h:87-181) happens here once per solver instance, and the
+// result is flattened to SoA int32 arrays for upload.  On top of that the <2,3,9>
+// case gets a packing plan: observations are grouped by point into 64-slot tiles
+// (one wavefront each) such that no point straddles a tile unless it has more than
+// 64 observations, which is what lets the fused kernels do every per-point
+// reduction with wavefront shuffles and no inter-workgroup traffic.
+#include <algorithm>
+#include <numeric>
+
+#include "common.h"
+
+namespace chip {
+
+std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs) {
+  HostStructure& h = *hs;
+  h = HostStructure();
+  if (bs.num_row_blocks < 0 || bs.num_col_blocks < 0) return "negative block count";
+  h.nrb = bs.num_row_blocks;
+  h.ncb = bs.num_col_blocks;
+  if (nelim < 0 || nelim > h.ncb) return "num_eliminate_blocks out of range";
+  h.nelim = nelim;
+  h.rsz.assign(bs.row_block_size, bs.row_block_size + h.nrb);
+  h.rpos.assign(bs.row_block_pos, bs.row_block_pos + h.nrb);
+  h.csz.assign(bs.col_block_size, bs.col_block_size + h.ncb);
+  h.cpos.assign(bs.col_block_pos, bs.col_block_pos + h.ncb);
+  h.rptr.assign(bs.row_cell_ptr, bs.row_cell_ptr + h.nrb + 1);
+  if (h.rptr[0] != 0) return "row_cell_ptr[0] != 0";
+  for (int i = 0; i < h.nrb; ++i)
+    if (h.rptr[i + 1] < h.rptr[i]) return "row_cell_ptr not monotone";
+  h.ncells = h.rptr[h.nrb];
+  h.ccol.assign(bs.cell_col_block, bs.cell_col_block + h.ncells);
+  h.cval.assign(bs.cell_value_pos, bs.cell_value_pos + h.ncells);
+
+  // Rows and columns must tile [0, num_rows) / [0, num_cols) in order, as every
+  // BlockSparseMatrix does (I/block_sparse_matrix.cc:178-216).
+  int pos = 0;
+  for (int i = 0; i < h.nrb; ++i) {
+    if (h.rsz[i] <= 0) return "row block with non-positive size";
+    if (h.rpos[i] != pos) return "row block positions are not the running sum of sizes";
+    pos += h.rsz[i];
+    h.max_block = std::max(h.max_block, h.rsz[i]);
+  }
+  h.num_rows = pos;
+  pos = 0;
+  for (int j = 0; j < h.ncb; ++j) {
+    if (h.csz[j] <= 0) return "column block with non-positive size";
+    if (h.cpos[j] != pos) return "column block positions are not the running sum of sizes";
+    pos += h.csz[j];
+    h.max_block = std::max(h.max_block, h.csz[j]);
+    (j < nelim ? h.num_cols_e : h.num_cols_f) += h.csz[j];
+  }
+  h.num_cols = pos;
+  h.row_block_of.resize(h.num_rows);
+  for (int i = 0; i < h.nrb; ++i) std::fill_n(h.row_block_of.begin() + h.rpos[i], h.rsz[i], i);
+  h.col_block_of.resize(h.num_cols);
+  for (int j = 0; j < h.ncb; ++j) std::fill_n(h.col_block_of.begin() + h.cpos[j], h.csz[j], j);
+
+  for (int i = 0; i < h.nrb; ++i)
+    for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
+      const int j = h.ccol[k];
+      if (j < 0 || j >= h.ncb) return "cell with column block id out of range";
+      if (h.cval[k] < 0) return "cell with negative value position";
+      const int64_t n = int64_t(h.rsz[i]) * h.csz[j];
+      h.nnz += n;
+      h.values_extent = std::max(h.values_extent, int64_t(h.cval[k]) + n);
+    }
+
+  // Diagonal block stores.
+  h.diag_off_all.assign(h.ncb + 1, 0);
+  for (int j = 0; j < h.ncb; ++j) h.diag_off_all[j + 1] = h.diag_off_all[j] + int64_t(h.csz[j]) * h.csz[j];
+  h.diag_off_e.assign(nelim + 1, 0);
+  for (int j = 0; j < nelim; ++j) h.diag_off_e[j + 1] = h.diag_off_e[j] + int64_t(h.csz[j]) * h.csz[j];
+  h.diag_off_f.assign(h.ncb - nelim + 1, 0);
+  for (int j = nelim; j < h.ncb; ++j)
+    h.diag_off_f[j - nelim + 1] = h.diag_off_f[j - nelim] + int64_t(h.csz[j]) * h.csz[j];
+
+  // Transpose: counting sort by column block keeps row order inside a column.
+  h.tptr.assign(h.ncb + 1, 0);
+  for (int k = 0; k < h.ncells; ++k) ++h.tptr[h.ccol[k] + 1];
+  for (int j = 0; j < h.ncb; ++j) h.tptr[j + 1] += h.tptr[j];
+  h.trow.resize(h.ncells);
+  h.tcell.resize(h.ncells);
+  {
+    std::vector<int32_t> cur(h.tptr.begin(), h.tptr.end() - 1);
+    for (int i = 0; i < h.nrb; ++i)
+      for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
+        const int p = cur[h.ccol[k]]++;
+        h.trow[p] = i;
+        h.tcell[p] = k;
+      }
+  }
+
+  // E rows: first cell in an eliminated block.  They must precede all other rows
+  // (PartitionedMatrixView indexes "the first num_row_blocks_e_ rows") and the rows
+  // of one E block must be contiguous (SchurEliminator's chunks).
+  h.row_e_block.assign(h.nrb, -1);
+  h.chunk_start.assign(nelim, 0);
+  h.chunk_size.assign(nelim, 0);
+  bool seen_non_e = false;
+  for (int i = 0; i < h.nrb; ++i) {
+    const bool is_e = h.rptr[i] < h.rptr[i + 1] && h.ccol[h.rptr[i]] < nelim;
+    if (!is_e) { seen_non_e = true; continue; }
+    if (seen_non_e) h.chunks_contiguous = false;
+    const int e = h.ccol[h.rptr[i]];
+    h.row_e_block[i] = e;
+    ++h.num_row_blocks_e;
+    if (h.chunk_size[e] == 0) h.chunk_start[e] = i;
+    else if (h.chunk_start[e] + h.chunk_size[e] != i) h.chunks_contiguous = false;
+    ++h.chunk_size[e];
+    for (int k = h.rptr[i] + 1; k < h.rptr[i + 1]; ++k)
+      if (h.ccol[k] < nelim) return "row with more than one cell in the eliminated (E) blocks";
+  }
+
+  // DetectStructure: only E rows vote; two different values make a size dynamic (-1).
+  auto vote = [](int* cur, int v) { if (*cur == 0) *cur = v; else if (*cur != -1 && *cur != v) *cur = -1; };
+  for (int i = 0; i < h.nrb; ++i) {
+    if (h.row_e_block[i] < 0) continue;
+    vote(&h.det_row, h.rsz[i]);
+    vote(&h.det_e, h.csz[h.row_e_block[i]]);
+    for (int k = h.rptr[i] + 1; k < h.rptr[i + 1]; ++k) vote(&h.det_f, h.csz[h.ccol[k]]);
+  }
+  return "";
+}
+
+void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan* plan) {
+  BalPlan& P = *plan;
+  P = BalPlan();
+  auto no = [&](const char* why) { P.eligible = false; P.why_not = why; };
+  if (h.nrb == 0) return no("empty matrix");
+  // Classify column blocks.
+  P.pt_block.clear();
+  P.cam_block.clear();
+  std::vector<int32_t> id_of(h.ncb, -1);  // point id or camera id of a column block
+  for (int j = 0; j < h.ncb; ++j) {
+    const bool as_point = h.nelim > 0 ? (j < h.nelim) : (h.csz[j] == 3);
+    if (as_point) {
+      if (h.csz[j] != 3) return no("an eliminated block is not 3 wide");
+      id_of[j] = int(P.pt_block.size());
+      P.pt_block.push_back(j);
+    } else {
+      if (h.csz[j] != 9) return no("a non-eliminated block is not 9 wide");
+      id_of[j] = int(P.cam_block.size());
+      P.cam_block.push_back(j);
+    }
+  }
+  P.n_points = int(P.pt_block.size());
+  P.n_cameras = int(P.cam_block.size());
+  if (P.n_points == 0 || P.n_cameras == 0) return no("no point or no camera blocks");
+  auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
+
+  // Every row: 2 scalar rows, exactly one point cell and one camera cell.
+  std::vector<int32_t> row_pt(h.nrb), row_cam(h.nrb), row_epos(h.nrb), row_fpos(h.nrb);
+  for (int i = 0; i < h.nrb; ++i) {
+    if (h.rsz[i] != 2) return no("row block that is not 2 high");
+    if (h.rptr[i + 1] - h.rptr[i] != 2) return no("row without exactly two cells");
+    const int k0 = h.rptr[i], k1 = k0 + 1;
+    int kp, kc;
+    if (is_point(h.ccol[k0]) && !is_point(h.ccol[k1])) { kp = k0; kc = k1; }
+    else if (!is_point(h.ccol[k0]) && is_point(h.ccol[k1])) {
+      if (h.nelim > 0) return no("E cell is not the first cell of its row");
+      kp = k1; kc = k0;
+    } else return no("row is not one point cell plus one camera cell");
+    row_pt[i] = id_of[h.ccol[kp]];
+    row_cam[i] = id_of[h.ccol[kc]];
+    row_epos[i] = h.cval[kp];
+    row_fpos[i] = h.cval[kc];
+  }
+  if (h.nelim > 0 && !h.chunks_contiguous) return no("rows of one E block are not contiguous");
+
+  // Observations grouped by point (stable: keeps the caller's order inside a point).
+  std::vector<int32_t> order(h.nrb);
+  std::iota(order.begin(), order.end(), 0);
+  bool sorted = true;
+  for (int i = 1; i < h.nrb && sorted; ++i) sorted = row_pt[i - 1] <= row_pt[i];
+  if (!sorted) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return row_pt[a] < row_pt[b]; });
+  std::vector<int32_t> track(P.n_points, 0);
+  for (int i = 0; i < h.nrb; ++i) ++track[row_pt[i]];
+  for (int p = 0; p < P.n_points; ++p) {
+    if (track[p] == 0) return no("point without observations");
+    P.max_track = std::max(P.max_track, track[p]);
+  }
+  // Distinct cameras inside a point (the fused SCHUR_JACOBI kernel relies on it; BAL
+  // always satisfies it).
+  {
+    std::vector<int32_t> last_point_of_cam(P.n_cameras, -1);
+    for (int idx = 0; idx < h.nrb; ++idx) {
+      const int i = order[idx];
+      if (last_point_of_cam[row_cam[i]] == row_pt[i]) return no("a point observes one camera twice");
+      last_point_of_cam[row_cam[i]] = row_pt[i];
+    }
+  }
+  P.n_obs = h.nrb;
+
+  // Vector offsets.
+  P.pt_pos.resize(P.n_points);
+  P.cam_pos.resize(P.n_cameras);
+  P.contiguous_layout = true;
+  for (int p = 0; p < P.n_points; ++p) {
+    P.pt_pos[p] = h.cpos[P.pt_block[p]];
+    if (P.pt_pos[p] != 3 * p) P.contiguous_layout = false;
+  }
+  for (int c = 0; c < P.n_cameras; ++c) {
+    P.cam_pos[c] = h.cpos[P.cam_block[c]] - h.num_cols_e;
+    if (P.cam_pos[c] != 9 * c) P.contiguous_layout = false;
+  }
+
+  // Tiles.  Greedy in point order; a point longer than one tile gets tiles of its own.
+  auto new_tile = [&](int kind, int aux) {
+    P.tile_kind.push_back(kind);
+    P.tile_aux.push_back(aux);
+    P.slot_epos.resize(P.slot_epos.size() + kTile, -1);
+    P.slot_fpos.resize(P.slot_fpos.size() + kTile, -1);
+    P.slot_bpos.resize(P.slot_bpos.size() + kTile, -1);
+    P.slot_cam.resize(P.slot_cam.size() + kTile, -1);
+    P.slot_pt.resize(P.slot_pt.size() + kTile, -1);
+    P.slot_seg.resize(P.slot_seg.size() + kTile, 0u);
+    return int64_t(P.tile_kind.size()) - 1;
+  };
+  int64_t tile = -1;
+  int used = kTile;  // slots used in the current tile (kTile forces a new one)
+  int idx = 0;
+  for (int p = 0; p < P.n_points; ++p) {
+    const int k = track[p];
+    if (k > kTile) {
+      const int nt = (k + kTile - 1) / kTile;
+      for (int t = 0; t < nt; ++t) {
+        tile = new_tile(t == 0 ? 1 : 2, t == 0 ? nt : 0);
+        const int cnt = std::min(kTile, k - t * kTile);
+        for (int l = 0; l < cnt; ++l) {
+          const int i = order[idx++];
+          const int64_t s = tile * kTile + l;
+          P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
+          P.slot_cam[s] = row_cam[i]; P.slot_pt[s] = p;
+          P.slot_seg[s] = 0u | (uint32_t(cnt - 1) << 8) | (1u << 16);
+        }
+      }
+      used = kTile;  // nothing shares a tile with a long point
+      continue;
+    }
+    if (used + k > kTile) { tile = new_tile(0, 0); used = 0; }
+    for (int l = 0; l < k; ++l) {
+      const int i = order[idx++];
+      const int64_t s = tile * kTile + used + l;
+      P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
+      P.slot_cam[s] = row_cam[i]; P.slot_pt[s] = p;
+      P.slot_seg[s] = uint32_t(used) | (uint32_t(used + k - 1) << 8) | (1u << 16);
+    }
+    used += k;
+  }
+  P.n_tiles = int64_t(P.tile_kind.size());
+  // Normal tiles: tile_aux = longest track in the tile (bounds the segmented-scan steps).
+  for (int64_t t = 0; t < P.n_tiles; ++t) {
+    if (P.tile_kind[t] != 0) continue;
+    int longest = 1;
+    for (int l = 0; l < kTile; ++l) {
+      const uint32_t sg = P.slot_seg[t * kTile + l];
+      if (sg >> 16) longest = std::max(longest, int((sg >> 8) & 0xff) - int(sg & 0xff) + 1);
+    }
+    P.tile_aux[t] = longest;
+  }
+  // Padding slots form singleton segments so that shuffles stay in range.
+  for (int64_t s = 0; s < P.n_tiles * kTile; ++s)
+    if (!(P.slot_seg[s] >> 16)) { const uint32_t l = uint32_t(s % kTile); P.slot_seg[s] = l | (l << 8); }
+
+  // Camera-major lists (counting sort over slots keeps point order inside a camera).
+  P.cam_ptr.assign(P.n_cameras + 1, 0);
+  for (int64_t s = 0; s < P.n_tiles * kTile; ++s) if (P.slot_cam[s] >= 0) ++P.cam_ptr[P.slot_cam[s] + 1];
+  for (int c = 0; c < P.n_cameras; ++c) {
+    P.max_camera_degree = std::max(P.max_camera_degree, P.cam_ptr[c + 1]);
+    P.cam_ptr[c + 1] += P.cam_ptr[c];
+  }
+  P.cam_fpos.resize(P.n_obs);
+  P.cam_slot.resize(P.n_obs);
+  {
+    std::vector<int32_t> cur(P.cam_ptr.begin(), P.cam_ptr.end() - 1);
+    for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
+      if (P.slot_cam[s] < 0) continue;
+      const int q = cur[P.slot_cam[s]]++;
+      P.cam_fpos[q] = P.slot_fpos[s];
+      P.cam_slot[q] = int32_t(s);
+    }
+  }
+  if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
+  P.eligible = true;
+}
+
+}  // namespace chip

@@ -1,0 +1,1240 @@
+// solver.hip — the C ABI of include/ceres_hip.h: solver objects, the two LinearSolver
+// implementations (CGNR, ITERATIVE_SCHUR), operator-level entry points and timing.
+//
+// A solver instance is device resident: the structure (and, for <2,3,9> problems, the
+// tile packing plan) is uploaded once; per solve only values/b/D go up and x comes down
+// (SURVEY.md §7 "design stance").  Everything runs on one HIP stream owned by the
+// instance; the host blocks only to poll the CG status word and to hand back x.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device.h"
+
+namespace chip {
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buf {  // device allocation owned by a solver
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+}  // namespace chip
+
+using namespace chip;
+
+struct ceres_hip_solver {
+  ceres_hip_options opt{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[10] = {};
+  int num_cus = 256;
+  bool have_structure = false, loaded = false, have_b = false, have_D = false;
+  int path = CERES_HIP_PATH_GENERIC;
+  HostStructure hs;
+  BalPlan plan;
+  std::vector<void*> allocs;
+  int64_t device_bytes = 0;
+
+  // structure on device
+  GenStructure G;
+  // BAL plan on device
+  int32_t *d_slot_epos = nullptr, *d_slot_fpos = nullptr, *d_slot_bpos = nullptr, *d_slot_cam = nullptr, *d_slot_pt = nullptr;
+  uint32_t* d_slot_seg = nullptr;
+  int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
+  int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
+  int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
+  double2 *d_J = nullptr, *d_bt = nullptr;
+  double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
+  bool lds_mode = false;
+  int fused_grid = 0;
+
+  // per-solve inputs: either owned copies (host entry points) or caller's device memory
+  double *own_values = nullptr, *own_b = nullptr, *own_D = nullptr, *own_x = nullptr;
+  const double *values = nullptr, *b = nullptr, *D = nullptr;
+
+  // Schur state
+  double* etei = nullptr;         // BAL: 6/point packed; generic: dense e x e blocks (diag_off_e)
+  double* rhs_f = nullptr;        // num_cols_f
+  double *tmp_rows = nullptr, *tmp_e = nullptr, *tmp_e2 = nullptr;
+  // preconditioner blocks: F blocks (diag_off_f) for ITERATIVE_SCHUR, all blocks (diag_off_all) for CGNR
+  double* precond = nullptr;
+  bool precond_valid = false;
+  int* d_fail_flag = nullptr;
+  // CG
+  CgBuffers cg;
+  double* cg_rhs = nullptr;
+  CgScalars* h_scalars = nullptr;  // pinned
+  double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
+  // comm
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  ceres_hip_solve_timing timing{};
+};
+
+namespace {
+
+int fail(ceres_hip_solver* s, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (s) s->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(s, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) return fail(s, CERES_HIP_E_HIP, "%s failed: %s (%s:%d)", #expr,    \
+                                      hipGetErrorString(_e), __FILE__, __LINE__);            \
+  } while (0)
+#define NCCL_TRY(s, expr)                                                                     \
+  do {                                                                                        \
+    ncclResult_t _r = (expr);                                                                 \
+    if (_r != ncclSuccess) return fail(s, CERES_HIP_E_COMM, "%s failed: %s (%s:%d)", #expr,  \
+                                       ncclGetErrorString(_r), __FILE__, __LINE__);          \
+  } while (0)
+#define TRY(expr)              \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != 0) return _rc;  \
+  } while (0)
+
+template <typename T>
+int dev_alloc(ceres_hip_solver* s, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  void* q = nullptr;
+  HIP_TRY(s, hipMalloc(&q, n * sizeof(T)));
+  s->allocs.push_back(q);
+  s->device_bytes += int64_t(n * sizeof(T));
+  *p = static_cast<T*>(q);
+  return 0;
+}
+template <typename T>
+int dev_upload(ceres_hip_solver* s, T** p, const std::vector<T>& v) {
+  TRY(dev_alloc(s, p, v.size()));
+  if (!v.empty()) HIP_TRY(s, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+  return 0;
+}
+void free_all(ceres_hip_solver* s) {
+  for (void* p : s->allocs) (void)hipFree(p);
+  s->allocs.clear();
+  s->device_bytes = 0;
+}
+
+int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
+  if (s->world <= 1 || n == 0) return 0;
+  NCCL_TRY(s, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, s->comm, s->stream));
+  return 0;
+}
+
+bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HIP_ITERATIVE_SCHUR; }
+
+// ---------------------------------------------------------------------------
+// Operators.  All take device pointers and enqueue on s->stream.
+// ---------------------------------------------------------------------------
+BalArgs bal_args(ceres_hip_solver* s) {
+  BalArgs A;
+  A.J = s->d_J; A.b = s->d_bt;
+  A.slot_cam = s->d_slot_cam; A.slot_pt = s->d_slot_pt; A.slot_seg = s->d_slot_seg;
+  A.tile_kind = s->d_tile_kind; A.tile_aux = s->d_tile_aux;
+  A.n_tiles = s->plan.n_tiles; A.n_slots = s->plan.n_tiles * kTile;
+  A.pt_pos = s->plan.contiguous_layout ? nullptr : s->d_pt_pos;
+  A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  A.etei = s->etei;
+  A.partials = s->d_partials; A.global_acc = s->d_global_acc;
+  A.n_f9 = 9 * s->plan.n_cameras;
+  A.have_b = s->have_b ? 1 : 0;
+  return A;
+}
+
+// Run one fused kernel that scatters into camera space and produce y_f.
+// add_diag: y_f += D_f^2 x_f (after the all-reduce when sharded).
+int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
+                const int* status) {
+  const int n9 = A.n_f9;
+  const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
+  const int32_t* cam_pos = A.cam_pos;
+  A.status = status;
+  if (!s->lds_mode) HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
+  HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
+  const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
+  const int nparts = s->lds_mode ? s->fused_grid : 1;
+  if (s->world <= 1) {
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, s->stream));
+  } else {
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, s->stream));
+    // camera scalars are contiguous in the Schur-ordered (sharded) layout
+    TRY(allreduce(s, y_f, size_t(n9)));
+    if (D_f) HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, s->stream));
+  }
+  return 0;
+}
+
+// y = S x on F-space vectors.  ImplicitSchurComplement::RightMultiplyAndAccumulate.
+int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
+  const HostStructure& h = s->hs;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalArgs A = bal_args(s);
+    A.x_f = x;
+    return bal_scatter(s, kBalSx, A, x, y, true, status);
+  }
+  const double* v = s->values;
+  hipStream_t st = s->stream;
+  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kF, x, s->tmp_rows, status, st));
+  HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kE, s->tmp_rows, s->tmp_e, status, st));
+  HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, status, st));
+  HIP_TRY(s, LaunchAxpby(-1.0, s->tmp_e2, 0.0, s->tmp_e2, s->tmp_e2, h.num_cols_e, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kE, s->tmp_e2, s->tmp_rows, status, st));
+  const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
+  if (s->world <= 1) {
+    HIP_TRY(s, LaunchSquareScale(D_f, x, y, h.num_cols_f, status, st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kF, s->tmp_rows, y, status, st));
+  } else {
+    HIP_TRY(s, LaunchSquareScale(nullptr, x, y, h.num_cols_f, status, st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kF, s->tmp_rows, y, status, st));
+    TRY(allreduce(s, y, size_t(h.num_cols_f)));
+    HIP_TRY(s, LaunchAddSquareScale(D_f, x, y, h.num_cols_f, status, st));
+  }
+  return 0;
+}
+
+// y = (A^T A + D^2) x on full-space vectors.  CgnrLinearOperator (y zeroed by CG first).
+int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalArgs A = bal_args(s);
+    A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
+    return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status);
+  }
+  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, status, st));
+  HIP_TRY(s, LaunchSquareScale(nullptr, x, y, h.num_cols, status, st));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, s->tmp_rows, y, status, st));
+  if (s->world > 1) TRY(allreduce(s, y + h.num_cols_e, size_t(h.num_cols_f)));
+  HIP_TRY(s, LaunchAddSquareScale(s->D, x, y, h.num_cols, status, st));
+  return 0;
+}
+
+// y = A^T b
+int op_jtb(ceres_hip_solver* s, double* y) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "no residual vector loaded");
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalArgs A = bal_args(s);
+    A.y_e = y;
+    return bal_scatter(s, kBalJtb, A, nullptr, y + h.num_cols_e, false, nullptr);
+  }
+  HIP_TRY(s, hipMemsetAsync(y, 0, sizeof(double) * h.num_cols, st));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, s->b, y, nullptr, st));
+  if (s->world > 1) TRY(allreduce(s, y + h.num_cols_e, size_t(h.num_cols_f)));
+  return 0;
+}
+
+// ImplicitSchurComplement::Init: (E^T E + D_e^2)^-1 blocks and rhs.
+int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalArgs A = bal_args(s);
+    A.D_e = s->D;
+    A.Mo = want_Mo ? s->d_Mo : nullptr;
+    if (s->have_b) return bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr);
+    // no residuals: only the inverses (and M_o) are needed; nothing is scattered
+    HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->fused_grid, st));
+    return 0;
+  }
+  // block diagonal of E^T E + D_e^2, inverted in place
+  HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kE, s->D, s->etei, h.diag_off_e.back(), st));
+  HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  HIP_TRY(s, LaunchGenInvertBlocks(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->d_fail_flag, st));
+  if (!s->have_b) return 0;
+  // rhs = F^T (b - E (E^T E)^-1 E^T b)           UpdateRhs
+  HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->b, s->tmp_e, nullptr, st));
+  HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, nullptr, st));
+  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kE, s->tmp_e2, s->tmp_rows, nullptr, st));
+  HIP_TRY(s, LaunchAxpby(1.0, s->b, -1.0, s->tmp_rows, s->tmp_rows, h.num_rows, st));
+  HIP_TRY(s, hipMemsetAsync(s->rhs_f, 0, sizeof(double) * std::max(1, h.num_cols_f), st));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kF, s->tmp_rows, s->rhs_f, nullptr, st));
+  TRY(allreduce(s, s->rhs_f, size_t(h.num_cols_f)));
+  return 0;
+}
+
+// ImplicitSchurComplement::BackSubstitute: z (F space, may be nullptr if there are no F
+// blocks) -> x (full space).
+int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "no residual vector loaded");
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalArgs A = bal_args(s);
+    A.x_f = z; A.y_e = x;
+    HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
+  } else {
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    if (h.num_cols_f > 0) HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kF, z, s->tmp_rows, nullptr, st));
+    HIP_TRY(s, LaunchAxpby(1.0, s->b, -1.0, s->tmp_rows, s->tmp_rows, h.num_rows, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->tmp_rows, s->tmp_e, nullptr, st));
+    HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols, st));
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, x, nullptr, st));
+  }
+  if (h.num_cols_f > 0)
+    HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, z, sizeof(double) * h.num_cols_f, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// Preconditioner blocks into `out`; invert = false leaves them as assembled.
+//   ITERATIVE_SCHUR: SCHUR_JACOBI (diag blocks of S) or JACOBI (blockdiag(F^T F + D_f^2)), F blocks
+//   CGNR:            JACOBI, all column blocks
+int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
+  HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  if (is_schur(s)) {
+    const int nf = h.ncb - h.nelim;
+    const int64_t len = h.diag_off_f.back();
+    if (s->path == CERES_HIP_PATH_BAL) {
+      const bool schur = type == CERES_HIP_SCHUR_JACOBI;
+      // raw sums first (no diagonal) so that a sharded run can add them up
+      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_Mo,
+                                       s->plan.n_tiles * kTile, s->world > 1 ? nullptr : D_f, nullptr, nullptr, out,
+                                       s->plan.n_cameras, st));
+      if (s->world > 1) {
+        TRY(allreduce(s, out, size_t(len)));
+        if (D_f) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
+      }
+      if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, st));
+    } else {
+      if (type == CERES_HIP_SCHUR_JACOBI) {
+        HIP_TRY(s, LaunchGenSchurJacobi(s->G, s->values, s->etei, s->D, s->world > 1 ? 0 : 1, out, len, st));
+      } else {
+        HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kF, s->world > 1 ? nullptr : s->D, out, len, st));
+      }
+      if (s->world > 1) {
+        TRY(allreduce(s, out, size_t(len)));
+        if (D_f) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
+      }
+      if (invert) HIP_TRY(s, LaunchGenInvertBlocks(s->G, h.nelim, nf, s->G.diag_off_f, out, s->d_fail_flag, st));
+    }
+    return 0;
+  }
+  // CGNR JACOBI
+  const int64_t len = h.diag_off_all.back();
+  if (s->path == CERES_HIP_PATH_BAL && s->world <= 1 && invert) {
+    BalArgs A = bal_args(s);
+    A.etei = nullptr;
+    A.D_e = s->D;
+    A.point_blocks = out;
+    A.pt_diag_off = s->d_pt_diag_off;
+    HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
+    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
+                                     s->plan.n_tiles * kTile, D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos,
+                                     s->d_cam_diag_off, out, s->plan.n_cameras, st));
+    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
+    return 0;
+  }
+  HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kAll, s->world > 1 ? nullptr : s->D, out, len, st));
+  if (s->world > 1) {
+    // shared (camera) blocks follow the local (point) blocks in the sharded layout
+    const int64_t first = h.diag_off_all[h.nelim];
+    TRY(allreduce(s, out + first, size_t(len - first)));
+    if (s->D) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, 0, h.ncb, s->G.diag_off_all, s->D, out, st));
+  }
+  if (invert) HIP_TRY(s, LaunchGenInvertBlocks(s->G, 0, h.ncb, s->G.diag_off_all, out, s->d_fail_flag, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Conjugate gradients driver (I/conjugate_gradients_solver.h:108-306).
+// ---------------------------------------------------------------------------
+struct CgSpec {
+  int64_t n = 0;
+  int64_t n_local = 0;                                  // sharded CGNR: E-space prefix
+  std::function<int(const double*, double*)> apply;     // y = A x (assigns)
+  int first_block = 0, col_begin = 0;
+  const int64_t* diag_off = nullptr;
+  const double* blocks = nullptr;                       // nullptr = IDENTITY
+};
+
+void fill_summary(const CgScalars& S, int device_status, ceres_hip_summary* out) {
+  out->residual_norm = -1.0;
+  out->num_iterations = S.iter;
+  char* m = out->message;
+  const size_t n = sizeof(out->message);
+  switch (device_status) {
+    case kCgZeroRhs:
+      out->termination_type = CERES_HIP_SUCCESS; out->num_iterations = 0;
+      snprintf(m, n, "Convergence. |b| = 0."); break;
+    case kCgInitialResidual:
+      out->termination_type = CERES_HIP_SUCCESS; out->num_iterations = 0;
+      snprintf(m, n, "Convergence. |r| = %e <= %e.", S.norm_r, S.tol_r); break;
+    case kCgConvergedZeta:
+      out->termination_type = CERES_HIP_SUCCESS;
+      snprintf(m, n, "Iteration: %d Convergence: zeta = %e < %e. |r| = %e", S.iter, S.zeta, S.q_tol, S.norm_r); break;
+    case kCgConvergedResidual:
+      out->termination_type = CERES_HIP_SUCCESS;
+      snprintf(m, n, "Iteration: %d Convergence. |r| = %e <= %e.", S.iter, S.norm_r, S.tol_r); break;
+    case kCgMaxIterations:
+      out->termination_type = CERES_HIP_NO_CONVERGENCE;
+      snprintf(m, n, "Maximum number of iterations reached."); break;
+    case kCgFailRho:
+      out->termination_type = CERES_HIP_FAILURE;
+      snprintf(m, n, "Numerical failure. rho = r'z = %e.", S.rho_new); break;
+    case kCgFailBeta:
+      out->termination_type = CERES_HIP_FAILURE;
+      snprintf(m, n, "Numerical failure. beta = rho_n / rho_{n-1} = %e, rho_n = %e, rho_{n-1} = %e", S.beta, S.rho_new, S.rho); break;
+    case kCgIndefinite:
+      out->termination_type = CERES_HIP_NO_CONVERGENCE;
+      snprintf(m, n, "Matrix is indefinite, no more progress can be made. p'q = %e.", S.pq); break;
+    case kCgFailAlpha:
+      out->termination_type = CERES_HIP_FAILURE;
+      snprintf(m, n, "Numerical failure. alpha = rho / pq = %e, rho = %e, pq = %e.", S.alpha, S.rho_new, S.pq); break;
+    default:
+      out->termination_type = CERES_HIP_FATAL_ERROR;
+      snprintf(m, n, "CG ended in unknown device state %d", device_status);
+  }
+}
+
+int poll_scalars(ceres_hip_solver* s) {
+  HIP_TRY(s, hipMemcpyAsync(s->h_scalars, s->cg.S, sizeof(CgScalars), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int collapse_and_reduce(ceres_hip_solver* s, int first_slot, int count) {
+  if (s->cg.grid_e == 0) return 0;
+  HIP_TRY(s, LaunchCgCollapse(s->cg, first_slot, count, s->stream));
+  return allreduce(s, s->cg.comm + first_slot, size_t(count));
+}
+
+// rhs in s->cg_rhs; solution left in s->cg.x.
+int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, ceres_hip_summary* summary) {
+  hipStream_t st = s->stream;
+  CgBuffers& B = s->cg;
+  B.n = spec.n;
+  B.n_local = (s->world > 1) ? spec.n_local : 0;
+  B.rhs = s->cg_rhs;
+  auto grid_for = [](int64_t n, int cap) {
+    int64_t g = (n + int64_t(kVecBlock) * 4 - 1) / (int64_t(kVecBlock) * 4);
+    return int(std::max<int64_t>(1, std::min<int64_t>(g, cap)));
+  };
+  if (B.n_local > 0) {
+    B.grid_e = grid_for(B.n_local, kMaxVecGrid / 2);
+    B.grid = B.grid_e + grid_for(B.n - B.n_local, kMaxVecGrid / 2);
+  } else {
+    B.grid_e = 0;
+    B.grid = grid_for(B.n, kMaxVecGrid);
+  }
+  const int min_it = s->opt.min_num_iterations, max_it = s->opt.max_num_iterations;
+  const int reset_period = std::max(1, s->opt.residual_reset_period);
+  const int* status = &B.S->status;
+  int interval = s->opt.cg_check_interval > 0 ? s->opt.cg_check_interval : 8;
+
+  HIP_TRY(s, LaunchCgRhsNorm(B, st));
+  TRY(collapse_and_reduce(s, 0, 1));
+  HIP_TRY(s, LaunchCgInit(B, q_tol, r_tol, min_it, max_it, st));
+  TRY(poll_scalars(s));
+  s->timing.operator_applications = 0;
+  int it = 1;
+  while (s->h_scalars->status == kCgRunning) {
+    const int batch_end = std::min(max_it, it + interval - 1);
+    for (; it <= batch_end; ++it) {
+      HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.diag_off, spec.blocks, st));
+      TRY(collapse_and_reduce(s, 0, 1));
+      HIP_TRY(s, LaunchCgDirection(B, st));
+      TRY(spec.apply(B.p, B.z));
+      HIP_TRY(s, LaunchCgDotPq(B, st));
+      TRY(collapse_and_reduce(s, 1, 1));
+      const int reset = (it % reset_period == 0) ? 1 : 0;
+      HIP_TRY(s, LaunchCgStep(B, reset, st));
+      ++s->timing.operator_applications;
+      if (reset) {
+        TRY(spec.apply(B.x, B.z));
+        HIP_TRY(s, LaunchCgResidualReset(B, B.z, st));
+        ++s->timing.operator_applications;
+      }
+      TRY(collapse_and_reduce(s, 2, 2));
+      HIP_TRY(s, LaunchCgFinalize(B, st));
+    }
+    TRY(poll_scalars(s));
+    if (it > max_it && s->h_scalars->status == kCgRunning)
+      return fail(s, CERES_HIP_E_INVALID, "CG did not terminate after max_num_iterations (device status 0)");
+  }
+  (void)status;
+  fill_summary(*s->h_scalars, s->h_scalars->status, summary);
+  return 0;
+}
+
+int check_factorization(ceres_hip_solver* s, bool* failed) {
+  int flag = 0;
+  HIP_TRY(s, hipMemcpyAsync(&flag, s->d_fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  *failed = flag != 0;
+  return 0;
+}
+
+int require_loaded(ceres_hip_solver* s) {
+  if (!s) return CERES_HIP_E_INVALID;
+  if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
+  if (!s->loaded) return fail(s, CERES_HIP_E_INVALID, "no values loaded (ceres_hip_load / ceres_hip_solve)");
+  return 0;
+}
+
+// values/b/D are device pointers valid until the next load.
+int load_device(ceres_hip_solver* s, const double* dv, const double* db, const double* dD) {
+  if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
+  if (!dv) return fail(s, CERES_HIP_E_INVALID, "values == NULL");
+  s->values = dv; s->b = db; s->D = dD;
+  s->have_b = db != nullptr;
+  s->have_D = dD != nullptr;
+  s->precond_valid = false;
+  if (s->path == CERES_HIP_PATH_BAL)
+    HIP_TRY(s, LaunchBalPack(dv, db, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, s->stream));
+  s->loaded = true;
+  return 0;
+}
+
+int load_host(ceres_hip_solver* s, const double* hv, const double* hb, const double* hD) {
+  if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
+  if (!hv) return fail(s, CERES_HIP_E_INVALID, "values == NULL");
+  const HostStructure& h = s->hs;
+  HIP_TRY(s, hipMemcpyAsync(s->own_values, hv, sizeof(double) * h.values_extent, hipMemcpyHostToDevice, s->stream));
+  if (hb) HIP_TRY(s, hipMemcpyAsync(s->own_b, hb, sizeof(double) * h.num_rows, hipMemcpyHostToDevice, s->stream));
+  if (hD) HIP_TRY(s, hipMemcpyAsync(s->own_D, hD, sizeof(double) * h.num_cols, hipMemcpyHostToDevice, s->stream));
+  return load_device(s, s->own_values, hb ? s->own_b : nullptr, hD ? s->own_D : nullptr);
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+
+// The two LinearSolver::SolveImpl bodies.  x is a device pointer (num_cols).
+int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  memset(summary, 0, sizeof(*summary));
+  summary->residual_norm = -1.0;
+  if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "Solve needs the residual vector b");
+  HIP_TRY(s, hipEventRecord(s->ev[2], st));
+  if (is_schur(s)) {
+    // IterativeSchurComplementSolver::SolveImpl, I/iterative_schur_complement_solver.cc:64-157
+    const int pre = s->opt.preconditioner_type;
+    TRY(op_schur_init(s, pre == CERES_HIP_SCHUR_JACOBI));
+    bool bad = false;
+    if (s->path != CERES_HIP_PATH_BAL) TRY(check_factorization(s, &bad));
+    if (bad) {
+      summary->termination_type = CERES_HIP_FAILURE;
+      snprintf(summary->message, sizeof(summary->message), "E^T E + D^2 is not positive definite.");
+      return 0;
+    }
+    HIP_TRY(s, hipEventRecord(s->ev[3], st));
+    const int nf_blocks = h.ncb - h.nelim;
+    if (nf_blocks == 0) {  // :88-95
+      summary->termination_type = CERES_HIP_SUCCESS;
+      summary->num_iterations = 0;
+      TRY(op_back_substitute(s, nullptr, x));
+      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      return 0;
+    }
+    if (pre != CERES_HIP_IDENTITY) {
+      TRY(op_preconditioner(s, pre, s->precond, true));
+      TRY(check_factorization(s, &bad));
+      if (bad) {  // Preconditioner::Update returned false, :113-121
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+        return 0;
+      }
+      s->precond_valid = true;
+    }
+    HIP_TRY(s, hipEventRecord(s->ev[4], st));
+    HIP_TRY(s, hipMemcpyAsync(s->cg_rhs, s->rhs_f, sizeof(double) * h.num_cols_f, hipMemcpyDeviceToDevice, st));
+    CgSpec spec;
+    spec.n = h.num_cols_f;
+    spec.n_local = 0;  // camera space is replicated: no inner product crosses ranks
+    const int* status = &s->cg.S->status;
+    spec.apply = [s, status](const double* in, double* out) { return op_sx(s, in, out, status); };
+    spec.first_block = h.nelim;
+    spec.col_begin = h.num_cols_e;
+    spec.diag_off = s->G.diag_off_f;
+    spec.blocks = pre == CERES_HIP_IDENTITY ? nullptr : s->precond;
+    TRY(run_cg(s, spec, q_tol, r_tol, summary));
+    HIP_TRY(s, hipEventRecord(s->ev[5], st));
+    if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR)
+      TRY(op_back_substitute(s, s->cg.x, x));
+    HIP_TRY(s, hipEventRecord(s->ev[6], st));
+    return 0;
+  }
+  // CgnrSolver::SolveImpl, I/cgnr_solver.cc:146-207
+  const int pre = s->opt.preconditioner_type;
+  HIP_TRY(s, hipEventRecord(s->ev[3], st));
+  if (pre == CERES_HIP_JACOBI) {
+    TRY(op_preconditioner(s, pre, s->precond, true));
+    bool bad = false;
+    TRY(check_factorization(s, &bad));
+    if (bad) {
+      summary->termination_type = CERES_HIP_FAILURE;
+      snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+      return 0;
+    }
+    s->precond_valid = true;
+  }
+  TRY(op_jtb(s, s->cg_rhs));
+  HIP_TRY(s, hipEventRecord(s->ev[4], st));
+  CgSpec spec;
+  spec.n = h.num_cols;
+  spec.n_local = h.num_cols_e;  // sharded: first nelim column blocks are this rank's points
+  const int* status = &s->cg.S->status;
+  spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status); };
+  spec.first_block = 0;
+  spec.col_begin = 0;
+  spec.diag_off = s->G.diag_off_all;
+  spec.blocks = pre == CERES_HIP_JACOBI ? s->precond : nullptr;
+  TRY(run_cg(s, spec, q_tol, r_tol, summary));
+  HIP_TRY(s, hipEventRecord(s->ev[5], st));
+  HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(s, hipEventRecord(s->ev[6], st));
+  return 0;
+}
+
+void collect_timing(ceres_hip_solver* s) {
+  ceres_hip_solve_timing& t = s->timing;
+  t.upload_ms = elapsed(s->ev[0], s->ev[1]);
+  t.pack_ms = elapsed(s->ev[1], s->ev[2]);
+  t.setup_ms = elapsed(s->ev[2], s->ev[3]);
+  t.preconditioner_ms = elapsed(s->ev[3], s->ev[4]);
+  t.cg_ms = elapsed(s->ev[4], s->ev[5]);
+  t.back_substitute_ms = elapsed(s->ev[5], s->ev[6]);
+  t.download_ms = elapsed(s->ev[6], s->ev[7]);
+  t.total_ms = elapsed(s->ev[0], s->ev[7]);
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int ceres_hip_abi_version(void) { return CERES_HIP_ABI_VERSION; }
+
+int ceres_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+const char* ceres_hip_last_error(const ceres_hip_solver* s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
+  if (!o) { fail(nullptr, CERES_HIP_E_INVALID, "options == NULL"); return nullptr; }
+  if (o->solver_type != CERES_HIP_CGNR && o->solver_type != CERES_HIP_ITERATIVE_SCHUR) {
+    fail(nullptr, CERES_HIP_E_UNSUPPORTED, "solver_type %d is not CGNR or ITERATIVE_SCHUR", o->solver_type);
+    return nullptr;
+  }
+  const int pre = o->preconditioner_type;
+  const bool pre_ok = o->solver_type == CERES_HIP_CGNR ? (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI)
+                                                       : (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI || pre == CERES_HIP_SCHUR_JACOBI);
+  if (!pre_ok) {  // CgnrSolver's ctor LOG(FATAL)s on the same condition, I/cgnr_solver.cc:119-128
+    fail(nullptr, CERES_HIP_E_UNSUPPORTED, "preconditioner_type %d is not available for solver_type %d", pre, o->solver_type);
+    return nullptr;
+  }
+  if (o->max_num_iterations < 1 || o->min_num_iterations < 0) {
+    fail(nullptr, CERES_HIP_E_INVALID, "bad iteration limits");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fail(nullptr, CERES_HIP_E_NODEVICE, "no HIP device is visible; this library has no CPU fallback");
+    return nullptr;
+  }
+  if (o->device < 0 || o->device >= ndev) { fail(nullptr, CERES_HIP_E_INVALID, "device %d out of range", o->device); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, o->device) != hipSuccess) { fail(nullptr, CERES_HIP_E_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fail(nullptr, CERES_HIP_E_NODEVICE, "device %d is %s; the kernels are built for gfx950 only", o->device, prop.gcnArchName);
+    return nullptr;
+  }
+  auto s = std::make_unique<ceres_hip_solver>();
+  s->opt = *o;
+  s->num_cus = prop.multiProcessorCount;
+  if (hipSetDevice(o->device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(nullptr, CERES_HIP_E_HIP, "could not create a stream on device %d", o->device);
+    return nullptr;
+  }
+  for (auto& e : s->ev) (void)hipEventCreate(&e);
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), sizeof(CgScalars), hipHostMallocDefault) != hipSuccess) {
+    fail(nullptr, CERES_HIP_E_HIP, "hipHostMalloc failed");
+    return nullptr;
+  }
+  memset(s->h_scalars, 0, sizeof(CgScalars));
+  return s.release();
+}
+
+void ceres_hip_destroy(ceres_hip_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->opt.device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->comm) (void)ncclCommDestroy(s->comm);
+  free_all(s);
+  if (s->h_scalars) (void)hipHostFree(s->h_scalars);
+  for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure* bs) {
+  if (!s || !bs) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "structure already set: one instance sees one sparsity (I/linear_solver.h:137-142)");
+  const int nelim = s->opt.num_eliminate_blocks;
+  std::string e = AnalyzeStructure(*bs, nelim, &s->hs);
+  if (!e.empty()) return fail(s, CERES_HIP_E_INVALID, "invalid block structure: %s", e.c_str());
+  HostStructure& h = s->hs;
+  if (is_schur(s)) {
+    if (nelim <= 0) return fail(s, CERES_HIP_E_INVALID, "ITERATIVE_SCHUR needs num_eliminate_blocks > 0 (LinearSolver::Create falls back to CGNR otherwise, I/linear_solver.cc:51-73: do that on the host)");
+    if (!h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "rows are not ordered for a Schur solver: E rows must come first, grouped by E block (I/reorder_program.cc:278-360)");
+  }
+  if (s->world > 1 && !h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "sharded runs need the Schur ordering");
+  BuildBalPlan(h, true, &s->plan);
+  s->path = (s->plan.eligible && !s->opt.force_generic_path) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
+    return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
+  if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !s->plan.contiguous_layout)
+    return fail(s, CERES_HIP_E_UNSUPPORTED, "sharded <2,3,9> runs need points-then-cameras column order");
+
+  // ---- structure arrays ----
+  GenStructure& G = s->G;
+  G.nrb = h.nrb; G.ncb = h.ncb; G.nelim = h.nelim; G.nrbe = h.num_row_blocks_e;
+  G.num_rows = h.num_rows; G.num_cols = h.num_cols; G.nce = h.num_cols_e; G.ncf = h.num_cols_f;
+  int32_t* p32 = nullptr;
+  int64_t* p64 = nullptr;
+#define UP32(field, vec) TRY(dev_upload(s, &p32, vec)); G.field = p32
+#define UP64(field, vec) TRY(dev_upload(s, &p64, vec)); G.field = p64
+  UP32(rsz, h.rsz); UP32(rpos, h.rpos); UP32(rptr, h.rptr); UP32(ccol, h.ccol); UP32(cval, h.cval);
+  UP32(csz, h.csz); UP32(cpos, h.cpos); UP32(tptr, h.tptr); UP32(trow, h.trow); UP32(tcell, h.tcell);
+  UP32(row_block_of, h.row_block_of); UP32(col_block_of, h.col_block_of); UP32(row_e_block, h.row_e_block);
+  UP64(diag_off_all, h.diag_off_all); UP64(diag_off_e, h.diag_off_e); UP64(diag_off_f, h.diag_off_f);
+#undef UP32
+#undef UP64
+
+  // ---- inputs, temporaries, CG state ----
+  TRY(dev_alloc(s, &s->own_values, size_t(h.values_extent)));
+  TRY(dev_alloc(s, &s->own_b, size_t(h.num_rows)));
+  TRY(dev_alloc(s, &s->own_D, size_t(h.num_cols)));
+  TRY(dev_alloc(s, &s->own_x, size_t(h.num_cols)));
+  TRY(dev_alloc(s, &s->scratch_vec, size_t(h.num_cols) + size_t(h.num_rows)));
+  TRY(dev_alloc(s, &s->d_fail_flag, 1));
+  TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
+  const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
+  TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg.r, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg.p, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg.z, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg_rhs, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg.partials, size_t(4 * kMaxVecGrid)));
+  TRY(dev_alloc(s, &s->cg.comm, 4));
+  TRY(dev_alloc(s, &s->cg.S, 1));
+  HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
+  TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back())));
+
+  if (s->path == CERES_HIP_PATH_BAL) {
+    BalPlan& P = s->plan;
+    TRY(dev_upload(s, &s->d_slot_epos, P.slot_epos));
+    TRY(dev_upload(s, &s->d_slot_fpos, P.slot_fpos));
+    TRY(dev_upload(s, &s->d_slot_bpos, P.slot_bpos));
+    TRY(dev_upload(s, &s->d_slot_cam, P.slot_cam));
+    TRY(dev_upload(s, &s->d_slot_pt, P.slot_pt));
+    TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
+    TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));
+    TRY(dev_upload(s, &s->d_tile_aux, P.tile_aux));
+    TRY(dev_upload(s, &s->d_pt_pos, P.pt_pos));
+    TRY(dev_upload(s, &s->d_cam_pos, P.cam_pos));
+    TRY(dev_upload(s, &s->d_cam_ptr, P.cam_ptr));
+    TRY(dev_upload(s, &s->d_cam_fpos, P.cam_fpos));
+    TRY(dev_upload(s, &s->d_cam_slot, P.cam_slot));
+    std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
+    for (int p = 0; p < P.n_points; ++p) pdo[p] = h.diag_off_all[P.pt_block[p]];
+    for (int c = 0; c < P.n_cameras; ++c) cdo[c] = h.diag_off_all[P.cam_block[c]];
+    TRY(dev_upload(s, &s->d_pt_diag_off, pdo));
+    TRY(dev_upload(s, &s->d_cam_diag_off, cdo));
+    const size_t n_slots = size_t(P.n_tiles) * kTile;
+    TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
+    TRY(dev_alloc(s, &s->d_bt, n_slots));
+    TRY(dev_alloc(s, &s->d_Mo, 3 * n_slots));
+    TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
+    const size_t n9 = size_t(9) * P.n_cameras;
+    s->lds_mode = n9 * sizeof(double) <= kMaxLdsBytes - 512;
+    s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
+    const int64_t tiles_per_wg = kBalBlock / kTile;
+    s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
+    TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
+    TRY(dev_alloc(s, &s->d_global_acc, n9));
+  } else {
+    TRY(dev_alloc(s, &s->etei, size_t(h.diag_off_e.back())));
+    TRY(dev_alloc(s, &s->tmp_rows, size_t(h.num_rows)));
+    TRY(dev_alloc(s, &s->tmp_e, size_t(h.num_cols_e)));
+    TRY(dev_alloc(s, &s->tmp_e2, size_t(h.num_cols_e)));
+  }
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  s->have_structure = true;
+  return 0;
+}
+
+int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
+  if (!s || !info) return CERES_HIP_E_INVALID;
+  memset(info, 0, sizeof(*info));
+  const HostStructure& h = s->hs;
+  info->kernel_path = s->path;
+  info->num_rows = h.num_rows; info->num_cols = h.num_cols;
+  info->num_cols_e = h.num_cols_e; info->num_cols_f = h.num_cols_f;
+  info->num_row_blocks_e = h.num_row_blocks_e;
+  info->num_e_blocks = h.nelim; info->num_f_blocks = h.ncb - h.nelim;
+  info->row_block_size = h.det_row; info->e_block_size = h.det_e; info->f_block_size = h.det_f;
+  info->num_nonzeros = h.nnz;
+  info->num_observations = s->path == CERES_HIP_PATH_BAL ? s->plan.n_obs : 0;
+  info->num_tiles = s->path == CERES_HIP_PATH_BAL ? s->plan.n_tiles : 0;
+  info->device_bytes = s->device_bytes;
+  info->camera_accum_in_lds = s->lds_mode ? 1 : 0;
+  info->world_size = s->world; info->rank = s->rank;
+  return 0;
+}
+
+int ceres_hip_comm_get_unique_id(uint8_t id[CERES_HIP_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == CERES_HIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return CERES_HIP_E_COMM;
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_ID_BYTES], int32_t rank, int32_t world) {
+  if (!s || !id || world < 1 || rank < 0 || rank >= world) return CERES_HIP_E_INVALID;
+  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_init before ceres_hip_set_structure");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  s->rank = rank; s->world = world;
+  if (world == 1) return 0;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  NCCL_TRY(s, ncclCommInitRank(&s->comm, world, u, rank));
+  return 0;
+}
+
+int ceres_hip_load(ceres_hip_solver* s, const double* hv, const double* hb, const double* hD) {
+  if (!s) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  TRY(load_host(s, hv, hb, hD));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+int ceres_hip_load_device(ceres_hip_solver* s, const double* dv, const double* db, const double* dD) {
+  if (!s) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  TRY(load_device(s, dv, db, dD));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_solve(ceres_hip_solver* s, const double* hv, const double* hb, const double* hD, double q_tol,
+                    double r_tol, double* hx, ceres_hip_summary* summary) {
+  if (!s || !summary || !hx) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  auto fatal = [&](int rc) {
+    summary->termination_type = CERES_HIP_FATAL_ERROR;
+    summary->residual_norm = -1;
+    snprintf(summary->message, sizeof(summary->message), "%s", s->err.c_str());
+    return rc;
+  };
+  if (!s->have_structure) return fatal(fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called"));
+  (void)hipEventRecord(s->ev[0], s->stream);
+  // upload (ev0..ev1), pack (ev1..ev2)
+  const HostStructure& h = s->hs;
+  if (!hv || !hb) return fatal(fail(s, CERES_HIP_E_INVALID, "values and b must not be NULL"));
+  if (hipMemcpyAsync(s->own_values, hv, sizeof(double) * h.values_extent, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+      hipMemcpyAsync(s->own_b, hb, sizeof(double) * h.num_rows, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
+      (hD && hipMemcpyAsync(s->own_D, hD, sizeof(double) * h.num_cols, hipMemcpyHostToDevice, s->stream) != hipSuccess))
+    return fatal(fail(s, CERES_HIP_E_HIP, "host-to-device copy failed"));
+  (void)hipEventRecord(s->ev[1], s->stream);
+  int rc = load_device(s, s->own_values, s->own_b, hD ? s->own_D : nullptr);
+  if (rc) return fatal(rc);
+  rc = solve_loaded(s, q_tol, r_tol, s->own_x, summary);
+  if (rc) return fatal(rc);
+  if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR) {
+    if (hipMemcpyAsync(hx, s->own_x, sizeof(double) * h.num_cols, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
+      return fatal(fail(s, CERES_HIP_E_HIP, "device-to-host copy failed"));
+  }
+  (void)hipEventRecord(s->ev[7], s->stream);
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
+  collect_timing(s);
+  return 0;
+}
+
+int ceres_hip_solve_device(ceres_hip_solver* s, const double* dv, const double* db, const double* dD, double q_tol,
+                           double r_tol, double* dx, ceres_hip_summary* summary) {
+  if (!s || !summary || !dx) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  auto fatal = [&](int rc) {
+    summary->termination_type = CERES_HIP_FATAL_ERROR;
+    summary->residual_norm = -1;
+    snprintf(summary->message, sizeof(summary->message), "%s", s->err.c_str());
+    return rc;
+  };
+  (void)hipEventRecord(s->ev[0], s->stream);
+  (void)hipEventRecord(s->ev[1], s->stream);
+  int rc = load_device(s, dv, db, dD);
+  if (rc) return fatal(rc);
+  rc = solve_loaded(s, q_tol, r_tol, dx, summary);
+  if (rc) return fatal(rc);
+  (void)hipEventRecord(s->ev[7], s->stream);
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
+  collect_timing(s);
+  return 0;
+}
+
+int ceres_hip_get_last_timing(const ceres_hip_solver* s, ceres_hip_solve_timing* t) {
+  if (!s || !t) return CERES_HIP_E_INVALID;
+  *t = s->timing;
+  return 0;
+}
+
+// ---- operator-level entry points: host vectors in, host vectors out ----------
+namespace {
+int up(ceres_hip_solver* s, double* dev, const double* host, size_t n) {
+  if (n) HIP_TRY(s, hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  return 0;
+}
+int down(ceres_hip_solver* s, double* host, const double* dev, size_t n) {
+  if (n) HIP_TRY(s, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+}  // namespace
+
+int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  double *dx = s->scratch_vec, *dy = s->scratch_vec + h.num_cols;
+  TRY(up(s, dx, x, h.num_cols));
+  TRY(up(s, dy, y, h.num_rows));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, dx, dy, nullptr, s->stream));
+  return down(s, y, dy, h.num_rows);
+}
+
+int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  double *dy = s->scratch_vec, *dx = s->scratch_vec + h.num_cols;
+  TRY(up(s, dx, x, h.num_rows));
+  TRY(up(s, dy, y, h.num_cols));
+  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, dx, dy, nullptr, s->stream));
+  return down(s, y, dy, h.num_cols);
+}
+
+int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  HIP_TRY(s, LaunchGenSquaredColumnNorm(s->G, s->values, s->scratch_vec, s->stream));
+  return down(s, x, s->scratch_vec, s->hs.num_cols);
+}
+
+int ceres_hip_op_jtjx(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "jtjx is the CGNR operator; this instance is ITERATIVE_SCHUR");
+  TRY(up(s, s->cg.p, x, s->hs.num_cols));
+  TRY(op_jtjx(s, s->cg.p, s->cg.z, nullptr));
+  return down(s, y, s->cg.z, s->hs.num_cols);
+}
+
+int ceres_hip_op_jtb(ceres_hip_solver* s, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  TRY(op_jtb(s, s->scratch_vec));
+  return down(s, y, s->scratch_vec, s->hs.num_cols);
+}
+
+int ceres_hip_op_schur_init(ceres_hip_solver* s) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  TRY(op_schur_init(s, true));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_get_schur_rhs(ceres_hip_solver* s, double* rhs) {
+  TRY(require_loaded(s));
+  return down(s, rhs, s->rhs_f, s->hs.num_cols_f);
+}
+
+int ceres_hip_get_ete_inverse(ceres_hip_solver* s, double* blocks, int64_t capacity) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  const int64_t len = h.diag_off_e.back();
+  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
+  if (s->path == CERES_HIP_PATH_BAL) {
+    double* tmp = nullptr;
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * len));
+    hipError_t e = LaunchExpandSym3(s->etei, tmp, nullptr, s->plan.n_points, s->stream);
+    int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "expand failed");
+    (void)hipFree(tmp);
+    return rc;
+  }
+  return down(s, blocks, s->etei, size_t(len));
+}
+
+int ceres_hip_op_schur_sx(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  TRY(up(s, s->cg.p, x, s->hs.num_cols_f));
+  TRY(op_sx(s, s->cg.p, s->cg.z, nullptr));
+  return down(s, y, s->cg.z, s->hs.num_cols_f);
+}
+
+int ceres_hip_op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  if (s->hs.num_cols_f > 0) TRY(up(s, s->cg.p, z, s->hs.num_cols_f));
+  TRY(op_back_substitute(s, s->hs.num_cols_f > 0 ? s->cg.p : nullptr, s->own_x));
+  return down(s, x, s->own_x, s->hs.num_cols);
+}
+
+int ceres_hip_op_block_jacobi_update(ceres_hip_solver* s) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (is_schur(s)) {
+    TRY(op_schur_init(s, false));
+    TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));
+  } else {
+    TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));
+  }
+  s->precond_valid = true;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_op_schur_jacobi_update(ceres_hip_solver* s) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  TRY(op_schur_init(s, true));
+  TRY(op_preconditioner(s, CERES_HIP_SCHUR_JACOBI, s->precond, true));
+  s->precond_valid = true;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_get_preconditioner_blocks(ceres_hip_solver* s, int32_t not_inverted, double* blocks, int64_t capacity) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  const int64_t len = is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back();
+  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
+  if (!not_inverted) {
+    if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
+    return down(s, blocks, s->precond, size_t(len));
+  }
+  // re-assemble without inverting, into a temporary
+  double* tmp = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * std::max<int64_t>(1, len)));
+  int type = s->opt.preconditioner_type == CERES_HIP_IDENTITY ? CERES_HIP_JACOBI : s->opt.preconditioner_type;
+  int rc = 0;
+  if (is_schur(s)) rc = op_schur_init(s, true);
+  if (!rc) rc = op_preconditioner(s, type, tmp, false);
+  if (!rc) rc = down(s, blocks, tmp, size_t(len));
+  (void)hipFree(tmp);
+  return rc;
+}
+
+int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
+  const HostStructure& h = s->hs;
+  const int n = is_schur(s) ? h.num_cols_f : h.num_cols;
+  TRY(up(s, s->cg.p, x, n));
+  TRY(up(s, s->cg.z, y, n));
+  if (is_schur(s))
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->precond, s->cg.p, s->cg.z, nullptr, s->stream));
+  else
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.ncb, s->G.diag_off_all, s->precond, s->cg.p, s->cg.z, nullptr, s->stream));
+  return down(s, y, s->cg.z, n);
+}
+
+int ceres_hip_op_schur_eliminate_dense(ceres_hip_solver* s, double* lhs, double* rhs) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  if (s->path != CERES_HIP_PATH_GENERIC) return fail(s, CERES_HIP_E_UNSUPPORTED, "dense elimination runs on the generic path: create the solver with force_generic_path = 1");
+  const HostStructure& h = s->hs;
+  TRY(op_schur_init(s, false));
+  const int64_t n = h.num_cols_f;
+  double* d_lhs = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d_lhs), sizeof(double) * std::max<int64_t>(1, n * n)));
+  hipError_t e = LaunchGenSchurDense(s->G, s->values, s->etei, s->D, d_lhs, s->stream);
+  int rc = e == hipSuccess ? down(s, lhs, d_lhs, size_t(n * n)) : fail(s, CERES_HIP_E_HIP, "dense Schur kernel failed");
+  (void)hipFree(d_lhs);
+  if (rc) return rc;
+  if (rhs && s->have_b) return down(s, rhs, s->rhs_f, size_t(n));
+  return 0;
+}
+
+int ceres_hip_op_eliminator_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
+  // SchurEliminator::BackSubstitute recomputes (E^T E + D^2)^-1 per chunk and applies it to
+  // E^T (b - F z): the same result as ImplicitSchurComplement::BackSubstitute after Init.
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  TRY(op_schur_init(s, false));
+  return ceres_hip_op_back_substitute(s, z, x);
+}
+
+int ceres_hip_op_dot(ceres_hip_solver* s, const double* x, const double* y, int64_t n, double* result) {
+  if (!s || !s->have_structure) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (n > s->hs.num_cols) return fail(s, CERES_HIP_E_INVALID, "n exceeds num_cols");
+  double *dx = s->scratch_vec, *dy = s->own_x;
+  TRY(up(s, dx, x, size_t(n)));
+  TRY(up(s, dy, y, size_t(n)));
+  HIP_TRY(s, LaunchDot(dx, dy, n, s->cg.partials, s->cg.comm, s->stream));
+  return down(s, result, s->cg.comm, 1);
+}
+
+int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b, const double* y, int64_t n, double* z) {
+  if (!s || !s->have_structure) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (n > s->hs.num_cols) return fail(s, CERES_HIP_E_INVALID, "n exceeds num_cols");
+  double *dx = s->scratch_vec, *dy = s->own_x;
+  TRY(up(s, dx, x, size_t(n)));
+  TRY(up(s, dy, y, size_t(n)));
+  HIP_TRY(s, LaunchAxpby(a, dx, b, dy, dy, n, s->stream));  // z may alias y (CG does both, I/conjugate_gradients_solver.h:190,220-226)
+  return down(s, z, dy, size_t(n));
+}
+
+int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (iters < 1 || !avg_ms) return CERES_HIP_E_INVALID;
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  const int64_t n = is_schur(s) ? h.num_cols_f : h.num_cols;
+  std::function<int()> body;
+  switch (op) {
+    case CERES_HIP_TIMED_JTJX:
+      if (is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "jtjx needs a CGNR instance");
+      body = [&] { return op_jtjx(s, s->cg.p, s->cg.z, nullptr); };
+      break;
+    case CERES_HIP_TIMED_SX:
+      if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "Sx needs an ITERATIVE_SCHUR instance");
+      TRY(op_schur_init(s, true));
+      body = [&] { return op_sx(s, s->cg.p, s->cg.z, nullptr); };
+      break;
+    case CERES_HIP_TIMED_SCHUR_INIT:
+      if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "needs an ITERATIVE_SCHUR instance");
+      body = [&] { return op_schur_init(s, true); };
+      break;
+    case CERES_HIP_TIMED_SCHUR_JACOBI:
+      if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "needs an ITERATIVE_SCHUR instance");
+      TRY(op_schur_init(s, true));
+      body = [&] { return op_preconditioner(s, CERES_HIP_SCHUR_JACOBI, s->precond, true); };
+      break;
+    case CERES_HIP_TIMED_BLOCK_JACOBI:
+      if (is_schur(s)) TRY(op_schur_init(s, false));
+      body = [&] { return op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true); };
+      break;
+    case CERES_HIP_TIMED_BACK_SUBSTITUTE:
+      if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "needs an ITERATIVE_SCHUR instance");
+      TRY(op_schur_init(s, false));
+      body = [&] { return op_back_substitute(s, s->cg.p, s->own_x); };
+      break;
+    case CERES_HIP_TIMED_PACK:
+      if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "pack exists on the <2,3,9> path only");
+      body = [&] { HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, st)); return 0; };
+      break;
+    case CERES_HIP_TIMED_COPY:
+      if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "copy probe uses the packed buffer of the <2,3,9> path");
+      body = [&] {
+        HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTile * 24), hipMemcpyDeviceToDevice, st));
+        return 0;
+      };
+      break;
+    default:
+      return fail(s, CERES_HIP_E_INVALID, "unknown timed op %d", op);
+  }
+  HIP_TRY(s, LaunchSet(s->cg.p, 1.0, n, st));
+  for (int w = 0; w < 3; ++w) TRY(body());
+  HIP_TRY(s, hipEventRecord(s->ev[8], st));
+  for (int i = 0; i < iters; ++i) TRY(body());
+  HIP_TRY(s, hipEventRecord(s->ev[9], st));
+  HIP_TRY(s, hipStreamSynchronize(st));
+  *avg_ms = double(elapsed(s->ev[8], s->ev[9])) / iters;
+  if (op == CERES_HIP_TIMED_COPY) TRY(load_device(s, s->values, s->b, s->D));  // restore the packed tiles
+  HIP_TRY(s, hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---- debug exports: the host-side packing plan, testable without a GPU -------
+int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t* eligible,
+                         int64_t* n_tiles, int32_t* slot_row_out, int32_t* slot_cam_out, int32_t* slot_pt_out,
+                         uint32_t* slot_seg_out, int32_t* tile_kind_out, int32_t* tile_aux_out, int64_t slot_capacity,
+                         char* why_not, int32_t why_capacity) {
+  HostStructure h;
+  std::string e = AnalyzeStructure(*bs, num_eliminate_blocks, &h);
+  if (!e.empty()) { if (why_not) snprintf(why_not, why_capacity, "%s", e.c_str()); *eligible = 0; return CERES_HIP_E_INVALID; }
+  BalPlan P;
+  BuildBalPlan(h, true, &P);
+  *eligible = P.eligible ? 1 : 0;
+  if (why_not) snprintf(why_not, why_capacity, "%s", P.why_not.c_str());
+  *n_tiles = P.n_tiles;
+  if (!P.eligible) return 0;
+  const int64_t n_slots = P.n_tiles * kTile;
+  if (slot_capacity < n_slots) return 0;  // caller only wanted the counts
+  for (int64_t i = 0; i < n_slots; ++i) {
+    slot_row_out[i] = P.slot_bpos[i] < 0 ? -1 : P.slot_bpos[i] / 2;
+    slot_cam_out[i] = P.slot_cam[i];
+    slot_pt_out[i] = P.slot_pt[i];
+    slot_seg_out[i] = P.slot_seg[i];
+  }
+  for (int64_t t = 0; t < P.n_tiles; ++t) { tile_kind_out[t] = P.tile_kind[t]; tile_aux_out[t] = P.tile_aux[t]; }
+  return 0;
+}
+
+}  // extern "C"

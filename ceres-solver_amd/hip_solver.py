@@ -1,0 +1,431 @@
+"""Python host side above the C ABI (include/ceres_hip.h).
+
+Mirrors the reference's plugin interface for this path — same names, argument meaning
+and error behaviour — so that the parity tests read like the reference's own tests:
+
+    LinearSolverOptions   ~ ceres::internal::LinearSolver::Options         internal/ceres/linear_solver.h:148-230
+    PerSolveOptions       ~ LinearSolver::PerSolveOptions                   internal/ceres/linear_solver.h:237-318
+    Summary               ~ LinearSolver::Summary                           internal/ceres/linear_solver.h:320-326
+    HipLinearSolver.solve ~ LinearSolver::Solve(A, b, per_solve_options, x) internal/ceres/linear_solver.h:339-342
+    create_linear_solver  ~ LinearSolver::Create incl. its fall-backs        internal/ceres/linear_solver.cc:51-126
+
+There is no CPU fall-back here: without libceres_hip.so or without a gfx950 device
+every constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char, c_char_p, c_double, c_int32, c_int64, c_uint8, c_uint32, c_void_p
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .block_structure import BlockStructure, CBlockStructure
+
+# enum values equal the reference's (include/ceres/types.h:57-141, internal/ceres/linear_solver.h:57-74)
+ITERATIVE_SCHUR, CGNR = 5, 6
+IDENTITY, JACOBI, SCHUR_JACOBI = 0, 1, 2
+SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
+PATH_GENERIC, PATH_BAL = 0, 1
+TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_ERROR"}
+UNIQUE_ID_BYTES = 128
+
+TIMED_JTJX, TIMED_SX, TIMED_SCHUR_INIT, TIMED_SCHUR_JACOBI, TIMED_BACK_SUBSTITUTE, TIMED_PACK, TIMED_BLOCK_JACOBI, TIMED_COPY = range(1, 9)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "csrc", "libceres_hip.so")
+
+
+class COptions(ctypes.Structure):
+    _fields_ = [("solver_type", c_int32), ("preconditioner_type", c_int32), ("min_num_iterations", c_int32),
+                ("max_num_iterations", c_int32), ("residual_reset_period", c_int32), ("num_eliminate_blocks", c_int32),
+                ("device", c_int32), ("force_generic_path", c_int32), ("cg_check_interval", c_int32),
+                ("reserved", c_int32 * 7)]
+
+
+class CSummary(ctypes.Structure):
+    _fields_ = [("residual_norm", c_double), ("num_iterations", c_int32), ("termination_type", c_int32),
+                ("message", c_char * 256)]
+
+
+class CInfo(ctypes.Structure):
+    _fields_ = [("kernel_path", c_int32), ("num_rows", c_int32), ("num_cols", c_int32), ("num_cols_e", c_int32),
+                ("num_cols_f", c_int32), ("num_row_blocks_e", c_int32), ("num_e_blocks", c_int32),
+                ("num_f_blocks", c_int32), ("row_block_size", c_int32), ("e_block_size", c_int32),
+                ("f_block_size", c_int32), ("num_nonzeros", c_int64), ("num_observations", c_int64),
+                ("num_tiles", c_int64), ("device_bytes", c_int64), ("camera_accum_in_lds", c_int32),
+                ("world_size", c_int32), ("rank", c_int32)]
+
+
+class CTiming(ctypes.Structure):
+    _fields_ = [("upload_ms", c_double), ("pack_ms", c_double), ("setup_ms", c_double), ("preconditioner_ms", c_double),
+                ("cg_ms", c_double), ("back_substitute_ms", c_double), ("download_ms", c_double), ("total_ms", c_double),
+                ("operator_applications", c_int32), ("reserved", c_int32)]
+
+
+# every symbol include/ceres_hip.h declares: (name, restype, argtypes)
+_DP = POINTER(c_double)
+ABI = [
+    ("ceres_hip_abi_version", c_int32, []),
+    ("ceres_hip_device_count", c_int32, []),
+    ("ceres_hip_create", c_void_p, [POINTER(COptions)]),
+    ("ceres_hip_destroy", None, [c_void_p]),
+    ("ceres_hip_last_error", c_char_p, [c_void_p]),
+    ("ceres_hip_set_structure", c_int32, [c_void_p, POINTER(CBlockStructure)]),
+    ("ceres_hip_get_info", c_int32, [c_void_p, POINTER(CInfo)]),
+    ("ceres_hip_comm_get_unique_id", c_int32, [POINTER(c_uint8)]),
+    ("ceres_hip_comm_init", c_int32, [c_void_p, POINTER(c_uint8), c_int32, c_int32]),
+    ("ceres_hip_solve", c_int32, [c_void_p, _DP, _DP, _DP, c_double, c_double, _DP, POINTER(CSummary)]),
+    ("ceres_hip_solve_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, POINTER(CSummary)]),
+    ("ceres_hip_load", c_int32, [c_void_p, _DP, _DP, _DP]),
+    ("ceres_hip_load_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("ceres_hip_op_right_multiply", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_left_multiply", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_squared_column_norm", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_op_jtjx", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_jtb", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_op_schur_init", c_int32, [c_void_p]),
+    ("ceres_hip_get_schur_rhs", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_get_ete_inverse", c_int32, [c_void_p, _DP, c_int64]),
+    ("ceres_hip_op_schur_sx", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_back_substitute", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_block_jacobi_update", c_int32, [c_void_p]),
+    ("ceres_hip_op_schur_jacobi_update", c_int32, [c_void_p]),
+    ("ceres_hip_get_preconditioner_blocks", c_int32, [c_void_p, c_int32, _DP, c_int64]),
+    ("ceres_hip_op_precond_apply", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_schur_eliminate_dense", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_eliminator_back_substitute", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_dot", c_int32, [c_void_p, _DP, _DP, c_int64, _DP]),
+    ("ceres_hip_op_axpby", c_int32, [c_void_p, c_double, _DP, c_double, _DP, c_int64, _DP]),
+    ("ceres_hip_time_op", c_int32, [c_void_p, c_int32, c_int32, _DP]),
+    ("ceres_hip_get_last_timing", c_int32, [c_void_p, POINTER(CTiming)]),
+    ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
+                                       POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
+                                       POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen csrc/libceres_hip.so and bind every ABI symbol; raises if anything is missing."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first; "
+                               "there is no fall-back implementation")
+        lib = ctypes.CDLL(path)
+        for name, restype, argtypes in ABI:
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.ceres_hip_abi_version() != 1:
+            raise RuntimeError("ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def device_count() -> int:
+    return int(load_library().ceres_hip_device_count())
+
+
+class HipError(RuntimeError):
+    pass
+
+
+@dataclass
+class LinearSolverOptions:
+    """LinearSolver::Options (internal/ceres/linear_solver.h:148-230), the fields this path reads."""
+    type: int = ITERATIVE_SCHUR
+    preconditioner_type: int = JACOBI
+    min_num_iterations: int = 1          # reference default
+    max_num_iterations: int = 1          # reference default (!); callers set it
+    residual_reset_period: int = 10
+    elimination_groups: List[int] = field(default_factory=list)
+    # device-side knobs (not in the reference)
+    device: int = 0
+    force_generic_path: bool = False
+    cg_check_interval: int = 0
+
+
+@dataclass
+class PerSolveOptions:
+    """LinearSolver::PerSolveOptions (internal/ceres/linear_solver.h:237-318)."""
+    D: Optional[np.ndarray] = None
+    q_tolerance: float = 0.0
+    r_tolerance: float = 0.0
+
+
+@dataclass
+class Summary:
+    residual_norm: float = -1.0
+    num_iterations: int = -1
+    termination_type: int = FAILURE
+    message: str = ""
+
+    @property
+    def termination_name(self):
+        return TERMINATION_NAMES.get(self.termination_type, "?")
+
+
+def _f64(a, n=None, name="array"):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.shape[0] < n:
+        raise ValueError(f"{name} has {a.shape[0]} elements, need {n}")
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+class HipLinearSolver:
+    """One device-resident solver instance = one ceres::internal::LinearSolver object.
+
+    The structure is set once (the reference guarantees constant sparsity per instance,
+    internal/ceres/linear_solver.h:137-142); each `solve` uploads values / b / D and returns x.
+    """
+
+    def __init__(self, options: LinearSolverOptions, comm_id: Optional[bytes] = None, rank: int = 0,
+                 world_size: int = 1):
+        self._lib = load_library()
+        self.options = options
+        nelim = options.elimination_groups[0] if options.elimination_groups else 0
+        c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
+                     options.max_num_iterations, options.residual_reset_period, nelim, options.device,
+                     int(options.force_generic_path), options.cg_check_interval)
+        self._h = self._lib.ceres_hip_create(byref(c))
+        if not self._h:
+            raise HipError(self._lib.ceres_hip_last_error(None).decode())
+        self.bs = None
+        if world_size > 1:
+            buf = (c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(comm_id)
+            self._check(self._lib.ceres_hip_comm_init(self._h, buf, rank, world_size))
+
+    # -- plumbing ----------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise HipError(f"ceres_hip error {rc}: {self._lib.ceres_hip_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ceres_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- structure ---------------------------------------------------------
+    def set_structure(self, bs: BlockStructure):
+        self.bs = bs
+        self._cbs = bs.as_ctypes()
+        self._check(self._lib.ceres_hip_set_structure(self._h, byref(self._cbs)))
+        self._info = self.info()
+
+    def info(self) -> CInfo:
+        i = CInfo()
+        self._check(self._lib.ceres_hip_get_info(self._h, byref(i)))
+        return i
+
+    # -- the boundary call -------------------------------------------------
+    def solve(self, values, b, per_solve_options: PerSolveOptions = PerSolveOptions()):
+        """LinearSolver::Solve.  Returns (x, Summary).  x is pre-poisoned with NaN like the
+        caller does (internal/ceres/levenberg_marquardt_strategy.cc:110)."""
+        n = self._info
+        values = _f64(values, self.bs.values_extent(), "values")
+        b = _f64(b, n.num_rows, "b")
+        D = _f64(per_solve_options.D, n.num_cols, "D")
+        x = np.full(n.num_cols, np.nan)
+        s = CSummary()
+        rc = self._lib.ceres_hip_solve(self._h, _p(values), _p(b), _p(D), per_solve_options.q_tolerance,
+                                       per_solve_options.r_tolerance, _p(x), byref(s))
+        summary = Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace"))
+        if rc != 0:
+            summary.termination_type = FATAL_ERROR
+            summary.message = self._lib.ceres_hip_last_error(self._h).decode()
+        return x, summary
+
+    def solve_device(self, d_values: int, d_b: int, d_D: int, d_x: int, q_tolerance=0.0, r_tolerance=0.0):
+        """Same with raw device pointers (e.g. torch tensor .data_ptr()); nothing crosses PCIe."""
+        s = CSummary()
+        rc = self._lib.ceres_hip_solve_device(self._h, d_values, d_b, d_D or None, q_tolerance, r_tolerance, d_x, byref(s))
+        summary = Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace"))
+        if rc != 0:
+            summary.termination_type = FATAL_ERROR
+            summary.message = self._lib.ceres_hip_last_error(self._h).decode()
+        return summary
+
+    def last_timing(self) -> CTiming:
+        t = CTiming()
+        self._check(self._lib.ceres_hip_get_last_timing(self._h, byref(t)))
+        return t
+
+    # -- operator level ----------------------------------------------------
+    def load(self, values, b=None, D=None):
+        n = self._info
+        self._keep = (_f64(values, self.bs.values_extent(), "values"), _f64(b, n.num_rows, "b"), _f64(D, n.num_cols, "D"))
+        self._check(self._lib.ceres_hip_load(self._h, *map(_p, self._keep)))
+
+    def load_device(self, d_values: int, d_b: int = 0, d_D: int = 0):
+        self._check(self._lib.ceres_hip_load_device(self._h, d_values, d_b or None, d_D or None))
+
+    def _xy(self, fn, x, n_out, y=None):
+        x = _f64(x)
+        y = np.zeros(n_out) if y is None else _f64(y).copy()
+        self._check(fn(self._h, _p(x), _p(y)))
+        return y
+
+    def right_multiply(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_right_multiply, x, self._info.num_rows, y)
+
+    def left_multiply(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_left_multiply, x, self._info.num_cols, y)
+
+    def squared_column_norm(self):
+        out = np.zeros(self._info.num_cols)
+        self._check(self._lib.ceres_hip_op_squared_column_norm(self._h, _p(out)))
+        return out
+
+    def jtjx(self, x):
+        return self._xy(self._lib.ceres_hip_op_jtjx, x, self._info.num_cols, np.full(self._info.num_cols, np.nan))
+
+    def jtb(self):
+        out = np.full(self._info.num_cols, np.nan)
+        self._check(self._lib.ceres_hip_op_jtb(self._h, _p(out)))
+        return out
+
+    def schur_init(self):
+        self._check(self._lib.ceres_hip_op_schur_init(self._h))
+
+    def schur_rhs(self):
+        out = np.full(self._info.num_cols_f, np.nan)
+        self._check(self._lib.ceres_hip_get_schur_rhs(self._h, _p(out)))
+        return out
+
+    def ete_inverse(self):
+        sizes = self.bs.col_block_size[: self._info.num_e_blocks].astype(np.int64)
+        out = np.full(int((sizes ** 2).sum()), np.nan)
+        self._check(self._lib.ceres_hip_get_ete_inverse(self._h, _p(out), out.shape[0]))
+        return out
+
+    def schur_sx(self, x):
+        return self._xy(self._lib.ceres_hip_op_schur_sx, x, self._info.num_cols_f, np.full(self._info.num_cols_f, np.nan))
+
+    def back_substitute(self, z):
+        z = _f64(z) if z is not None else np.zeros(1)
+        x = np.full(self._info.num_cols, np.nan)
+        self._check(self._lib.ceres_hip_op_back_substitute(self._h, _p(z), _p(x)))
+        return x
+
+    def block_jacobi_update(self):
+        self._check(self._lib.ceres_hip_op_block_jacobi_update(self._h))
+
+    def schur_jacobi_update(self):
+        self._check(self._lib.ceres_hip_op_schur_jacobi_update(self._h))
+
+    def preconditioner_blocks(self, not_inverted=False):
+        i = self._info
+        sizes = self.bs.col_block_size.astype(np.int64)
+        if self.options.type == ITERATIVE_SCHUR:
+            sizes = sizes[i.num_e_blocks:]
+        out = np.full(int((sizes ** 2).sum()), np.nan)
+        self._check(self._lib.ceres_hip_get_preconditioner_blocks(self._h, int(not_inverted), _p(out), out.shape[0]))
+        return out
+
+    def precond_apply(self, x, y=None):
+        n = self._info.num_cols_f if self.options.type == ITERATIVE_SCHUR else self._info.num_cols
+        return self._xy(self._lib.ceres_hip_op_precond_apply, x, n, y)
+
+    def schur_eliminate_dense(self, want_rhs=True):
+        n = self._info.num_cols_f
+        lhs, rhs = np.full(n * n, np.nan), (np.full(n, np.nan) if want_rhs else None)
+        self._check(self._lib.ceres_hip_op_schur_eliminate_dense(self._h, _p(lhs), _p(rhs)))
+        return lhs.reshape(n, n), rhs
+
+    def eliminator_back_substitute(self, z):
+        x = np.full(self._info.num_cols, np.nan)
+        self._check(self._lib.ceres_hip_op_eliminator_back_substitute(self._h, _p(_f64(z)), _p(x)))
+        return x
+
+    def dot(self, x, y):
+        x, y = _f64(x), _f64(y)
+        out = np.zeros(1)
+        self._check(self._lib.ceres_hip_op_dot(self._h, _p(x), _p(y), x.shape[0], _p(out)))
+        return float(out[0])
+
+    def axpby(self, a, x, b, y):
+        x, y = _f64(x), _f64(y)
+        z = np.zeros_like(x)
+        self._check(self._lib.ceres_hip_op_axpby(self._h, a, _p(x), b, _p(y), x.shape[0], _p(z)))
+        return z
+
+    def time_op(self, op: int, iters: int = 20) -> float:
+        """Average milliseconds per application (HIP events on the solver's stream)."""
+        out = np.zeros(1)
+        self._check(self._lib.ceres_hip_time_op(self._h, op, iters, _p(out)))
+        return float(out[0])
+
+
+def comm_unique_id() -> bytes:
+    buf = (c_uint8 * UNIQUE_ID_BYTES)()
+    rc = load_library().ceres_hip_comm_get_unique_id(buf)
+    if rc != 0:
+        raise HipError(f"ncclGetUniqueId failed ({rc})")
+    return bytes(buf)
+
+
+def create_linear_solver(options: LinearSolverOptions, bs: BlockStructure, **kw) -> HipLinearSolver:
+    """LinearSolver::Create with the reference's fall-backs (internal/ceres/linear_solver.cc:51-73,
+    internal/ceres/preconditioner.cc:39-47): ITERATIVE_SCHUR without eliminated blocks becomes CGNR,
+    and SCHUR_JACOBI becomes JACOBI with it."""
+    import copy
+    o = copy.copy(options)
+    nelim = o.elimination_groups[0] if o.elimination_groups else 0
+    if o.type == ITERATIVE_SCHUR and nelim == 0:
+        o.type = CGNR
+        if o.preconditioner_type == SCHUR_JACOBI:
+            o.preconditioner_type = JACOBI
+    s = HipLinearSolver(o, **kw)
+    s.set_structure(bs)
+    return s
+
+
+def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
+    """The host-side tile packing plan (no device needed).  Returns a dict or {'eligible': False, 'why': ...}."""
+    lib = load_library()
+    c = bs.as_ctypes()
+    eligible, n_tiles = c_int32(), c_int64()
+    why = ctypes.create_string_buffer(256)
+    null32, nullu = POINTER(c_int32)(), POINTER(c_uint32)()
+    rc = lib.ceres_hip_debug_plan(byref(c), num_eliminate_blocks, byref(eligible), byref(n_tiles), null32, null32, null32,
+                                  nullu, null32, null32, 0, why, 256)
+    if rc != 0 or not eligible.value:
+        return {"eligible": False, "why": why.value.decode()}
+    nt = n_tiles.value
+    ns = nt * 64
+    row, cam, pt = (np.zeros(ns, np.int32) for _ in range(3))
+    seg = np.zeros(ns, np.uint32)
+    kind, aux = np.zeros(nt, np.int32), np.zeros(nt, np.int32)
+    ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
+    rc = lib.ceres_hip_debug_plan(byref(c), num_eliminate_blocks, byref(eligible), byref(n_tiles), ip(row), ip(cam), ip(pt),
+                                  seg.ctypes.data_as(POINTER(c_uint32)), ip(kind), ip(aux), ns, why, 256)
+    assert rc == 0
+    return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
+            "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tile_kind": kind, "tile_aux": aux}

@@ -268,6 +268,15 @@ typedef struct ceres_hip_solve_timing {
 } ceres_hip_solve_timing;
 int ceres_hip_get_last_timing(const ceres_hip_solver* s, ceres_hip_solve_timing* t);
 
+/* ---- debug: the host-side tile packing plan of the <2,3,9> path -------------
+ * Pure host code (no device needed): lets the CPU test-suite check the plan the
+ * fused kernels rely on.  Arrays are sized n_tiles*64 (slots) / n_tiles; call once
+ * with slot_capacity = 0 to obtain n_tiles.  slot_row = row block of the slot or -1. */
+int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t* eligible,
+                         int64_t* n_tiles, int32_t* slot_row, int32_t* slot_cam, int32_t* slot_pt,
+                         uint32_t* slot_seg, int32_t* tile_kind, int32_t* tile_aux, int64_t slot_capacity,
+                         char* why_not, int32_t why_capacity);
+
 #ifdef __cplusplus
 }
 #endif

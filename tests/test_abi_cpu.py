@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/ceres_hip.h declares,
+and refuses to run without a device (no CPU fall-back).  No compute calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ceres_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ceres_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    hs = pkg.hip_solver
+    lib = hs.load_library()
+    declared = declared_symbols()
+    bound = sorted(name for name, _, _ in hs.ABI)
+    assert declared == bound, (set(declared) ^ set(bound))
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ceres_hip_abi_version() == 1
+
+
+def test_enums_match_reference_values():
+    hs = pkg.hip_solver
+    # include/ceres/types.h:57-141, internal/ceres/linear_solver.h:57-74
+    assert (hs.ITERATIVE_SCHUR, hs.CGNR) == (5, 6)
+    assert (hs.IDENTITY, hs.JACOBI, hs.SCHUR_JACOBI) == (0, 1, 2)
+    assert (hs.SUCCESS, hs.NO_CONVERGENCE, hs.FAILURE, hs.FATAL_ERROR) == (0, 1, 2, 3)
+    text = open(os.path.join(ROOT, "include", "ceres_hip.h")).read()
+    for name, val in (("CERES_HIP_ITERATIVE_SCHUR", 5), ("CERES_HIP_CGNR", 6), ("CERES_HIP_SCHUR_JACOBI", 2),
+                      ("CERES_HIP_FATAL_ERROR", 3)):
+        assert re.search(rf"#define {name} {val}\b", text)
+
+
+def test_no_device_means_loud_failure():
+    hs = pkg.hip_solver
+    if hs.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hs.HipError) as e:
+        hs.HipLinearSolver(hs.LinearSolverOptions(type=hs.CGNR, max_num_iterations=5))
+    assert "no HIP device" in str(e.value) or "no CPU fallback" in str(e.value)
+
+
+def test_option_validation_before_device():
+    hs = pkg.hip_solver
+    # CGNR + SCHUR_JACOBI is rejected like CgnrSolver's constructor does (internal/ceres/cgnr_solver.cc:119-128)
+    with pytest.raises(hs.HipError) as e:
+        hs.HipLinearSolver(hs.LinearSolverOptions(type=hs.CGNR, preconditioner_type=hs.SCHUR_JACOBI, max_num_iterations=5))
+    assert "preconditioner_type" in str(e.value)
+    with pytest.raises(hs.HipError):
+        hs.HipLinearSolver(hs.LinearSolverOptions(type=3, max_num_iterations=5))  # DENSE_SCHUR: not this path
+
+
+def test_product_does_not_import_the_oracle():
+    # the oracle is test infrastructure: nothing under ceres-solver_amd/ may reference it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ceres-solver_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".cc", ".hip")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "libceres_oracle" not in src and "ceres_oracle.h" not in src and "oracle_" not in src, f

@@ -1,0 +1,160 @@
+"""Rungs (2)-(4) of the parity ladder for the two LinearSolver implementations,
+through the C ABI on a real MI355X."""
+import numpy as np
+import pytest
+
+from test_gpu_operators import make_solver, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_solve(oracle, p, solver_type, hip, pre, **kw):
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks if solver_type == hip.ITERATIVE_SCHUR else 0)
+    fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m.cgnr_solve
+    return fn(p.values, p.b, p.D, preconditioner=pre, **kw)
+
+
+def hip_solve(hip, p, solver_type, pre, q_tol, r_tol, force_generic=False, **kw):
+    s = make_solver(hip, p, solver_type, pre, force_generic, **kw)
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=q_tol, r_tolerance=r_tol))
+    path = s.info().kernel_path
+    s.close()
+    return x, summ, path
+
+
+@pytest.mark.parametrize("pid", [2, 4, 5, 6])
+def test_known_answer_problems_vs_dense(hip, oracle, problems, pid):
+    # internal/ceres/iterative_schur_complement_solver_test.cc:75-117: r_tolerance 1e-12,
+    # max iterations = num_cols, compare with a dense solve
+    p = problems.linear_least_squares_problem(pid)
+    A = p.bs.to_dense(p.values)
+    ref = np.linalg.lstsq(np.vstack([A, np.diag(p.D)]), np.concatenate([p.b, np.zeros(p.num_cols)]), rcond=None)[0]
+    for pre in (hip.IDENTITY, hip.JACOBI, hip.SCHUR_JACOBI):
+        x, s, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, pre, 0.0, 1e-12, max_it=p.num_cols)
+        assert np.linalg.norm(x - ref) < 1e-12 * max(1.0, np.linalg.norm(ref)), (pre, s)
+    for pre in (hip.IDENTITY, hip.JACOBI):
+        x, s, _ = hip_solve(hip, p, hip.CGNR, pre, 0.0, 1e-14, max_it=4 * p.num_cols)
+        assert np.linalg.norm(x - ref) < 1e-10 * max(1.0, np.linalg.norm(ref)), (pre, s)
+    if p.known.get("x") is not None and pid in (2, 5):
+        q = type(p)(p.bs, p.values, p.b, None, p.num_eliminate_blocks)
+        x, s, _ = hip_solve(hip, q, hip.ITERATIVE_SCHUR, hip.JACOBI, 0.0, 1e-14, max_it=50)
+        np.testing.assert_allclose(x, p.known["x"], atol=1.1e-4)  # the reference's 4-digit A\b
+
+
+def test_no_f_blocks_shortcut(hip, oracle, problems):
+    # problem 3: num_schur_complement_blocks == 0 (iterative_schur_complement_solver.cc:88-95)
+    p = problems.linear_least_squares_problem(3)
+    x, s, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.0, 0.0, max_it=5)
+    assert s.termination_type == hip.SUCCESS and s.num_iterations == 0
+    A = p.bs.to_dense(p.values)
+    np.testing.assert_allclose(x, np.linalg.solve(A.T @ A + np.diag(p.D ** 2), A.T @ p.b), rtol=1e-13)
+
+
+SOLVER_CASES = [("schur", 5, 2), ("schur", 5, 1), ("schur", 5, 0), ("cgnr", 6, 1), ("cgnr", 6, 0), ("schur", 6, 1)]
+
+
+@pytest.mark.parametrize("layout,solver_type,pre", SOLVER_CASES)
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_fixed_iteration_count_matches_oracle(hip, oracle, problems, layout, solver_type, pre, force_generic):
+    # rung (2): min = max = k iterations, solution rel-l2 <= 1e-9
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=40, num_points=3000, num_observations=14000, seed=12)
+    if solver_type == hip.CGNR:
+        p.num_eliminate_blocks = 0 if layout == "cgnr" else p.num_eliminate_blocks
+    for k in (1, 7, 25):  # 25 crosses two residual resets (period 10)
+        x, s, path = hip_solve(hip, p, solver_type, pre, 0.0, 0.0, force_generic, min_it=k, max_it=k)
+        xo, so = oracle_solve(oracle, p, solver_type, hip, pre, min_it=k, max_it=k, q_tol=0.0, r_tol=0.0)
+        assert path == (hip.PATH_GENERIC if force_generic else hip.PATH_BAL)
+        assert (s.termination_type, s.num_iterations) == (so.termination_type, so.num_iterations), (s, so)
+        assert rel(x, xo) <= 1e-9, (k, rel(x, xo))
+
+
+@pytest.mark.parametrize("layout,solver_type,pre", SOLVER_CASES)
+def test_converged_solve_matches_oracle_and_dense(hip, oracle, problems, layout, solver_type, pre):
+    # rung (3): r_tolerance = 1e-12, large max; step vs oracle <= 1e-8 and vs dense <= 1e-8 (CGNR: cond-limited)
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=8, num_points=60, num_observations=260, seed=13)
+    if solver_type == hip.CGNR and layout == "cgnr":
+        p.num_eliminate_blocks = 0
+    x, s, _ = hip_solve(hip, p, solver_type, pre, 0.0, 1e-12, max_it=2000)
+    xo, so = oracle_solve(oracle, p, solver_type, hip, pre, max_it=2000, q_tol=0.0, r_tol=1e-12)
+    assert s.termination_type == hip.SUCCESS == so.termination_type, (s, so)
+    A = p.bs.to_dense(p.values)
+    ref = np.linalg.solve(A.T @ A + np.diag(p.D ** 2), A.T @ p.b)
+    tol = 1e-8 if solver_type == hip.ITERATIVE_SCHUR else 1e-6
+    assert rel(x, xo) <= tol and rel(x, ref) <= tol, (rel(x, xo), rel(x, ref))
+
+
+@pytest.mark.parametrize("layout,solver_type,pre", [("schur", 5, 2), ("cgnr", 6, 1)])
+def test_default_eta_termination(hip, oracle, problems, layout, solver_type, pre):
+    # rung (4) at the linear-solve level: LM's call, q_tolerance = eta = 0.1, r_tolerance = -1.
+    # Same termination type; iteration count within +-1 (summation order may move the zeta test).
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=60, num_points=5000, num_observations=24000, seed=14, skew=0.5)
+    if layout == "cgnr":
+        p.num_eliminate_blocks = 0
+    x, s, _ = hip_solve(hip, p, solver_type, pre, 0.1, -1.0, max_it=500, min_it=0)
+    xo, so = oracle_solve(oracle, p, solver_type, hip, pre, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+    assert s.termination_type == so.termination_type == hip.SUCCESS, (s, so)
+    assert abs(s.num_iterations - so.num_iterations) <= 1, (s, so)
+    assert "zeta" in s.message and "zeta" in so.message
+    if s.num_iterations == so.num_iterations:
+        assert rel(x, xo) <= 1e-9
+
+
+def test_summary_edge_cases(hip, oracle, problems):
+    p = problems.synthetic_bal(None, num_cameras=10, num_points=300, num_observations=1300, seed=15)
+    # |b| = 0  ->  x = 0, SUCCESS, "Convergence. |b| = 0."   (conjugate_gradients_solver.h:130-136)
+    q = type(p)(p.bs, p.values, np.zeros_like(p.b), p.D, p.num_eliminate_blocks)
+    for solver_type, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        x, s, _ = hip_solve(hip, q, solver_type, pre, 0.1, -1.0, max_it=10)
+        assert s.termination_type == hip.SUCCESS and "|b| = 0" in s.message and not x.any(), s
+    # max iterations  ->  NO_CONVERGENCE and the step is still returned, finite
+    x, s, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.IDENTITY, 0.0, 1e-30, max_it=3)
+    assert s.termination_type == hip.NO_CONVERGENCE and s.num_iterations == 3 and "Maximum number" in s.message
+    assert np.isfinite(x).all()
+    # polling interval does not change the result
+    xa, sa, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, max_it=100, cg_check_interval=1)
+    xb, sb, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, max_it=100, cg_check_interval=16)
+    assert sa.num_iterations == sb.num_iterations and np.array_equal(xa, xb)
+
+
+def test_device_resident_solve_with_torch(hip, problems):
+    # ceres_hip_solve_device: all four arrays already in HBM (the form bench.py times)
+    import torch
+    p = problems.synthetic_bal(None, num_cameras=30, num_points=2500, num_observations=11000, seed=16)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=200)
+    xh, sh = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    dev = torch.device("cuda:0")
+    tv, tb, tD = (torch.from_numpy(a).to(dev) for a in (p.values, p.b, p.D))
+    tx = torch.full((p.num_cols,), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    sd = s.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+    assert (sd.termination_type, sd.num_iterations) == (sh.termination_type, sh.num_iterations)
+    assert np.array_equal(tx.cpu().numpy(), xh)
+    s.close()
+
+
+def test_lm_loop_with_hip_linear_solver(hip, oracle):
+    # rung (4): the LM loop (oracle/bal_harness.cc restating trust_region_minimizer.cc) driven once by
+    # the oracle's ITERATIVE_SCHUR and once by ceres_hip_solve: same accept/reject sequence, final
+    # cost within 1e-6 relative, CG iteration counts within +-1 per linear solve.
+    prob_a = oracle.BalProblem.generate(12, 800, 3600, seed=5)
+    prob_b = oracle.BalProblem.generate(12, 800, 3600, seed=5)
+    bs, nelim = prob_a.build_structure(True)
+    prob_b.build_structure(True)
+    Sa = prob_a.lm_solve(solver_type=5, preconditioner=2, max_it=500, max_num_iterations=12)
+    o = hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, min_num_iterations=0,
+                                max_num_iterations=500, elimination_groups=[nelim])
+    solver = hip.HipLinearSolver(o)
+    solver.set_structure(bs)
+
+    def solve(values, b, D, q_tol, r_tol):
+        x, s = solver.solve(values, b, hip.PerSolveOptions(D=D, q_tolerance=q_tol, r_tolerance=r_tol))
+        return x, s.termination_type, s.num_iterations
+    Sb = prob_b.lm_solve(solve_fn=solve, max_num_iterations=12)
+    solver.close()
+    assert Sa.num_iterations_logged == Sb.num_iterations_logged
+    for i in range(Sa.num_iterations_logged):
+        a, b = Sa.iterations[i], Sb.iterations[i]
+        assert a.step_is_successful == b.step_is_successful and a.step_is_valid == b.step_is_valid, i
+        assert abs(a.linear_solver_iterations - b.linear_solver_iterations) <= 1, i
+    assert Sa.final_cost < 0.5 * Sa.initial_cost
+    assert abs(Sa.final_cost - Sb.final_cost) <= 1e-6 * Sa.final_cost, (Sa.final_cost, Sb.final_cost)

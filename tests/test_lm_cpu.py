@@ -1,0 +1,61 @@
+"""The caller of the boundary restated (oracle/bal_harness.cc): synthetic BAL scene, Snavely
+residual with dual-number Jacobians, LM loop.  CPU only; pins the harness the GPU tests drive."""
+import numpy as np
+
+
+def test_jacobian_matches_finite_differences(oracle):
+    prob = oracle.BalProblem.generate(5, 40, 160, seed=3)
+    bs, nelim = prob.build_structure(True)
+    x = prob.state()
+    cost, res, vals = prob.evaluate(x)
+    assert abs(cost - 0.5 * res @ res) < 1e-12 * cost
+    J = bs.to_dense(vals)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        d = rng.standard_normal(x.shape[0]) * 1e-6
+        _, r1, _ = prob.evaluate(x + d, jacobian=False)
+        _, r0, _ = prob.evaluate(x - d, jacobian=False)
+        np.testing.assert_allclose((r1 - r0) / 2, J @ d, rtol=0, atol=1e-9 * np.abs(J @ d).max() + 1e-13)
+
+
+def test_two_layouts_describe_the_same_problem(oracle):
+    prob = oracle.BalProblem.generate(6, 50, 210, seed=4)
+    bs_s, nelim = prob.build_structure(True)
+    xs = prob.state()
+    cs, rs, vs = prob.evaluate(xs)
+    Js = bs_s.to_dense(vs)
+    bs_c, zero = prob.build_structure(False)
+    assert zero == 0 and nelim == 50
+    xc = prob.state()
+    cc, rc, vc = prob.evaluate(xc)
+    Jc = bs_c.to_dense(vc)
+    assert abs(cs - cc) < 1e-12 * cs
+    # same singular values: one is a row/column permutation of the other
+    np.testing.assert_allclose(np.linalg.svd(Js, compute_uv=False), np.linalg.svd(Jc, compute_uv=False), rtol=0, atol=1e-9 * np.abs(Js).max())  # 7 gauge directions are ~0
+    # first column block of the CGNR layout is a camera (first use order), sizes interleave
+    assert bs_c.col_block_size[0] == 9 and bs_c.col_block_size[1] == 3
+
+
+def test_bal_file_round_trip(oracle, tmp_path):
+    prob = oracle.BalProblem.generate(4, 30, 100, seed=6)
+    f = str(tmp_path / "problem.txt")
+    assert prob.write(f) == 0
+    back = oracle.BalProblem.read(f)
+    assert (back.num_cameras, back.num_points, back.num_observations) == (4, 30, 100)
+    prob.build_structure(True)
+    back.build_structure(True)
+    np.testing.assert_allclose(back.state(), prob.state(), rtol=1e-15)
+    assert abs(back.evaluate(back.state())[0] - prob.evaluate(prob.state())[0]) < 1e-9
+
+
+def test_lm_reduces_cost_with_both_solvers(oracle):
+    costs = {}
+    for name, schur, st, pre in (("iterative_schur", True, 5, 2), ("cgnr", False, 6, 1)):
+        prob = oracle.BalProblem.generate(10, 400, 1800, seed=5)
+        prob.build_structure(schur)
+        S = prob.lm_solve(solver_type=st, preconditioner=pre, max_it=500, max_num_iterations=15)
+        assert S.num_successful_steps >= 3
+        assert S.final_cost < 0.2 * S.initial_cost, (name, S.initial_cost, S.final_cost, S.message)
+        costs[name] = S.final_cost
+    # both solvers minimise the same function: final costs close (inexact Newton, so not identical)
+    assert abs(costs["cgnr"] - costs["iterative_schur"]) < 0.05 * costs["cgnr"]

@@ -1,0 +1,133 @@
+"""Host logic of the <2,3,9> path: the tile packing plan (csrc/plan.cc) checked on CPU, and the
+packed formulation the fused kernels implement (per-point segment sums, per-camera scatter)
+emulated in numpy against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+
+def plan_of(p):
+    return pkg.hip_solver.debug_plan(p.bs, p.num_eliminate_blocks)
+
+
+def check_plan_invariants(p, plan):
+    assert plan["eligible"]
+    nt = plan["n_tiles"]
+    row, pt, cam = plan["slot_row"], plan["slot_pt"], plan["slot_cam"]
+    valid = plan["valid"].astype(bool)
+    # every row block appears exactly once
+    assert np.array_equal(np.sort(row[valid]), np.arange(p.bs.num_row_blocks))
+    assert (row[~valid] == -1).all() and (pt[~valid] == -1).all()
+    first, last = plan["seg_first"].astype(int), plan["seg_last"].astype(int)
+    lane = np.tile(np.arange(64), nt)
+    assert (first <= lane).all() and (lane <= last).all() and (last < 64).all()
+    kind, aux = plan["tile_kind"], plan["tile_aux"]
+    # inside a normal tile a segment is exactly one whole point
+    track = np.bincount(pt[valid])
+    for t in np.flatnonzero(kind == 0):
+        sl = slice(t * 64, t * 64 + 64)
+        v = valid[sl]
+        pts = pt[sl][v]
+        assert (np.diff(pts) >= 0).all()
+        for q in np.unique(pts):
+            lanes = np.flatnonzero(v & (pt[sl] == q))
+            assert len(lanes) == track[q] <= 64
+            assert (first[sl][lanes] == lanes[0]).all() and (last[sl][lanes] == lanes[-1]).all()
+            assert np.array_equal(lanes, np.arange(lanes[0], lanes[-1] + 1))
+        longest = max(np.bincount(pts).max(), 1)
+        assert aux[t] == longest
+    # a long point owns its tiles
+    t = 0
+    while t < nt:
+        if kind[t] == 1:
+            n = aux[t]
+            assert n >= 2 and (kind[t + 1:t + n] == 2).all()
+            sl = slice(t * 64, (t + n) * 64)
+            q = np.unique(pt[sl][valid[sl]])
+            assert len(q) == 1 and track[q[0]] == valid[sl].sum() > 64
+            t += n
+        else:
+            assert kind[t] == 0
+            t += 1
+    # cameras of one point are distinct
+    key = pt[valid].astype(np.int64) * (cam.max() + 1) + cam[valid]
+    assert len(np.unique(key)) == valid.sum()
+    return track
+
+
+@pytest.mark.parametrize("layout", ["schur", "cgnr"])
+def test_plan_invariants_and_padding(problems, layout):
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=40, num_points=2500, num_observations=11000, seed=5)
+    plan = plan_of(p)
+    track = check_plan_invariants(p, plan)
+    waste = 1.0 - p.bs.num_row_blocks / (plan["n_tiles"] * 64)
+    assert waste < 0.08, waste
+
+
+def test_plan_long_points(problems):
+    # a few cameras-heavy points: tracks of 65..200 observations
+    p = problems.synthetic_bal(None, num_cameras=220, num_points=300, num_observations=9000, seed=9, skew=0.0)
+    plan = plan_of(p)
+    track = check_plan_invariants(p, plan)
+    assert (plan["tile_kind"] == 1).sum() == (track > 64).sum()
+
+
+def test_plan_rejections(problems):
+    hs = pkg.hip_solver
+    assert not hs.debug_plan(problems.linear_least_squares_problem(2).bs, 2)["eligible"]
+    p = problems.random_schur_problem(static_sizes=(2, 3, 6), seed=1)
+    r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
+    assert not r["eligible"] and "9 wide" in r["why"]
+    # a point that sees the same camera twice cannot use the fused SCHUR_JACOBI kernel
+    q = problems.synthetic_bal(None, num_cameras=5, num_points=6, num_observations=14, seed=2)
+    cc = q.bs.cell_col_block.copy()
+    cc[3] = cc[1]  # second observation of point 0 -> same camera as the first
+    from ceres_solver_amd import BlockStructure
+    bad = BlockStructure(q.bs.row_block_size, q.bs.row_block_pos, q.bs.col_block_size, q.bs.col_block_pos, q.bs.row_cell_ptr,
+                         cc, q.bs.cell_value_pos)
+    r = hs.debug_plan(bad, q.num_eliminate_blocks)
+    assert not r["eligible"] and "twice" in r["why"]
+
+
+def test_packed_formulation_matches_oracle(oracle, problems):
+    """S x computed the way the fused kernel does it (segment sum of E^T F x over the slots of a
+    point, 3x3 inverse, per-observation correction, scatter by camera) equals the oracle's
+    four-pass ImplicitSchurComplement product."""
+    p = problems.synthetic_bal(None, num_cameras=30, num_points=700, num_observations=3300, seed=21)
+    plan = plan_of(p)
+    n_o, n_p, n_c = p.bs.num_row_blocks, p.num_eliminate_blocks, 30
+    E = p.values[: 6 * n_o].reshape(n_o, 2, 3)
+    F = p.values[6 * n_o:].reshape(n_o, 2, 9)
+    valid = plan["valid"].astype(bool)
+    rows, pts, cams = plan["slot_row"][valid], plan["slot_pt"][valid], plan["slot_cam"][valid]
+    Es, Fs = E[rows], F[rows]
+    De, Df = p.D[: 3 * n_p].reshape(n_p, 3), p.D[3 * n_p:]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(9 * n_c)
+    t = np.einsum("oij,oj->oi", Fs, x.reshape(n_c, 9)[cams])
+    u = np.zeros((n_p, 3))
+    np.add.at(u, pts, np.einsum("oij,oi->oj", Es, t))
+    ete = np.zeros((n_p, 3, 3))
+    np.add.at(ete, pts, np.einsum("oki,okj->oij", Es, Es))
+    ete += np.einsum("pi,ij->pij", De ** 2, np.eye(3))
+    v = np.linalg.solve(ete, u[:, :, None])[:, :, 0]
+    z = t - np.einsum("oij,oj->oi", Es, v[pts])
+    y = np.zeros((n_c, 9))
+    np.add.at(y, cams, np.einsum("oij,oi->oj", Fs, z))
+    y = y.reshape(-1) + Df ** 2 * x
+    m = oracle.Matrix(p.bs, n_p)
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    ref = isc.sx(x)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    # and the SCHUR_JACOBI diagonal blocks through M_o = I - E (E^T E)^-1 E^T
+    einv = np.linalg.inv(ete)
+    M = np.eye(2)[None] - np.einsum("oij,ojk,olk->oil", Es, einv[pts], Es)
+    blocks = np.zeros((n_c, 9, 9))
+    np.add.at(blocks, cams, np.einsum("oia,oij,ojb->oab", Fs, M, Fs))
+    blocks += np.einsum("ci,ij->cij", Df.reshape(n_c, 9) ** 2, np.eye(9))
+    _, raw = m.schur_jacobi(p.values, p.D)
+    raw = raw.reshape(n_c, 9, 9)
+    iu = np.triu_indices(9)
+    np.testing.assert_allclose(blocks[:, iu[0], iu[1]], raw[:, iu[0], iu[1]], rtol=0, atol=1e-12 * np.abs(raw).max())
