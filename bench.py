@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — LM linear-solve steps/s and JtJx SpMV HBM GB/s on BAL-shaped input, MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: one Levenberg–
+Marquardt linear solve exactly as LevenbergMarquardtStrategy::ComputeStep issues it
+(reference internal/ceres/levenberg_marquardt_strategy.cc:98-116): LinearSolver::Solve with
+D = sqrt(clamp(diag(J^T J))/radius), q_tolerance = eta = 0.1, r_tolerance = -1,
+max_num_iterations = 500 — i.e. re-layout of the step's Jacobian values, preconditioner,
+right-hand side, preconditioned CG to the Nash–Sofer test, solution — with values / b / D
+already resident in HBM when the timed region starts (ceres_hip_solve_device).
+
+Workload (config.workload): synthetic BAL-shaped Jacobian with Venice-1778's block counts
+(1778 cameras, 993923 points, 5001946 observations; SURVEY.md §8d generator, seed 38401) —
+the configuration BASELINE.json's targets are quoted on.  Default solver: CGNR + JACOBI,
+whose dominant kernel is the fused JtJx SpMV the metric names; `--solver iterative_schur`
+switches to ITERATIVE_SCHUR + SCHUR_JACOBI (dominant kernel: fused S·x).
+
+N > 1 (strong scaling): the SAME problem sharded by point across the ranks
+(ceres-solver_amd/partition.py); camera-space sums and the CGNR inner products go through
+RCCL all-reduce inside the library.  Launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (must precede the HIP library: see hip_solver.load_library)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(kind, n_obs, n_points, n_cameras, s=8):
+    """SURVEY.md §8(d) / BASELINE.md §3, per application of the operator."""
+    n_cols = 3 * n_points + 9 * n_cameras
+    if kind == "jtjx":
+        return n_obs * (24 * s + 8) + n_cols * 4 * s
+    return n_obs * (24 * s + 8) + n_points * 9 * s + n_cameras * 36 * s  # sx
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="venice1778", choices=["dubrovnik16", "ladybug1723", "venice1778"])
+    ap.add_argument("--solver", default="cgnr", choices=["cgnr", "iterative_schur"])
+    ap.add_argument("--skew", type=float, default=0.6, help="power-law exponent of camera popularity")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--both-solvers", type=int, default=1, help="also report the other solver in `extra` (N=1 only)")
+    return ap.parse_args()
+
+
+def make_solver(hs, bs, nelim, solver, device, comm=None):
+    typ, pre = (hs.CGNR, hs.JACOBI) if solver == "cgnr" else (hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)
+    o = hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
+                               residual_reset_period=10, elimination_groups=[nelim], device=device)
+    kw = {} if comm is None else dict(comm_id=comm[0], rank=comm[1], world_size=comm[2])
+    s = hs.HipLinearSolver(o, **kw)
+    s.set_structure(bs)
+    return s
+
+
+def timed_steps(solver, ptrs, steps, warmup, sync):
+    tv, tb, tD, tx = ptrs
+    iters = []
+    for _ in range(warmup):
+        s = solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+        assert s.termination_type in (0, 1), s
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s = solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+        iters.append(s.num_iterations)
+    sync()
+    return time.perf_counter() - t0, iters, s
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    pkg = entry.load_package()
+    hs = pkg.hip_solver
+    hs.load_library()
+    if hs.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no gfx950 device visible (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- workload -----------------------------------------------------------------
+    n_cams, n_points, n_obs = pkg.problems.BAL_SHAPES[args.workload]
+    # Schur ordering (points then cameras) serves both solvers and is what sharding needs.
+    prob = pkg.problems.synthetic_bal(args.workload, layout="schur", seed=38401, skew=args.skew)
+    nelim = prob.num_eliminate_blocks
+    comm = None
+    if world > 1:
+        from ceres_solver_amd import partition
+        sh = partition.shard_by_point(prob.bs, nelim, world, rank)
+        bs, values, b, D, nelim_local = sh.bs, sh.local_values(prob.values), sh.local_rows(prob.b), sh.local_cols(prob.D), sh.num_eliminate_blocks
+        idt = torch.zeros(hs.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.tensor(list(hs.comm_unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(idt, 0)
+        comm = (bytes(idt.cpu().tolist()), rank, world)
+    else:
+        bs, values, b, D, nelim_local = prob.bs, prob.values, prob.b, prob.D, nelim
+    solver = make_solver(hs, bs, nelim_local, args.solver, local_rank, comm)
+    info = solver.info()
+    tv, tb, tD = (torch.from_numpy(a).to(dev) for a in (values, b, D))
+    tx = torch.full((bs.num_cols,), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    # ---- timed region: K LM linear solves, inputs resident in HBM -------------------
+    elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = solver.last_timing()
+    step_ok = bool(torch.isfinite(tx).all().item())
+
+    # ---- dominant kernel against the HBM roofline (HIP events on the solver's stream) ----
+    kind = "jtjx" if args.solver == "cgnr" else "sx"
+    op = hs.TIMED_JTJX if args.solver == "cgnr" else hs.TIMED_SX
+    solver.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())
+    op_ms = solver.time_op(op, args.kernel_iters)
+    my_obs = int(info.num_observations)
+    my_points = int(info.num_e_blocks)
+    alg_bytes = algorithmic_bytes(kind, my_obs, my_points, n_cams)
+    achieved = alg_bytes / (op_ms * 1e-3) / 1e9
+    extra = {"pack_ms": solver.time_op(hs.TIMED_PACK, 10), "device_copy_GBs": None}
+    copy_ms = solver.time_op(hs.TIMED_COPY, 10)
+    extra["device_copy_GBs"] = 2 * 8 * min(int(info.num_nonzeros), int(info.num_tiles) * 64 * 24) / (copy_ms * 1e-3) / 1e9
+    if dist is not None:
+        t = torch.tensor([achieved], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # aggregate GB/s over ranks, each on its shard
+        achieved = float(t.item())
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world == 1 and os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            traffic = rec.get(f"{args.workload}:{kind}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": f"bal_fused_kernel<{'kJtJx' if kind == 'jtjx' else 'kSx'}> + bal_reduce_partials_kernel",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(op_ms, 5)}
+
+    # ---- the other solver, for the record (N = 1) -------------------------------------
+    if world == 1 and args.both_solvers:
+        other = "iterative_schur" if args.solver == "cgnr" else "cgnr"
+        s2 = make_solver(hs, bs, nelim_local, other, local_rank)
+        e2, it2, _ = timed_steps(s2, (tv, tb, tD, tx), max(3, args.steps // 4), 1, sync)
+        s2.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())
+        k2 = "sx" if other == "iterative_schur" else "jtjx"
+        ms2 = s2.time_op(hs.TIMED_SX if k2 == "sx" else hs.TIMED_JTJX, args.kernel_iters)
+        gb2 = algorithmic_bytes(k2, my_obs, my_points, n_cams) / (ms2 * 1e-3) / 1e9
+        extra[other] = {"steps_per_s": round(max(3, args.steps // 4) / e2, 3), "cg_iterations": it2[-1],
+                        f"{k2}_GBs": round(gb2, 1), f"{k2}_frac_hbm": round(gb2 / HBM_PEAK_GBS, 4), f"{k2}_ms": round(ms2, 5)}
+        if other == "iterative_schur":
+            extra[other]["schur_init_ms"] = round(s2.time_op(hs.TIMED_SCHUR_INIT, 10), 4)
+            extra[other]["schur_jacobi_ms"] = round(s2.time_op(hs.TIMED_SCHUR_JACOBI, 10), 4)
+        s2.close()
+    extra["solve_phases_ms"] = {k: round(getattr(timing, k), 4) for k in
+                                ("pack_ms", "setup_ms", "preconditioner_ms", "cg_ms", "back_substitute_ms", "total_ms")}
+    extra["operator_applications_per_step"] = int(timing.operator_applications)
+
+    # ---- CPU baseline: the oracle (a restatement of Ceres' algorithm, "port") on this box's cores ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        oracle = entry.load_oracle()
+        cores = os.cpu_count() or 1
+        oracle.set_num_threads(cores)
+        m = oracle.Matrix(prob.bs, nelim if args.solver == "iterative_schur" else 0)
+        fn = m.iterative_schur_solve if args.solver == "iterative_schur" else m.cgnr_solve
+        pre = 2 if args.solver == "iterative_schur" else 1
+        n_done, t0, cpu_iters = 0, time.perf_counter(), None
+        while True:
+            xo, so = fn(prob.values, prob.b, prob.D, preconditioner=pre, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+            n_done += 1
+            cpu_iters = so.num_iterations
+            if time.perf_counter() - t0 > args.cpu_seconds or n_done >= args.steps:
+                break
+        cpu_t = time.perf_counter() - t0
+        xg = tx.cpu().numpy()
+        parity = float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)) if cpu_iters == iters[-1] else None
+        cpu = {"value": round(n_done / cpu_t, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+               "sample": f"{n_done} full {args.workload}-shaped {args.solver} solves (same inputs, eta=0.1), "
+                         f"oracle/libceres_oracle.so with OpenMP over {cores} threads, {cpu_t:.1f} s",
+               "cg_iterations": cpu_iters, "step_rel_diff_vs_gpu": parity}
+        oracle.set_num_threads(1)
+
+    if rank == 0:
+        value = args.steps / elapsed
+        line = {
+            "metric": "LM trust-region steps/sec (linear-solve hot path) + JtJx SpMV HBM GB/s on BAL",
+            "value": round(value, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped synthetic BAL Jacobian <2,3,9>: {n_cams} cameras, {n_points} points, "
+                                   f"{n_obs} observations, N(0,1) values, seed 38401, camera popularity skew {args.skew}",
+                       "solver": "CGNR + JACOBI" if args.solver == "cgnr" else "ITERATIVE_SCHUR + SCHUR_JACOBI",
+                       "eta": 0.1, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
+                       "termination": hs.TERMINATION_NAMES[last.termination_type],
+                       "parallelism": f"points sharded over {world} GPU(s), RCCL all-reduce of camera space"
+                       if world > 1 else "1 GPU", "inputs_resident_in_hbm": True, "step_finite": step_ok,
+                       "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",
+                       "camera_accumulators_in_lds": bool(info.camera_accum_in_lds)},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+        print(json.dumps(line), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,16 @@ def load_library():
     """dlopen csrc/libceres_hip.so and bind every ABI symbol; raises if anything is missing."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 / librccl (same
+        # SONAMEs as /opt/rocm's).  Two HIP runtimes in one process cannot both own the GPU, so
+        # if torch is going to be used in this process it must be loaded FIRST; our library's
+        # NEEDED entries then bind to the copies torch already mapped.
+        import sys
+        if "torch" not in sys.modules and os.environ.get("CERES_HIP_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         path = library_path()
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first; "

@@ -61,8 +61,9 @@ def test_fixed_iteration_count_matches_oracle(hip, oracle, problems, layout, sol
     if solver_type == hip.CGNR:
         p.num_eliminate_blocks = 0 if layout == "cgnr" else p.num_eliminate_blocks
     for k in (1, 7, 25):  # 25 crosses two residual resets (period 10)
-        x, s, path = hip_solve(hip, p, solver_type, pre, 0.0, 0.0, force_generic, min_it=k, max_it=k)
-        xo, so = oracle_solve(oracle, p, solver_type, hip, pre, min_it=k, max_it=k, q_tol=0.0, r_tol=0.0)
+        # q_tolerance = -1: zeta is rounding noise once CG has converged, it must not decide anything here
+        x, s, path = hip_solve(hip, p, solver_type, pre, -1.0, 0.0, force_generic, min_it=k, max_it=k)
+        xo, so = oracle_solve(oracle, p, solver_type, hip, pre, min_it=k, max_it=k, q_tol=-1.0, r_tol=0.0)
         assert path == (hip.PATH_GENERIC if force_generic else hip.PATH_BAL)
         assert (s.termination_type, s.num_iterations) == (so.termination_type, so.num_iterations), (s, so)
         assert rel(x, xo) <= 1e-9, (k, rel(x, xo))
@@ -110,10 +111,15 @@ def test_summary_edge_cases(hip, oracle, problems):
     x, s, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.IDENTITY, 0.0, 1e-30, max_it=3)
     assert s.termination_type == hip.NO_CONVERGENCE and s.num_iterations == 3 and "Maximum number" in s.message
     assert np.isfinite(x).all()
-    # polling interval does not change the result
+    # the polling interval does not change the result (beyond the rounding-level run-to-run
+    # variation of the LDS atomics; the reference's own threaded sums vary the same way)
     xa, sa, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, max_it=100, cg_check_interval=1)
     xb, sb, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, max_it=100, cg_check_interval=16)
-    assert sa.num_iterations == sb.num_iterations and np.array_equal(xa, xb)
+    assert sa.num_iterations == sb.num_iterations and rel(xa, xb) <= 1e-13
+    # the generic kernels use no atomics: bit-reproducible
+    xc, sc, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, True, max_it=100, cg_check_interval=1)
+    xd, sd, _ = hip_solve(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 0.1, -1.0, True, max_it=100, cg_check_interval=16)
+    assert sc.num_iterations == sd.num_iterations and np.array_equal(xc, xd)
 
 
 def test_device_resident_solve_with_torch(hip, problems):
@@ -128,7 +134,7 @@ def test_device_resident_solve_with_torch(hip, problems):
     torch.cuda.synchronize()
     sd = s.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
     assert (sd.termination_type, sd.num_iterations) == (sh.termination_type, sh.num_iterations)
-    assert np.array_equal(tx.cpu().numpy(), xh)
+    assert rel(tx.cpu().numpy(), xh) <= 1e-13
     s.close()
 
 
