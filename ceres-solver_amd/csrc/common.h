@@ -22,6 +22,7 @@ namespace chip {
 
 constexpr int kTile = 64;           // observation slots per tile = one wavefront
 constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
+constexpr int kCamChunk = 2048;     // observations per work item of the camera-block kernel
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
 
 // ---------------------------------------------------------------------------
@@ -69,6 +70,8 @@ struct BalPlan {
   std::vector<int32_t> cam_ptr;    // n_cameras+1
   std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major
   std::vector<int32_t> cam_slot;   // slot of each observation, camera-major
+  // work items of the camera-block kernel: (camera, [begin,end) in the camera-major list)
+  std::vector<int32_t> item_cam, item_begin, item_end;
   int max_track = 0, max_camera_degree = 0;
 };
 

@@ -10,7 +10,7 @@
 
 namespace chip {
 
-constexpr int kBalBlock = 512;               // threads per workgroup of the fused kernels (8 waves)
+int BalBlockFor(int mode);                   // threads per workgroup of the fused kernels (512 | 1024)
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
@@ -39,7 +39,7 @@ struct BalArgs {
   double* etei = nullptr;
   double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
   const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => 9*p
-  double* Mo = nullptr;                   // [3][n_slots] symmetric 2x2 per observation (kInit)
+  double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 pad (kInit)
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
@@ -56,11 +56,15 @@ hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double*
                                  const int* status, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
                          const int32_t* slot_bpos, int64_t n_tiles, double2* J, double2* bt, hipStream_t stream);
-hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                 const int32_t* cam_slot, const double* Mo, int64_t n_slots, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, int n_cameras,
-                                 hipStream_t stream);
-
+// Work items of the camera-block kernel: <= kCamChunk consecutive observations of one camera.
+struct CamItems {
+  const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;
+  int count = 0;
+};
+// blocks must be zeroed by the caller (items of one camera are combined with atomics).
+hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
+                                 const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------

@@ -194,9 +194,9 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     double q0[3], q1[3];
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
-    A.Mo[sl] = 1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]);
-    A.Mo[A.n_slots + sl] = -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]);
-    A.Mo[2 * A.n_slots + sl] = 1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]);
+    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * sl);  // [slot][4]: m00 m01 m11 pad, 32 B per slot
+    mo[0] = make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]));
+    mo[1] = make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0);
   }
 }
 
@@ -223,13 +223,16 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
     scatter_ft<LDS>(s, acc, z0, z1);
   } else if constexpr (MODE == kJtJx || MODE == kJtb) {
-    double z0, z1, xp[3] = {0, 0, 0};
+    double z0, z1, xp[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
     if constexpr (MODE == kJtJx) {
+      // every load of the tile is issued up front, by all lanes (lanes of one point read the
+      // same address): nothing is fetched behind the per-point reduction
       double xc[9];
       const int co = cam_off(A, s.cam);
 #pragma unroll
       for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
       xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
+      if (A.D_e) { dd[0] = A.D_e[po]; dd[1] = A.D_e[po + 1]; dd[2] = A.D_e[po + 2]; }
       f_times(s, xc, z0, z1);
       z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
       z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
@@ -243,11 +246,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     seg_scan<3>(w, lane, s.first, span);
     if (s.valid && lane == s.last) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double d = 0;
-        if (MODE == kJtJx && A.D_e) { d = A.D_e[po + j]; d = d * d * xp[j]; }
-        A.y_e[po + j] = w[j] + d;
-      }
+      for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j] + dd[j] * dd[j] * xp[j];
     }
   } else if constexpr (MODE == kInit || MODE == kEte) {
     double r[9];
@@ -411,8 +410,8 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
   }
 }
 
-template <int MODE, bool LDS>
-__global__ __launch_bounds__(kBalBlock) void bal_fused_kernel(BalArgs A) {
+template <int MODE, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
   constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit);
@@ -420,15 +419,15 @@ __global__ __launch_bounds__(kBalBlock) void bal_fused_kernel(BalArgs A) {
   if constexpr (kScatters) {
     if constexpr (LDS) {
       acc = lds_acc;
-      for (int i = threadIdx.x; i < A.n_f9; i += kBalBlock) acc[i] = 0.0;
+      for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) acc[i] = 0.0;
       __syncthreads();
     } else {
       acc = A.global_acc;
     }
   }
   const int lane = threadIdx.x & 63;
-  const int64_t wave = int64_t(blockIdx.x) * (kBalBlock / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = int64_t(gridDim.x) * (kBalBlock / 64);
+  const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   for (int64_t tile = wave; tile < A.n_tiles; tile += nwaves) {
     const int kind = A.tile_kind[tile];
     if (kind == 2) continue;
@@ -439,28 +438,34 @@ __global__ __launch_bounds__(kBalBlock) void bal_fused_kernel(BalArgs A) {
   if constexpr (kScatters && LDS) {
     __syncthreads();
     double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
-    for (int i = threadIdx.x; i < A.n_f9; i += kBalBlock) out[i] = acc[i];
+    for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
   }
 }
 
 // y_f[pos(i)] = sum over workgroup partials (+ D_f^2 x_f).  One thread per F scalar.
-__global__ void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
+// Workgroup = 64 consecutive scalars x 4 waves, wave w sums partials w, w+4, w+8, ...; the four
+// wave sums are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
                                            const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
                                            const double* __restrict__ x_f, double* __restrict__ y_f,
                                            const int* __restrict__ status) {
+  __shared__ double sh[4][64];
   if (status && *status != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_f9) return;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int w = 0;
-  for (; w + 4 <= nparts; w += 4) {
-    s0 += partials[int64_t(w) * n_f9 + i];
-    s1 += partials[int64_t(w + 1) * n_f9 + i];
-    s2 += partials[int64_t(w + 2) * n_f9 + i];
-    s3 += partials[int64_t(w + 3) * n_f9 + i];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s0 = 0, s1 = 0;
+  if (i < n_f9) {
+    int w = wv;
+    for (; w + 4 < nparts; w += 8) {
+      s0 += partials[int64_t(w) * n_f9 + i];
+      s1 += partials[int64_t(w + 4) * n_f9 + i];
+    }
+    if (w < nparts) s0 += partials[int64_t(w) * n_f9 + i];
   }
-  for (; w < nparts; ++w) s0 += partials[int64_t(w) * n_f9 + i];
-  double s = (s0 + s1) + (s2 + s3);
+  sh[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (wv != 0 || i >= n_f9) return;
+  double s = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
   const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
   if (D_f) { const double d = D_f[o]; s += d * d * x_f[o]; }
   y_f[o] = s;
@@ -511,21 +516,27 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // Per-camera 9x9 blocks: sum over the camera's observations of F^T M F (+ D^2), with
 // M = I (JACOBI: block diagonal of F^T F) or M = I - E (E^T E)^-1 E^T (SCHUR_JACOBI:
 // the diagonal blocks SchurEliminator::Eliminate writes into a block-diagonal lhs).
-// One workgroup per camera, observations gathered through the camera-major lists;
-// F is read from the caller-layout values (contiguous 144 B per observation).
+// Camera degrees are heavily skewed (a few cameras see most points), so the unit of work
+// is an ITEM: at most kCamChunk consecutive observations of one camera in the camera-major
+// list (plan.cc).  One workgroup per item; its 9x9 sum is added to the (zeroed) block
+// with global_atomic_add_f64, the first item of a camera also adds D^2.  F is read from
+// the caller-layout values (contiguous 144 B per observation), M from [slot][4].
 template <bool SCHUR>
 __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __restrict__ values,
+                                                                const int32_t* __restrict__ item_cam,
+                                                                const int32_t* __restrict__ item_begin,
+                                                                const int32_t* __restrict__ item_end,
                                                                 const int32_t* __restrict__ cam_ptr,
                                                                 const int32_t* __restrict__ cam_fpos,
                                                                 const int32_t* __restrict__ cam_slot,
-                                                                const double* __restrict__ Mo, int64_t n_slots,
+                                                                const double* __restrict__ Mo,
                                                                 const double* __restrict__ D_f,
                                                                 const int32_t* __restrict__ cam_pos,
                                                                 const int64_t* __restrict__ cam_diag_off,
                                                                 double* __restrict__ blocks) {
   __shared__ double red[4][45];
-  const int c = blockIdx.x;
-  const int beg = cam_ptr[c], end = cam_ptr[c + 1];
+  const int c = item_cam[blockIdx.x];
+  const int beg = item_begin[blockIdx.x], end = item_end[blockIdx.x];
   double acc[45];
 #pragma unroll
   for (int i = 0; i < 45; ++i) acc[i] = 0.0;
@@ -536,8 +547,9 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
     for (int k = 0; k < 9; ++k) { f0[k] = f[k]; f1[k] = f[9 + k]; }
     double m00 = 1.0, m01 = 0.0, m11 = 1.0;
     if constexpr (SCHUR) {
-      const int64_t sl = cam_slot[q];
-      m00 = Mo[sl]; m01 = Mo[n_slots + sl]; m11 = Mo[2 * n_slots + sl];
+      const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
+      const double2 a = mo[0], b = mo[1];
+      m00 = a.x; m01 = a.y; m11 = b.x;
     }
     int idx = 0;
 #pragma unroll
@@ -566,8 +578,8 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
     const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
     const int idx = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);
     double v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-    if (a == bb && D_f) { const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + a]; v += d * d; }
-    blocks[(cam_diag_off ? cam_diag_off[c] : int64_t(81) * c) + threadIdx.x] = v;
+    if (a == bb && D_f && beg == cam_ptr[c]) { const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + a]; v += d * d; }
+    unsafeAtomicAdd(&blocks[(cam_diag_off ? cam_diag_off[c] : int64_t(81) * c) + threadIdx.x], v);
   }
 }
 
@@ -627,34 +639,42 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int BLOCK>
 static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
     const size_t bytes = size_t(A.n_f9) * sizeof(double);
-    auto k = bal_fused_kernel<MODE, true>;
+    auto k = bal_fused_kernel<MODE, true, BLOCK>;
     static bool attr_set = false;
-    static size_t attr_bytes = 0;
-    if (!attr_set || bytes > attr_bytes) {
+    if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
       if (e != hipSuccess) return e;
       attr_set = true;
-      attr_bytes = kMaxLdsBytes;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBalBlock), bytes, stream, A);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   } else {
-    hipLaunchKernelGGL((bal_fused_kernel<MODE, false>), dim3(grid), dim3(kBalBlock), 0, stream, A);
+    hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, A);
   }
   return hipGetLastError();
 }
 
+// Threads per workgroup of the streaming kernels: 1024 (16 waves per CU) hides HBM latency
+// best for the light modes; kInit needs more registers and runs at 512.
+int BalBlockFor(int mode) {
+  static int forced = [] { const char* e = getenv("CERES_HIP_BAL_BLOCK"); return e ? atoi(e) : 0; }();
+  if (mode == kInit) return 512;
+  if (forced == 512 || forced == 1024) return forced;
+  return 1024;
+}
+
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  const bool big = BalBlockFor(mode) == 1024;
   switch (mode) {
-    case kSx: return launch_fused<kSx>(A, lds, grid, stream);
-    case kJtJx: return launch_fused<kJtJx>(A, lds, grid, stream);
-    case kJtb: return launch_fused<kJtb>(A, lds, grid, stream);
-    case kInit: return launch_fused<kInit>(A, lds, grid, stream);
-    case kEte: return launch_fused<kEte>(A, false, grid, stream);
-    case kBackSub: return launch_fused<kBackSub>(A, false, grid, stream);
+    case kSx: return big ? launch_fused<kSx, 1024>(A, lds, grid, stream) : launch_fused<kSx, 512>(A, lds, grid, stream);
+    case kJtJx: return big ? launch_fused<kJtJx, 1024>(A, lds, grid, stream) : launch_fused<kJtJx, 512>(A, lds, grid, stream);
+    case kJtb: return big ? launch_fused<kJtb, 1024>(A, lds, grid, stream) : launch_fused<kJtb, 512>(A, lds, grid, stream);
+    case kInit: return launch_fused<kInit, 512>(A, lds, grid, stream);
+    case kEte: return big ? launch_fused<kEte, 1024>(A, false, grid, stream) : launch_fused<kEte, 512>(A, false, grid, stream);
+    case kBackSub: return big ? launch_fused<kBackSub, 1024>(A, false, grid, stream) : launch_fused<kBackSub, 512>(A, false, grid, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -662,7 +682,7 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
                                    hipStream_t stream) {
-  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 255) / 256), dim3(256), 0, stream, partials, nparts,
+  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 63) / 64), dim3(256), 0, stream, partials, nparts,
                      n_f9, cam_pos, D_f, x_f, y_f, status);
   return hipGetLastError();
 }
@@ -687,16 +707,16 @@ hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_c
   return hipGetLastError();
 }
 
-hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                 const int32_t* cam_slot, const double* Mo, int64_t n_slots, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, int n_cameras,
-                                 hipStream_t stream) {
+hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
+                                 const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream) {
+  if (items.count == 0) return hipSuccess;
   if (schur)
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), dim3(n_cameras), dim3(256), 0, stream, values, cam_ptr,
-                       cam_fpos, cam_slot, Mo, n_slots, D_f, cam_pos, cam_diag_off, blocks);
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), dim3(items.count), dim3(256), 0, stream, values, items.cam,
+                       items.begin, items.end, cam_ptr, cam_fpos, cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
   else
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), dim3(n_cameras), dim3(256), 0, stream, values, cam_ptr,
-                       cam_fpos, cam_slot, Mo, n_slots, D_f, cam_pos, cam_diag_off, blocks);
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), dim3(items.count), dim3(256), 0, stream, values, items.cam,
+                       items.begin, items.end, cam_ptr, cam_fpos, cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
   return hipGetLastError();
 }
 

@@ -286,6 +286,14 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       P.cam_slot[q] = int32_t(s);
     }
   }
+  for (int c = 0; c < P.n_cameras; ++c) {
+    int b = P.cam_ptr[c];
+    do {  // a camera without observations still gets one (empty) item so that D^2 is added
+      const int e = std::min(P.cam_ptr[c + 1], b + kCamChunk);
+      P.item_cam.push_back(c); P.item_begin.push_back(b); P.item_end.push_back(e);
+      b = e;
+    } while (b < P.cam_ptr[c + 1]);
+  }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
   P.eligible = true;
 }

@@ -55,6 +55,7 @@ struct ceres_hip_solver {
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
+  CamItems cam_items;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
@@ -321,9 +322,9 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     if (s->path == CERES_HIP_PATH_BAL) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
       // raw sums first (no diagonal) so that a sharded run can add them up
-      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_Mo,
-                                       s->plan.n_tiles * kTile, s->world > 1 ? nullptr : D_f, nullptr, nullptr, out,
-                                       s->plan.n_cameras, st));
+      HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));
+      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_Mo,
+                                       s->world > 1 ? nullptr : D_f, nullptr, nullptr, out, st));
       if (s->world > 1) {
         TRY(allreduce(s, out, size_t(len)));
         if (D_f) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
@@ -351,10 +352,10 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     A.D_e = s->D;
     A.point_blocks = out;
     A.pt_diag_off = s->d_pt_diag_off;
+    HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));  // camera blocks are accumulated with atomics
     HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
-    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     s->plan.n_tiles * kTile, D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos,
-                                     s->d_cam_diag_off, out, s->plan.n_cameras, st));
+    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
+                                     D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos, s->d_cam_diag_off, out, st));
     HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
     return 0;
   }
@@ -453,7 +454,11 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   const int min_it = s->opt.min_num_iterations, max_it = s->opt.max_num_iterations;
   const int reset_period = std::max(1, s->opt.residual_reset_period);
   const int* status = &B.S->status;
-  int interval = s->opt.cg_check_interval > 0 ? s->opt.cg_check_interval : 8;
+  // Iterations enqueued between polls of the device status word: fixed if the caller asked
+  // for it, otherwise 2, 4, 8, 16, 16, ... (short solves do not pay for no-op launches,
+  // long ones poll rarely).
+  const bool adaptive = s->opt.cg_check_interval <= 0;
+  int interval = adaptive ? 2 : s->opt.cg_check_interval;
 
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
   TRY(collapse_and_reduce(s, 0, 1));
@@ -482,6 +487,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
       HIP_TRY(s, LaunchCgFinalize(B, st));
     }
     TRY(poll_scalars(s));
+    if (adaptive) interval = std::min(16, interval * 2);
     if (it > max_it && s->h_scalars->status == kCgRunning)
       return fail(s, CERES_HIP_E_INVALID, "CG did not terminate after max_num_iterations (device status 0)");
   }
@@ -786,6 +792,14 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_cam_ptr, P.cam_ptr));
     TRY(dev_upload(s, &s->d_cam_fpos, P.cam_fpos));
     TRY(dev_upload(s, &s->d_cam_slot, P.cam_slot));
+    {
+      int32_t *ic = nullptr, *ib = nullptr, *ie = nullptr;
+      TRY(dev_upload(s, &ic, P.item_cam));
+      TRY(dev_upload(s, &ib, P.item_begin));
+      TRY(dev_upload(s, &ie, P.item_end));
+      s->cam_items.cam = ic; s->cam_items.begin = ib; s->cam_items.end = ie;
+      s->cam_items.count = int(P.item_cam.size());
+    }
     std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
     for (int p = 0; p < P.n_points; ++p) pdo[p] = h.diag_off_all[P.pt_block[p]];
     for (int c = 0; c < P.n_cameras; ++c) cdo[c] = h.diag_off_all[P.cam_block[c]];
@@ -794,12 +808,12 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     const size_t n_slots = size_t(P.n_tiles) * kTile;
     TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
-    TRY(dev_alloc(s, &s->d_Mo, 3 * n_slots));
+    TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
     const size_t n9 = size_t(9) * P.n_cameras;
     s->lds_mode = n9 * sizeof(double) <= kMaxLdsBytes - 512;
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
-    const int64_t tiles_per_wg = kBalBlock / kTile;
+    const int64_t tiles_per_wg = 512 / kTile;
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Times the dominant operators on a cached Venice-shaped problem (GPU box helper).
+usage: kernel_times.py [workload] ; honours CERES_HIP_BAL_BLOCK."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import __graft_entry__ as entry
+pkg = entry.load_package()
+hs = pkg.hip_solver
+wl = sys.argv[1] if len(sys.argv) > 1 else "venice1778"
+cache = f"/tmp/{wl}.npz"
+P = pkg.problems
+if os.path.exists(cache):
+    z = np.load(cache)
+    bs = pkg.BlockStructure(*(z[k] for k in ("rsz", "rpos", "csz", "cpos", "rptr", "ccol", "cval")))
+    prob = P.LinearProblem(bs, z["values"], z["b"], z["D"], int(z["nelim"]))
+else:
+    prob = P.synthetic_bal(wl, layout="schur", seed=38401, skew=0.6)
+    b = prob.bs
+    np.savez(cache, rsz=b.row_block_size, rpos=b.row_block_pos, csz=b.col_block_size, cpos=b.col_block_pos, rptr=b.row_cell_ptr,
+             ccol=b.cell_col_block, cval=b.cell_value_pos, values=prob.values, b=prob.b, D=prob.D, nelim=prob.num_eliminate_blocks)
+n_c, n_p, n_o = P.BAL_SHAPES[wl]
+B_jtjx = n_o * 200 + (3 * n_p + 9 * n_c) * 32
+B_sx = n_o * 200 + n_p * 72 + n_c * 288
+out = {"block": os.environ.get("CERES_HIP_BAL_BLOCK", "default"), "workload": wl}
+for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JTJX, B_jtjx), ("block_jacobi", hs.TIMED_BLOCK_JACOBI, None)]),
+                              ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, [("sx", hs.TIMED_SX, B_sx), ("schur_init", hs.TIMED_SCHUR_INIT, None),
+                                                                                  ("schur_jacobi", hs.TIMED_SCHUR_JACOBI, None), ("back_substitute", hs.TIMED_BACK_SUBSTITUTE, None),
+                                                                                  ("pack", hs.TIMED_PACK, None)])):
+    s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
+                                                  elimination_groups=[prob.num_eliminate_blocks]))
+    s.set_structure(prob.bs)
+    s.load(prob.values, prob.b, prob.D)
+    for name, op, nbytes in ops:
+        ms = min(s.time_op(op, 30) for _ in range(3))
+        out[name + "_ms"] = round(ms, 4)
+        if nbytes:
+            out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
+            out[name + "_frac"] = round(nbytes / ms / 1e6 / 8000, 4)
+    x, summ = s.solve(prob.values, prob.b, hs.PerSolveOptions(D=prob.D, q_tolerance=0.1, r_tolerance=-1.0))
+    t = s.last_timing()
+    out[solver + "_solve"] = {"its": summ.num_iterations, "total_ms": round(t.total_ms, 3), "upload_ms": round(t.upload_ms, 3), "pack_ms": round(t.pack_ms, 3),
+                              "setup_ms": round(t.setup_ms, 3), "precond_ms": round(t.preconditioner_ms, 3), "cg_ms": round(t.cg_ms, 3),
+                              "backsub_ms": round(t.back_substitute_ms, 3), "download_ms": round(t.download_ms, 3)}
+    s.close()
+print(json.dumps(out))
