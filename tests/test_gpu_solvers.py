@@ -164,3 +164,14 @@ def test_lm_loop_with_hip_linear_solver(hip, oracle):
         assert abs(a.linear_solver_iterations - b.linear_solver_iterations) <= 1, i
     assert Sa.final_cost < 0.5 * Sa.initial_cost
     assert abs(Sa.final_cost - Sb.final_cost) <= 1e-6 * Sa.final_cost, (Sa.final_cost, Sb.final_cost)
+
+
+def test_cpp_host_mirror_driver(hip):
+    # the C++ host side (ceres-solver_amd/host/hip_linear_solver.h) through its driver binary
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ceres-solver_amd", "host", "host_driver")
+    assert os.path.exists(exe), "host_driver was not built (python __graft_entry__.py)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all cases passed" in r.stdout, r.stdout + r.stderr
