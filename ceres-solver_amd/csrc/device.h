@@ -18,6 +18,8 @@ constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
 enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5 };
 
+constexpr int kFlagNontemporal = 1;
+
 struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][12][64]
@@ -33,6 +35,8 @@ struct BalArgs {
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
   const double* x_e = nullptr;
   const double* x_f = nullptr;
+  const double* x_f_pad = nullptr;  // optional [n_cameras][10] copy of x_f (16-byte aligned gathers)
+  int flags = 0;                    // kFlag*
   double* y_e = nullptr;
   const double* D_e = nullptr;  // nullptr => no regularisation on the point part
   // per-point 3x3 inverses, packed symmetric 6 doubles / point
@@ -52,6 +56,9 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
                                    hipStream_t stream);
+hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
+hipError_t LaunchBalPadCameraVector(const double* x_f, const int32_t* cam_pos, int n_cameras, double* xpad,
+                                    const int* status, hipStream_t stream);
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
                                  const int* status, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,

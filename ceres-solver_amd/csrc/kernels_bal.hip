@@ -108,7 +108,14 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
   const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
   double2 p[kPairsPerSlot];
 #pragma unroll
-  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
+  for (int j = 0; j < kPairsPerSlot; ++j) {
+    if (A.flags & kFlagNontemporal) {  // streamed once: keep it out of the way of x / D / ids in L2
+      p[j].x = __builtin_nontemporal_load(&J[j * kTile].x);
+      p[j].y = __builtin_nontemporal_load(&J[j * kTile].y);
+    } else {
+      p[j] = J[j * kTile];
+    }
+  }
   s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
 #pragma unroll
   for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
@@ -134,6 +141,20 @@ __device__ __forceinline__ void sym3_mul(const double (&m)[6], const double (&u)
   v[0] = m[0] * u[0] + m[1] * u[1] + m[2] * u[2];
   v[1] = m[1] * u[0] + m[3] * u[1] + m[4] * u[2];
   v[2] = m[2] * u[0] + m[4] * u[1] + m[5] * u[2];
+}
+
+// The 9 camera scalars of a slot: from the 16-byte aligned padded copy ([camera][10],
+// 5 x dwordx4 per lane) when one was prepared, else 9 x 8-byte loads from the vector itself.
+__device__ __forceinline__ void load_xc(const BalArgs& A, int cam, double (&xc)[9]) {
+  if (A.x_f_pad) {
+    const double2* q = reinterpret_cast<const double2*>(A.x_f_pad + 10 * int64_t(cam));
+    const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    xc[0] = a.x; xc[1] = a.y; xc[2] = b.x; xc[3] = b.y; xc[4] = c.x; xc[5] = c.y; xc[6] = d.x; xc[7] = d.y; xc[8] = e.x;
+  } else {
+    const int co = cam_off(A, cam);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+  }
 }
 
 // t = F * xc
@@ -207,17 +228,14 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
   const int64_t sl = tile * kTile + lane;
   const int po = pt_off(A, s.pt);
   if constexpr (MODE == kSx) {
-    double xc[9];
-    const int co = cam_off(A, s.cam);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+    double xc[9], ei[6], v[3];
+    load_xc(A, s.cam, xc);
+    load_ete_inverse(A, s.pt, ei);
     double t0, t1;
     f_times(s, xc, t0, t1);
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_allreduce<3>(u, lane, s.first, s.last, span);
-    double ei[6], v[3];
-    load_ete_inverse(A, s.pt, ei);
     sym3_mul(ei, u, v);
     const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
     const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
@@ -228,9 +246,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       // every load of the tile is issued up front, by all lanes (lanes of one point read the
       // same address): nothing is fetched behind the per-point reduction
       double xc[9];
-      const int co = cam_off(A, s.cam);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+      load_xc(A, s.cam, xc);
       xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
       if (A.D_e) { dd[0] = A.D_e[po]; dd[1] = A.D_e[po + 1]; dd[2] = A.D_e[po + 2]; }
       f_times(s, xc, z0, z1);
@@ -279,20 +295,18 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
     }
   } else if constexpr (MODE == kBackSub) {
-    double zc[9];
-    const int co = cam_off(A, s.cam);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) zc[k] = A.x_f[co + k];
+    double zc[9], ei[6];
+    load_xc(A, s.cam, zc);
+    const double2 bb = A.b[sl];
+    load_ete_inverse(A, s.pt, ei);  // issued with the other loads, by all lanes, not behind the scan
     double t0, t1;
     f_times(s, zc, t0, t1);
-    const double2 bb = A.b[sl];
     t0 = bb.x - t0; t1 = bb.y - t1;
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_scan<3>(u, lane, s.first, span);
     if (s.valid && lane == s.last) {
-      double ei[6], v[3];
-      load_ete_inverse(A, s.pt, ei);
+      double v[3];
       sym3_mul(ei, u, v);
       A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2];
     }
@@ -312,9 +326,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       load_slot(A, tile + t, lane, s);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       double xc[9];
-      const int co = cam_off(A, s.cam);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+      load_xc(A, s.cam, xc);
       double t0, t1;
       f_times(s, xc, t0, t1);
       if constexpr (MODE == kBackSub) { const double2 bb = A.b[(tile + t) * kTile + lane]; t0 = bb.x - t0; t1 = bb.y - t1; }
@@ -330,9 +342,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       for (int t = 0; t < nt; ++t) {
         load_slot(A, tile + t, lane, s);
         double xc[9];
-        const int co = cam_off(A, s.cam);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+        load_xc(A, s.cam, xc);
         double t0, t1;
         f_times(s, xc, t0, t1);
         const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
@@ -353,9 +363,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       double z0, z1;
       if constexpr (MODE == kJtJx) {
         double xc[9];
-        const int co = cam_off(A, s.cam);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
+        load_xc(A, s.cam, xc);
         f_times(s, xc, z0, z1);
         z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
         z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
@@ -443,32 +451,65 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
 }
 
 // y_f[pos(i)] = sum over workgroup partials (+ D_f^2 x_f).  One thread per F scalar.
-// Workgroup = 64 consecutive scalars x 4 waves, wave w sums partials w, w+4, w+8, ...; the four
+// Workgroup = 64 consecutive scalars x 8 waves, wave w sums partials w, w+8, w+16, ...; the eight
 // wave sums are combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
+__global__ __launch_bounds__(512) void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
                                            const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
                                            const double* __restrict__ x_f, double* __restrict__ y_f,
                                            const int* __restrict__ status) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[8][64];
   if (status && *status != 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   double s0 = 0, s1 = 0;
   if (i < n_f9) {
     int w = wv;
-    for (; w + 4 < nparts; w += 8) {
+    for (; w + 8 < nparts; w += 16) {
       s0 += partials[int64_t(w) * n_f9 + i];
-      s1 += partials[int64_t(w + 4) * n_f9 + i];
+      s1 += partials[int64_t(w + 8) * n_f9 + i];
     }
     if (w < nparts) s0 += partials[int64_t(w) * n_f9 + i];
   }
   sh[wv][lane] = s0 + s1;
   __syncthreads();
   if (wv != 0 || i >= n_f9) return;
-  double s = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+  double s = ((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane])) + ((sh[4][lane] + sh[5][lane]) + (sh[6][lane] + sh[7][lane]));
   const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
   if (D_f) { const double d = D_f[o]; s += d * d * x_f[o]; }
   y_f[o] = s;
+}
+
+// HBM read-stream probe: the same tile walk and 16-byte-per-lane loads as the fused kernels,
+// nothing else (one double per workgroup written).  Gives the ceiling the fused kernels are
+// measured against next to the 8 TB/s datasheet figure.
+__global__ __launch_bounds__(1024) void bal_stream_probe_kernel(const double2* __restrict__ J, int64_t n_tiles, double* __restrict__ out) {
+  __shared__ double sh[16];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 6), nwaves = int64_t(gridDim.x) * 16;
+  double acc = 0;
+  for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
+    const double2* p = J + tile * (kPairsPerSlot * kTile) + lane;
+    double2 v[kPairsPerSlot];
+#pragma unroll
+    for (int j = 0; j < kPairsPerSlot; ++j) v[j] = p[j * kTile];
+#pragma unroll
+    for (int j = 0; j < kPairsPerSlot; ++j) acc += v[j].x + v[j].y;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 16; ++i) s += sh[i]; out[blockIdx.x] = s; }
+}
+
+// xpad[c][0..8] = x_f[cam_pos[c] + 0..8], xpad[c][9] = 0
+__global__ void bal_pad_camera_vector_kernel(const double* __restrict__ x_f, const int32_t* __restrict__ cam_pos, int n_cameras,
+                                             double* __restrict__ xpad, const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 10 * n_cameras) return;
+  const int c = i / 10, k = i % 10;
+  xpad[i] = k < 9 ? x_f[(cam_pos ? cam_pos[c] : 9 * c) + k] : 0.0;
 }
 
 // y_f += D_f^2 x_f over the camera scalars (after an all-reduce of the raw sums).
@@ -682,8 +723,20 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
                                    hipStream_t stream) {
-  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 63) / 64), dim3(256), 0, stream, partials, nparts,
+  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 63) / 64), dim3(512), 0, stream, partials, nparts,
                      n_f9, cam_pos, D_f, x_f, y_f, status);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bal_stream_probe_kernel, dim3(grid), dim3(1024), 0, stream, J, n_tiles, out);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalPadCameraVector(const double* x_f, const int32_t* cam_pos, int n_cameras, double* xpad,
+                                    const int* status, hipStream_t stream) {
+  hipLaunchKernelGGL(bal_pad_camera_vector_kernel, dim3((10 * n_cameras + 255) / 256), dim3(256), 0, stream, x_f, cam_pos,
+                     n_cameras, xpad, status);
   return hipGetLastError();
 }
 

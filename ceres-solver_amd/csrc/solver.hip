@@ -58,7 +58,9 @@ struct ceres_hip_solver {
   CamItems cam_items;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
-  double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
+  double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
+  int bal_flags = 0;
+  bool use_xpad = false;
   bool lds_mode = false;
   int fused_grid = 0;
 
@@ -161,6 +163,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.partials = s->d_partials; A.global_acc = s->d_global_acc;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
+  A.flags = s->bal_flags;
   return A;
 }
 
@@ -193,6 +196,10 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
   if (s->path == CERES_HIP_PATH_BAL) {
     BalArgs A = bal_args(s);
     A.x_f = x;
+    if (s->use_xpad) {
+      HIP_TRY(s, LaunchBalPadCameraVector(x, A.cam_pos, s->plan.n_cameras, s->d_xpad, status, s->stream));
+      A.x_f_pad = s->d_xpad;
+    }
     return bal_scatter(s, kBalSx, A, x, y, true, status);
   }
   const double* v = s->values;
@@ -225,6 +232,10 @@ int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status) 
   if (s->path == CERES_HIP_PATH_BAL) {
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
+    if (s->use_xpad) {
+      HIP_TRY(s, LaunchBalPadCameraVector(A.x_f, A.cam_pos, s->plan.n_cameras, s->d_xpad, status, st));
+      A.x_f_pad = s->d_xpad;
+    }
     return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status);
   }
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
@@ -817,6 +828,13 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
+    TRY(dev_alloc(s, &s->d_xpad, size_t(10) * P.n_cameras));
+    {
+      const char* e = getenv("CERES_HIP_NT");
+      s->bal_flags = (e && atoi(e) != 0) ? kFlagNontemporal : 0;
+      e = getenv("CERES_HIP_XPAD");
+      s->use_xpad = e && atoi(e) != 0;
+    }
   } else {
     TRY(dev_alloc(s, &s->etei, size_t(h.diag_off_e.back())));
     TRY(dev_alloc(s, &s->tmp_rows, size_t(h.num_rows)));
@@ -864,6 +882,22 @@ int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_I
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   NCCL_TRY(s, ncclCommInitRank(&s->comm, world, u, rank));
+  return 0;
+}
+
+// Debug: drive every `world > 1` branch on ONE GPU.  A 1-rank RCCL communicator is created
+// (so the all-reduces really go through ncclAllReduce on the solver's stream) while the
+// solver behaves as rank 0 of `logical_world` ranks.  With the whole problem given to this
+// instance the other ranks' contributions are zero, so results must equal the unsharded ones.
+int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world) {
+  if (!s || logical_world < 2) return CERES_HIP_E_INVALID;
+  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call before ceres_hip_set_structure");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  ncclUniqueId u;
+  NCCL_TRY(s, ncclGetUniqueId(&u));
+  NCCL_TRY(s, ncclCommInitRank(&s->comm, 1, u, 0));
+  s->rank = 0;
+  s->world = logical_world;
   return 0;
 }
 
@@ -1209,6 +1243,10 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
         HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTile * 24), hipMemcpyDeviceToDevice, st));
         return 0;
       };
+      break;
+    case CERES_HIP_TIMED_READ_STREAM:
+      if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "read-stream probe uses the packed tiles of the <2,3,9> path");
+      body = [&] { HIP_TRY(s, LaunchBalStreamProbe(s->d_J, s->plan.n_tiles, s->num_cus, s->d_global_acc, st)); return 0; };
       break;
     default:
       return fail(s, CERES_HIP_E_INVALID, "unknown timed op %d", op);

@@ -32,7 +32,8 @@ PATH_GENERIC, PATH_BAL = 0, 1
 TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_ERROR"}
 UNIQUE_ID_BYTES = 128
 
-TIMED_JTJX, TIMED_SX, TIMED_SCHUR_INIT, TIMED_SCHUR_JACOBI, TIMED_BACK_SUBSTITUTE, TIMED_PACK, TIMED_BLOCK_JACOBI, TIMED_COPY = range(1, 9)
+(TIMED_JTJX, TIMED_SX, TIMED_SCHUR_INIT, TIMED_SCHUR_JACOBI, TIMED_BACK_SUBSTITUTE, TIMED_PACK, TIMED_BLOCK_JACOBI, TIMED_COPY,
+ TIMED_READ_STREAM) = range(1, 10)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -104,6 +105,7 @@ ABI = [
     ("ceres_hip_op_axpby", c_int32, [c_void_p, c_double, _DP, c_double, _DP, c_int64, _DP]),
     ("ceres_hip_time_op", c_int32, [c_void_p, c_int32, c_int32, _DP]),
     ("ceres_hip_get_last_timing", c_int32, [c_void_p, POINTER(CTiming)]),
+    ("ceres_hip_debug_comm_loopback", c_int32, [c_void_p, c_int32]),
     ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
                                        POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
@@ -205,7 +207,7 @@ class HipLinearSolver:
     """
 
     def __init__(self, options: LinearSolverOptions, comm_id: Optional[bytes] = None, rank: int = 0,
-                 world_size: int = 1):
+                 world_size: int = 1, loopback_world: int = 0):
         self._lib = load_library()
         self.options = options
         nelim = options.elimination_groups[0] if options.elimination_groups else 0
@@ -219,6 +221,8 @@ class HipLinearSolver:
         if world_size > 1:
             buf = (c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(comm_id)
             self._check(self._lib.ceres_hip_comm_init(self._h, buf, rank, world_size))
+        if loopback_world > 1:  # debug: sharded code paths on one GPU (see include/ceres_hip.h)
+            self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
 
     # -- plumbing ----------------------------------------------------------
     def _check(self, rc):

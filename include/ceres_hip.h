@@ -258,6 +258,7 @@ int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b,
 #define CERES_HIP_TIMED_PACK 6
 #define CERES_HIP_TIMED_BLOCK_JACOBI 7
 #define CERES_HIP_TIMED_COPY 8 /* plain device copy of the values array: HBM ceiling probe */
+#define CERES_HIP_TIMED_READ_STREAM 9 /* read-only pass over the packed tiles, same loads as the fused kernels */
 int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms);
 /* Per-phase event timings (ms) of the most recent ceres_hip_solve*. */
 typedef struct ceres_hip_solve_timing {
@@ -276,6 +277,10 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
                          int64_t* n_tiles, int32_t* slot_row, int32_t* slot_cam, int32_t* slot_pt,
                          uint32_t* slot_seg, int32_t* tile_kind, int32_t* tile_aux, int64_t slot_capacity,
                          char* why_not, int32_t why_capacity);
+
+/* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
+ * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */
+int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world);
 
 #ifdef __cplusplus
 }

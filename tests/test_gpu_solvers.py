@@ -175,3 +175,49 @@ def test_cpp_host_mirror_driver(hip):
     assert os.path.exists(exe), "host_driver was not built (python __graft_entry__.py)"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all cases passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (5, 1), (5, 0), (6, 1), (6, 0)])
+@pytest.mark.parametrize("kind", ["bal", "general"])
+def test_sharded_code_paths_in_loopback(hip, oracle, problems, solver_type, pre, kind):
+    """Every `world > 1` branch (diagonal added after the all-reduce, shard/replica split of the
+    inner products, preconditioner blocks summed before inversion) driven on one GPU through a
+    1-rank RCCL communicator: with the whole problem on this rank the result must equal the
+    unsharded solve.  The two-rank arithmetic itself is covered on CPU (tests/test_distributed_cpu.py)."""
+    if kind == "bal":
+        p = problems.synthetic_bal(None, num_cameras=25, num_points=1500, num_observations=7000, seed=31)
+    else:
+        p = problems.random_schur_problem(num_e_blocks=40, num_f_blocks=9, num_no_e_rows=3, seed=32)
+    o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=300,
+                                elimination_groups=[p.num_eliminate_blocks])
+    ref = hip.HipLinearSolver(o)
+    ref.set_structure(p.bs)
+    loop = hip.HipLinearSolver(o, loopback_world=4)
+    loop.set_structure(p.bs)
+    assert loop.info().world_size == 4 and ref.info().world_size == 1
+    assert loop.info().kernel_path == (hip.PATH_BAL if kind == "bal" else hip.PATH_GENERIC)
+    for q_tol, r_tol in ((0.1, -1.0), (0.0, 1e-11)):
+        ps = hip.PerSolveOptions(D=p.D, q_tolerance=q_tol, r_tolerance=r_tol)
+        xr, sr = ref.solve(p.values, p.b, ps)
+        xl, sl = loop.solve(p.values, p.b, ps)
+        assert sr.termination_type == sl.termination_type, (sr, sl)
+        if q_tol > 0:
+            assert sr.termination_type == hip.SUCCESS, sr
+        assert abs(sr.num_iterations - sl.num_iterations) <= 1
+        if sr.num_iterations == sl.num_iterations and sr.termination_type == hip.SUCCESS:
+            assert rel(xl, xr) <= 1e-9, rel(xl, xr)
+    # operators too
+    loop.load(p.values, p.b, p.D)
+    ref.load(p.values, p.b, p.D)
+    rng = np.random.default_rng(0)
+    if solver_type == hip.ITERATIVE_SCHUR:
+        loop.schur_init(); ref.schur_init()
+        x = rng.standard_normal(loop.info().num_cols_f)
+        assert rel(loop.schur_sx(x), ref.schur_sx(x)) <= 1e-12
+        assert rel(loop.schur_rhs(), ref.schur_rhs()) <= 1e-12
+    else:
+        x = rng.standard_normal(loop.info().num_cols)
+        assert rel(loop.jtjx(x), ref.jtjx(x)) <= 1e-12
+        assert rel(loop.jtb(), ref.jtb()) <= 1e-12
+    ref.close()
+    loop.close()

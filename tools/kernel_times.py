@@ -27,7 +27,7 @@ out = {"block": os.environ.get("CERES_HIP_BAL_BLOCK", "default"), "workload": wl
 for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JTJX, B_jtjx), ("block_jacobi", hs.TIMED_BLOCK_JACOBI, None)]),
                               ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, [("sx", hs.TIMED_SX, B_sx), ("schur_init", hs.TIMED_SCHUR_INIT, None),
                                                                                   ("schur_jacobi", hs.TIMED_SCHUR_JACOBI, None), ("back_substitute", hs.TIMED_BACK_SUBSTITUTE, None),
-                                                                                  ("pack", hs.TIMED_PACK, None)])):
+                                                                                  ("pack", hs.TIMED_PACK, None), ("read_stream", hs.TIMED_READ_STREAM, 82327 * 12288 if wl == "venice1778" else None)])):
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                   elimination_groups=[prob.num_eliminate_blocks]))
     s.set_structure(prob.bs)
