@@ -16,7 +16,7 @@ constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
-enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5 };
+enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6 };
 
 constexpr int kFlagNontemporal = 1;
 
@@ -24,6 +24,13 @@ struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][12][64]
   const double2* b = nullptr;   // [n_tiles][64]
+  // fused re-layout: when src_values != nullptr the kernel gathers from the caller's layout and
+  // writes the tiles (J_out, b_out) as it goes (first pass of a step)
+  const double* src_values = nullptr;
+  const double* src_b = nullptr;
+  const int32_t *slot_epos = nullptr, *slot_fpos = nullptr, *slot_bpos = nullptr;
+  double2* J_out = nullptr;
+  double2* b_out = nullptr;
   const int32_t* slot_cam = nullptr;
   const int32_t* slot_pt = nullptr;
   const uint32_t* slot_seg = nullptr;
@@ -171,8 +178,8 @@ hipError_t LaunchCgRhsNorm(const CgBuffers& B, hipStream_t stream);
 hipError_t LaunchCgInit(const CgBuffers& B, double q_tol, double r_tol, int min_it, int max_it, hipStream_t stream);
 // z = M^-1 r (block diagonal over column blocks [first_block, ..), vectors start at scalar
 // column col_begin; blocks == nullptr => identity) and slot 0 <- partial r.z
-hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin,
-                                const int64_t* diag_off, const double* blocks, hipStream_t stream);
+hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
+                                int n_local_blocks, const int64_t* diag_off, const double* blocks, hipStream_t stream);
 // rho = sum(slot 0); beta; p = z + beta p
 hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t stream);
 // slot 1 <- partial p.q  (q lives in z)

@@ -100,26 +100,51 @@ __device__ __forceinline__ void acc_add(double* acc, int idx, double v) {
 
 struct Slot {
   double e[6], f[18];
+  double b0, b1;
   int cam, pt, first, last;
   bool valid;
 };
 
-__device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int lane, Slot& s) {
-  const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
-  double2 p[kPairsPerSlot];
-#pragma unroll
-  for (int j = 0; j < kPairsPerSlot; ++j) {
-    if (A.flags & kFlagNontemporal) {  // streamed once: keep it out of the way of x / D / ids in L2
-      p[j].x = __builtin_nontemporal_load(&J[j * kTile].x);
-      p[j].y = __builtin_nontemporal_load(&J[j * kTile].y);
-    } else {
-      p[j] = J[j * kTile];
-    }
-  }
-  s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
+// Loads one slot.  Normally from the packed tiles; on the FIRST pass over a step's Jacobian
+// (A.src_values != nullptr and may_gather) the 24 doubles are gathered from the caller's
+// layout through slot_epos / slot_fpos and the tile is written on the way, which fuses the
+// re-layout (bal_pack_kernel) into the first kernel that needs the data anyway.
+__device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int lane, Slot& s, bool want_b,
+                                          bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
+  s.b0 = 0.0; s.b1 = 0.0;
+  if (A.src_values && may_gather) {
+    const int ep = A.slot_epos[sl], fp = A.slot_fpos[sl];
+    double v[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) v[i] = 0.0;
+    if (ep >= 0) {
+      const double* e = A.src_values + ep;
+      const double* f = A.src_values + fp;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = e[i];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) v[6 + i] = f[i];
+      if (A.src_b) { const int bp = A.slot_bpos[sl]; s.b0 = A.src_b[bp]; s.b1 = A.src_b[bp + 1]; }
+    }
+    double2* o = A.J_out + tile * (kPairsPerSlot * kTile) + lane;
+#pragma unroll
+    for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+    if (A.src_b) A.b_out[sl] = make_double2(s.b0, s.b1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.e[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) s.f[i] = v[6 + i];
+  } else {
+    const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
+    double2 p[kPairsPerSlot];
+#pragma unroll
+    for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
+    if (want_b && A.have_b) { const double2 bb = A.b[sl]; s.b0 = bb.x; s.b1 = bb.y; }
+    s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
+  }
   s.cam = A.slot_cam[sl];
   s.pt = A.slot_pt[sl];
   const uint32_t sg = A.slot_seg[sl];
@@ -171,7 +196,10 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
   for (int k = 0; k < 9; ++k) acc_add<LDS>(acc, base + k, s.f[k] * z0 + s.f[9 + k] * z1);
 }
 
-enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5 };
+enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6 };
+
+template <int MODE>
+constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit);
 
 // E^T E (packed symmetric) of one slot.
 __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
@@ -224,7 +252,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
 template <int MODE, bool LDS>
 __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, double* acc) {
   Slot s;
-  load_slot(A, tile, lane, s);
+  load_slot(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
   const int po = pt_off(A, s.pt);
   if constexpr (MODE == kSx) {
@@ -253,8 +281,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
       z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
     } else {
-      const double2 bb = A.b[sl];
-      z0 = bb.x; z1 = bb.y;
+      z0 = s.b0; z1 = s.b1;
     }
     scatter_ft<LDS>(s, acc, z0, z1);
     double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
@@ -272,8 +299,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
 #pragma unroll
       for (int i = 0; i < 6; ++i) r[i] = s.valid ? a[i] : 0.0;
     }
-    double b0 = 0, b1 = 0;
-    if (MODE == kInit && A.have_b) { const double2 bb = A.b[sl]; b0 = bb.x; b1 = bb.y; }
+    const double b0 = s.b0, b1 = s.b1;
     r[6] = s.valid ? s.e[0] * b0 + s.e[3] * b1 : 0.0;
     r[7] = s.valid ? s.e[1] * b0 + s.e[4] * b1 : 0.0;
     r[8] = s.valid ? s.e[2] * b0 + s.e[5] * b1 : 0.0;
@@ -294,14 +320,37 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       const double g[3] = {r[6], r[7], r[8]};
       init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
     }
+  } else if constexpr (MODE == kCgnrInit) {
+    // CGNR set-up in one pass: rhs = J^T b (point part by segment sums, camera part scattered)
+    // and, if requested, the JACOBI point blocks (E^T E + D^2)^-1.
+    double r[9];
+    {
+      double a[6];
+      ete_of(s, a);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = s.valid ? a[i] : 0.0;
+    }
+    r[6] = s.valid ? s.e[0] * s.b0 + s.e[3] * s.b1 : 0.0;
+    r[7] = s.valid ? s.e[1] * s.b0 + s.e[4] * s.b1 : 0.0;
+    r[8] = s.valid ? s.e[2] * s.b0 + s.e[5] * s.b1 : 0.0;
+    scatter_ft<LDS>(s, acc, s.b0, s.b1);
+    seg_scan<9>(r, lane, s.first, span);
+    if (s.valid && lane == s.last) {
+      A.y_e[po] = r[6]; A.y_e[po + 1] = r[7]; A.y_e[po + 2] = r[8];
+      if (A.point_blocks) {
+        double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
+        add_e_diagonal(A, po, a);
+        invert_spd3(a, ei);
+        store_ete_inverse(A, s.pt, ei);
+      }
+    }
   } else if constexpr (MODE == kBackSub) {
     double zc[9], ei[6];
     load_xc(A, s.cam, zc);
-    const double2 bb = A.b[sl];
     load_ete_inverse(A, s.pt, ei);  // issued with the other loads, by all lanes, not behind the scan
     double t0, t1;
     f_times(s, zc, t0, t1);
-    t0 = bb.x - t0; t1 = bb.y - t1;
+    t0 = s.b0 - t0; t1 = s.b1 - t1;
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_scan<3>(u, lane, s.first, span);
@@ -323,13 +372,13 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double u[3] = {0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s);
+      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       double xc[9];
       load_xc(A, s.cam, xc);
       double t0, t1;
       f_times(s, xc, t0, t1);
-      if constexpr (MODE == kBackSub) { const double2 bb = A.b[(tile + t) * kTile + lane]; t0 = bb.x - t0; t1 = bb.y - t1; }
+      if constexpr (MODE == kBackSub) { t0 = s.b0 - t0; t1 = s.b1 - t1; }
       if (s.valid) { u[0] += s.e[0] * t0 + s.e[3] * t1; u[1] += s.e[1] * t0 + s.e[4] * t1; u[2] += s.e[2] * t0 + s.e[5] * t1; }
     }
     wave_allreduce<3>(u);
@@ -340,7 +389,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
     } else {
       for (int t = 0; t < nt; ++t) {
-        load_slot(A, tile + t, lane, s);
+        load_slot(A, tile + t, lane, s, false, false);
         double xc[9];
         load_xc(A, s.cam, xc);
         double t0, t1;
@@ -354,7 +403,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double w[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
     int pt = 0, po = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s);
+      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) {
         pt = __shfl(s.pt, 0, 64);
         po = pt_off(A, pt);
@@ -368,8 +417,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
         z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
         z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
       } else {
-        const double2 bb = A.b[(tile + t) * kTile + lane];
-        z0 = bb.x; z1 = bb.y;
+        z0 = s.b0; z1 = s.b1;
       }
       scatter_ft<LDS>(s, acc, z0, z1);
       if (s.valid) { w[0] += s.e[0] * z0 + s.e[3] * z1; w[1] += s.e[1] * z0 + s.e[4] * z1; w[2] += s.e[2] * z0 + s.e[5] * z1; }
@@ -383,36 +431,40 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
         A.y_e[po + j] = w[j] + d;
       }
     }
-  } else if constexpr (MODE == kInit || MODE == kEte) {
+  } else if constexpr (MODE == kInit || MODE == kEte || MODE == kCgnrInit) {
     double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s);
+      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
+      if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(s, acc, s.b0, s.b1);
       if (s.valid) {
         double a[6];
         ete_of(s, a);
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[i] += a[i];
-        if (MODE == kInit && A.have_b) {
-          const double2 bb = A.b[(tile + t) * kTile + lane];
-          r[6] += s.e[0] * bb.x + s.e[3] * bb.y; r[7] += s.e[1] * bb.x + s.e[4] * bb.y; r[8] += s.e[2] * bb.x + s.e[5] * bb.y;
-        }
+        r[6] += s.e[0] * s.b0 + s.e[3] * s.b1; r[7] += s.e[1] * s.b0 + s.e[4] * s.b1; r[8] += s.e[2] * s.b0 + s.e[5] * s.b1;
       }
     }
     wave_allreduce<9>(r);
+    const int po = pt_off(A, pt);
     double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-    add_e_diagonal(A, pt_off(A, pt), a);
+    add_e_diagonal(A, po, a);
     invert_spd3(a, ei);
-    if (lane == 0) store_ete_inverse(A, pt, ei);
+    if constexpr (MODE == kCgnrInit) {
+      if (lane == 0) {
+        A.y_e[po] = r[6]; A.y_e[po + 1] = r[7]; A.y_e[po + 2] = r[8];
+        if (A.point_blocks) store_ete_inverse(A, pt, ei);
+      }
+    } else {
+      if (lane == 0) store_ete_inverse(A, pt, ei);
+    }
     if constexpr (MODE == kInit) {
       const double g[3] = {r[6], r[7], r[8]};
       for (int t = 0; t < nt; ++t) {
-        load_slot(A, tile + t, lane, s);
-        double b0 = 0, b1 = 0;
+        load_slot(A, tile + t, lane, s, true, false);  // second sweep: from the tiles just written
         const int64_t sl = (tile + t) * kTile + lane;
-        if (A.have_b) { const double2 bb = A.b[sl]; b0 = bb.x; b1 = bb.y; }
-        init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
+        init_apply<LDS>(A, s, sl, s.b0, s.b1, ei, g, acc);
       }
     }
   }
@@ -422,7 +474,7 @@ template <int MODE, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
-  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit);
+  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit);
   double* acc = nullptr;
   if constexpr (kScatters) {
     if constexpr (LDS) {
@@ -702,7 +754,7 @@ static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t
 // best for the light modes; kInit needs more registers and runs at 512.
 int BalBlockFor(int mode) {
   static int forced = [] { const char* e = getenv("CERES_HIP_BAL_BLOCK"); return e ? atoi(e) : 0; }();
-  if (mode == kInit) return 512;
+  if (mode == kInit || mode == kCgnrInit) return 512;
   if (forced == 512 || forced == 1024) return forced;
   return 1024;
 }
@@ -716,6 +768,7 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
     case kInit: return launch_fused<kInit, 512>(A, lds, grid, stream);
     case kEte: return big ? launch_fused<kEte, 1024>(A, false, grid, stream) : launch_fused<kEte, 512>(A, false, grid, stream);
     case kBackSub: return big ? launch_fused<kBackSub, 1024>(A, false, grid, stream) : launch_fused<kBackSub, 512>(A, false, grid, stream);
+    case kCgnrInit: return launch_fused<kCgnrInit, 512>(A, lds, grid, stream);
   }
   return hipErrorInvalidValue;
 }

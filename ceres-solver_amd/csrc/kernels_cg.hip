@@ -138,25 +138,58 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_kernel(CgBuffers B, double 
   }
 }
 
+// One thread per COLUMN BLOCK (not per scalar): the block's metadata is read once, its
+// n x n inverse and the n entries of r are contiguous reads, and 3- and 9-wide blocks (the
+// bundle-adjustment case) are fully unrolled.  Workgroups [0, grid_e) take the shard's
+// blocks [0, n_local_blocks), the others the replicated blocks.
+template <int N>
+__device__ __forceinline__ double precondition_block(const double* __restrict__ m, const double* __restrict__ r, double* __restrict__ z) {
+  double rr[N], v = 0;
+#pragma unroll
+  for (int c = 0; c < N; ++c) rr[c] = r[c];
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) s += m[a * N + c] * rr[c];
+    z[a] = s;
+    v += rr[a] * s;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(kVecBlock) void cg_precondition_kernel(CgBuffers B, GenStructure G, int first_block, int col_begin,
+                                                                    int nblocks, int n_local_blocks,
                                                                     const int64_t* diag_off, const double* blocks) {
   __shared__ double sh[4];
   if (B.S->status != 0) return;
   double v = 0;
-  for (Span s = my_span(B); s.i < s.end; s.i += s.step) {
-    double z;
-    if (blocks) {
-      const int j = G.col_block_of[col_begin + s.i];
+  if (!blocks) {  // IDENTITY
+    for (Span s = my_span(B); s.i < s.end; s.i += s.step) { const double r = B.r[s.i]; B.z[s.i] = r; v += r * r; }
+  } else {
+    int64_t q, q_end, q_step;
+    if (int(blockIdx.x) < B.grid_e) {
+      q = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; q_end = n_local_blocks; q_step = int64_t(B.grid_e) * kVecBlock;
+    } else {
+      q = n_local_blocks + int64_t(blockIdx.x - B.grid_e) * kVecBlock + threadIdx.x; q_end = nblocks;
+      q_step = int64_t(B.grid - B.grid_e) * kVecBlock;
+    }
+    for (; q < q_end; q += q_step) {
+      const int j = first_block + int(q);
       const int n = G.csz[j];
       const int64_t pos = G.cpos[j] - col_begin;
-      const double* m = blocks + (diag_off[j - first_block] - diag_off[0]) + int64_t(s.i - pos) * n;
-      z = 0;
-      for (int c = 0; c < n; ++c) z += m[c] * B.r[pos + c];
-    } else {
-      z = B.r[s.i];
+      const double* m = blocks + (diag_off[q] - diag_off[0]);
+      if (n == 3) v += precondition_block<3>(m, B.r + pos, B.z + pos);
+      else if (n == 9) v += precondition_block<9>(m, B.r + pos, B.z + pos);
+      else {
+        for (int a = 0; a < n; ++a) {
+          double s = 0;
+          for (int c = 0; c < n; ++c) s += m[a * n + c] * B.r[pos + c];
+          B.z[pos + a] = s;
+          v += B.r[pos + a] * s;
+        }
+      }
     }
-    B.z[s.i] = z;
-    v += B.r[s.i] * z;
   }
   v = block_sum(v, sh);
   if (threadIdx.x == 0) B.partials[0 * kMaxVecGrid + blockIdx.x] = v;
@@ -332,9 +365,10 @@ hipError_t LaunchCgInit(const CgBuffers& B, double q_tol, double r_tol, int min_
   hipLaunchKernelGGL(cg_init_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, q_tol, r_tol, min_it, max_it);
   return hipGetLastError();
 }
-hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin,
-                                const int64_t* diag_off, const double* blocks, hipStream_t s) {
-  hipLaunchKernelGGL(cg_precondition_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, diag_off, blocks);
+hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
+                                int n_local_blocks, const int64_t* diag_off, const double* blocks, hipStream_t s) {
+  hipLaunchKernelGGL(cg_precondition_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks,
+                     n_local_blocks, diag_off, blocks);
   return hipGetLastError();
 }
 hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t s) {

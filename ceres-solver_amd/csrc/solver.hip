@@ -42,6 +42,7 @@ struct ceres_hip_solver {
   hipEvent_t ev[10] = {};
   int num_cus = 256;
   bool have_structure = false, loaded = false, have_b = false, have_D = false;
+  bool packed = false;  // <2,3,9> path: tiles hold the currently loaded values
   int path = CERES_HIP_PATH_GENERIC;
   HostStructure hs;
   BalPlan plan;
@@ -167,6 +168,24 @@ BalArgs bal_args(ceres_hip_solver* s) {
   return A;
 }
 
+// First pass over a step's Jacobian: let the kernel gather from the caller's layout and write
+// the tiles on the way (fused re-layout).  Call right before launching; marks the tiles valid.
+void use_gather_if_unpacked(ceres_hip_solver* s, BalArgs& A) {
+  if (s->packed) return;
+  A.src_values = s->values;
+  A.src_b = s->b;
+  A.slot_epos = s->d_slot_epos; A.slot_fpos = s->d_slot_fpos; A.slot_bpos = s->d_slot_bpos;
+  A.J_out = s->d_J; A.b_out = s->d_bt;
+  s->packed = true;
+}
+
+int ensure_packed(ceres_hip_solver* s) {
+  if (s->path != CERES_HIP_PATH_BAL || s->packed) return 0;
+  HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, s->stream));
+  s->packed = true;
+  return 0;
+}
+
 // Run one fused kernel that scatters into camera space and produce y_f.
 // add_diag: y_f += D_f^2 x_f (after the all-reduce when sharded).
 int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
@@ -194,6 +213,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
 int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
   const HostStructure& h = s->hs;
   if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_f = x;
     if (s->use_xpad) {
@@ -230,6 +250,7 @@ int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status) 
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
     if (s->use_xpad) {
@@ -253,6 +274,7 @@ int op_jtb(ceres_hip_solver* s, double* y) {
   hipStream_t st = s->stream;
   if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "no residual vector loaded");
   if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.y_e = y;
     return bal_scatter(s, kBalJtb, A, nullptr, y + h.num_cols_e, false, nullptr);
@@ -271,6 +293,7 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
     BalArgs A = bal_args(s);
     A.D_e = s->D;
     A.Mo = want_Mo ? s->d_Mo : nullptr;
+    use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
     if (s->have_b) return bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr);
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
     HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->fused_grid, st));
@@ -302,6 +325,7 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
   hipStream_t st = s->stream;
   if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "no residual vector loaded");
   if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_f = z; A.y_e = x;
     HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
@@ -358,6 +382,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
   // CGNR JACOBI
   const int64_t len = h.diag_off_all.back();
   if (s->path == CERES_HIP_PATH_BAL && s->world <= 1 && invert) {
+    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.etei = nullptr;
     A.D_e = s->D;
@@ -381,6 +406,43 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
   return 0;
 }
 
+// CGNR set-up on the <2,3,9> path in ONE pass over J: rhs = J^T b and (JACOBI) the inverted
+// point blocks; the camera blocks follow from the camera-major pass.  Replaces
+// BlockSparseJacobiPreconditioner::UpdateImpl + A->LeftMultiplyAndAccumulate(b)
+// (I/cgnr_solver.cc:152-191) = two passes over J, and absorbs the re-layout pass.
+int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blocks) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
+  const int64_t len = h.diag_off_all.back();
+  if (jacobi) HIP_TRY(s, hipMemsetAsync(blocks, 0, sizeof(double) * len, st));  // camera blocks use atomics
+  HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  BalArgs A = bal_args(s);
+  A.etei = nullptr;
+  A.D_e = s->D;
+  A.y_e = rhs;
+  A.point_blocks = jacobi ? blocks : nullptr;
+  A.pt_diag_off = s->d_pt_diag_off;
+  use_gather_if_unpacked(s, A);
+  TRY(bal_scatter(s, kBalCgnrInit, A, nullptr, rhs + h.num_cols_e, false, nullptr));
+  if (!jacobi) return 0;
+  const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  if (s->world <= 1) {
+    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
+                                     D_f, cam_pos, s->d_cam_diag_off, blocks, st));
+  } else {
+    // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
+    // behind the point blocks in the Schur-ordered layout a sharded run requires)
+    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
+                                     nullptr, cam_pos, s->d_cam_diag_off, blocks, st));
+    const int64_t first = h.diag_off_all[h.nelim];
+    TRY(allreduce(s, blocks + first, size_t(len - first)));
+    if (s->D) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
+  }
+  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Conjugate gradients driver (I/conjugate_gradients_solver.h:108-306).
 // ---------------------------------------------------------------------------
@@ -388,7 +450,7 @@ struct CgSpec {
   int64_t n = 0;
   int64_t n_local = 0;                                  // sharded CGNR: E-space prefix
   std::function<int(const double*, double*)> apply;     // y = A x (assigns)
-  int first_block = 0, col_begin = 0;
+  int first_block = 0, col_begin = 0, nblocks = 0, n_local_blocks = 0;
   const int64_t* diag_off = nullptr;
   const double* blocks = nullptr;                       // nullptr = IDENTITY
 };
@@ -474,13 +536,16 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
   TRY(collapse_and_reduce(s, 0, 1));
   HIP_TRY(s, LaunchCgInit(B, q_tol, r_tol, min_it, max_it, st));
-  TRY(poll_scalars(s));
+  // No poll here: if |b| = 0 or r0 already meets the tolerance the status word is set and the
+  // first batch below is a string of no-ops; the first poll comes after it.
+  s->h_scalars->status = kCgRunning;
   s->timing.operator_applications = 0;
   int it = 1;
   while (s->h_scalars->status == kCgRunning) {
     const int batch_end = std::min(max_it, it + interval - 1);
     for (; it <= batch_end; ++it) {
-      HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.diag_off, spec.blocks, st));
+      HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.nblocks,
+                                      B.grid_e > 0 ? spec.n_local_blocks : 0, spec.diag_off, spec.blocks, st));
       TRY(collapse_and_reduce(s, 0, 1));
       HIP_TRY(s, LaunchCgDirection(B, st));
       TRY(spec.apply(B.p, B.z));
@@ -530,8 +595,7 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->have_b = db != nullptr;
   s->have_D = dD != nullptr;
   s->precond_valid = false;
-  if (s->path == CERES_HIP_PATH_BAL)
-    HIP_TRY(s, LaunchBalPack(dv, db, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, s->stream));
+  s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
   s->loaded = true;
   return 0;
 }
@@ -600,6 +664,7 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     const int* status = &s->cg.S->status;
     spec.apply = [s, status](const double* in, double* out) { return op_sx(s, in, out, status); };
     spec.first_block = h.nelim;
+    spec.nblocks = h.ncb - h.nelim;
     spec.col_begin = h.num_cols_e;
     spec.diag_off = s->G.diag_off_f;
     spec.blocks = pre == CERES_HIP_IDENTITY ? nullptr : s->precond;
@@ -613,8 +678,13 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   // CgnrSolver::SolveImpl, I/cgnr_solver.cc:146-207
   const int pre = s->opt.preconditioner_type;
   HIP_TRY(s, hipEventRecord(s->ev[3], st));
+  if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(op_cgnr_setup_bal(s, pre == CERES_HIP_JACOBI, s->cg_rhs, s->precond));
+  } else {
+    if (pre == CERES_HIP_JACOBI) TRY(op_preconditioner(s, pre, s->precond, true));
+    TRY(op_jtb(s, s->cg_rhs));
+  }
   if (pre == CERES_HIP_JACOBI) {
-    TRY(op_preconditioner(s, pre, s->precond, true));
     bool bad = false;
     TRY(check_factorization(s, &bad));
     if (bad) {
@@ -624,7 +694,6 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     }
     s->precond_valid = true;
   }
-  TRY(op_jtb(s, s->cg_rhs));
   HIP_TRY(s, hipEventRecord(s->ev[4], st));
   CgSpec spec;
   spec.n = h.num_cols;
@@ -632,6 +701,8 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   const int* status = &s->cg.S->status;
   spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status); };
   spec.first_block = 0;
+  spec.nblocks = h.ncb;
+  spec.n_local_blocks = h.nelim;
   spec.col_begin = 0;
   spec.diag_off = s->G.diag_off_all;
   spec.blocks = pre == CERES_HIP_JACOBI ? s->precond : nullptr;
@@ -1215,9 +1286,13 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       TRY(op_schur_init(s, true));
       body = [&] { return op_sx(s, s->cg.p, s->cg.z, nullptr); };
       break;
-    case CERES_HIP_TIMED_SCHUR_INIT:
+    case CERES_HIP_TIMED_SCHUR_INIT:  // as a solve runs it: fused with the re-layout of the step's values
       if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "needs an ITERATIVE_SCHUR instance");
-      body = [&] { return op_schur_init(s, true); };
+      body = [&] { s->packed = false; return op_schur_init(s, true); };
+      break;
+    case CERES_HIP_TIMED_CGNR_SETUP:
+      if (is_schur(s) || s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "needs a CGNR instance on the <2,3,9> path");
+      body = [&] { s->packed = false; return op_cgnr_setup_bal(s, s->opt.preconditioner_type == CERES_HIP_JACOBI, s->cg_rhs, s->precond); };
       break;
     case CERES_HIP_TIMED_SCHUR_JACOBI:
       if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "needs an ITERATIVE_SCHUR instance");
@@ -1251,6 +1326,7 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
     default:
       return fail(s, CERES_HIP_E_INVALID, "unknown timed op %d", op);
   }
+  TRY(ensure_packed(s));
   HIP_TRY(s, LaunchSet(s->cg.p, 1.0, n, st));
   for (int w = 0; w < 3; ++w) TRY(body());
   HIP_TRY(s, hipEventRecord(s->ev[8], st));
@@ -1258,7 +1334,7 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
   HIP_TRY(s, hipEventRecord(s->ev[9], st));
   HIP_TRY(s, hipStreamSynchronize(st));
   *avg_ms = double(elapsed(s->ev[8], s->ev[9])) / iters;
-  if (op == CERES_HIP_TIMED_COPY) TRY(load_device(s, s->values, s->b, s->D));  // restore the packed tiles
+  if (op == CERES_HIP_TIMED_COPY) { s->packed = false; TRY(ensure_packed(s)); }  // restore the tiles
   HIP_TRY(s, hipStreamSynchronize(st));
   return 0;
 }

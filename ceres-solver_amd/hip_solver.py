@@ -33,7 +33,7 @@ TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_
 UNIQUE_ID_BYTES = 128
 
 (TIMED_JTJX, TIMED_SX, TIMED_SCHUR_INIT, TIMED_SCHUR_JACOBI, TIMED_BACK_SUBSTITUTE, TIMED_PACK, TIMED_BLOCK_JACOBI, TIMED_COPY,
- TIMED_READ_STREAM) = range(1, 10)
+ TIMED_READ_STREAM, TIMED_CGNR_SETUP) = range(1, 11)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -295,3 +295,170 @@ def synthetic_bal(shape="dubrovnik16", layout="schur", seed=38401, skew=0.0, num
         diag += np.bincount(col_pos[cam_block] + c, weights=f2[:, c], minlength=bs.num_cols)
     D = np.sqrt(np.clip(diag, 1e-6, 1e32) / 1e4)
     return LinearProblem(bs, values, b, D, nelim, {}, cam_block, point_block)
+
+
+# --------------------------------------------------------------------------
+# Scene-based values: the first LM linear system of a synthetic bundle-adjustment problem
+# --------------------------------------------------------------------------
+class _Dual:
+    """Forward-mode dual numbers vectorised over observations: v (N,), d (N, 12) =
+    d/d(camera[0..8], point[0..2]) — what AutoDiffCostFunction<SnavelyReprojectionError, 2, 9, 3>
+    evaluates with Jets (examples/snavely_reprojection_error.h:53-105)."""
+    __slots__ = ("v", "d")
+
+    def __init__(self, v, d):
+        self.v, self.d = v, d
+
+    @staticmethod
+    def var(v, k):
+        d = np.zeros((v.shape[0], 12))
+        d[:, k] = 1.0
+        return _Dual(v, d)
+
+    def _lift(self, o):
+        return o if isinstance(o, _Dual) else _Dual(np.broadcast_to(np.asarray(o, dtype=np.float64), self.v.shape), 0.0)
+
+    def __add__(self, o):
+        o = self._lift(o)
+        return _Dual(self.v + o.v, self.d + o.d)
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = self._lift(o)
+        return _Dual(self.v - o.v, self.d - o.d)
+
+    def __rsub__(self, o):
+        return self._lift(o) - self
+
+    def __neg__(self):
+        return _Dual(-self.v, -self.d)
+
+    def __mul__(self, o):
+        o = self._lift(o)
+        return _Dual(self.v * o.v, self.d * o.v[:, None] + np.asarray(o.d) * self.v[:, None])
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        o = self._lift(o)
+        q = self.v / o.v
+        return _Dual(q, (self.d - np.asarray(o.d) * q[:, None]) / o.v[:, None])
+
+    def sqrt(self):
+        r = np.sqrt(self.v)
+        return _Dual(r, self.d * (0.5 / r)[:, None])
+
+    def sin(self):
+        return _Dual(np.sin(self.v), self.d * np.cos(self.v)[:, None])
+
+    def cos(self):
+        return _Dual(np.cos(self.v), self.d * (-np.sin(self.v))[:, None])
+
+
+def _snavely(cam, pt, dual):
+    """Snavely projection (no observation subtracted).  cam (N,9), pt (N,3).  With dual=True
+    returns (value (N,2), jacobian (N,2,12)), else value only.  Rotation: Rodrigues formula
+    (include/ceres/rotation.h AngleAxisRotatePoint, theta != 0 branch)."""
+    if dual:
+        c = [_Dual.var(cam[:, i], i) for i in range(9)]
+        p = [_Dual.var(pt[:, i], 9 + i) for i in range(3)]
+        sqrt, sin, cos = (lambda a: a.sqrt()), (lambda a: a.sin()), (lambda a: a.cos())
+    else:
+        c = [cam[:, i] for i in range(9)]
+        p = [pt[:, i] for i in range(3)]
+        sqrt, sin, cos = np.sqrt, np.sin, np.cos
+    theta = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2])
+    ct, st = cos(theta), sin(theta)
+    w = [c[i] / theta for i in range(3)]
+    wxp = [w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]]
+    tmp = (w[0] * p[0] + w[1] * p[1] + w[2] * p[2]) * (1.0 - ct)
+    q = [p[i] * ct + wxp[i] * st + w[i] * tmp + c[3 + i] for i in range(3)]
+    xp, yp = -(q[0] / q[2]), -(q[1] / q[2])
+    r2 = xp * xp + yp * yp
+    dist = 1.0 + r2 * (c[7] + c[8] * r2)
+    u, v = c[6] * dist * xp, c[6] * dist * yp
+    if dual:
+        return np.stack([u.v, v.v], 1), np.stack([u.d, v.d], 1)
+    return np.stack([u, v], 1)
+
+
+def _scene(rng, n_cams, n_points):
+    """Cameras on a ring looking at a point cloud around the origin (BAL camera model: looks
+    down -z, 9 parameters = angle-axis, translation, focal, k1, k2)."""
+    ang = 2 * np.pi * (np.arange(n_cams) + 0.25 * rng.random(n_cams)) / n_cams
+    rad = 8.0 + 4.0 * rng.random(n_cams)
+    C = np.stack([rad * np.cos(ang), rad * np.sin(ang), 1.5 * rng.standard_normal(n_cams)], 1)
+    z = C / np.linalg.norm(C, axis=1, keepdims=True)
+    up = np.stack([0.05 * rng.standard_normal(n_cams), 0.05 * rng.standard_normal(n_cams), np.ones(n_cams)], 1)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], 1)  # rows = camera axes
+    tr = np.clip((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2] - 1.0) / 2.0, -1.0, 1.0)
+    theta = np.arccos(tr)
+    ax = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], 1)
+    ax /= np.maximum(np.linalg.norm(ax, axis=1, keepdims=True), 1e-12)
+    cams = np.zeros((n_cams, 9))
+    cams[:, :3] = ax * theta[:, None]
+    cams[:, 3:6] = -np.einsum("cij,cj->ci", R, C)
+    cams[:, 6] = 800.0 + 400.0 * rng.random(n_cams)
+    cams[:, 7] = 2e-2 * rng.standard_normal(n_cams)
+    cams[:, 8] = 1e-3 * rng.standard_normal(n_cams)
+    pts = np.stack([1.5 * rng.standard_normal(n_points), 1.5 * rng.standard_normal(n_points), 0.8 * rng.standard_normal(n_points)], 1)
+    return cams, pts
+
+
+def scene_values(prob: LinearProblem, n_cams: int, n_points: int, seed=38401, pixel_noise=0.5, param_noise=0.02,
+                 jacobi_scaling=True, radius=1e4, chunk=400_000):
+    """Replace the N(0,1) values of a BAL-shaped problem (either layout) by the Jacobian, residuals
+    and LM diagonal of the FIRST trust-region step of a synthetic bundle-adjustment scene: J at the
+    perturbed start, column-scaled as TrustRegionMinimizer does when jacobi_scaling is on
+    (internal/ceres/trust_region_minimizer.cc:263-279), D = sqrt(clamp(diag(J^T J), 1e-6, 1e32) / radius)."""
+    rng = np.random.default_rng(seed + 17)
+    bs = prob.bs
+    n_obs = bs.num_row_blocks
+    pt_ids = np.unique(prob.point_of_row, return_inverse=True)[1]   # 0..n_points-1 in column order
+    cam_ids = np.unique(prob.camera_of_row, return_inverse=True)[1]
+    cams_true, pts_true = _scene(rng, n_cams, n_points)
+    cams0 = cams_true.copy()
+    cams0[:, :3] += 0.02 * param_noise * rng.standard_normal((n_cams, 3))
+    cams0[:, 3:6] += 0.2 * param_noise * rng.standard_normal((n_cams, 3))
+    cams0[:, 6] *= 1.0 + 0.02 * param_noise * rng.standard_normal(n_cams)
+    pts0 = pts_true + param_noise * rng.standard_normal((n_points, 3))
+    values = np.empty(24 * n_obs)
+    b = np.empty(2 * n_obs)
+    # where each row's E and F cells live
+    first_is_pt = bs.col_block_size[bs.cell_col_block[0::2]] == 3
+    epos = np.where(first_is_pt, bs.cell_value_pos[0::2], bs.cell_value_pos[1::2]).astype(np.int64)
+    fpos = np.where(first_is_pt, bs.cell_value_pos[1::2], bs.cell_value_pos[0::2]).astype(np.int64)
+    for lo in range(0, n_obs, chunk):
+        hi = min(n_obs, lo + chunk)
+        ci, pi = cam_ids[lo:hi], pt_ids[lo:hi]
+        observed = _snavely(cams_true[ci], pts_true[pi], False) + pixel_noise * rng.standard_normal((hi - lo, 2))
+        val, jac = _snavely(cams0[ci], pts0[pi], True)
+        b[2 * lo:2 * hi] = (val - observed).reshape(-1)
+        values[(epos[lo:hi, None] + np.arange(6)[None, :]).reshape(-1)] = jac[:, :, 9:].reshape(-1)
+        values[(fpos[lo:hi, None] + np.arange(18)[None, :]).reshape(-1)] = jac[:, :, :9].reshape(-1)
+    col_pos = bs.col_block_pos.astype(np.int64)
+    pcol, ccol = col_pos[prob.point_of_row], col_pos[prob.camera_of_row]
+
+    def colnorm2(vals):
+        E = vals[(epos[:, None] + np.arange(6)[None, :])].reshape(n_obs, 2, 3)
+        F = vals[(fpos[:, None] + np.arange(18)[None, :])].reshape(n_obs, 2, 9)
+        d = np.zeros(bs.num_cols)
+        e2, f2 = (E * E).sum(1), (F * F).sum(1)
+        for k in range(3):
+            d += np.bincount(pcol + k, weights=e2[:, k], minlength=bs.num_cols)
+        for k in range(9):
+            d += np.bincount(ccol + k, weights=f2[:, k], minlength=bs.num_cols)
+        return d
+    if jacobi_scaling:
+        scale = 1.0 / (1.0 + np.sqrt(colnorm2(values)))
+        se = scale[(pcol[:, None] + np.arange(3)[None, :])]            # (n_obs, 3)
+        sf = scale[(ccol[:, None] + np.arange(9)[None, :])]            # (n_obs, 9)
+        idx_e = (epos[:, None] + np.arange(6)[None, :])
+        idx_f = (fpos[:, None] + np.arange(18)[None, :])
+        values[idx_e] *= np.tile(se, (1, 2))
+        values[idx_f] *= np.tile(sf, (1, 2))
+    D = np.sqrt(np.clip(colnorm2(values), 1e-6, 1e32) / radius)
+    prob.values, prob.b, prob.D = values, b, D
+    return prob

@@ -252,12 +252,13 @@ int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b,
  * that same stream; returns the average milliseconds per application.        */
 #define CERES_HIP_TIMED_JTJX 1
 #define CERES_HIP_TIMED_SX 2
-#define CERES_HIP_TIMED_SCHUR_INIT 3
+#define CERES_HIP_TIMED_SCHUR_INIT 3 /* incl. the fused re-layout, as a solve runs it */
 #define CERES_HIP_TIMED_SCHUR_JACOBI 4
 #define CERES_HIP_TIMED_BACK_SUBSTITUTE 5
 #define CERES_HIP_TIMED_PACK 6
 #define CERES_HIP_TIMED_BLOCK_JACOBI 7
 #define CERES_HIP_TIMED_COPY 8 /* plain device copy of the values array: HBM ceiling probe */
+#define CERES_HIP_TIMED_CGNR_SETUP 10 /* CGNR per-step set-up on the <2,3,9> path (re-layout + J^T b + JACOBI blocks) */
 #define CERES_HIP_TIMED_READ_STREAM 9 /* read-only pass over the packed tiles, same loads as the fused kernels */
 int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms);
 /* Per-phase event timings (ms) of the most recent ceres_hip_solve*. */

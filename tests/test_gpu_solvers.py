@@ -196,7 +196,7 @@ def test_sharded_code_paths_in_loopback(hip, oracle, problems, solver_type, pre,
     loop.set_structure(p.bs)
     assert loop.info().world_size == 4 and ref.info().world_size == 1
     assert loop.info().kernel_path == (hip.PATH_BAL if kind == "bal" else hip.PATH_GENERIC)
-    for q_tol, r_tol in ((0.1, -1.0), (0.0, 1e-11)):
+    for q_tol, r_tol in ((0.1, -1.0), (-1.0, 1e-11)):  # -1: zeta is rounding noise near convergence
         ps = hip.PerSolveOptions(D=p.D, q_tolerance=q_tol, r_tolerance=r_tol)
         xr, sr = ref.solve(p.values, p.b, ps)
         xl, sl = loop.solve(p.values, p.b, ps)
