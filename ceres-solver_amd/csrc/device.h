@@ -54,7 +54,7 @@ struct BalArgs {
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
-  double* global_acc = nullptr;  // [n_f9]         (global-atomic mode)
+  double2* zbuf = nullptr;       // [n_slots]      (cameras do not fit in LDS: z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
@@ -79,6 +79,9 @@ struct CamItems {
 hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
                                  const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
                                  const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream);
+hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
+                                const int32_t* cam_slot, const double2* zbuf, double* out, const int* status,
+                                hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------

@@ -92,15 +92,11 @@ __device__ __forceinline__ void invert_spd3(const double (&a)[6], double (&o)[6]
   o[5] = i22 * i22;
 }
 
-template <bool LDS>
-__device__ __forceinline__ void acc_add(double* acc, int idx, double v) {
-  if constexpr (LDS) atomicAdd(&acc[idx], v);   // ds_add_f64
-  else unsafeAtomicAdd(&acc[idx], v);           // global_atomic_add_f64
-}
 
 struct Slot {
   double e[6], f[18];
   double b0, b1;
+  int64_t slot;
   int cam, pt, first, last;
   bool valid;
 };
@@ -109,11 +105,15 @@ struct Slot {
 // (A.src_values != nullptr and may_gather) the 24 doubles are gathered from the caller's
 // layout through slot_epos / slot_fpos and the tile is written on the way, which fuses the
 // re-layout (bal_pack_kernel) into the first kernel that needs the data anyway.
+// CAN_GATHER is a compile-time property of the mode (only kInit / kCgnrInit are ever a step's
+// first pass): the streaming kernels do not carry the gather code or its registers.
+template <bool CAN_GATHER>
 __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int lane, Slot& s, bool want_b,
                                           bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
+  s.slot = sl;
   s.b0 = 0.0; s.b1 = 0.0;
-  if (A.src_values && may_gather) {
+  if (CAN_GATHER && A.src_values && may_gather) {
     const int ep = A.slot_epos[sl], fp = A.slot_fpos[sl];
     double v[24];
 #pragma unroll
@@ -188,18 +188,28 @@ __device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], do
 #pragma unroll
   for (int k = 0; k < 9; ++k) { t0 += s.f[k] * xc[k]; t1 += s.f[9 + k] * xc[k]; }
 }
+// Camera-space contribution F^T z of one observation.  LDS: nine ds_add_f64 into the
+// workgroup's accumulator.  Otherwise (cameras do not fit in LDS) only z is stored, 16 bytes
+// per slot, and bal_camera_apply_kernel forms F^T z camera by camera in a second pass —
+// global fp64 atomics on a few thousand hot addresses are an order of magnitude slower.
 template <bool LDS>
 __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
   if (!s.valid) return;
-  const int base = 9 * s.cam;
+  if constexpr (LDS) {
+    const int base = 9 * s.cam;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc_add<LDS>(acc, base + k, s.f[k] * z0 + s.f[9 + k] * z1);
+    for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);  // ds_add_f64
+  } else {
+    reinterpret_cast<double2*>(acc)[s.slot] = make_double2(z0, z1);
+  }
 }
 
 enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6 };
 
 template <int MODE>
 constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit);
+template <int MODE>
+constexpr bool kCanGather = (MODE == kInit || MODE == kCgnrInit);
 
 // E^T E (packed symmetric) of one slot.
 __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
@@ -252,7 +262,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
 template <int MODE, bool LDS>
 __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, double* acc) {
   Slot s;
-  load_slot(A, tile, lane, s, kWantsB<MODE>);
+  load_slot<kCanGather<MODE>>(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
   const int po = pt_off(A, s.pt);
   if constexpr (MODE == kSx) {
@@ -372,7 +382,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double u[3] = {0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       double xc[9];
       load_xc(A, s.cam, xc);
@@ -389,7 +399,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
     } else {
       for (int t = 0; t < nt; ++t) {
-        load_slot(A, tile + t, lane, s, false, false);
+        load_slot<false>(A, tile + t, lane, s, false, false);
         double xc[9];
         load_xc(A, s.cam, xc);
         double t0, t1;
@@ -403,7 +413,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double w[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
     int pt = 0, po = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) {
         pt = __shfl(s.pt, 0, 64);
         po = pt_off(A, pt);
@@ -435,7 +445,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(s, acc, s.b0, s.b1);
       if (s.valid) {
@@ -462,7 +472,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     if constexpr (MODE == kInit) {
       const double g[3] = {r[6], r[7], r[8]};
       for (int t = 0; t < nt; ++t) {
-        load_slot(A, tile + t, lane, s, true, false);  // second sweep: from the tiles just written
+        load_slot<false>(A, tile + t, lane, s, true, false);  // second sweep: from the tiles just written
         const int64_t sl = (tile + t) * kTile + lane;
         init_apply<LDS>(A, s, sl, s.b0, s.b1, ei, g, acc);
       }
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
       for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) acc[i] = 0.0;
       __syncthreads();
     } else {
-      acc = A.global_acc;
+      acc = reinterpret_cast<double*>(A.zbuf);
     }
   }
   const int lane = threadIdx.x & 63;
@@ -606,19 +616,20 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
   if (b) bt[sl] = make_double2(b0, b1);
 }
 
-// Per-camera 9x9 blocks: sum over the camera's observations of F^T M F (+ D^2), with
-// M = I (JACOBI: block diagonal of F^T F) or M = I - E (E^T E)^-1 E^T (SCHUR_JACOBI:
-// the diagonal blocks SchurEliminator::Eliminate writes into a block-diagonal lhs).
-// Camera degrees are heavily skewed (a few cameras see most points), so the unit of work
-// is an ITEM: at most kCamChunk consecutive observations of one camera in the camera-major
-// list (plan.cc).  One workgroup per item; its 9x9 sum is added to the (zeroed) block
-// with global_atomic_add_f64, the first item of a camera also adds D^2.  F is read from
-// the caller-layout values (contiguous 144 B per observation), M from [slot][4].
+// ---- camera-major passes ---------------------------------------------------------------
+// Unit of work = ITEM: at most kCamChunk consecutive observations of ONE camera in the
+// camera-major list (plan.cc); camera degrees are heavily skewed, so heavy cameras are split.
+// One WAVEFRONT per item (4 items per workgroup): lanes stride over the item's observations,
+// gather F from the caller-layout values (144 contiguous bytes per observation) and reduce
+// with __shfl_xor.  A camera covered by a single item is stored directly; split cameras are
+// combined with global_atomic_add_f64 into a zeroed output (rounding-level order effects
+// only there).
+
+// Per-camera 9x9 blocks: sum of F^T M F (+ D^2), with M = I (JACOBI: block diagonal of
+// F^T F) or M = I - E (E^T E)^-1 E^T read from [slot][4] (SCHUR_JACOBI: the diagonal blocks
+// SchurEliminator::Eliminate writes into a block-diagonal lhs).  `blocks` must be zeroed.
 template <bool SCHUR>
-__global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __restrict__ values,
-                                                                const int32_t* __restrict__ item_cam,
-                                                                const int32_t* __restrict__ item_begin,
-                                                                const int32_t* __restrict__ item_end,
+__global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __restrict__ values, CamItems items,
                                                                 const int32_t* __restrict__ cam_ptr,
                                                                 const int32_t* __restrict__ cam_fpos,
                                                                 const int32_t* __restrict__ cam_slot,
@@ -627,13 +638,15 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
                                                                 const int32_t* __restrict__ cam_pos,
                                                                 const int64_t* __restrict__ cam_diag_off,
                                                                 double* __restrict__ blocks) {
-  __shared__ double red[4][45];
-  const int c = item_cam[blockIdx.x];
-  const int beg = item_begin[blockIdx.x], end = item_end[blockIdx.x];
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items.count) return;
+  const int c = items.cam[item];
+  const int beg = items.begin[item], end = items.end[item];
   double acc[45];
 #pragma unroll
   for (int i = 0; i < 45; ++i) acc[i] = 0.0;
-  for (int q = beg + threadIdx.x; q < end; q += 256) {
+  for (int q = beg + lane; q < end; q += 64) {
     const double* f = values + cam_fpos[q];
     double f0[9], f1[9];
 #pragma unroll
@@ -660,19 +673,64 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     acc[i] = v;
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) {
+  // lanes 0..44 each own one upper-triangle entry (static register index via a select chain
+  // would be long: go through LDS-free broadcast instead — every lane holds all 45 sums)
+  const bool first = beg == cam_ptr[c];
+  const bool single = first && end == cam_ptr[c + 1];
+  double* out = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c);
+  const int dpos = cam_pos ? cam_pos[c] : 9 * c;
+  int idx = 0;
 #pragma unroll
-    for (int i = 0; i < 45; ++i) red[wv][i] = acc[i];
+  for (int a = 0; a < 9; ++a) {
+#pragma unroll
+    for (int bb = a; bb < 9; ++bb, ++idx) {
+      if (lane == (idx & 63)) {
+        double v = acc[idx];
+        if (a == bb && D_f && first) { const double d = D_f[dpos + a]; v += d * d; }
+        if (single) { out[a * 9 + bb] = v; if (a != bb) out[bb * 9 + a] = v; }
+        else { unsafeAtomicAdd(&out[a * 9 + bb], v); if (a != bb) unsafeAtomicAdd(&out[bb * 9 + a], v); }
+      }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < 81) {
-    const int a = threadIdx.x / 9, bb = threadIdx.x % 9;
-    const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
-    const int idx = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);
-    double v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-    if (a == bb && D_f && beg == cam_ptr[c]) { const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + a]; v += d * d; }
-    unsafeAtomicAdd(&blocks[(cam_diag_off ? cam_diag_off[c] : int64_t(81) * c) + threadIdx.x], v);
+}
+
+// y_c = sum over the camera's observations of F_o^T z_o, z from the per-slot buffer written by
+// the fused kernel in its non-LDS mode.  Output: contiguous [9c + k], zeroed by the caller.
+__global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __restrict__ values, CamItems items,
+                                                               const int32_t* __restrict__ cam_ptr,
+                                                               const int32_t* __restrict__ cam_fpos,
+                                                               const int32_t* __restrict__ cam_slot,
+                                                               const double2* __restrict__ zbuf,
+                                                               double* __restrict__ out, const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items.count) return;
+  const int c = items.cam[item];
+  const int beg = items.begin[item], end = items.end[item];
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int q = beg + lane; q < end; q += 64) {
+    const double* f = values + cam_fpos[q];
+    const double2 z = zbuf[cam_slot[q]];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] += f[k] * z.x + f[9 + k] * z.y;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    acc[k] = v;
+  }
+  const bool single = beg == cam_ptr[c] && end == cam_ptr[c + 1];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (lane == k) {
+      if (single) out[9 * int64_t(c) + k] = acc[k];
+      else unsafeAtomicAdd(&out[9 * int64_t(c) + k], acc[k]);
+    }
   }
 }
 
@@ -817,12 +875,22 @@ hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItem
                                  const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
                                  const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
+  const dim3 grid((items.count + 3) / 4);
   if (schur)
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), dim3(items.count), dim3(256), 0, stream, values, items.cam,
-                       items.begin, items.end, cam_ptr, cam_fpos, cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
+                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
   else
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), dim3(items.count), dim3(256), 0, stream, values, items.cam,
-                       items.begin, items.end, cam_ptr, cam_fpos, cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
+    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
+                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
+                                const int32_t* cam_slot, const double2* zbuf, double* out, const int* status,
+                                hipStream_t stream) {
+  if (items.count == 0) return hipSuccess;
+  hipLaunchKernelGGL(bal_camera_apply_kernel, dim3((items.count + 3) / 4), dim3(256), 0, stream, values, items, cam_ptr,
+                     cam_fpos, cam_slot, zbuf, out, status);
   return hipGetLastError();
 }
 

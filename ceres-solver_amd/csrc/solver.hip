@@ -60,6 +60,7 @@ struct ceres_hip_solver {
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
+  double2* d_zbuf = nullptr;
   int bal_flags = 0;
   bool use_xpad = false;
   bool lds_mode = false;
@@ -161,7 +162,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.pt_pos = s->plan.contiguous_layout ? nullptr : s->d_pt_pos;
   A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
-  A.partials = s->d_partials; A.global_acc = s->d_global_acc;
+  A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -194,8 +195,12 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
   const int32_t* cam_pos = A.cam_pos;
   A.status = status;
-  if (!s->lds_mode) HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
   HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
+  if (!s->lds_mode) {  // second pass by camera over the z the fused kernel left per slot
+    HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
+    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_zbuf,
+                                    s->d_global_acc, status, s->stream));
+  }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
   const int nparts = s->lds_mode ? s->fused_grid : 1;
   if (s->world <= 1) {
@@ -899,6 +904,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? 1 : n_slots));
     TRY(dev_alloc(s, &s->d_xpad, size_t(10) * P.n_cameras));
     {
       const char* e = getenv("CERES_HIP_NT");
@@ -1321,7 +1327,7 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       break;
     case CERES_HIP_TIMED_READ_STREAM:
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "read-stream probe uses the packed tiles of the <2,3,9> path");
-      body = [&] { HIP_TRY(s, LaunchBalStreamProbe(s->d_J, s->plan.n_tiles, s->num_cus, s->d_global_acc, st)); return 0; };
+      body = [&] { HIP_TRY(s, LaunchBalStreamProbe(s->d_J, s->plan.n_tiles, std::min(s->num_cus, 9 * s->plan.n_cameras), s->d_global_acc, st)); return 0; };
       break;
     default:
       return fail(s, CERES_HIP_E_INVALID, "unknown timed op %d", op);

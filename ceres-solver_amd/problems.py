@@ -28,6 +28,8 @@ BAL_SHAPES = {
     "ladybug1723": (1723, 156502, 678718),
     "venice1778": (1778, 993923, 5001946),
     "synthetic10M": (50000, 10_000_000, 30_000_000),
+    # the 50 k-camera regime of synthetic10M at a tenth of its points (camera accumulators do not fit in LDS)
+    "synthetic1M": (50000, 1_000_000, 3_000_000),
 }
 
 

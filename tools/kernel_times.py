@@ -24,15 +24,18 @@ n_c, n_p, n_o = P.BAL_SHAPES[wl]
 B_jtjx = n_o * 200 + (3 * n_p + 9 * n_c) * 32
 B_sx = n_o * 200 + n_p * 72 + n_c * 288
 out = {"block": os.environ.get("CERES_HIP_BAL_BLOCK", "default"), "workload": wl}
+skew = 0.6
 for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JTJX, B_jtjx), ("block_jacobi", hs.TIMED_BLOCK_JACOBI, None), ("cgnr_setup", hs.TIMED_CGNR_SETUP, None)]),
                               ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, [("sx", hs.TIMED_SX, B_sx), ("schur_init", hs.TIMED_SCHUR_INIT, None),
                                                                                   ("schur_jacobi", hs.TIMED_SCHUR_JACOBI, None), ("back_substitute", hs.TIMED_BACK_SUBSTITUTE, None),
-                                                                                  ("pack", hs.TIMED_PACK, None), ("read_stream", hs.TIMED_READ_STREAM, 82327 * 12288 if wl == "venice1778" else None)])):
+                                                                                  ("pack", hs.TIMED_PACK, None), ("read_stream", hs.TIMED_READ_STREAM, "tiles")])):
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                   elimination_groups=[prob.num_eliminate_blocks]))
     s.set_structure(prob.bs)
     s.load(prob.values, prob.b, prob.D)
     for name, op, nbytes in ops:
+        if nbytes == "tiles":
+            nbytes = int(s.info().num_tiles) * 12288
         ms = min(s.time_op(op, 30) for _ in range(3))
         out[name + "_ms"] = round(ms, 4)
         if nbytes:
