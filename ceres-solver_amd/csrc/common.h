@@ -63,8 +63,9 @@ struct BalPlan {
   // per slot (n_tiles * 64)
   std::vector<int32_t> slot_epos, slot_fpos, slot_bpos;  // value / residual offsets, -1 = padding
   std::vector<int32_t> slot_cam, slot_pt;                // ids, -1 = padding
-  std::vector<uint32_t> slot_seg;  // first | last<<8 | flags<<16 ; flags bit0 valid
-  // per tile: 0 normal, 1 head of a long point (tile_aux = #tiles), 2 continuation
+  // first | last<<8 | valid<<16 | tailA<<17 | hasA<<23 | tailB<<24 | hasB<<30   (tails: see plan.cc)
+  std::vector<uint32_t> slot_seg;
+  // per tile: 0 normal (tile_aux = longest track | #points<<8), 1 head of a long point (tile_aux = #tiles), 2 continuation
   std::vector<int32_t> tile_kind, tile_aux;
   // camera-major lists
   std::vector<int32_t> cam_ptr;    // n_cameras+1

@@ -97,6 +97,7 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
+  uint32_t seg;
   int cam, pt, first, last;
   bool valid;
 };
@@ -148,6 +149,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
   s.cam = A.slot_cam[sl];
   s.pt = A.slot_pt[sl];
   const uint32_t sg = A.slot_seg[sl];
+  s.seg = sg;
   s.first = sg & 0xff;
   s.last = (sg >> 8) & 0xff;
   s.valid = (sg >> 16) & 1;
@@ -260,7 +262,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
 }
 
 template <int MODE, bool LDS>
-__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, double* acc) {
+__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc) {
   Slot s;
   load_slot<kCanGather<MODE>>(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
@@ -280,13 +282,37 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     scatter_ft<LDS>(s, acc, z0, z1);
   } else if constexpr (MODE == kJtJx || MODE == kJtb) {
     double z0, z1, xp[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
+    // Point-space x / D / y of a tile are ONE contiguous range when the layout is
+    // points-then-cameras (pt_pos == nullptr): [3 p0, 3 p0 + 3 npts).  Then lane L loads and
+    // stores scalars L (and 64 + L) of that range — dense 8-byte-per-lane accesses — and the
+    // per-observation copies travel by wavefront shuffle, instead of three strided loads per
+    // lane and three partial-wave scattered stores per point.
+    const bool coop = (MODE == kJtJx) && A.pt_pos == nullptr;
+    const int n3 = 3 * npts;
+    int64_t base = 0;
+    double xa = 0, xb = 0, da = 0, db = 0;
     if constexpr (MODE == kJtJx) {
-      // every load of the tile is issued up front, by all lanes (lanes of one point read the
-      // same address): nothing is fetched behind the per-point reduction
       double xc[9];
       load_xc(A, s.cam, xc);
-      xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
-      if (A.D_e) { dd[0] = A.D_e[po]; dd[1] = A.D_e[po + 1]; dd[2] = A.D_e[po + 2]; }
+      if (coop) {
+        base = 3 * int64_t(__builtin_amdgcn_readfirstlane(s.pt));  // lane 0 of a normal tile is valid
+        if (lane < n3) { xa = A.x_e[base + lane]; if (A.D_e) da = A.D_e[base + lane]; }
+        if (n3 > 64 && lane + 64 < n3) { xb = A.x_e[base + 64 + lane]; if (A.D_e) db = A.D_e[base + 64 + lane]; }
+        const int li = s.valid ? 3 * s.pt - int(base) : 0;
+        if (n3 <= 64) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) xp[j] = shfl_idx(xa, li + j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const double va = shfl_idx(xa, (li + j) & 63), vb = shfl_idx(xb, (li + j) & 63);
+            xp[j] = (li + j) < 64 ? va : vb;
+          }
+        }
+      } else {
+        xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
+        if (A.D_e) { dd[0] = A.D_e[po]; dd[1] = A.D_e[po + 1]; dd[2] = A.D_e[po + 2]; }
+      }
       f_times(s, xc, z0, z1);
       z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
       z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
@@ -297,7 +323,22 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
     if (!s.valid) { w[0] = w[1] = w[2] = 0; }
     seg_scan<3>(w, lane, s.first, span);
-    if (s.valid && lane == s.last) {
+    if (coop) {
+      // lane L gathers component L % 3 of point L / 3 from that point's last lane and stores scalar L
+      const int ta = (s.seg >> 17) & 63, tb = (s.seg >> 24) & 63;
+      {
+        const double v0 = shfl_idx(w[0], ta), v1 = shfl_idx(w[1], ta), v2 = shfl_idx(w[2], ta);
+        const int c = lane % 3;
+        const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
+        if ((s.seg >> 23) & 1) A.y_e[base + lane] = v + da * da * xa;
+      }
+      if (n3 > 64) {
+        const double v0 = shfl_idx(w[0], tb), v1 = shfl_idx(w[1], tb), v2 = shfl_idx(w[2], tb);
+        const int c = (lane + 1) % 3;  // (64 + lane) % 3
+        const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
+        if ((s.seg >> 30) & 1) A.y_e[base + 64 + lane] = v + db * db * xb;
+      }
+    } else if (s.valid && lane == s.last) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j] + dd[j] * dd[j] * xp[j];
     }
@@ -502,7 +543,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     const int kind = A.tile_kind[tile];
     if (kind == 2) continue;
     const int aux = A.tile_aux[tile];
-    if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux, acc);
+    if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux & 0xff, aux >> 8, acc);
     else process_long_point<MODE, LDS>(A, tile, aux, lane, acc);
   }
   if constexpr (kScatters && LDS) {

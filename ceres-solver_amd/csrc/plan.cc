@@ -260,13 +260,28 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
     int longest = 1;
     for (int l = 0; l < kTile; ++l) {
       const uint32_t sg = P.slot_seg[t * kTile + l];
-      if (sg >> 16) longest = std::max(longest, int((sg >> 8) & 0xff) - int(sg & 0xff) + 1);
+      if (sg & (1u << 16)) longest = std::max(longest, int((sg >> 8) & 0xff) - int(sg & 0xff) + 1);
     }
-    P.tile_aux[t] = longest;
+    // Points of a normal tile are consecutive ids, so their 3-vectors are one contiguous range
+    // [3 p0, 3 p0 + 3 npts) of every point-space vector.  Lane L of the tile owns scalars L and
+    // 64 + L of that range; it needs to know which lane holds the finished sum of "its" point:
+    // tailA = last lane of point L / 3, tailB = last lane of point (64 + L) / 3.
+    int tails[kTile], npts = 0;
+    for (int l = 0; l < kTile; ++l) {
+      const uint32_t sg = P.slot_seg[t * kTile + l];
+      if ((sg & (1u << 16)) && int((sg >> 8) & 0xff) == l) tails[npts++] = l;
+    }
+    for (int l = 0; l < kTile; ++l) {
+      uint32_t& sg = P.slot_seg[t * kTile + l];
+      const int ia = l / 3, ib = (kTile + l) / 3;
+      if (ia < npts) sg |= (uint32_t(tails[ia]) << 17) | (1u << 23);
+      if (ib < npts) sg |= (uint32_t(tails[ib]) << 24) | (1u << 30);
+    }
+    P.tile_aux[t] = longest | (npts << 8);
   }
   // Padding slots form singleton segments so that shuffles stay in range.
   for (int64_t s = 0; s < P.n_tiles * kTile; ++s)
-    if (!(P.slot_seg[s] >> 16)) { const uint32_t l = uint32_t(s % kTile); P.slot_seg[s] = l | (l << 8); }
+    if (!(P.slot_seg[s] & (1u << 16))) { const uint32_t l = uint32_t(s % kTile); P.slot_seg[s] |= l | (l << 8); }
 
   // Camera-major lists (counting sort over slots keeps point order inside a camera).
   P.cam_ptr.assign(P.n_cameras + 1, 0);

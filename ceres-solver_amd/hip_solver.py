@@ -442,4 +442,5 @@ def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
                                   seg.ctypes.data_as(POINTER(c_uint32)), ip(kind), ip(aux), ns, why, 256)
     assert rc == 0
     return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
-            "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tile_kind": kind, "tile_aux": aux}
+            "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tail_a": (seg >> 17) & 63, "has_a": (seg >> 23) & 1,
+            "tail_b": (seg >> 24) & 63, "has_b": (seg >> 30) & 1, "tile_kind": kind, "tile_aux": aux}

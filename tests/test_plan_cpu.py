@@ -36,7 +36,16 @@ def check_plan_invariants(p, plan):
             assert (first[sl][lanes] == lanes[0]).all() and (last[sl][lanes] == lanes[-1]).all()
             assert np.array_equal(lanes, np.arange(lanes[0], lanes[-1] + 1))
         longest = max(np.bincount(pts).max(), 1)
-        assert aux[t] == longest
+        assert aux[t] & 0xff == longest and aux[t] >> 8 == len(np.unique(pts))
+        # lane L owns scalars L and 64 + L of the tile's point range: tail lanes of points L/3, (64+L)/3
+        upts = np.unique(pts)
+        tails = [np.flatnonzero(v & (pt[sl] == q))[-1] for q in upts]
+        for L in range(64):
+            for off, has, tail in ((0, plan["has_a"][sl][L], plan["tail_a"][sl][L]), (64, plan["has_b"][sl][L], plan["tail_b"][sl][L])):
+                i = (off + L) // 3
+                assert bool(has) == (i < len(upts))
+                if has:
+                    assert tail == tails[i]
     # a long point owns its tiles
     t = 0
     while t < nt:
