@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--workload", default="venice1778", choices=["dubrovnik16", "ladybug1723", "venice1778"])
     ap.add_argument("--solver", default="cgnr", choices=["cgnr", "iterative_schur"])
     ap.add_argument("--skew", type=float, default=0.6, help="power-law exponent of camera popularity")
+    ap.add_argument("--values", default="normal", choices=["normal", "scene"],
+                    help="normal: N(0,1) Jacobian values (SURVEY.md §8d); scene: the first LM linear system of a synthetic "
+                         "bundle-adjustment scene (Snavely camera model, Jacobi-scaled like TrustRegionMinimizer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--kernel-iters", type=int, default=50)
@@ -117,6 +120,8 @@ def main():
     n_cams, n_points, n_obs = pkg.problems.BAL_SHAPES[args.workload]
     # Schur ordering (points then cameras) serves both solvers and is what sharding needs.
     prob = pkg.problems.synthetic_bal(args.workload, layout="schur", seed=38401, skew=args.skew)
+    if args.values == "scene":
+        prob = pkg.problems.scene_values(prob, n_cams, n_points, seed=38401)
     nelim = prob.num_eliminate_blocks
     comm = None
     if world > 1:
@@ -242,7 +247,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic BAL Jacobian <2,3,9>: {n_cams} cameras, {n_points} points, "
-                                   f"{n_obs} observations, N(0,1) values, seed 38401, camera popularity skew {args.skew}",
+                                   f"{n_obs} observations, " + ("N(0,1) values" if args.values == "normal" else "values = Jacobi-scaled Snavely Jacobian "
+                                   "of a synthetic scene (first LM step)") + f", seed 38401, camera popularity skew {args.skew}",
                        "solver": "CGNR + JACOBI" if args.solver == "cgnr" else "ITERATIVE_SCHUR + SCHUR_JACOBI",
                        "eta": 0.1, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
                        "termination": hs.TERMINATION_NAMES[last.termination_type],

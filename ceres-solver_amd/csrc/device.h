@@ -18,8 +18,6 @@ constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
 enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6 };
 
-constexpr int kFlagNontemporal = 1;
-
 struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][12][64]
@@ -43,7 +41,7 @@ struct BalArgs {
   const double* x_e = nullptr;
   const double* x_f = nullptr;
   const double* x_f_pad = nullptr;  // optional [n_cameras][10] copy of x_f (16-byte aligned gathers)
-  int flags = 0;                    // kFlag*
+  int flags = 0;                    // reserved
   double* y_e = nullptr;
   const double* D_e = nullptr;  // nullptr => no regularisation on the point part
   // per-point 3x3 inverses, packed symmetric 6 doubles / point
