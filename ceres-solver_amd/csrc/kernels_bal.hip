@@ -287,7 +287,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     // stores scalars L (and 64 + L) of that range — dense 8-byte-per-lane accesses — and the
     // per-observation copies travel by wavefront shuffle, instead of three strided loads per
     // lane and three partial-wave scattered stores per point.
-    const bool coop = (MODE == kJtJx) && A.pt_pos == nullptr;
+    const bool coop = (MODE == kJtJx) && A.pt_pos == nullptr && !(A.flags & 1);
     const int n3 = 3 * npts;
     int64_t base = 0;
     double xa = 0, xb = 0, da = 0, db = 0;

@@ -909,6 +909,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     {  // measured alternative (16-byte aligned padded camera gathers); off by default: no gain
       const char* e = getenv("CERES_HIP_XPAD");
       s->use_xpad = e && atoi(e) != 0;
+      e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
+      s->bal_flags = (e && atoi(e) == 0) ? 1 : 0;
     }
   } else {
     TRY(dev_alloc(s, &s->etei, size_t(h.diag_off_e.back())));
