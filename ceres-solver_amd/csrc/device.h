@@ -16,7 +16,7 @@ constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
-enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6 };
+enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8 };
 
 struct BalArgs {
   // packed problem
@@ -54,6 +54,7 @@ struct BalArgs {
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
   double2* zbuf = nullptr;       // [n_slots]      (cameras do not fit in LDS: z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
+  double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
 
@@ -133,6 +134,13 @@ hipError_t LaunchSquareScale(const double* D, const double* x, double* y, int64_
 hipError_t LaunchAddSquareScale(const double* D, const double* x, double* y, int64_t n, const int* status, hipStream_t stream);
 // out[0] = x . y  (two-stage, deterministic); partials has kMaxVecGrid doubles
 hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partials, double* out, hipStream_t stream);
+// D = sqrt(clamp(diag, lo, hi) / radius); diag is clamped in place (LevenbergMarquardtStrategy::ComputeStep,
+// I/levenberg_marquardt_strategy.cc:84-96)
+hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t stream);
+// x = -x and *nonfinite += number of non-finite entries (IsArrayValid + negation, :124-132)
+hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
+// values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
+hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);
 hipError_t LaunchExpandSym3(const double* packed6, double* dense9, const int64_t* pt_diag_off, int n_points, hipStream_t stream);
 
 // Status word values (device side) — 0 means "keep iterating".

@@ -206,12 +206,20 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
   }
 }
 
-enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6 };
+// Camera-column squared norms: sum over the observation of F[:,k]^2 (LDS accumulators only).
+__device__ __forceinline__ void scatter_f_squares(const Slot& s, double* acc) {
+  if (!s.valid) return;
+  const int base = 9 * s.cam;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * s.f[k] + s.f[9 + k] * s.f[9 + k]);
+}
+
+enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6, kColNorm = 7, kJx = 8 };
 
 template <int MODE>
-constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit);
+constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit || MODE == kJx);
 template <int MODE>
-constexpr bool kCanGather = (MODE == kInit || MODE == kCgnrInit);
+constexpr bool kCanGather = (MODE == kInit || MODE == kCgnrInit || MODE == kColNorm);
 
 // E^T E (packed symmetric) of one slot.
 __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
@@ -262,7 +270,8 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
 }
 
 template <int MODE, bool LDS>
-__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc) {
+__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc,
+                                             double& lane_acc) {
   Slot s;
   load_slot<kCanGather<MODE>>(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
@@ -371,6 +380,24 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       const double g[3] = {r[6], r[7], r[8]};
       init_apply<LDS>(A, s, sl, b0, b1, ei, g, acc);
     }
+  } else if constexpr (MODE == kColNorm) {
+    // diag(J^T J): BlockSparseMatrix::SquaredColumnNorm (I/block_sparse_matrix.cc:351-401), one pass
+    double w[3] = {s.e[0] * s.e[0] + s.e[3] * s.e[3], s.e[1] * s.e[1] + s.e[4] * s.e[4], s.e[2] * s.e[2] + s.e[5] * s.e[5]};
+    if (!s.valid) { w[0] = w[1] = w[2] = 0; }
+    scatter_f_squares(s, acc);
+    seg_scan<3>(w, lane, s.first, span);
+    if (s.valid && lane == s.last) { A.y_e[po] = w[0]; A.y_e[po + 1] = w[1]; A.y_e[po + 2] = w[2]; }
+  } else if constexpr (MODE == kJx) {
+    // model cost change of a trust-region step: -(J x)'(f + J x / 2), I/trust_region_minimizer.cc:420-438;
+    // no per-point or per-camera reduction, every tile (also those of long points) is independent
+    double xc[9];
+    load_xc(A, s.cam, xc);
+    const double x0 = A.x_e[po], x1 = A.x_e[po + 1], x2 = A.x_e[po + 2];
+    double m0, m1;
+    f_times(s, xc, m0, m1);
+    m0 += s.e[0] * x0 + s.e[1] * x1 + s.e[2] * x2;
+    m1 += s.e[3] * x0 + s.e[4] * x1 + s.e[5] * x2;
+    if (s.valid) lane_acc -= m0 * (s.b0 + 0.5 * m0) + m1 * (s.b1 + 0.5 * m1);
   } else if constexpr (MODE == kCgnrInit) {
     // CGNR set-up in one pass: rhs = J^T b (point part by segment sums, camera part scattered)
     // and, if requested, the JACOBI point blocks (E^T E + D^2)^-1.
@@ -419,6 +446,19 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
 template <int MODE, bool LDS>
 __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t tile, int nt, int lane, double* acc) {
   Slot s;
+  if constexpr (MODE == kColNorm) {
+    double w[3] = {0, 0, 0};
+    int pt = 0;
+    for (int t = 0; t < nt; ++t) {
+      load_slot<true>(A, tile + t, lane, s, false);
+      if (t == 0) pt = __shfl(s.pt, 0, 64);
+      scatter_f_squares(s, acc);
+      if (s.valid) { w[0] += s.e[0] * s.e[0] + s.e[3] * s.e[3]; w[1] += s.e[1] * s.e[1] + s.e[4] * s.e[4]; w[2] += s.e[2] * s.e[2] + s.e[5] * s.e[5]; }
+    }
+    wave_allreduce<3>(w);
+    if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = w[0]; A.y_e[po + 1] = w[1]; A.y_e[po + 2] = w[2]; }
+    return;
+  }
   if constexpr (MODE == kSx || MODE == kBackSub) {
     double u[3] = {0, 0, 0};
     int pt = 0;
@@ -525,7 +565,7 @@ template <int MODE, bool LDS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
-  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit);
+  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm);
   double* acc = nullptr;
   if constexpr (kScatters) {
     if constexpr (LDS) {
@@ -537,14 +577,32 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     }
   }
   const int lane = threadIdx.x & 63;
+  double lane_acc = 0.0;
   const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   for (int64_t tile = wave; tile < A.n_tiles; tile += nwaves) {
     const int kind = A.tile_kind[tile];
-    if (kind == 2) continue;
     const int aux = A.tile_aux[tile];
-    if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux & 0xff, aux >> 8, acc);
-    else process_long_point<MODE, LDS>(A, tile, aux, lane, acc);
+    if constexpr (MODE == kJx) {
+      process_tile<MODE, LDS>(A, tile, lane, 1, 0, acc, lane_acc);
+    } else {
+      if (kind == 2) continue;
+      if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux & 0xff, aux >> 8, acc, lane_acc);
+      else process_long_point<MODE, LDS>(A, tile, aux, lane, acc);
+    }
+  }
+  if constexpr (MODE == kJx) {  // one partial per workgroup, summed in fixed order by the caller
+    __shared__ double red[16];
+    double v = lane_acc;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+      for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      A.scalar_out[blockIdx.x] = t;
+    }
   }
   if constexpr (kScatters && LDS) {
     __syncthreads();
@@ -853,7 +911,7 @@ static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t
 // best for the light modes; kInit needs more registers and runs at 512.
 int BalBlockFor(int mode) {
   static int forced = [] { const char* e = getenv("CERES_HIP_BAL_BLOCK"); return e ? atoi(e) : 0; }();
-  if (mode == kInit || mode == kCgnrInit) return 512;
+  if (mode == kInit || mode == kCgnrInit || mode == kColNorm) return 512;
   if (forced == 512 || forced == 1024) return forced;
   return 1024;
 }
@@ -868,6 +926,8 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
     case kEte: return big ? launch_fused<kEte, 1024>(A, false, grid, stream) : launch_fused<kEte, 512>(A, false, grid, stream);
     case kBackSub: return big ? launch_fused<kBackSub, 1024>(A, false, grid, stream) : launch_fused<kBackSub, 512>(A, false, grid, stream);
     case kCgnrInit: return launch_fused<kCgnrInit, 512>(A, lds, grid, stream);
+    case kColNorm: return launch_fused<kColNorm, 512>(A, true, grid, stream);
+    case kJx: return launch_fused<kJx, 1024>(A, false, grid, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -109,6 +109,23 @@ __global__ void expand_sym3_kernel(const double* p6, double* d9, const int64_t* 
   o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
 }
 
+__global__ __launch_bounds__(kVecBlock) void lm_diagonal_kernel(double* diag, double lo, double hi, double radius, double* D, int64_t n) {
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) {
+    const double d = fmin(fmax(diag[i], lo), hi);
+    diag[i] = d;
+    D[i] = sqrt(d / radius);
+  }
+}
+__global__ __launch_bounds__(kVecBlock) void negate_and_check_kernel(double* x, int64_t n, int* nonfinite) {
+  int bad = 0;
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) {
+    const double v = x[i];
+    if (!isfinite(v)) ++bad;
+    x[i] = -v;
+  }
+  if (bad) atomicAdd(nonfinite, bad);
+}
+
 // ---- CG ---------------------------------------------------------------------
 __global__ __launch_bounds__(kVecBlock) void cg_rhs_norm_kernel(CgBuffers B) {
   __shared__ double sh[4];
@@ -350,6 +367,14 @@ hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partia
   const int g = vec_grid(n);
   hipLaunchKernelGGL(dot_partial_kernel, dim3(g), dim3(kVecBlock), 0, s, x, y, n, partials);
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kVecBlock), 0, s, partials, g, out);
+  return hipGetLastError();
+}
+hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, diag, lo, hi, radius, D, n);
+  return hipGetLastError();
+}
+hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(negate_and_check_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, x, n, nonfinite);
   return hipGetLastError();
 }
 hipError_t LaunchExpandSym3(const double* p6, double* d9, const int64_t* off, int n, hipStream_t s) {

@@ -129,6 +129,22 @@ __global__ __launch_bounds__(kB) void gen_squared_column_norm_kernel(GenStructur
   x[col] = s;
 }
 
+// One thread per scalar row of a cell would need a cell index; instead one thread per scalar ROW of the
+// matrix walks that row's cells (each value is touched exactly once).
+__global__ __launch_bounds__(kB) void gen_scale_columns_kernel(GenStructure G, double* __restrict__ v, const double* __restrict__ scale) {
+  const int row = blockIdx.x * kB + threadIdx.x;
+  if (row >= G.num_rows) return;
+  const int i = G.row_block_of[row];
+  const int r = row - G.rpos[i];
+  for (int k = G.rptr[i]; k < G.rptr[i + 1]; ++k) {
+    const int j = G.ccol[k];
+    const int cs = G.csz[j];
+    double* a = v + G.cval[k] + int64_t(r) * cs;
+    const double* sc = scale + G.cpos[j];
+    for (int c = 0; c < cs; ++c) a[c] *= sc[c];
+  }
+}
+
 // In-place inverse of SPD block from its upper triangle: Cholesky + solves against I.
 // One thread per block; n <= kMaxGenericBlock.
 __global__ __launch_bounds__(64) void gen_invert_blocks_kernel(GenStructure G, int first_block, int nblocks,
@@ -322,6 +338,10 @@ hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, in
 }
 hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* values, double* x, hipStream_t s) {
   if (G.num_cols > 0) hipLaunchKernelGGL(gen_squared_column_norm_kernel, dim3(blocks_for(G.num_cols)), dim3(kB), 0, s, G, values, x);
+  return hipGetLastError();
+}
+hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t s) {
+  if (G.num_rows > 0) hipLaunchKernelGGL(gen_scale_columns_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, scale);
   return hipGetLastError();
 }
 hipError_t LaunchGenInvertBlocks(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off, double* blocks,

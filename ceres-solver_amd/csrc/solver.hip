@@ -57,6 +57,10 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   CamItems cam_items;
+  // f1: LM step state
+  double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
+  int* d_nonfinite = nullptr;
+  bool have_lm_diag = false;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
@@ -445,6 +449,54 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
     if (s->D) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
   }
   HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
+  return 0;
+}
+
+// diag(J^T J) into out (num_cols).  BlockSparseMatrix::SquaredColumnNorm.
+int op_squared_column_norm(ceres_hip_solver* s, double* out) {
+  const HostStructure& h = s->hs;
+  if (s->path == CERES_HIP_PATH_BAL && s->lds_mode && s->world <= 1) {
+    BalArgs A = bal_args(s);
+    A.y_e = out;
+    use_gather_if_unpacked(s, A);
+    return bal_scatter(s, kBalColNorm, A, nullptr, out + h.num_cols_e, false, nullptr);
+  }
+  HIP_TRY(s, LaunchGenSquaredColumnNorm(s->G, s->values, out, s->stream));
+  if (s->world > 1) TRY(allreduce(s, out + h.num_cols_e, size_t(h.num_cols_f)));
+  return 0;
+}
+
+// -(J x)'(b + J x / 2) into *host_out.
+int op_model_cost_change(ceres_hip_solver* s, const double* x, double* host_out) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  int nparts = 0;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
+    BalArgs A = bal_args(s);
+    A.x_e = x; A.x_f = x + h.num_cols_e;
+    A.scalar_out = s->scalar_partials;
+    nparts = std::min(s->fused_grid, kMaxVecGrid);
+    HIP_TRY(s, LaunchBalFused(kBalJx, A, false, nparts, st));
+  } else {
+    // model = J x ; partial sums of -model .* (b + model / 2)
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, nullptr, st));
+    double* t2 = s->scratch_vec + h.num_cols;  // num_rows doubles
+    HIP_TRY(s, LaunchAxpby(-1.0, s->b, -0.5, s->tmp_rows, t2, h.num_rows, st));
+    HIP_TRY(s, LaunchDot(s->tmp_rows, t2, h.num_rows, s->scalar_partials, s->cg.comm, st));
+    double v = 0;
+    HIP_TRY(s, hipMemcpyAsync(&v, s->cg.comm, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    *host_out = v;
+    return 0;
+  }
+  std::vector<double> parts(nparts);
+  HIP_TRY(s, hipMemcpyAsync(parts.data(), s->scalar_partials, sizeof(double) * nparts, hipMemcpyDeviceToHost, st));
+  HIP_TRY(s, hipStreamSynchronize(st));
+  double v = 0;
+  for (double p : parts) v += p;
+  *host_out = v;
   return 0;
 }
 
@@ -851,6 +903,10 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->own_x, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->scratch_vec, size_t(h.num_cols) + size_t(h.num_rows)));
   TRY(dev_alloc(s, &s->d_fail_flag, 1));
+  TRY(dev_alloc(s, &s->d_nonfinite, 1));
+  TRY(dev_alloc(s, &s->lm_diag, size_t(h.num_cols)));
+  TRY(dev_alloc(s, &s->lm_D, size_t(h.num_cols)));
+  TRY(dev_alloc(s, &s->scalar_partials, size_t(kMaxVecGrid)));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
@@ -1049,6 +1105,92 @@ int ceres_hip_solve_device(ceres_hip_solver* s, const double* dv, const double* 
   return 0;
 }
 
+namespace {
+int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* dx, ceres_hip_lm_result* res) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  memset(res, 0, sizeof(*res));
+  if (!(o->radius > 0) || !(o->min_diagonal > 0) || o->min_diagonal > o->max_diagonal)
+    return fail(s, CERES_HIP_E_INVALID, "bad LM options");
+  if (!o->reuse_diagonal || !s->have_lm_diag) {
+    TRY(op_squared_column_norm(s, s->lm_diag));
+    s->have_lm_diag = true;
+  }
+  HIP_TRY(s, LaunchLmDiagonal(s->lm_diag, o->min_diagonal, o->max_diagonal, o->radius, s->lm_D, h.num_cols, st));
+  s->D = s->lm_D;
+  s->have_D = true;
+  TRY(solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver));
+  res->step_is_finite = 0;
+  const int term = res->linear_solver.termination_type;
+  if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) return 0;
+  HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
+  HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
+  int bad = 0;
+  HIP_TRY(s, hipMemcpyAsync(&bad, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(s, hipStreamSynchronize(st));
+  if (bad) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
+    res->linear_solver.termination_type = CERES_HIP_FAILURE;
+    snprintf(res->linear_solver.message, sizeof(res->linear_solver.message), "Failed to compute a finite step.");
+    return 0;
+  }
+  res->step_is_finite = 1;
+  return op_model_cost_change(s, dx, &res->model_cost_change);
+}
+}  // namespace
+
+int ceres_hip_lm_compute_step_device(ceres_hip_solver* s, const double* dv, const double* db,
+                                     const ceres_hip_lm_options* o, double* dx, ceres_hip_lm_result* res) {
+  if (!s || !o || !dx || !res) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  (void)hipEventRecord(s->ev[0], s->stream);
+  (void)hipEventRecord(s->ev[1], s->stream);
+  TRY(load_device(s, dv, db, nullptr));
+  TRY(lm_step_loaded(s, o, dx, res));
+  (void)hipEventRecord(s->ev[7], s->stream);
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  collect_timing(s);
+  return 0;
+}
+
+int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const double* hb, const ceres_hip_lm_options* o,
+                              double* hx, ceres_hip_lm_result* res) {
+  if (!s || !o || !hx || !res) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  (void)hipEventRecord(s->ev[0], s->stream);
+  TRY(load_host(s, hv, hb, nullptr));
+  (void)hipEventRecord(s->ev[1], s->stream);
+  TRY(lm_step_loaded(s, o, s->own_x, res));
+  const int term = res->linear_solver.termination_type;
+  if (term != CERES_HIP_FAILURE && term != CERES_HIP_FATAL_ERROR)
+    HIP_TRY(s, hipMemcpyAsync(hx, s->own_x, sizeof(double) * s->hs.num_cols, hipMemcpyDeviceToHost, s->stream));
+  (void)hipEventRecord(s->ev[7], s->stream);
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  collect_timing(s);
+  return 0;
+}
+
+int ceres_hip_get_lm_diagonal(ceres_hip_solver* s, double* host_D) {
+  TRY(require_loaded(s));
+  if (!s->have_lm_diag) return fail(s, CERES_HIP_E_INVALID, "no LM step has been computed");
+  HIP_TRY(s, hipMemcpyAsync(host_D, s->lm_D, sizeof(double) * s->hs.num_cols, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, double* host_values_out) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (s->values != s->own_values) return fail(s, CERES_HIP_E_INVALID, "scale_columns works on the copy made by ceres_hip_load");
+  HIP_TRY(s, hipMemcpyAsync(s->scratch_vec, host_scale, sizeof(double) * s->hs.num_cols, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, LaunchGenScaleColumns(s->G, s->own_values, s->scratch_vec, s->stream));
+  s->packed = false;
+  s->precond_valid = false;
+  if (host_values_out)
+    HIP_TRY(s, hipMemcpyAsync(host_values_out, s->own_values, sizeof(double) * s->hs.values_extent, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
 int ceres_hip_get_last_timing(const ceres_hip_solver* s, ceres_hip_solve_timing* t) {
   if (!s || !t) return CERES_HIP_E_INVALID;
   *t = s->timing;
@@ -1093,7 +1235,7 @@ int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) 
 int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x) {
   TRY(require_loaded(s));
   HIP_TRY(s, hipSetDevice(s->opt.device));
-  HIP_TRY(s, LaunchGenSquaredColumnNorm(s->G, s->values, s->scratch_vec, s->stream));
+  TRY(op_squared_column_norm(s, s->scratch_vec));
   return down(s, x, s->scratch_vec, s->hs.num_cols);
 }
 

@@ -69,6 +69,16 @@ class CTiming(ctypes.Structure):
                 ("operator_applications", c_int32), ("reserved", c_int32)]
 
 
+class CLmOptions(ctypes.Structure):
+    _fields_ = [("radius", c_double), ("min_diagonal", c_double), ("max_diagonal", c_double), ("eta", c_double),
+                ("reuse_diagonal", c_int32), ("reserved", c_int32)]
+
+
+class CLmResult(ctypes.Structure):
+    _fields_ = [("linear_solver", CSummary), ("model_cost_change", c_double), ("step_is_finite", c_int32),
+                ("reserved", c_int32)]
+
+
 # every symbol include/ceres_hip.h declares: (name, restype, argtypes)
 _DP = POINTER(c_double)
 ABI = [
@@ -103,6 +113,10 @@ ABI = [
     ("ceres_hip_op_eliminator_back_substitute", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_dot", c_int32, [c_void_p, _DP, _DP, c_int64, _DP]),
     ("ceres_hip_op_axpby", c_int32, [c_void_p, c_double, _DP, c_double, _DP, c_int64, _DP]),
+    ("ceres_hip_lm_compute_step", c_int32, [c_void_p, _DP, _DP, POINTER(CLmOptions), _DP, POINTER(CLmResult)]),
+    ("ceres_hip_lm_compute_step_device", c_int32, [c_void_p, c_void_p, c_void_p, POINTER(CLmOptions), c_void_p, POINTER(CLmResult)]),
+    ("ceres_hip_get_lm_diagonal", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_op_scale_columns", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_time_op", c_int32, [c_void_p, c_int32, c_int32, _DP]),
     ("ceres_hip_get_last_timing", c_int32, [c_void_p, POINTER(CTiming)]),
     ("ceres_hip_debug_comm_loopback", c_int32, [c_void_p, c_int32]),
@@ -285,6 +299,42 @@ class HipLinearSolver:
             summary.termination_type = FATAL_ERROR
             summary.message = self._lib.ceres_hip_last_error(self._h).decode()
         return summary
+
+    # -- f1: one trust-region step's linear algebra on the device ----------------
+    def lm_compute_step(self, values, residuals, radius, eta=0.1, min_diagonal=1e-6, max_diagonal=1e32,
+                        reuse_diagonal=False):
+        """LevenbergMarquardtStrategy::ComputeStep + the model-cost bookkeeping of
+        TrustRegionMinimizer::ComputeTrustRegionStep.  Returns (step, Summary, model_cost_change)."""
+        n = self._info
+        values = _f64(values, self.bs.values_extent(), "values")
+        residuals = _f64(residuals, n.num_rows, "residuals")
+        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), 0)
+        r = CLmResult()
+        step = np.full(n.num_cols, np.nan)
+        self._check(self._lib.ceres_hip_lm_compute_step(self._h, _p(values), _p(residuals), byref(o), _p(step), byref(r)))
+        s = r.linear_solver
+        return step, Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace")), \
+            float(r.model_cost_change)
+
+    def lm_compute_step_device(self, d_values: int, d_residuals: int, d_step: int, radius, eta=0.1, min_diagonal=1e-6,
+                               max_diagonal=1e32, reuse_diagonal=False):
+        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), 0)
+        r = CLmResult()
+        self._check(self._lib.ceres_hip_lm_compute_step_device(self._h, d_values, d_residuals, byref(o), d_step, byref(r)))
+        s = r.linear_solver
+        return Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace")), \
+            float(r.model_cost_change), bool(r.step_is_finite)
+
+    def lm_diagonal(self):
+        out = np.full(self._info.num_cols, np.nan)
+        self._check(self._lib.ceres_hip_get_lm_diagonal(self._h, _p(out)))
+        return out
+
+    def scale_columns(self, scale):
+        scale = _f64(scale, self._info.num_cols, "scale")
+        out = np.full(self.bs.values_extent(), np.nan)
+        self._check(self._lib.ceres_hip_op_scale_columns(self._h, _p(scale), _p(out)))
+        return out
 
     def last_timing(self) -> CTiming:
         t = CTiming()

@@ -246,6 +246,38 @@ int ceres_hip_op_dot(ceres_hip_solver* s, const double* x, const double* y, int6
 int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b, const double* y,
                        int64_t n, double* z);
 
+/* ---- the neighbours of Solve inside one trust-region step, on the device ----
+ * LevenbergMarquardtStrategy::ComputeStep (I/levenberg_marquardt_strategy.cc:69-157):
+ *   diag = clamp(SquaredColumnNorm(J), min, max) unless reuse_diagonal; D = sqrt(diag / radius);
+ *   Solve(J, residuals, {D, eta, -1}, step); finite check; step = -step
+ * and the model-cost bookkeeping of TrustRegionMinimizer::ComputeTrustRegionStep
+ * (I/trust_region_minimizer.cc:420-438): model_cost_change = -(J step)'(f + J step / 2).
+ * J is read in place; nothing but the step and a few scalars returns to the host.            */
+typedef struct ceres_hip_lm_options {
+  double radius;          /* trust-region radius                                   */
+  double min_diagonal;    /* Solver::Options::min_lm_diagonal (1e-6)               */
+  double max_diagonal;    /* Solver::Options::max_lm_diagonal (1e32)               */
+  double eta;             /* q_tolerance of the linear solve                       */
+  int32_t reuse_diagonal; /* 1 after a rejected step: keep the previous diag(J'J)  */
+  int32_t reserved;
+} ceres_hip_lm_options;
+typedef struct ceres_hip_lm_result {
+  ceres_hip_summary linear_solver; /* FAILURE also when the step is not finite      */
+  double model_cost_change;
+  int32_t step_is_finite;
+  int32_t reserved;
+} ceres_hip_lm_result;
+int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* host_values, const double* host_residuals,
+                              const ceres_hip_lm_options* options, double* host_step, ceres_hip_lm_result* result);
+int ceres_hip_lm_compute_step_device(ceres_hip_solver* s, const double* dev_values, const double* dev_residuals,
+                                     const ceres_hip_lm_options* options, double* dev_step,
+                                     ceres_hip_lm_result* result);
+/* The D the last ceres_hip_lm_compute_step* used (num_cols doubles). */
+int ceres_hip_get_lm_diagonal(ceres_hip_solver* s, double* host_D);
+/* values[.., col] *= scale[col] on the loaded (device) copy; returns the scaled values if
+ * host_values_out != NULL.  BlockSparseMatrix::ScaleColumns       I/block_sparse_matrix.cc:403-450 */
+int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, double* host_values_out);
+
 /* ---- timing for the roofline numbers --------------------------------------
  * Runs `iters` back-to-back launches of one operator on the solver's stream
  * with device-resident operands and brackets them with HIP events recorded on

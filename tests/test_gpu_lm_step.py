@@ -1,0 +1,99 @@
+"""the neighbours of Solve inside one trust-region step, kept on the device
+(LM diagonal from diag(J^T J), solve, finite check + negation, model cost change, ScaleColumns),
+against the oracle and the formulas of levenberg_marquardt_strategy.cc:84-132 and
+trust_region_minimizer.cc:420-438."""
+import numpy as np
+import pytest
+
+from test_gpu_operators import make_solver, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_step(oracle, hip, p, solver_type, pre, radius, eta, diag=None, max_it=500):
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks if solver_type == hip.ITERATIVE_SCHUR else 0)
+    if diag is None:
+        diag = np.clip(m.squared_column_norm(p.values), 1e-6, 1e32)
+    D = np.sqrt(diag / radius)
+    fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m.cgnr_solve
+    x, s = fn(p.values, p.b, D, preconditioner=pre, min_it=0, max_it=max_it, q_tol=eta, r_tol=-1.0)
+    step = -x
+    model = oracle.Matrix(p.bs, 0).right_multiply(p.values, step)
+    return step, s, -model @ (p.b + model / 2.0), D, diag
+
+
+CASES = [("bal_schur", 5, 2), ("bal_schur", 6, 1), ("bal_cgnr", 6, 1), ("general", 5, 2), ("general", 6, 1)]
+
+
+@pytest.mark.parametrize("kind,solver_type,pre", CASES)
+def test_lm_compute_step_matches_reference(hip, oracle, problems, kind, solver_type, pre):
+    if kind == "bal_schur":
+        p = problems.synthetic_bal(None, layout="schur", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
+    elif kind == "bal_cgnr":
+        p = problems.synthetic_bal(None, layout="cgnr", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
+    else:
+        p = problems.random_schur_problem(num_e_blocks=50, num_f_blocks=8, num_no_e_rows=3, seed=42)
+    if solver_type == hip.CGNR and kind == "bal_cgnr":
+        p.num_eliminate_blocks = 0
+    s = make_solver(hip, p, solver_type, pre, max_it=500)
+    assert s.info().kernel_path == (hip.PATH_GENERIC if kind == "general" else hip.PATH_BAL)
+    radius, eta = 1e4, 0.1
+    step, summ, model_cost_change = s.lm_compute_step(p.values, p.b, radius, eta)
+    ref_step, ref_summ, ref_mcc, ref_D, diag = reference_step(oracle, hip, p, solver_type, pre, radius, eta)
+    assert rel(s.lm_diagonal(), ref_D) <= 1e-13
+    assert summ.termination_type == ref_summ.termination_type == hip.SUCCESS
+    assert abs(summ.num_iterations - ref_summ.num_iterations) <= 1
+    if summ.num_iterations == ref_summ.num_iterations:
+        assert rel(step, ref_step) <= 1e-9
+        assert abs(model_cost_change - ref_mcc) <= 1e-9 * abs(ref_mcc)
+    assert model_cost_change > 0  # a valid LM step decreases the model
+    # rejected step: radius halves, the diagonal is reused (StepRejected, :171-175) even if J changed
+    p2 = type(p)(p.bs, p.values * 1.5, p.b, None, p.num_eliminate_blocks)
+    step2, summ2, mcc2 = s.lm_compute_step(p2.values, p2.b, radius / 2, eta, reuse_diagonal=True)
+    ref2 = reference_step(oracle, hip, p2, solver_type, pre, radius / 2, eta, diag=diag)
+    assert rel(s.lm_diagonal(), ref2[3]) <= 1e-13
+    if summ2.num_iterations == ref2[1].num_iterations:
+        assert rel(step2, ref2[0]) <= 1e-9 and abs(mcc2 - ref2[2]) <= 1e-9 * abs(ref2[2])
+    # and a fresh diagonal again
+    step3, summ3, _ = s.lm_compute_step(p2.values, p2.b, radius, eta)
+    ref3 = reference_step(oracle, hip, p2, solver_type, pre, radius, eta)
+    assert rel(s.lm_diagonal(), ref3[3]) <= 1e-13
+    s.close()
+
+
+def test_lm_step_device_pointers_and_long_tracks(hip, oracle, problems):
+    import torch
+    p = problems.synthetic_bal(None, num_cameras=230, num_points=350, num_observations=11000, seed=43)  # tracks > 64
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    dev = torch.device("cuda:0")
+    tv, tb = torch.from_numpy(p.values).to(dev), torch.from_numpy(p.b).to(dev)
+    tx = torch.full((p.num_cols,), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    summ, mcc, finite = s.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), 1e4, 0.1)
+    ref_step, ref_summ, ref_mcc, ref_D, _ = reference_step(oracle, hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 1e4, 0.1)
+    assert finite and summ.termination_type == hip.SUCCESS
+    assert rel(s.lm_diagonal(), ref_D) <= 1e-13
+    if summ.num_iterations == ref_summ.num_iterations:
+        assert rel(tx.cpu().numpy(), ref_step) <= 1e-9 and abs(mcc - ref_mcc) <= 1e-9 * abs(ref_mcc)
+    s.close()
+
+
+@pytest.mark.parametrize("kind", ["bal", "general"])
+def test_scale_columns_and_column_norms(hip, oracle, problems, kind):
+    p = (problems.synthetic_bal(None, num_cameras=20, num_points=900, num_observations=4000, seed=44) if kind == "bal"
+         else problems.random_schur_problem(num_e_blocks=30, num_f_blocks=7, seed=45))
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    s.load(p.values, p.b, p.D)
+    assert rel(s.squared_column_norm(), m.squared_column_norm(p.values)) <= 1e-13
+    # jacobi scaling as TrustRegionMinimizer applies it (trust_region_minimizer.cc:263-279)
+    scale = 1.0 / (1.0 + np.sqrt(m.squared_column_norm(p.values)))
+    scaled = s.scale_columns(scale)
+    want = m.scale_columns(p.values, scale)
+    np.testing.assert_allclose(scaled[: len(want)], want, rtol=1e-15)
+    assert rel(s.squared_column_norm(), m.squared_column_norm(want)) <= 1e-13  # operates on the scaled copy now
+    s.schur_init()
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(want, p.D, p.b)
+    assert rel(s.schur_rhs(), isc.rhs()) <= 1e-12
+    s.close()
