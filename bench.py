@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — LM linear-solve steps/s and JtJx SpMV HBM GB/s on BAL-shaped input, MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input: one Levenberg–
-Marquardt linear solve exactly as LevenbergMarquardtStrategy::ComputeStep issues it
-(reference internal/ceres/levenberg_marquardt_strategy.cc:98-116): LinearSolver::Solve with
-D = sqrt(clamp(diag(J^T J))/radius), q_tolerance = eta = 0.1, r_tolerance = -1,
-max_num_iterations = 500 — i.e. re-layout of the step's Jacobian values, preconditioner,
-right-hand side, preconditioned CG to the Nash–Sofer test, solution — with values / b / D
-already resident in HBM when the timed region starts (ceres_hip_solve_device).
+A "step" is one pass of the hot path over one batch of synthetic input: the linear algebra of
+one Levenberg–Marquardt trust-region step exactly as the reference issues it —
+LevenbergMarquardtStrategy::ComputeStep (internal/ceres/levenberg_marquardt_strategy.cc:69-157:
+diag = clamp(SquaredColumnNorm(J)), D = sqrt(diag / radius), LinearSolver::Solve with
+q_tolerance = eta = 0.1, r_tolerance = -1, max_num_iterations = 500, finite check, negation)
+followed by the model-cost change -(J step)'(f + J step / 2) of
+TrustRegionMinimizer::ComputeTrustRegionStep (trust_region_minimizer.cc:420-438) — with the
+Jacobian values and residuals already resident in HBM when the timed region starts
+(ceres_hip_lm_compute_step_device).  `--step linear_solve` times LinearSolver::Solve alone
+(ceres_hip_solve_device).  Evaluating residuals / Jacobians is the Evaluator's job and outside
+this path.
 
 Workload (config.workload): synthetic BAL-shaped Jacobian with Venice-1778's block counts
 (1778 cameras, 993923 points, 5001946 observations; SURVEY.md §8d generator, seed 38401) —
@@ -55,6 +59,9 @@ def parse():
     ap.add_argument("--workload", default="venice1778", choices=["dubrovnik16", "ladybug1723", "venice1778"])
     ap.add_argument("--solver", default="cgnr", choices=["cgnr", "iterative_schur"])
     ap.add_argument("--skew", type=float, default=0.6, help="power-law exponent of camera popularity")
+    ap.add_argument("--step", default="lm_step", choices=["lm_step", "linear_solve"],
+                    help="lm_step: LevenbergMarquardtStrategy::ComputeStep on the device (diag(J'J), D, Solve, finite check, "
+                         "negation) + the model-cost change of TrustRegionMinimizer; linear_solve: LinearSolver::Solve only")
     ap.add_argument("--values", default="normal", choices=["normal", "scene"],
                     help="normal: N(0,1) Jacobian values (SURVEY.md §8d); scene: the first LM linear system of a synthetic "
                          "bundle-adjustment scene (Snavely camera model, Jacobi-scaled like TrustRegionMinimizer)")
@@ -75,16 +82,26 @@ def make_solver(hs, bs, nelim, solver, device, comm=None):
     return s
 
 
-def timed_steps(solver, ptrs, steps, warmup, sync):
+RADIUS = 1e4  # Solver::Options::initial_trust_region_radius; D = sqrt(clamp(diag(J'J)) / RADIUS)
+
+
+def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve"):
     tv, tb, tD, tx = ptrs
+
+    def one():
+        if step_kind == "lm_step":  # the diagonal is recomputed every step, as after an accepted step
+            s, mcc, finite = solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS, 0.1)
+            assert finite and mcc > 0, (s, mcc)
+            return s
+        return solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
     iters = []
     for _ in range(warmup):
-        s = solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+        s = one()
         assert s.termination_type in (0, 1), s
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        s = solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+        s = one()
         iters.append(s.num_iterations)
     sync()
     return time.perf_counter() - t0, iters, s
@@ -142,7 +159,7 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: K LM linear solves, inputs resident in HBM -------------------
-    elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync)
+    elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync, args.step)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,7 +201,7 @@ def main():
         other = "iterative_schur" if args.solver == "cgnr" else "cgnr"
         s2 = make_solver(hs, bs, nelim_local, other, local_rank)
         tx2 = torch.empty_like(tx)  # keep the primary solver's step in tx for the parity check below
-        e2, it2, _ = timed_steps(s2, (tv, tb, tD, tx2), max(3, args.steps // 4), 1, sync)
+        e2, it2, _ = timed_steps(s2, (tv, tb, tD, tx2), max(3, args.steps // 4), 1, sync, args.step)
         s2.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())
         k2 = "sx" if other == "iterative_schur" else "jtjx"
         ms2 = s2.time_op(hs.TIMED_SX if k2 == "sx" else hs.TIMED_JTJX, args.kernel_iters)
@@ -208,9 +225,20 @@ def main():
         fn = m.iterative_schur_solve if args.solver == "iterative_schur" else m.cgnr_solve
         pre = 2 if args.solver == "iterative_schur" else 1
 
+        m_all = oracle.Matrix(prob.bs, 0)
+
         def one():
             t = time.perf_counter()
-            xo_, so_ = fn(prob.values, prob.b, prob.D, preconditioner=pre, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+            if args.step == "lm_step":  # same work as the GPU step: diag(J'J), D, solve, negate, model cost
+                diag = np.clip(m_all.squared_column_norm(prob.values), 1e-6, 1e32)
+                Dc = np.sqrt(diag / RADIUS)
+            else:
+                Dc = prob.D
+            xo_, so_ = fn(prob.values, prob.b, Dc, preconditioner=pre, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+            if args.step == "lm_step":
+                xo_ = -xo_
+                model = m_all.right_multiply(prob.values, xo_)
+                _ = -model @ (prob.b + model / 2.0)
             return time.perf_counter() - t, xo_, so_
         # memory-bound sparse kernels do not scale to every core of a big host: probe a few thread
         # counts with one solve each, then spend the rest of the budget on the fastest
@@ -233,7 +261,7 @@ def main():
         xg = tx.cpu().numpy()
         parity = float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)) if cpu_iters == iters[-1] else None
         cpu = {"value": round(n_done / cpu_t, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_done} full {args.workload}-shaped {args.solver} solves (same inputs, eta=0.1), "
+               "sample": f"{n_done} full {args.workload}-shaped {args.solver} " + ("LM steps (diag, solve, model cost)" if args.step == "lm_step" else "solves") + " (same inputs, eta=0.1), "
                          f"oracle/libceres_oracle.so with OpenMP over {cores} threads, {cpu_t:.1f} s; "
                          f"one-solve probe seconds by thread count: { {k: round(v, 2) for k, v in probe.items()} } on {ncpu} host cpus",
                "cg_iterations": cpu_iters, "step_rel_diff_vs_gpu": parity}
@@ -250,6 +278,8 @@ def main():
                                    f"{n_obs} observations, " + ("N(0,1) values" if args.values == "normal" else "values = Jacobi-scaled Snavely Jacobian "
                                    "of a synthetic scene (first LM step)") + f", seed 38401, camera popularity skew {args.skew}",
                        "solver": "CGNR + JACOBI" if args.solver == "cgnr" else "ITERATIVE_SCHUR + SCHUR_JACOBI",
+                       "step": ("LevenbergMarquardtStrategy::ComputeStep (diag(J'J), D = sqrt(diag/1e4), Solve, finite check, negate) + "
+                                "model cost change, all on the device" if args.step == "lm_step" else "LinearSolver::Solve"),
                        "eta": 0.1, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
                        "termination": hs.TERMINATION_NAMES[last.termination_type],
                        "parallelism": f"points sharded over {world} GPU(s), RCCL all-reduce of camera space"

@@ -500,6 +500,17 @@ int op_model_cost_change(ceres_hip_solver* s, const double* x, double* host_out)
   return 0;
 }
 
+// Sum a few host scalars over the ranks of a sharded run (rows are partitioned: every rank
+// holds a share of the model cost, and all ranks must take the same finite/non-finite branch).
+int allreduce_host_scalars(ceres_hip_solver* s, double* v, int n) {
+  if (s->world <= 1) return 0;
+  HIP_TRY(s, hipMemcpyAsync(s->cg.comm, v, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+  TRY(allreduce(s, s->cg.comm, size_t(n)));
+  HIP_TRY(s, hipMemcpyAsync(v, s->cg.comm, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Conjugate gradients driver (I/conjugate_gradients_solver.h:108-306).
 // ---------------------------------------------------------------------------
@@ -1128,13 +1139,15 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   int bad = 0;
   HIP_TRY(s, hipMemcpyAsync(&bad, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(s, hipStreamSynchronize(st));
+  if (s->world > 1) { double b = bad; TRY(allreduce_host_scalars(s, &b, 1)); bad = b != 0.0; }
   if (bad) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
     res->linear_solver.termination_type = CERES_HIP_FAILURE;
     snprintf(res->linear_solver.message, sizeof(res->linear_solver.message), "Failed to compute a finite step.");
     return 0;
   }
   res->step_is_finite = 1;
-  return op_model_cost_change(s, dx, &res->model_cost_change);
+  TRY(op_model_cost_change(s, dx, &res->model_cost_change));
+  return allreduce_host_scalars(s, &res->model_cost_change, 1);
 }
 }  // namespace
 
