@@ -21,6 +21,7 @@ enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4,
 struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][12][64]
+  const float4* Jf = nullptr;   // [n_tiles][6][64]  fp32 storage mode (then J is unused)
   const double2* b = nullptr;   // [n_tiles][64]
   // fused re-layout: when src_values != nullptr the kernel gathers from the caller's layout and
   // writes the tiles (J_out, b_out) as it goes (first pass of a step)
@@ -28,6 +29,7 @@ struct BalArgs {
   const double* src_b = nullptr;
   const int32_t *slot_epos = nullptr, *slot_fpos = nullptr, *slot_bpos = nullptr;
   double2* J_out = nullptr;
+  float4* Jf_out = nullptr;
   double2* b_out = nullptr;
   const int32_t* slot_cam = nullptr;
   const int32_t* slot_pt = nullptr;
@@ -68,7 +70,7 @@ hipError_t LaunchBalPadCameraVector(const double* x_f, const int32_t* cam_pos, i
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
                                  const int* status, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
-                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, double2* bt, hipStream_t stream);
+                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, float4* Jf, double2* bt, hipStream_t stream);
 // Work items of the camera-block kernel: <= kCamChunk consecutive observations of one camera.
 struct CamItems {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;

@@ -108,7 +108,9 @@ struct Slot {
 // re-layout (bal_pack_kernel) into the first kernel that needs the data anyway.
 // CAN_GATHER is a compile-time property of the mode (only kInit / kCgnrInit are ever a step's
 // first pass): the streaming kernels do not carry the gather code or its registers.
-template <bool CAN_GATHER>
+// F32: the tiles hold the Jacobian rounded to fp32 ([tile][6][64] float4, 96 B per observation instead
+// of 192); all arithmetic stays fp64.  Not a parity mode: accuracy is reported.
+template <bool CAN_GATHER, bool F32>
 __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int lane, Slot& s, bool want_b,
                                           bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
@@ -128,10 +130,31 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
       for (int i = 0; i < 18; ++i) v[6 + i] = f[i];
       if (A.src_b) { const int bp = A.slot_bpos[sl]; s.b0 = A.src_b[bp]; s.b1 = A.src_b[bp + 1]; }
     }
-    double2* o = A.J_out + tile * (kPairsPerSlot * kTile) + lane;
+    if constexpr (F32) {
+      float4* o = A.Jf_out + tile * (6 * kTile) + lane;
 #pragma unroll
-    for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+      for (int q = 0; q < 6; ++q) o[q * kTile] = make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3]));
+#pragma unroll
+      for (int i = 0; i < 24; ++i) v[i] = double(float(v[i]));  // this pass computes with what later passes will read
+    } else {
+      double2* o = A.J_out + tile * (kPairsPerSlot * kTile) + lane;
+#pragma unroll
+      for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+    }
     if (A.src_b) A.b_out[sl] = make_double2(s.b0, s.b1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.e[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) s.f[i] = v[6 + i];
+  } else if constexpr (F32) {
+    const float4* J = A.Jf + tile * (6 * kTile) + lane;
+    float4 p[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) p[q] = J[q * kTile];
+    if (want_b && A.have_b) { const double2 bb = A.b[sl]; s.b0 = bb.x; s.b1 = bb.y; }
+    double v[24];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { v[4 * q] = p[q].x; v[4 * q + 1] = p[q].y; v[4 * q + 2] = p[q].z; v[4 * q + 3] = p[q].w; }
 #pragma unroll
     for (int i = 0; i < 6; ++i) s.e[i] = v[i];
 #pragma unroll
@@ -269,11 +292,11 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
   }
 }
 
-template <int MODE, bool LDS>
+template <int MODE, bool LDS, bool F32>
 __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc,
                                              double& lane_acc) {
   Slot s;
-  load_slot<kCanGather<MODE>>(A, tile, lane, s, kWantsB<MODE>);
+  load_slot<kCanGather<MODE>, F32>(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
   const int po = pt_off(A, s.pt);
   if constexpr (MODE == kSx) {
@@ -443,14 +466,14 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
 // A point with more than 64 observations: tiles [tile, tile+nt) belong to it alone.
 // Sweep 1 accumulates the per-point sums over all its tiles, sweep 2 (only where the
 // per-observation result depends on them) re-reads the tiles, which are L2-warm.
-template <int MODE, bool LDS>
+template <int MODE, bool LDS, bool F32>
 __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t tile, int nt, int lane, double* acc) {
   Slot s;
   if constexpr (MODE == kColNorm) {
     double w[3] = {0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot<true>(A, tile + t, lane, s, false);
+      load_slot<true, F32>(A, tile + t, lane, s, false);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       scatter_f_squares(s, acc);
       if (s.valid) { w[0] += s.e[0] * s.e[0] + s.e[3] * s.e[3]; w[1] += s.e[1] * s.e[1] + s.e[4] * s.e[4]; w[2] += s.e[2] * s.e[2] + s.e[5] * s.e[5]; }
@@ -463,7 +486,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double u[3] = {0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>, F32>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       double xc[9];
       load_xc(A, s.cam, xc);
@@ -480,7 +503,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
     } else {
       for (int t = 0; t < nt; ++t) {
-        load_slot<false>(A, tile + t, lane, s, false, false);
+        load_slot<false, F32>(A, tile + t, lane, s, false, false);
         double xc[9];
         load_xc(A, s.cam, xc);
         double t0, t1;
@@ -494,7 +517,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double w[3] = {0, 0, 0}, xp[3] = {0, 0, 0};
     int pt = 0, po = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>, F32>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) {
         pt = __shfl(s.pt, 0, 64);
         po = pt_off(A, pt);
@@ -526,7 +549,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
-      load_slot<kCanGather<MODE>>(A, tile + t, lane, s, kWantsB<MODE>);
+      load_slot<kCanGather<MODE>, F32>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
       if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(s, acc, s.b0, s.b1);
       if (s.valid) {
@@ -553,7 +576,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     if constexpr (MODE == kInit) {
       const double g[3] = {r[6], r[7], r[8]};
       for (int t = 0; t < nt; ++t) {
-        load_slot<false>(A, tile + t, lane, s, true, false);  // second sweep: from the tiles just written
+        load_slot<false, F32>(A, tile + t, lane, s, true, false);  // second sweep: from the tiles just written
         const int64_t sl = (tile + t) * kTile + lane;
         init_apply<LDS>(A, s, sl, s.b0, s.b1, ei, g, acc);
       }
@@ -561,7 +584,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
   }
 }
 
-template <int MODE, bool LDS, int BLOCK>
+template <int MODE, bool LDS, int BLOCK, bool F32>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
@@ -584,11 +607,11 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     const int kind = A.tile_kind[tile];
     const int aux = A.tile_aux[tile];
     if constexpr (MODE == kJx) {
-      process_tile<MODE, LDS>(A, tile, lane, 1, 0, acc, lane_acc);
+      process_tile<MODE, LDS, F32>(A, tile, lane, 1, 0, acc, lane_acc);
     } else {
       if (kind == 2) continue;
-      if (kind == 0) process_tile<MODE, LDS>(A, tile, lane, aux & 0xff, aux >> 8, acc, lane_acc);
-      else process_long_point<MODE, LDS>(A, tile, aux, lane, acc);
+      if (kind == 0) process_tile<MODE, LDS, F32>(A, tile, lane, aux & 0xff, aux >> 8, acc, lane_acc);
+      else process_long_point<MODE, LDS, F32>(A, tile, aux, lane, acc);
     }
   }
   if constexpr (MODE == kJx) {  // one partial per workgroup, summed in fixed order by the caller
@@ -686,11 +709,13 @@ __global__ void bal_add_f_diagonal_kernel(int n_f9, const int32_t* __restrict__ 
 }
 
 // Re-layout: caller's values (any cell.position) -> tiles.  One wavefront per tile.
+template <bool F32>
 __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict__ values, const double* __restrict__ b,
                                                        const int32_t* __restrict__ slot_epos,
                                                        const int32_t* __restrict__ slot_fpos,
                                                        const int32_t* __restrict__ slot_bpos, int64_t n_tiles,
-                                                       double2* __restrict__ J, double2* __restrict__ bt) {
+                                                       double2* __restrict__ J, float4* __restrict__ Jf,
+                                                       double2* __restrict__ bt) {
   const int lane = threadIdx.x & 63;
   const int64_t tile = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (tile >= n_tiles) return;
@@ -709,9 +734,15 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
     for (int i = 0; i < 18; ++i) v[6 + i] = f[i];
     if (b) { b0 = b[bp]; b1 = b[bp + 1]; }
   }
-  double2* o = J + tile * (kPairsPerSlot * kTile) + lane;
+  if constexpr (F32) {
+    float4* o = Jf + tile * (6 * kTile) + lane;
 #pragma unroll
-  for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+    for (int q = 0; q < 6; ++q) o[q * kTile] = make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3]));
+  } else {
+    double2* o = J + tile * (kPairsPerSlot * kTile) + lane;
+#pragma unroll
+    for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+  }
   if (b) bt[sl] = make_double2(b0, b1);
 }
 
@@ -889,11 +920,11 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-template <int MODE, int BLOCK>
-static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+template <int MODE, int BLOCK, bool F32>
+static hipError_t launch_fused2(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
     const size_t bytes = size_t(A.n_f9) * sizeof(double);
-    auto k = bal_fused_kernel<MODE, true, BLOCK>;
+    auto k = bal_fused_kernel<MODE, true, BLOCK, F32>;
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
@@ -902,13 +933,17 @@ static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   } else {
-    hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK>), dim3(grid), dim3(BLOCK), 0, stream, A);
+    hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK, F32>), dim3(grid), dim3(BLOCK), 0, stream, A);
   }
   return hipGetLastError();
 }
+template <int MODE, int BLOCK>
+static hipError_t launch_fused(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  return A.Jf ? launch_fused2<MODE, BLOCK, true>(A, lds, grid, stream) : launch_fused2<MODE, BLOCK, false>(A, lds, grid, stream);
+}
 
 // Threads per workgroup of the streaming kernels: 1024 (16 waves per CU) hides HBM latency
-// best for the light modes; kInit needs more registers and runs at 512.
+// best for the light modes; the set-up modes need more registers and run at 512.
 int BalBlockFor(int mode) {
   static int forced = [] { const char* e = getenv("CERES_HIP_BAL_BLOCK"); return e ? atoi(e) : 0; }();
   if (mode == kInit || mode == kCgnrInit || mode == kColNorm) return 512;
@@ -960,10 +995,14 @@ hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double*
 }
 
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
-                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, double2* bt, hipStream_t stream) {
+                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, float4* Jf, double2* bt, hipStream_t stream) {
   if (n_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(bal_pack_kernel, dim3(unsigned((n_tiles + 3) / 4)), dim3(256), 0, stream, values, b, slot_epos,
-                     slot_fpos, slot_bpos, n_tiles, J, bt);
+  if (Jf)
+    hipLaunchKernelGGL((bal_pack_kernel<true>), dim3(unsigned((n_tiles + 3) / 4)), dim3(256), 0, stream, values, b, slot_epos,
+                       slot_fpos, slot_bpos, n_tiles, J, Jf, bt);
+  else
+    hipLaunchKernelGGL((bal_pack_kernel<false>), dim3(unsigned((n_tiles + 3) / 4)), dim3(256), 0, stream, values, b, slot_epos,
+                       slot_fpos, slot_bpos, n_tiles, J, Jf, bt);
   return hipGetLastError();
 }
 

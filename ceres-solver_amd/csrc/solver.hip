@@ -63,6 +63,7 @@ struct ceres_hip_solver {
   bool have_lm_diag = false;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
+  float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
   double2* d_zbuf = nullptr;
   int bal_flags = 0;
@@ -159,7 +160,7 @@ bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HI
 // ---------------------------------------------------------------------------
 BalArgs bal_args(ceres_hip_solver* s) {
   BalArgs A;
-  A.J = s->d_J; A.b = s->d_bt;
+  A.J = s->d_J; A.Jf = s->d_Jf; A.b = s->d_bt;
   A.slot_cam = s->d_slot_cam; A.slot_pt = s->d_slot_pt; A.slot_seg = s->d_slot_seg;
   A.tile_kind = s->d_tile_kind; A.tile_aux = s->d_tile_aux;
   A.n_tiles = s->plan.n_tiles; A.n_slots = s->plan.n_tiles * kTile;
@@ -180,13 +181,13 @@ void use_gather_if_unpacked(ceres_hip_solver* s, BalArgs& A) {
   A.src_values = s->values;
   A.src_b = s->b;
   A.slot_epos = s->d_slot_epos; A.slot_fpos = s->d_slot_fpos; A.slot_bpos = s->d_slot_bpos;
-  A.J_out = s->d_J; A.b_out = s->d_bt;
+  A.J_out = s->d_J; A.Jf_out = s->d_Jf; A.b_out = s->d_bt;
   s->packed = true;
 }
 
 int ensure_packed(ceres_hip_solver* s) {
   if (s->path != CERES_HIP_PATH_BAL || s->packed) return 0;
-  HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, s->stream));
+  HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_Jf, s->d_bt, s->stream));
   s->packed = true;
   return 0;
 }
@@ -828,6 +829,10 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
     fail(nullptr, CERES_HIP_E_UNSUPPORTED, "preconditioner_type %d is not available for solver_type %d", pre, o->solver_type);
     return nullptr;
   }
+  if (o->jacobian_storage != 0 && o->jacobian_storage != 1) {
+    fail(nullptr, CERES_HIP_E_INVALID, "jacobian_storage must be 0 (fp64) or 1 (fp32 tiles)");
+    return nullptr;
+  }
   if (o->max_num_iterations < 1 || o->min_num_iterations < 0) {
     fail(nullptr, CERES_HIP_E_INVALID, "bad iteration limits");
     return nullptr;
@@ -960,7 +965,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_pt_diag_off, pdo));
     TRY(dev_upload(s, &s->d_cam_diag_off, cdo));
     const size_t n_slots = size_t(P.n_tiles) * kTile;
-    TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
+    if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));
+    else TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
     TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
@@ -1471,9 +1477,10 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       break;
     case CERES_HIP_TIMED_PACK:
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "pack exists on the <2,3,9> path only");
-      body = [&] { HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_bt, st)); return 0; };
+      body = [&] { HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_Jf, s->d_bt, st)); return 0; };
       break;
     case CERES_HIP_TIMED_COPY:
+      if (s->d_Jf) return fail(s, CERES_HIP_E_UNSUPPORTED, "copy probe needs the fp64 tile buffer");
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "copy probe uses the packed buffer of the <2,3,9> path");
       body = [&] {
         HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTile * 24), hipMemcpyDeviceToDevice, st));
@@ -1481,6 +1488,7 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       };
       break;
     case CERES_HIP_TIMED_READ_STREAM:
+      if (s->d_Jf) return fail(s, CERES_HIP_E_UNSUPPORTED, "read-stream probe needs the fp64 tile buffer");
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "read-stream probe uses the packed tiles of the <2,3,9> path");
       body = [&] { HIP_TRY(s, LaunchBalStreamProbe(s->d_J, s->plan.n_tiles, std::min(s->num_cus, 9 * s->plan.n_cameras), s->d_global_acc, st)); return 0; };
       break;

@@ -46,7 +46,7 @@ class COptions(ctypes.Structure):
     _fields_ = [("solver_type", c_int32), ("preconditioner_type", c_int32), ("min_num_iterations", c_int32),
                 ("max_num_iterations", c_int32), ("residual_reset_period", c_int32), ("num_eliminate_blocks", c_int32),
                 ("device", c_int32), ("force_generic_path", c_int32), ("cg_check_interval", c_int32),
-                ("reserved", c_int32 * 7)]
+                ("jacobian_storage", c_int32), ("reserved", c_int32 * 6)]
 
 
 class CSummary(ctypes.Structure):
@@ -178,6 +178,7 @@ class LinearSolverOptions:
     device: int = 0
     force_generic_path: bool = False
     cg_check_interval: int = 0
+    jacobian_storage: int = 0   # 1: fp32 tiles on the <2,3,9> path (accuracy mode, not parity)
 
 
 @dataclass
@@ -227,7 +228,7 @@ class HipLinearSolver:
         nelim = options.elimination_groups[0] if options.elimination_groups else 0
         c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
                      options.max_num_iterations, options.residual_reset_period, nelim, options.device,
-                     int(options.force_generic_path), options.cg_check_interval)
+                     int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage)
         self._h = self._lib.ceres_hip_create(byref(c))
         if not self._h:
             raise HipError(self._lib.ceres_hip_last_error(None).decode())

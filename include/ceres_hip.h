@@ -109,8 +109,11 @@ typedef struct ceres_hip_options {
   int32_t device;                /* HIP device ordinal                                     */
   int32_t force_generic_path;    /* 1: never select the fused BAL kernels (testing)        */
   int32_t cg_check_interval;     /* CG iterations enqueued between host polls of the
-                                    device-side termination flag; <=0 -> default (8)       */
-  int32_t reserved[7];
+                                    device-side termination flag; <=0 -> adaptive 2,4,8,16 */
+  int32_t jacobian_storage;      /* <2,3,9> path: 0 = fp64 tiles (parity mode); 1 = Jacobian rounded
+                                    to fp32 in the tiles, fp64 arithmetic (NOT parity: accuracy mode,
+                                    SURVEY.md §7 item 6; halves the HBM traffic of the hot kernels)  */
+  int32_t reserved[6];
 } ceres_hip_options;
 
 /* ---- LinearSolver::Summary (I/linear_solver.h:320-326) ------------------- */

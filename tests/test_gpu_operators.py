@@ -175,3 +175,42 @@ def test_bal_without_regulariser_and_global_accumulators(hip, oracle, problems):
     s.close()
     assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL), tol=1e-11)
     assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL), tol=1e-11)
+
+
+def test_fp32_tile_storage_is_accurate_not_exact(hip, oracle, problems):
+    """jacobian_storage = 1: the tiles hold J rounded to fp32, arithmetic stays fp64.  This is an
+    ACCURACY mode, never reported as parity: operators agree with the fp64
+    oracle to ~1e-7 relative, and exactly with the oracle run on the fp32-rounded Jacobian."""
+    p = problems.synthetic_bal(None, num_cameras=60, num_points=4000, num_observations=19000, seed=51, skew=0.5)
+    rounded = type(p)(p.bs, p.values.astype(np.float32).astype(np.float64), p.b, p.D, p.num_eliminate_blocks)
+    rng = np.random.default_rng(2)
+    for solver_type, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=200,
+                                    elimination_groups=[p.num_eliminate_blocks], jacobian_storage=1)
+        s = hip.HipLinearSolver(o)
+        s.set_structure(p.bs)
+        assert s.info().kernel_path == hip.PATH_BAL
+        s.load(p.values, p.b, p.D)
+        m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+        if solver_type == hip.ITERATIVE_SCHUR:
+            s.schur_init()
+            x = rng.standard_normal(m.num_cols_f)
+            got = s.schur_sx(x)
+            for prob, tol in ((p, 5e-7), (rounded, 1e-12)):
+                isc = oracle.ImplicitSchurComplement(m)
+                isc.init(prob.values, prob.D, prob.b)
+                assert rel(got, isc.sx(x)) <= tol
+                assert rel(s.schur_rhs(), isc.rhs()) <= tol
+        else:
+            x = rng.standard_normal(m.num_cols)
+            got = s.jtjx(x)
+            for prob, tol in ((p, 5e-7), (rounded, 1e-12)):
+                want = m.left_multiply(prob.values, m.right_multiply(prob.values, x)) + p.D ** 2 * x
+                assert rel(got, want) <= tol
+        xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+        fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else oracle.Matrix(p.bs, 0).cgnr_solve
+        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=200, q_tol=0.1, r_tol=-1.0)
+        assert summ.termination_type == hip.SUCCESS and abs(summ.num_iterations - so.num_iterations) <= 1
+        if summ.num_iterations == so.num_iterations:
+            assert rel(xs, xo) <= 1e-5
+        s.close()

@@ -29,8 +29,12 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
                               ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, [("sx", hs.TIMED_SX, B_sx), ("schur_init", hs.TIMED_SCHUR_INIT, None),
                                                                                   ("schur_jacobi", hs.TIMED_SCHUR_JACOBI, None), ("back_substitute", hs.TIMED_BACK_SUBSTITUTE, None),
                                                                                   ("pack", hs.TIMED_PACK, None), ("read_stream", hs.TIMED_READ_STREAM, "tiles")])):
+    storage = int(os.environ.get("STORAGE", "0"))
+    out["storage"] = "fp32" if storage else "fp64"
+    if storage:
+        ops = [o for o in ops if o[0] not in ("read_stream",)]
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
-                                                  elimination_groups=[prob.num_eliminate_blocks]))
+                                                  elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage))
     s.set_structure(prob.bs)
     s.load(prob.values, prob.b, prob.D)
     for name, op, nbytes in ops:
