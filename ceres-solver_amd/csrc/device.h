@@ -46,6 +46,10 @@ struct BalArgs {
   int flags = 0;                    // reserved
   double* y_e = nullptr;
   const double* D_e = nullptr;  // nullptr => no regularisation on the point part
+  // fused LM diagonal (lm_radius > 0): D_e is formed in the kernel from the point block's own diagonal
+  double lm_radius = 0.0, lm_min = 0.0, lm_max = 0.0;
+  double* lm_diag_e = nullptr;  // clamped diag(J^T J), point part (indexed like x_e)
+  double* lm_D_e = nullptr;     // D, point part
   // per-point 3x3 inverses, packed symmetric 6 doubles / point
   double* etei = nullptr;
   double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
@@ -71,6 +75,15 @@ hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double*
                                  const int* status, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
                          const int32_t* slot_bpos, int64_t n_tiles, double2* J, float4* Jf, double2* bt, hipStream_t stream);
+// Fused LM diagonal of the camera columns, applied by bal_invert9_kernel (radius > 0 to enable).
+struct LmFuse {
+  double radius = 0.0, min_d = 0.0, max_d = 0.0;
+  const double* camsq = nullptr;     // [9 c + k] column norms; nullptr => the block's own diagonal (F^T F blocks)
+  const int32_t* cam_pos = nullptr;  // nullptr => 9 c
+  double* diag_f = nullptr;
+  double* D_f = nullptr;
+};
+
 // Work items of the camera-block kernel: <= kCamChunk consecutive observations of one camera.
 struct CamItems {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;
@@ -79,11 +92,13 @@ struct CamItems {
 // blocks must be zeroed by the caller (items of one camera are combined with atomics).
 hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
                                  const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream);
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, double* camsq,
+                                 hipStream_t stream);
 hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
                                 const int32_t* cam_slot, const double2* zbuf, double* out, const int* status,
                                 hipStream_t stream);
-hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream);
+hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
+                            hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------
 struct GenStructure {

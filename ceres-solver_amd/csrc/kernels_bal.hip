@@ -254,8 +254,22 @@ __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
   a[5] = s.e[2] * s.e[2] + s.e[5] * s.e[5];
 }
 
-__device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int po, double (&a)[6]) {
-  if (A.D_e) {
+// Regularisation of the point block.  Either D is given (A.D_e), or — fused LM diagonal,
+// A.lm_radius > 0 — it is formed right here from the block's own diagonal, which IS
+// diag(J^T J) over the point's columns: d = clamp(a_jj, min, max), D^2 = d / radius
+// (LevenbergMarquardtStrategy::ComputeStep, I/levenberg_marquardt_strategy.cc:84-96); `writer`
+// lanes record d (for a later reuse_diagonal step) and D.
+__device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int po, double (&a)[6], bool writer) {
+  if (A.lm_radius > 0.0) {
+    const double d0 = fmin(fmax(a[0], A.lm_min), A.lm_max), d1 = fmin(fmax(a[3], A.lm_min), A.lm_max),
+                 d2 = fmin(fmax(a[5], A.lm_min), A.lm_max);
+    const double q0 = d0 / A.lm_radius, q1 = d1 / A.lm_radius, q2 = d2 / A.lm_radius;
+    if (writer) {
+      A.lm_diag_e[po] = d0; A.lm_diag_e[po + 1] = d1; A.lm_diag_e[po + 2] = d2;
+      A.lm_D_e[po] = sqrt(q0); A.lm_D_e[po + 1] = sqrt(q1); A.lm_D_e[po + 2] = sqrt(q2);
+    }
+    a[0] += q0; a[3] += q1; a[5] += q2;
+  } else if (A.D_e) {
     const double d0 = A.D_e[po], d1 = A.D_e[po + 1], d2 = A.D_e[po + 2];
     a[0] += d0 * d0; a[3] += d1 * d1; a[5] += d2 * d2;
   }
@@ -395,7 +409,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       for (int i = 0; i < 6; ++i) r[i] = a6[i];
     }
     double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-    add_e_diagonal(A, po, a);
+    add_e_diagonal(A, po, a, s.valid && lane == s.last);
     if (!s.valid) { a[0] = a[3] = a[5] = 1.0; a[1] = a[2] = a[4] = 0.0; }
     invert_spd3(a, ei);
     if (s.valid && lane == s.last) store_ete_inverse(A, s.pt, ei);
@@ -440,7 +454,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       A.y_e[po] = r[6]; A.y_e[po + 1] = r[7]; A.y_e[po + 2] = r[8];
       if (A.point_blocks) {
         double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-        add_e_diagonal(A, po, a);
+        add_e_diagonal(A, po, a, true);
         invert_spd3(a, ei);
         store_ete_inverse(A, s.pt, ei);
       }
@@ -563,7 +577,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     wave_allreduce<9>(r);
     const int po = pt_off(A, pt);
     double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-    add_e_diagonal(A, po, a);
+    add_e_diagonal(A, po, a, lane == 0);
     invert_spd3(a, ei);
     if constexpr (MODE == kCgnrInit) {
       if (lane == 0) {
@@ -767,15 +781,18 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
                                                                 const double* __restrict__ D_f,
                                                                 const int32_t* __restrict__ cam_pos,
                                                                 const int64_t* __restrict__ cam_diag_off,
-                                                                double* __restrict__ blocks) {
+                                                                double* __restrict__ blocks,
+                                                                double* __restrict__ camsq) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= items.count) return;
   const int c = items.cam[item];
   const int beg = items.begin[item], end = items.end[item];
-  double acc[45];
+  double acc[45], sq[9];
 #pragma unroll
   for (int i = 0; i < 45; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sq[i] = 0.0;
   for (int q = beg + lane; q < end; q += 64) {
     const double* f = values + cam_fpos[q];
     double f0[9], f1[9];
@@ -786,6 +803,10 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
       const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
       const double2 a = mo[0], b = mo[1];
       m00 = a.x; m01 = a.y; m11 = b.x;
+      if (camsq) {  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sq[k] += f0[k] * f0[k] + f1[k] * f1[k];
+      }
     }
     int idx = 0;
 #pragma unroll
@@ -807,6 +828,15 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
   // would be long: go through LDS-free broadcast instead — every lane holds all 45 sums)
   const bool first = beg == cam_ptr[c];
   const bool single = first && end == cam_ptr[c + 1];
+  if (SCHUR && camsq) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      double v = sq[k];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane == k) { if (single) camsq[9 * int64_t(c) + k] = v; else unsafeAtomicAdd(&camsq[9 * int64_t(c) + k], v); }
+    }
+  }
   double* out = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c);
   const int dpos = cam_pos ? cam_pos[c] : 9 * c;
   int idx = 0;
@@ -868,10 +898,21 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 // solves against I, like BlockRandomAccessDiagonalMatrix::Invert,
 // I/block_random_access_diagonal_matrix.cc:90-100).  One thread per camera.
 __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
-                                                         int n_cameras, int* fail_flag) {
+                                                         int n_cameras, int* fail_flag, LmFuse lm) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= n_cameras) return;
   double* a = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c);
+  if (lm.radius > 0.0) {  // fused LM diagonal of the camera columns: d = clamp(diag(F^T F)), D^2 = d / radius
+    const int o = lm.cam_pos ? lm.cam_pos[c] : 9 * c;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double v = lm.camsq ? lm.camsq[9 * int64_t(c) + k] : a[k * 9 + k];
+      const double d = fmin(fmax(v, lm.min_d), lm.max_d), q = d / lm.radius;
+      lm.diag_f[o + k] = d;
+      lm.D_f[o + k] = sqrt(q);
+      a[k * 9 + k] += q;
+    }
+  }
   double L[81], col[9];
   bool ok = true;
 #pragma unroll
@@ -1006,22 +1047,24 @@ hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* s
   return hipGetLastError();
 }
 
-hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, hipStream_t stream) {
-  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 63) / 64), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag);
+hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
+                            hipStream_t stream) {
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 63) / 64), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm);
   return hipGetLastError();
 }
 
 hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
                                  const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, hipStream_t stream) {
+                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, double* camsq,
+                                 hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
   const dim3 grid((items.count + 3) / 4);
   if (schur)
     hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
-                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
+                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks, camsq);
   else
     hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
-                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks);
+                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks, camsq);
   return hipGetLastError();
 }
 

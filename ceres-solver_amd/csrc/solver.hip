@@ -61,6 +61,9 @@ struct ceres_hip_solver {
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
   bool have_lm_diag = false;
+  bool lm_fuse_active = false;      // this step forms D inside the set-up kernels (no separate column-norm pass)
+  ceres_hip_lm_options lm_opts{};
+  double* d_camsq = nullptr;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
@@ -171,6 +174,10 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
+  if (s->lm_fuse_active) {
+    A.lm_radius = s->lm_opts.radius; A.lm_min = s->lm_opts.min_diagonal; A.lm_max = s->lm_opts.max_diagonal;
+    A.lm_diag_e = s->lm_diag; A.lm_D_e = s->lm_D;
+  }
   return A;
 }
 
@@ -190,6 +197,17 @@ int ensure_packed(ceres_hip_solver* s) {
   HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_Jf, s->d_bt, s->stream));
   s->packed = true;
   return 0;
+}
+
+LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
+  LmFuse f;
+  if (!s->lm_fuse_active) return f;
+  f.radius = s->lm_opts.radius; f.min_d = s->lm_opts.min_diagonal; f.max_d = s->lm_opts.max_diagonal;
+  f.camsq = schur_blocks ? s->d_camsq : nullptr;
+  f.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  f.diag_f = s->lm_diag + s->hs.num_cols_e;
+  f.D_f = s->lm_D + s->hs.num_cols_e;
+  return f;
 }
 
 // Run one fused kernel that scatters into camera space and produce y_f.
@@ -368,13 +386,16 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
       // raw sums first (no diagonal) so that a sharded run can add them up
       HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));
+      const bool fuse = s->lm_fuse_active && invert;
+      if (fuse && schur) HIP_TRY(s, hipMemsetAsync(s->d_camsq, 0, sizeof(double) * 9 * s->plan.n_cameras, st));
       HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_Mo,
-                                       s->world > 1 ? nullptr : D_f, nullptr, nullptr, out, st));
+                                       (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
+                                       (fuse && schur) ? s->d_camsq : nullptr, st));
       if (s->world > 1) {
         TRY(allreduce(s, out, size_t(len)));
         if (D_f) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
       }
-      if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, st));
+      if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), st));
     } else {
       if (type == CERES_HIP_SCHUR_JACOBI) {
         HIP_TRY(s, LaunchGenSchurJacobi(s->G, s->values, s->etei, s->D, s->world > 1 ? 0 : 1, out, len, st));
@@ -401,8 +422,8 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));  // camera blocks are accumulated with atomics
     HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
     HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos, s->d_cam_diag_off, out, st));
-    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
+                                     D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos, s->d_cam_diag_off, out, nullptr, st));
+    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), st));
     return 0;
   }
   HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kAll, s->world > 1 ? nullptr : s->D, out, len, st));
@@ -439,17 +460,17 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   if (s->world <= 1) {
     HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     D_f, cam_pos, s->d_cam_diag_off, blocks, st));
+                                     s->lm_fuse_active ? nullptr : D_f, cam_pos, s->d_cam_diag_off, blocks, nullptr, st));
   } else {
     // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
     // behind the point blocks in the Schur-ordered layout a sharded run requires)
     HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     nullptr, cam_pos, s->d_cam_diag_off, blocks, st));
+                                     nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, st));
     const int64_t first = h.diag_off_all[h.nelim];
     TRY(allreduce(s, blocks + first, size_t(len - first)));
     if (s->D) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
   }
-  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, st));
+  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), st));
   return 0;
 }
 
@@ -979,6 +1000,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->d_global_acc, n9));
     TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? 1 : n_slots));
     TRY(dev_alloc(s, &s->d_xpad, size_t(10) * P.n_cameras));
+    TRY(dev_alloc(s, &s->d_camsq, n9));
     {  // measured alternative (16-byte aligned padded camera gathers); off by default: no gain
       const char* e = getenv("CERES_HIP_XPAD");
       s->use_xpad = e && atoi(e) != 0;
@@ -1129,14 +1151,22 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   memset(res, 0, sizeof(*res));
   if (!(o->radius > 0) || !(o->min_diagonal > 0) || o->min_diagonal > o->max_diagonal)
     return fail(s, CERES_HIP_E_INVALID, "bad LM options");
-  if (!o->reuse_diagonal || !s->have_lm_diag) {
-    TRY(op_squared_column_norm(s, s->lm_diag));
-    s->have_lm_diag = true;
-  }
-  HIP_TRY(s, LaunchLmDiagonal(s->lm_diag, o->min_diagonal, o->max_diagonal, o->radius, s->lm_D, h.num_cols, st));
+  // A fresh diagonal is diag(J^T J), which the set-up kernels of the <2,3,9> path have in hand anyway
+  // (the point block's own diagonal; the camera columns' norms in the camera-major pass): then D
+  // is formed inside them and no separate column-norm pass runs.
+  const bool fresh = !o->reuse_diagonal || !s->have_lm_diag;
+  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->world <= 1 &&
+                      s->opt.preconditioner_type != CERES_HIP_IDENTITY;
+  s->lm_opts = *o;
+  if (fresh && !s->lm_fuse_active) TRY(op_squared_column_norm(s, s->lm_diag));
+  if (!s->lm_fuse_active)
+    HIP_TRY(s, LaunchLmDiagonal(s->lm_diag, o->min_diagonal, o->max_diagonal, o->radius, s->lm_D, h.num_cols, st));
+  s->have_lm_diag = true;
   s->D = s->lm_D;
   s->have_D = true;
-  TRY(solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver));
+  const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
+  s->lm_fuse_active = false;
+  if (rc) return rc;
   res->step_is_finite = 0;
   const int term = res->linear_solver.termination_type;
   if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) return 0;
