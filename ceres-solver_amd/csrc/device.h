@@ -155,6 +155,9 @@ hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partia
 // I/levenberg_marquardt_strategy.cc:84-96)
 hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t stream);
 // x = -x and *nonfinite += number of non-finite entries (IsArrayValid + negation, :124-132)
+// CGNR: y.g + y.r + |D y|^2 over [begin, end) as per-workgroup partials (nparts <= kMaxVecGrid)
+hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
+                               double* partials, int* nparts, hipStream_t stream);
 hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);

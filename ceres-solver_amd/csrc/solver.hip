@@ -1182,6 +1182,31 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     return 0;
   }
   res->step_is_finite = 1;
+  if (!is_schur(s)) {
+    // CGNR: no pass over J is needed.  With y the CG solution (step = -y), g = J^T f and r = g - (J^T J + D^2) y
+    // the residual CG carries:  -(J step)'(f + J step / 2) = y.g - |J y|^2 / 2 = (y.g + y.r + |D y|^2) / 2.
+    auto sum_range = [&](int64_t b, int64_t e, double* out) -> int {
+      *out = 0;
+      if (e <= b) return 0;
+      int nparts = 0;
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, b, e, s->scalar_partials, &nparts, st));
+      std::vector<double> parts(nparts);
+      HIP_TRY(s, hipMemcpyAsync(parts.data(), s->scalar_partials, sizeof(double) * nparts, hipMemcpyDeviceToHost, st));
+      HIP_TRY(s, hipStreamSynchronize(st));
+      for (double p : parts) *out += p;
+      return 0;
+    };
+    double local = 0, shared = 0;
+    if (s->world > 1) {  // the point part is sharded, the camera part replicated
+      TRY(sum_range(0, h.num_cols_e, &local));
+      TRY(allreduce_host_scalars(s, &local, 1));
+      TRY(sum_range(h.num_cols_e, h.num_cols, &shared));
+    } else {
+      TRY(sum_range(0, h.num_cols, &shared));
+    }
+    res->model_cost_change = 0.5 * (local + shared);
+    return 0;
+  }
   TRY(op_model_cost_change(s, dx, &res->model_cost_change));
   return allreduce_host_scalars(s, &res->model_cost_change, 1);
 }
