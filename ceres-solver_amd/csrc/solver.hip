@@ -702,7 +702,9 @@ int load_host(ceres_hip_solver* s, const double* hv, const double* hb, const dou
 
 float elapsed(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, a, b);
+  // An event of a phase that an early return skipped was never recorded: the query fails, the
+  // phase reads as 0 ms, and the runtime's sticky last-error must not leak into the next launch check.
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0.0f; }
   return ms;
 }
 
