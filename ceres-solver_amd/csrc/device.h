@@ -16,7 +16,7 @@ constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
-enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8 };
+enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8, kBalSpseZ = 9 };
 
 struct BalArgs {
   // packed problem
@@ -209,6 +209,11 @@ hipError_t LaunchCgInit(const CgBuffers& B, double q_tol, double r_tol, int min_
 // column col_begin; blocks == nullptr => identity) and slot 0 <- partial r.z
 hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
                                 int n_local_blocks, const int64_t* diag_off, const double* blocks, hipStream_t stream);
+// slot <- partial x.y over the CG vectors' range (used when the preconditioner is an operator)
+hipError_t LaunchCgDotSlot(const CgBuffers& B, const double* x, const double* y, int slot, hipStream_t stream);
+// Non-zero initial guess (use_spse_initialization): x is kept, r = rhs - tmp, slots 2,3 <- partial -x.(rhs + r), |r|^2
+hipError_t LaunchCgInitFromGuess(const CgBuffers& B, const double* tmp, double q_tol, double r_tol, int min_it, int max_it,
+                                 hipStream_t stream);
 // rho = sum(slot 0); beta; p = z + beta p
 hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t stream);
 // slot 1 <- partial p.q  (q lives in z)

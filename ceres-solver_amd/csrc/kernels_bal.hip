@@ -237,7 +237,7 @@ __device__ __forceinline__ void scatter_f_squares(const Slot& s, double* acc) {
   for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * s.f[k] + s.f[9 + k] * s.f[9 + k]);
 }
 
-enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6, kColNorm = 7, kJx = 8 };
+enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6, kColNorm = 7, kJx = 8, kSpseZ = 9 };
 
 template <int MODE>
 constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit || MODE == kJx);
@@ -313,7 +313,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
   load_slot<kCanGather<MODE>, F32>(A, tile, lane, s, kWantsB<MODE>);
   const int64_t sl = tile * kTile + lane;
   const int po = pt_off(A, s.pt);
-  if constexpr (MODE == kSx) {
+  if constexpr (MODE == kSx || MODE == kSpseZ) {
     double xc[9], ei[6], v[3];
     load_xc(A, s.cam, xc);
     load_ete_inverse(A, s.pt, ei);
@@ -323,8 +323,12 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_allreduce<3>(u, lane, s.first, s.last, span);
     sym3_mul(ei, u, v);
-    const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
-    const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
+    // kSx: F^T (F x - E (E^T E)^-1 E^T F x);  kSpseZ: only the second term, F^T E (E^T E)^-1 E^T F x
+    // (ImplicitSchurComplement::InversePowerSeriesOperatorRightMultiplyAccumulate, :146-174)
+    const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+    const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+    const double z0 = MODE == kSx ? t0 - ev0 : ev0;
+    const double z1 = MODE == kSx ? t1 - ev1 : ev1;
     scatter_ft<LDS>(s, acc, z0, z1);
   } else if constexpr (MODE == kJtJx || MODE == kJtb) {
     double z0, z1, xp[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
@@ -496,7 +500,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = w[0]; A.y_e[po + 1] = w[1]; A.y_e[po + 2] = w[2]; }
     return;
   }
-  if constexpr (MODE == kSx || MODE == kBackSub) {
+  if constexpr (MODE == kSx || MODE == kBackSub || MODE == kSpseZ) {
     double u[3] = {0, 0, 0};
     int pt = 0;
     for (int t = 0; t < nt; ++t) {
@@ -522,9 +526,9 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
         load_xc(A, s.cam, xc);
         double t0, t1;
         f_times(s, xc, t0, t1);
-        const double z0 = t0 - (s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2]);
-        const double z1 = t1 - (s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2]);
-        scatter_ft<LDS>(s, acc, z0, z1);
+        const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+        const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+        scatter_ft<LDS>(s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
       }
     }
   } else if constexpr (MODE == kJtJx || MODE == kJtb) {
@@ -602,7 +606,7 @@ template <int MODE, bool LDS, int BLOCK, bool F32>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
-  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm);
+  constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm || MODE == kSpseZ);
   double* acc = nullptr;
   if constexpr (kScatters) {
     if constexpr (LDS) {
@@ -1004,6 +1008,7 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
     case kCgnrInit: return launch_fused<kCgnrInit, 512>(A, lds, grid, stream);
     case kColNorm: return launch_fused<kColNorm, 512>(A, true, grid, stream);
     case kJx: return launch_fused<kJx, 1024>(A, false, grid, stream);
+    case kSpseZ: return big ? launch_fused<kSpseZ, 1024>(A, lds, grid, stream) : launch_fused<kSpseZ, 512>(A, lds, grid, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -168,6 +168,48 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_kernel(CgBuffers B, double 
   }
 }
 
+__global__ __launch_bounds__(kVecBlock) void cg_dot_slot_kernel(CgBuffers B, const double* x, const double* y, int slot) {
+  __shared__ double sh[4];
+  if (B.S->status != 0) return;
+  double v = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) v += x[s.i] * y[s.i];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) B.partials[slot * kMaxVecGrid + blockIdx.x] = v;
+}
+
+// CG from a non-zero initial guess (:138-159 with x != 0): r = rhs - A x (tmp = A x), Q0 = -x.(rhs + r).
+__global__ __launch_bounds__(kVecBlock) void cg_init_from_guess_kernel(CgBuffers B, const double* tmp) {
+  __shared__ double sh[4];
+  double q = 0, rr = 0;
+  for (Span s = my_span(B); s.i < s.end; s.i += s.step) {
+    const double r = B.rhs[s.i] - tmp[s.i];
+    B.r[s.i] = r;
+    q -= B.x[s.i] * (B.rhs[s.i] + r);
+    rr += r * r;
+  }
+  q = block_sum(q, sh);
+  rr = block_sum(rr, sh);
+  if (threadIdx.x == 0) { B.partials[2 * kMaxVecGrid + blockIdx.x] = q; B.partials[3 * kMaxVecGrid + blockIdx.x] = rr; }
+}
+__global__ __launch_bounds__(kVecBlock) void cg_init_from_guess_finish_kernel(CgBuffers B, double q_tol, double r_tol, int min_it, int max_it) {
+  __shared__ double sh[4];
+  const double nn = total_of(B, 0, sh);
+  const double Q0 = total_of(B, 2, sh);
+  const double rr = total_of(B, 3, sh);
+  if (threadIdx.x != 0) return;
+  CgScalars& S = *B.S;
+  S.norm_rhs = sqrt(nn);
+  S.tol_r = r_tol * S.norm_rhs;
+  S.q_tol = q_tol;
+  S.rho = 1.0; S.rho_new = 1.0; S.beta = 0; S.pq = 0; S.alpha = 0;
+  S.Q0 = Q0; S.Q1 = 0; S.zeta = 0; S.norm_r = sqrt(rr); S.norm_p = 0; S.norm_q = 0;
+  S.iter = 1; S.min_it = min_it; S.max_it = max_it;
+  S.status = kCgRunning;
+  S.fail_dir = 0; S.fail_step = 0;
+  if (S.norm_rhs == 0.0) S.status = kCgZeroRhs;  // the host zeroes x in that case
+  else if (min_it == 0 && S.norm_r <= S.tol_r) S.status = kCgInitialResidual;
+}
+
 // One thread per COLUMN BLOCK (not per scalar): the block's metadata is read once, its
 // n x n inverse and the n entries of r are contiguous reads, and 3- and 9-wide blocks (the
 // bundle-adjustment case) are fully unrolled.  Workgroups [0, grid_e) take the shard's
@@ -414,6 +456,16 @@ hipError_t LaunchCgPrecondition(const CgBuffers& B, const GenStructure& G, int f
                                 int n_local_blocks, const int64_t* diag_off, const double* blocks, hipStream_t s) {
   hipLaunchKernelGGL(cg_precondition_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks,
                      n_local_blocks, diag_off, blocks);
+  return hipGetLastError();
+}
+hipError_t LaunchCgDotSlot(const CgBuffers& B, const double* x, const double* y, int slot, hipStream_t s) {
+  hipLaunchKernelGGL(cg_dot_slot_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, x, y, slot);
+  return hipGetLastError();
+}
+hipError_t LaunchCgInitFromGuess(const CgBuffers& B, const double* tmp, double q_tol, double r_tol, int min_it, int max_it,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(cg_init_from_guess_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, tmp);
+  hipLaunchKernelGGL(cg_init_from_guess_finish_kernel, dim3(1), dim3(kVecBlock), 0, s, B, q_tol, r_tol, min_it, max_it);
   return hipGetLastError();
 }
 hipError_t LaunchCgDirection(const CgBuffers& B, hipStream_t s) {

@@ -85,6 +85,9 @@ struct ceres_hip_solver {
   // preconditioner blocks: F blocks (diag_off_f) for ITERATIVE_SCHUR, all blocks (diag_off_all) for CGNR
   double* precond = nullptr;
   bool precond_valid = false;
+  // SCHUR_POWER_SERIES_EXPANSION: blockdiag(F^T F + D_f^2)^-1 and two F-space temporaries
+  double *ftf_inv = nullptr, *spse_a = nullptr, *spse_b = nullptr;
+  bool ftf_inv_valid = false;
   int* d_fail_flag = nullptr;
   // CG
   CgBuffers cg;
@@ -474,6 +477,76 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   return 0;
 }
 
+// ---- SCHUR_POWER_SERIES_EXPANSION ---------------------------------------
+int ensure_ftf_inverse(ceres_hip_solver* s) {
+  if (s->ftf_inv_valid) return 0;
+  TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->ftf_inv, true));
+  s->ftf_inv_valid = true;
+  return 0;
+}
+
+// y += (F^T F)^-1 F^T E (E^T E)^-1 E^T F x.  InversePowerSeriesOperatorRightMultiplyAccumulate.
+// Uses spse_b as the F-space temporary.
+int op_power_series(ceres_hip_solver* s, const double* x, double* y, const int* status) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  TRY(ensure_ftf_inverse(s));
+  double* t = s->spse_b;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    TRY(ensure_packed(s));
+    BalArgs A = bal_args(s);
+    A.x_f = x;
+    TRY(bal_scatter(s, kBalSpseZ, A, x, t, false, status));
+  } else {
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kF, x, s->tmp_rows, status, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->tmp_rows, s->tmp_e, status, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, status, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kE, s->tmp_e2, s->tmp_rows, status, st));
+    HIP_TRY(s, hipMemsetAsync(t, 0, sizeof(double) * h.num_cols_f, st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kF, s->tmp_rows, t, status, st));
+    TRY(allreduce(s, t, size_t(h.num_cols_f)));
+  }
+  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->ftf_inv, t, y, status, st));
+  return 0;
+}
+
+// y = sum_k Z^k (F^T F)^-1 x.  PowerSeriesExpansionPreconditioner::RightMultiplyAndAccumulate.
+// tolerance == 0 (the preconditioner's setting) runs a fixed number of terms with no host sync.
+int op_spse_apply(ceres_hip_solver* s, const double* x, double* y, int max_iters, double tolerance, const int* status) {
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  const int64_t n = h.num_cols_f;
+  TRY(ensure_ftf_inverse(s));
+  HIP_TRY(s, hipMemsetAsync(y, 0, sizeof(double) * n, st));
+  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->ftf_inv, x, y, status, st));
+  double* prev = s->spse_a;
+  double* term = s->own_x;  // num_cols >= num_cols_f doubles, free during CG
+  HIP_TRY(s, hipMemcpyAsync(prev, y, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  double threshold = 0.0;
+  auto host_norm = [&](const double* v, double* out) -> int {
+    HIP_TRY(s, LaunchDot(v, v, n, s->scalar_partials, s->cg.comm + 3, st));
+    double d = 0;
+    HIP_TRY(s, hipMemcpyAsync(&d, s->cg.comm + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    *out = std::sqrt(d);
+    return 0;
+  };
+  if (tolerance > 0.0) { double ny = 0; TRY(host_norm(y, &ny)); threshold = tolerance * ny; }
+  for (int i = 1;; ++i) {
+    HIP_TRY(s, hipMemsetAsync(term, 0, sizeof(double) * n, st));
+    TRY(op_power_series(s, prev, term, status));
+    HIP_TRY(s, LaunchAxpby(1.0, y, 1.0, term, y, n, st));
+    if (i >= max_iters) break;
+    if (tolerance > 0.0) { double nt = 0; TRY(host_norm(term, &nt)); if (nt < threshold) break; }
+    std::swap(prev, term);
+  }
+  return 0;
+}
+
 // diag(J^T J) into out (num_cols).  BlockSparseMatrix::SquaredColumnNorm.
 int op_squared_column_norm(ceres_hip_solver* s, double* out) {
   const HostStructure& h = s->hs;
@@ -540,6 +613,8 @@ struct CgSpec {
   int64_t n = 0;
   int64_t n_local = 0;                                  // sharded CGNR: E-space prefix
   std::function<int(const double*, double*)> apply;     // y = A x (assigns)
+  std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
+  bool x0_nonzero = false;                              // B.x holds an initial guess
   int first_block = 0, col_begin = 0, nblocks = 0, n_local_blocks = 0;
   const int64_t* diag_off = nullptr;
   const double* blocks = nullptr;                       // nullptr = IDENTITY
@@ -625,7 +700,12 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
 
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
   TRY(collapse_and_reduce(s, 0, 1));
-  HIP_TRY(s, LaunchCgInit(B, q_tol, r_tol, min_it, max_it, st));
+  if (spec.x0_nonzero) {  // r = rhs - A x0, Q0 = -x0.(rhs + r)   (:138-159)
+    TRY(spec.apply(B.x, B.z));
+    HIP_TRY(s, LaunchCgInitFromGuess(B, B.z, q_tol, r_tol, min_it, max_it, st));
+  } else {
+    HIP_TRY(s, LaunchCgInit(B, q_tol, r_tol, min_it, max_it, st));
+  }
   // No poll here: if |b| = 0 or r0 already meets the tolerance the status word is set and the
   // first batch below is a string of no-ops; the first poll comes after it.
   s->h_scalars->status = kCgRunning;
@@ -634,8 +714,13 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   while (s->h_scalars->status == kCgRunning) {
     const int batch_end = std::min(max_it, it + interval - 1);
     for (; it <= batch_end; ++it) {
-      HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.nblocks,
-                                      B.grid_e > 0 ? spec.n_local_blocks : 0, spec.diag_off, spec.blocks, st));
+      if (spec.precondition) {
+        TRY(spec.precondition(B.r, B.z));
+        HIP_TRY(s, LaunchCgDotSlot(B, B.r, B.z, 0, st));
+      } else {
+        HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.nblocks,
+                                        B.grid_e > 0 ? spec.n_local_blocks : 0, spec.diag_off, spec.blocks, st));
+      }
       TRY(collapse_and_reduce(s, 0, 1));
       HIP_TRY(s, LaunchCgDirection(B, st));
       TRY(spec.apply(B.p, B.z));
@@ -658,6 +743,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
       return fail(s, CERES_HIP_E_INVALID, "CG did not terminate after max_num_iterations (device status 0)");
   }
   (void)status;
+  if (s->h_scalars->status == kCgZeroRhs && spec.x0_nonzero) HIP_TRY(s, hipMemsetAsync(B.x, 0, sizeof(double) * B.n, st));
   fill_summary(*s->h_scalars, s->h_scalars->status, summary);
   return 0;
 }
@@ -685,6 +771,7 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->have_b = db != nullptr;
   s->have_D = dD != nullptr;
   s->precond_valid = false;
+  s->ftf_inv_valid = false;
   s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
   s->loaded = true;
   return 0;
@@ -738,7 +825,18 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
       HIP_TRY(s, hipEventRecord(s->ev[6], st));
       return 0;
     }
-    if (pre != CERES_HIP_IDENTITY) {
+    const bool spse_pre = pre == CERES_HIP_SCHUR_POWER_SERIES_EXPANSION;
+    const int spse_iters = s->opt.max_num_spse_iterations > 0 ? s->opt.max_num_spse_iterations : 5;
+    if (spse_pre || s->opt.use_spse_initialization) {
+      TRY(ensure_ftf_inverse(s));
+      TRY(check_factorization(s, &bad));
+      if (bad) {
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "F^T F + D^2 is not positive definite.");
+        return 0;
+      }
+    }
+    if (pre != CERES_HIP_IDENTITY && !spse_pre) {
       TRY(op_preconditioner(s, pre, s->precond, true));
       TRY(check_factorization(s, &bad));
       if (bad) {  // Preconditioner::Update returned false, :113-121
@@ -759,7 +857,13 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     spec.nblocks = h.ncb - h.nelim;
     spec.col_begin = h.num_cols_e;
     spec.diag_off = s->G.diag_off_f;
-    spec.blocks = pre == CERES_HIP_IDENTITY ? nullptr : s->precond;
+    spec.blocks = (pre == CERES_HIP_IDENTITY || spse_pre) ? nullptr : s->precond;
+    if (spse_pre)  // tolerance 0: the preconditioner must stay fixed during CG (:178-186)
+      spec.precondition = [s, spse_iters, status](const double* in, double* out) { return op_spse_apply(s, in, out, spse_iters, 0.0, status); };
+    if (s->opt.use_spse_initialization) {  // :97-111
+      TRY(op_spse_apply(s, s->cg_rhs, s->cg.x, spse_iters, s->opt.spse_tolerance, nullptr));
+      spec.x0_nonzero = true;
+    }
     TRY(run_cg(s, spec, q_tol, r_tol, summary));
     HIP_TRY(s, hipEventRecord(s->ev[5], st));
     if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR)
@@ -847,7 +951,8 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
   }
   const int pre = o->preconditioner_type;
   const bool pre_ok = o->solver_type == CERES_HIP_CGNR ? (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI)
-                                                       : (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI || pre == CERES_HIP_SCHUR_JACOBI);
+                                                       : (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI || pre == CERES_HIP_SCHUR_JACOBI ||
+                                                          pre == CERES_HIP_SCHUR_POWER_SERIES_EXPANSION);
   if (!pre_ok) {  // CgnrSolver's ctor LOG(FATAL)s on the same condition, I/cgnr_solver.cc:119-128
     fail(nullptr, CERES_HIP_E_UNSUPPORTED, "preconditioner_type %d is not available for solver_type %d", pre, o->solver_type);
     return nullptr;
@@ -958,6 +1063,11 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->cg.S, 1));
   HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
   TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back())));
+  if (is_schur(s)) {
+    TRY(dev_alloc(s, &s->ftf_inv, size_t(h.diag_off_f.back())));
+    TRY(dev_alloc(s, &s->spse_a, size_t(h.num_cols_f)));
+    TRY(dev_alloc(s, &s->spse_b, size_t(h.num_cols_f)));
+  }
 
   if (s->path == CERES_HIP_PATH_BAL) {
     BalPlan& P = s->plan;
@@ -1378,6 +1488,28 @@ int ceres_hip_op_back_substitute(ceres_hip_solver* s, const double* z, double* x
   if (s->hs.num_cols_f > 0) TRY(up(s, s->cg.p, z, s->hs.num_cols_f));
   TRY(op_back_substitute(s, s->hs.num_cols_f > 0 ? s->cg.p : nullptr, s->own_x));
   return down(s, x, s->own_x, s->hs.num_cols);
+}
+
+int ceres_hip_op_power_series_operator(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  const int n = s->hs.num_cols_f;
+  TRY(up(s, s->cg.p, x, n));
+  TRY(up(s, s->cg.z, y, n));
+  TRY(op_power_series(s, s->cg.p, s->cg.z, nullptr));
+  return down(s, y, s->cg.z, n);
+}
+
+int ceres_hip_op_spse_apply(ceres_hip_solver* s, const double* x, double* y, int32_t max_iters, double tolerance) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
+  if (max_iters < 1) return fail(s, CERES_HIP_E_INVALID, "max_num_spse_iterations < 1");
+  const int n = s->hs.num_cols_f;
+  TRY(up(s, s->cg.p, x, n));
+  TRY(op_spse_apply(s, s->cg.p, s->cg.z, max_iters, tolerance, nullptr));
+  return down(s, y, s->cg.z, n);
 }
 
 int ceres_hip_op_block_jacobi_update(ceres_hip_solver* s) {

@@ -26,7 +26,7 @@ from .block_structure import BlockStructure, CBlockStructure
 
 # enum values equal the reference's (include/ceres/types.h:57-141, internal/ceres/linear_solver.h:57-74)
 ITERATIVE_SCHUR, CGNR = 5, 6
-IDENTITY, JACOBI, SCHUR_JACOBI = 0, 1, 2
+IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 PATH_GENERIC, PATH_BAL = 0, 1
 TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_ERROR"}
@@ -46,7 +46,8 @@ class COptions(ctypes.Structure):
     _fields_ = [("solver_type", c_int32), ("preconditioner_type", c_int32), ("min_num_iterations", c_int32),
                 ("max_num_iterations", c_int32), ("residual_reset_period", c_int32), ("num_eliminate_blocks", c_int32),
                 ("device", c_int32), ("force_generic_path", c_int32), ("cg_check_interval", c_int32),
-                ("jacobian_storage", c_int32), ("reserved", c_int32 * 6)]
+                ("jacobian_storage", c_int32), ("max_num_spse_iterations", c_int32), ("use_spse_initialization", c_int32),
+                ("spse_tolerance", c_double), ("reserved", c_int32 * 2)]
 
 
 class CSummary(ctypes.Structure):
@@ -105,6 +106,8 @@ ABI = [
     ("ceres_hip_get_ete_inverse", c_int32, [c_void_p, _DP, c_int64]),
     ("ceres_hip_op_schur_sx", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_back_substitute", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_power_series_operator", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_spse_apply", c_int32, [c_void_p, _DP, _DP, c_int32, c_double]),
     ("ceres_hip_op_block_jacobi_update", c_int32, [c_void_p]),
     ("ceres_hip_op_schur_jacobi_update", c_int32, [c_void_p]),
     ("ceres_hip_get_preconditioner_blocks", c_int32, [c_void_p, c_int32, _DP, c_int64]),
@@ -179,6 +182,9 @@ class LinearSolverOptions:
     force_generic_path: bool = False
     cg_check_interval: int = 0
     jacobian_storage: int = 0   # 1: fp32 tiles on the <2,3,9> path (accuracy mode, not parity)
+    max_num_spse_iterations: int = 5
+    use_spse_initialization: bool = False
+    spse_tolerance: float = 0.1
 
 
 @dataclass
@@ -228,7 +234,8 @@ class HipLinearSolver:
         nelim = options.elimination_groups[0] if options.elimination_groups else 0
         c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
                      options.max_num_iterations, options.residual_reset_period, nelim, options.device,
-                     int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage)
+                     int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage,
+                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance)
         self._h = self._lib.ceres_hip_create(byref(c))
         if not self._h:
             raise HipError(self._lib.ceres_hip_last_error(None).decode())
@@ -392,6 +399,15 @@ class HipLinearSolver:
 
     def schur_sx(self, x):
         return self._xy(self._lib.ceres_hip_op_schur_sx, x, self._info.num_cols_f, np.full(self._info.num_cols_f, np.nan))
+
+    def power_series_operator(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_power_series_operator, x, self._info.num_cols_f, y)
+
+    def spse_apply(self, x, max_num_spse_iterations=5, spse_tolerance=0.0):
+        x = _f64(x)
+        y = np.full(self._info.num_cols_f, np.nan)
+        self._check(self._lib.ceres_hip_op_spse_apply(self._h, _p(x), _p(y), max_num_spse_iterations, spse_tolerance))
+        return y
 
     def back_substitute(self, z):
         z = _f64(z) if z is not None else np.zeros(1)

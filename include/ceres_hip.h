@@ -65,6 +65,7 @@ extern "C" {
 #define CERES_HIP_IDENTITY 0
 #define CERES_HIP_JACOBI 1
 #define CERES_HIP_SCHUR_JACOBI 2
+#define CERES_HIP_SCHUR_POWER_SERIES_EXPANSION 3 /* ITERATIVE_SCHUR only */
 
 #define CERES_HIP_SUCCESS 0
 #define CERES_HIP_NO_CONVERGENCE 1
@@ -113,7 +114,11 @@ typedef struct ceres_hip_options {
   int32_t jacobian_storage;      /* <2,3,9> path: 0 = fp64 tiles (parity mode); 1 = Jacobian rounded
                                     to fp32 in the tiles, fp64 arithmetic (NOT parity: accuracy mode,
                                     SURVEY.md §7 item 6; halves the HBM traffic of the hot kernels)  */
-  int32_t reserved[6];
+  /* SCHUR_POWER_SERIES_EXPANSION (LinearSolver::Options, I/linear_solver.h:168-185) */
+  int32_t max_num_spse_iterations; /* 0 -> 5 (the reference's default)                       */
+  int32_t use_spse_initialization; /* start CG from the power-series estimate of S^-1 rhs    */
+  double spse_tolerance;           /* for the initialisation; the preconditioner uses 0     */
+  int32_t reserved[2];
 } ceres_hip_options;
 
 /* ---- LinearSolver::Summary (I/linear_solver.h:320-326) ------------------- */
@@ -220,6 +225,15 @@ int ceres_hip_op_schur_sx(ceres_hip_solver* s, const double* x, double* y);
 /* ImplicitSchurComplement::BackSubstitute: z (num_cols_f) -> x (num_cols)
  *                                                                I/implicit_schur_complement.cc:208-243 */
 int ceres_hip_op_back_substitute(ceres_hip_solver* s, const double* z, double* x);
+
+/* y += (F^T F + D_f^2)^-1 F^T E (E^T E + D_e^2)^-1 E^T F x
+ * ImplicitSchurComplement::InversePowerSeriesOperatorRightMultiplyAccumulate    I/implicit_schur_complement.cc:146-174
+ * (call after ceres_hip_op_schur_init; computes the F^T F inverse blocks on first use) */
+int ceres_hip_op_power_series_operator(ceres_hip_solver* s, const double* x, double* y);
+/* y = sum_{k=0..n} Z^k (F^T F)^-1 x, stopping early when |term| < tolerance * |first term|
+ * PowerSeriesExpansionPreconditioner::RightMultiplyAndAccumulate  I/power_series_expansion_preconditioner.cc:57-84 */
+int ceres_hip_op_spse_apply(ceres_hip_solver* s, const double* x, double* y, int32_t max_num_spse_iterations,
+                            double spse_tolerance);
 
 /* BlockSparseJacobiPreconditioner::UpdateImpl                    I/block_jacobi_preconditioner.cc:59-115 */
 int ceres_hip_op_block_jacobi_update(ceres_hip_solver* s);

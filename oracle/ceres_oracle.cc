@@ -519,6 +519,52 @@ void oracle_isc_sx(oracle_isc* s, const double* x, double* y) {
   oracle_left_multiply_f(m, s->values, s->tmp_rows.data(), y);
 }
 
+// InversePowerSeriesOperatorRightMultiplyAccumulate, :146-174:  y += (F'F)^-1 F'E (E'E)^-1 E'F x.
+// Needs block_diagonal_FtF_inverse (oracle_isc_compute_ftf_inverse).
+void oracle_isc_power_series_operator(oracle_isc* s, const double* x, double* y) {
+  const oracle_matrix* m = s->m;
+  std::fill(s->tmp_rows.begin(), s->tmp_rows.end(), 0.0);
+  oracle_right_multiply_f(m, s->values, x, s->tmp_rows.data());
+  std::fill(s->tmp_e.begin(), s->tmp_e.end(), 0.0);
+  oracle_left_multiply_e(m, s->values, s->tmp_rows.data(), s->tmp_e.data());
+  std::fill(s->tmp_e2.begin(), s->tmp_e2.end(), 0.0);
+  oracle_block_diagonal_apply(m->nelim, s->e_sizes.data(), s->ete_inv.data(), s->tmp_e.data(), s->tmp_e2.data());
+  std::fill(s->tmp_rows.begin(), s->tmp_rows.end(), 0.0);
+  oracle_right_multiply_e(m, s->values, s->tmp_e2.data(), s->tmp_rows.data());
+  std::fill(s->tmp_f.begin(), s->tmp_f.end(), 0.0);
+  oracle_left_multiply_f(m, s->values, s->tmp_rows.data(), s->tmp_f.data());
+  oracle_block_diagonal_apply(m->ncb - m->nelim, s->f_sizes.data(), s->ftf_inv.data(), s->tmp_f.data(), y);
+}
+
+// block_diagonal_FtF_inverse_ of ImplicitSchurComplement::Init (:57-91): blockdiag(F'F + D_f^2)^-1.
+void oracle_isc_compute_ftf_inverse(oracle_isc* s) {
+  const oracle_matrix* m = s->m;
+  oracle_block_diagonal_ftf(m, s->values, s->ftf_inv.data());
+  add_diagonal_and_invert(m, m->nelim, m->ncb - m->nelim, m->diag_offset_f, s->D, s->ftf_inv.data());
+}
+
+// PowerSeriesExpansionPreconditioner::RightMultiplyAndAccumulate,
+// I/power_series_expansion_preconditioner.cc:57-84 (y is ASSIGNED, as there).
+void oracle_isc_spse_apply(oracle_isc* s, const double* x, double* y, int max_num_spse_iterations, double spse_tolerance) {
+  const oracle_matrix* m = s->m;
+  const int n = m->num_cols_f;
+  Vec series(n), previous(n);
+  std::fill(y, y + n, 0.0);
+  oracle_block_diagonal_apply(m->ncb - m->nelim, s->f_sizes.data(), s->ftf_inv.data(), x, y);
+  std::copy(y, y + n, previous.begin());
+  double ny = 0;
+  for (int i = 0; i < n; ++i) ny += y[i] * y[i];
+  const double threshold = spse_tolerance * std::sqrt(ny);
+  for (int i = 1;; ++i) {
+    std::fill(series.begin(), series.end(), 0.0);
+    oracle_isc_power_series_operator(s, previous.data(), series.data());
+    double nt = 0;
+    for (int k = 0; k < n; ++k) { y[k] += series[k]; nt += series[k] * series[k]; }
+    if (i >= max_num_spse_iterations || std::sqrt(nt) < threshold) break;
+    std::swap(previous, series);
+  }
+}
+
 void oracle_isc_rhs(const oracle_isc* s, double* rhs) { std::copy(s->rhs.begin(), s->rhs.end(), rhs); }
 void oracle_isc_ete_inverse(const oracle_isc* s, double* blocks) { std::copy(s->ete_inv.begin(), s->ete_inv.end(), blocks); }
 
@@ -998,6 +1044,44 @@ void oracle_iterative_schur_solve_sharded(const oracle_matrix* m, const double* 
   cg_solve(nf, lhs, isc->rhs.data(), pre, dot, min_it, max_it, reset_period, q_tol, r_tol, sol.data(), summary);
   if (summary->termination_type != 2 && summary->termination_type != 3)
     oracle_isc_back_substitute(isc.get(), sol.data(), x);
+}
+
+// The same solver with the SCHUR_POWER_SERIES_EXPANSION options of LinearSolver::Options
+// (I/linear_solver.h:168-185): preconditioner = 3 uses PowerSeriesExpansionPreconditioner with
+// tolerance 0 (fixed max_num_spse_iterations terms, :178-186 of the solver), and
+// use_spse_initialization starts CG from the power-series estimate of S^-1 rhs (:97-111).
+void oracle_iterative_schur_solve_spse(const oracle_matrix* m, const double* v, const double* b, const double* D,
+                                       int preconditioner, int min_it, int max_it, int reset_period, double q_tol,
+                                       double r_tol, int use_spse_initialization, int max_num_spse_iterations,
+                                       double spse_tolerance, double* x, oracle_summary* summary) {
+  std::unique_ptr<oracle_isc, void (*)(oracle_isc*)> isc(oracle_isc_create(m), oracle_isc_destroy);
+  oracle_isc_init(isc.get(), v, D, b);
+  const int nf = m->num_cols_f;
+  if (m->ncb - m->nelim == 0) {
+    summary->num_iterations = 0; summary->termination_type = 0; summary->residual_norm = -1; summary->message[0] = 0;
+    oracle_isc_back_substitute(isc.get(), nullptr, x);
+    return;
+  }
+  if (use_spse_initialization || preconditioner == 1 || preconditioner == 3) oracle_isc_compute_ftf_inverse(isc.get());
+  Vec sol(nf, 0.0);
+  if (use_spse_initialization)
+    oracle_isc_spse_apply(isc.get(), isc->rhs.data(), sol.data(), max_num_spse_iterations, spse_tolerance);
+  Vec minv;
+  if (preconditioner == 2) { minv.resize(m->diag_offset_f.back()); schur_jacobi(m, v, D, minv.data(), nullptr, nullptr, nullptr); }
+  Op lhs = [&](const double* in, double* out) {
+    Vec y(nf);
+    oracle_isc_sx(isc.get(), in, y.data());
+    for (int i = 0; i < nf; ++i) out[i] += y[i];
+  };
+  Op pre = [&](const double* in, double* out) {
+    if (preconditioner == 0) for (int i = 0; i < nf; ++i) out[i] += in[i];
+    else if (preconditioner == 1) oracle_block_diagonal_apply(m->ncb - m->nelim, isc->f_sizes.data(), isc->ftf_inv.data(), in, out);
+    else if (preconditioner == 2) oracle_block_diagonal_apply(m->ncb - m->nelim, isc->f_sizes.data(), minv.data(), in, out);
+    else { Vec y(nf); oracle_isc_spse_apply(isc.get(), in, y.data(), max_num_spse_iterations, 0.0); for (int i = 0; i < nf; ++i) out[i] += y[i]; }
+  };
+  DotFn dot = [&](const double* a, const double* c) { double s = 0; for (int i = 0; i < nf; ++i) s += a[i] * c[i]; return s; };
+  cg_solve(nf, lhs, isc->rhs.data(), pre, dot, min_it, max_it, reset_period, q_tol, r_tol, sol.data(), summary);
+  if (summary->termination_type != 2 && summary->termination_type != 3) oracle_isc_back_substitute(isc.get(), sol.data(), x);
 }
 
 void oracle_iterative_schur_solve(const oracle_matrix* m, const double* v, const double* b, const double* D,

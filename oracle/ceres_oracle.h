@@ -137,6 +137,16 @@ void oracle_iterative_schur_solve(const oracle_matrix* m, const double* values, 
                                   const double* D, int preconditioner, int min_it, int max_it,
                                   int reset_period, double q_tol, double r_tol, double* x,
                                   oracle_summary* summary);
+/* SCHUR_POWER_SERIES_EXPANSION (I/power_series_expansion_preconditioner.cc:57-84,
+ * I/implicit_schur_complement.cc:146-174): preconditioner = 3 and/or use_spse_initialization. */
+void oracle_iterative_schur_solve_spse(const oracle_matrix* m, const double* values, const double* b,
+                                       const double* D, int preconditioner, int min_it, int max_it,
+                                       int reset_period, double q_tol, double r_tol, int use_spse_initialization,
+                                       int max_num_spse_iterations, double spse_tolerance, double* x,
+                                       oracle_summary* summary);
+void oracle_isc_compute_ftf_inverse(oracle_isc* s);
+void oracle_isc_power_series_operator(oracle_isc* s, const double* x, double* y);
+void oracle_isc_spse_apply(oracle_isc* s, const double* x, double* y, int max_num_spse_iterations, double spse_tolerance);
 /* The same two solvers on one rank's shard of the rows (E blocks disjoint
  * across ranks, F blocks replicated).  F-space vectors and
  * diagonal blocks are summed with `allreduce`; for CGNR the E-space parts of

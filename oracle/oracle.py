@@ -117,6 +117,11 @@ def lib():
         L.oracle_iterative_schur_solve.argtypes = solve_args
         L.oracle_cgnr_solve_sharded.argtypes = solve_args + [ALLREDUCE_FN, c_void_p]
         L.oracle_iterative_schur_solve_sharded.argtypes = solve_args + [ALLREDUCE_FN, c_void_p]
+        L.oracle_iterative_schur_solve_spse.argtypes = [c_void_p, dp, dp, dp, c_int, c_int, c_int, c_int, c_double, c_double,
+                                                        c_int, c_int, c_double, dp, POINTER(CSummary)]
+        L.oracle_isc_compute_ftf_inverse.argtypes = [c_void_p]
+        L.oracle_isc_power_series_operator.argtypes = [c_void_p, dp, dp]
+        L.oracle_isc_spse_apply.argtypes = [c_void_p, dp, dp, c_int, c_double]
         L.oracle_bal_generate.restype = c_void_p
         L.oracle_bal_generate.argtypes = [c_int, c_int, c_int64, c_double, c_double, c_double, c_uint64]
         L.oracle_bal_read.restype = c_void_p
@@ -301,6 +306,17 @@ class Matrix:
                            q_tol, r_tol, allreduce)
 
 
+def iterative_schur_solve_spse(matrix, values, b, D, preconditioner=3, min_it=0, max_it=500, reset_period=10, q_tol=0.0,
+                               r_tol=0.0, use_spse_initialization=False, max_num_spse_iterations=5, spse_tolerance=0.1):
+    x = np.full(matrix.num_cols, np.nan)
+    s = CSummary()
+    values, b, D = _f64(values), _f64(b), _f64(D)
+    lib().oracle_iterative_schur_solve_spse(matrix.h, _dp(values), _dp(b), _dp(D), int(preconditioner), int(min_it), int(max_it),
+                                            int(reset_period), float(q_tol), float(r_tol), int(use_spse_initialization),
+                                            int(max_num_spse_iterations), float(spse_tolerance), _dp(x), byref(s))
+    return x, Summary(s)
+
+
 class ImplicitSchurComplement:
     def __init__(self, matrix: Matrix):
         self.m = matrix
@@ -331,6 +347,19 @@ class ImplicitSchurComplement:
         out = np.zeros(self.m.e_diag_len)
         lib().oracle_isc_ete_inverse(self.h, _dp(out))
         return out
+
+    def compute_ftf_inverse(self):
+        lib().oracle_isc_compute_ftf_inverse(self.h)
+
+    def power_series_operator(self, x, y=None):
+        y = np.zeros(self.m.num_cols_f) if y is None else _f64(y).copy()
+        lib().oracle_isc_power_series_operator(self.h, _dp(_f64(x)), _dp(y))
+        return y
+
+    def spse_apply(self, x, max_num_spse_iterations=5, spse_tolerance=0.0):
+        y = np.full(self.m.num_cols_f, np.nan)
+        lib().oracle_isc_spse_apply(self.h, _dp(_f64(x)), _dp(y), int(max_num_spse_iterations), float(spse_tolerance))
+        return y
 
     def back_substitute(self, z):
         x = np.zeros(self.m.num_cols)

@@ -156,3 +156,41 @@ def test_bal_shaped_solvers_match_dense(oracle, problems, layout):
     x, s = m.cgnr_solve(p.values, p.b, p.D, preconditioner=1, max_it=500, r_tol=1e-13)
     assert s.termination_type == 0
     np.testing.assert_allclose(x, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("with_D", [True, False])
+def test_power_series_expansion_against_dense(oracle, problems, with_D):
+    """implicit_schur_complement_test.cc:185-217: the operator Z = (F'F)^-1 F'E (E'E)^-1 E'F column by column
+    against dense algebra; S^-1 = sum_k Z^k (F'F)^-1, so the SPSE estimate converges to S^-1 x; and
+    iterative_schur_complement_solver_test.cc's SPSE variants: preconditioner and initialisation vs a dense solve."""
+    p = problems.synthetic_bal(None, num_cameras=5, num_points=60, num_observations=260, seed=61)
+    if not with_D:
+        p.D = None
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    A = p.bs.to_dense(p.values)
+    ne = m.num_cols_e
+    H = A.T @ A + (np.diag(p.D ** 2) if with_D else 0)
+    P, Q, R = H[:ne, :ne], H[:ne, ne:], H[ne:, ne:]
+    Rbd = np.zeros_like(R)
+    for c in range(5):
+        Rbd[9 * c:9 * c + 9, 9 * c:9 * c + 9] = R[9 * c:9 * c + 9, 9 * c:9 * c + 9]
+    Z = np.linalg.solve(Rbd, Q.T @ np.linalg.solve(P, Q))
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    isc.compute_ftf_inverse()
+    cols = np.stack([isc.power_series_operator(e) for e in np.eye(m.num_cols_f)], axis=1)
+    np.testing.assert_allclose(cols, Z, rtol=0, atol=1e-13 * max(1.0, np.abs(Z).max()))
+    x = np.random.default_rng(0).standard_normal(m.num_cols_f)
+    want = np.linalg.solve(Rbd, x)
+    acc = want.copy()
+    term = want.copy()
+    for _ in range(4):
+        term = Z @ term
+        acc += term
+    np.testing.assert_allclose(isc.spse_apply(x, 4, 0.0), acc, rtol=0, atol=1e-12 * np.abs(acc).max())
+    ref = np.linalg.lstsq(np.vstack([A, np.diag(p.D)]) if with_D else A, np.concatenate([p.b, np.zeros(p.num_cols)]) if with_D else p.b, rcond=None)[0]
+    for pre, init in ((3, False), (2, True), (3, True)):
+        xs, s = oracle.iterative_schur_solve_spse(m, p.values, p.b, p.D, preconditioner=pre, max_it=300, r_tol=1e-12,
+                                                  use_spse_initialization=init, max_num_spse_iterations=5, spse_tolerance=0.1)
+        assert s.termination_type == 0, s
+        assert np.linalg.norm(xs - ref) <= 1e-8 * np.linalg.norm(ref)
