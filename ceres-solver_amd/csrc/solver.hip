@@ -701,6 +701,8 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
   TRY(collapse_and_reduce(s, 0, 1));
   if (spec.x0_nonzero) {  // r = rhs - A x0, Q0 = -x0.(rhs + r)   (:138-159)
+    // the operator kernels return early on a non-zero status word: clear what the previous solve left
+    HIP_TRY(s, hipMemsetAsync(&B.S->status, 0, sizeof(int), st));
     TRY(spec.apply(B.x, B.z));
     HIP_TRY(s, LaunchCgInitFromGuess(B, B.z, q_tol, r_tol, min_it, max_it, st));
   } else {
