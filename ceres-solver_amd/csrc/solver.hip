@@ -550,7 +550,7 @@ int op_spse_apply(ceres_hip_solver* s, const double* x, double* y, int max_iters
 // diag(J^T J) into out (num_cols).  BlockSparseMatrix::SquaredColumnNorm.
 int op_squared_column_norm(ceres_hip_solver* s, double* out) {
   const HostStructure& h = s->hs;
-  if (s->path == CERES_HIP_PATH_BAL && s->lds_mode && s->world <= 1) {
+  if (s->path == CERES_HIP_PATH_BAL && s->lds_mode) {  // sharded: bal_scatter all-reduces the camera part
     BalArgs A = bal_args(s);
     A.y_e = out;
     use_gather_if_unpacked(s, A);
