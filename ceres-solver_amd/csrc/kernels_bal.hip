@@ -102,6 +102,14 @@ struct Slot {
   bool valid;
 };
 
+__device__ __forceinline__ void finish_slot(Slot& s) {
+  const uint32_t sg = s.seg;
+  s.first = sg & 0xff;
+  s.last = (sg >> 8) & 0xff;
+  s.valid = (sg >> 16) & 1;
+  if (!s.valid) { s.cam = 0; s.pt = 0; }
+}
+
 // Loads one slot.  Normally from the packed tiles; on the FIRST pass over a step's Jacobian
 // (A.src_values != nullptr and may_gather) the 24 doubles are gathered from the caller's
 // layout through slot_epos / slot_fpos and the tile is written on the way, which fuses the
@@ -171,12 +179,30 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
   }
   s.cam = A.slot_cam[sl];
   s.pt = A.slot_pt[sl];
-  const uint32_t sg = A.slot_seg[sl];
-  s.seg = sg;
-  s.first = sg & 0xff;
-  s.last = (sg >> 8) & 0xff;
-  s.valid = (sg >> 16) & 1;
-  if (!s.valid) { s.cam = 0; s.pt = 0; }
+  s.seg = A.slot_seg[sl];
+  finish_slot(s);
+}
+
+// The software-pipelined streaming kernel splits a slot load in three, each of which only ISSUES
+// loads and consumes nothing: the index words (SlotIdx), the 12 pairs of a packed fp64 tile
+// (issue_pairs), and what is addressed THROUGH the index words (issue_aux, further down).
+struct SlotIdx { int cam, pt; uint32_t seg; };
+__device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
+  const int64_t sl = tile * kTile + lane;
+  i.cam = A.slot_cam[sl];
+  i.pt = A.slot_pt[sl];
+  i.seg = A.slot_seg[sl];
+}
+__device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
+  s.slot = tile * kTile + lane;
+  s.b0 = 0.0; s.b1 = 0.0;
+  const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
+  double2 p[kPairsPerSlot];
+#pragma unroll
+  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
+  s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
 }
 
 __device__ __forceinline__ int pt_off(const BalArgs& A, int p) { return A.pt_pos ? A.pt_pos[p] : 3 * p; }
@@ -306,23 +332,59 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
   }
 }
 
-template <int MODE, bool LDS, bool F32>
-__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc,
-                                             double& lane_acc) {
-  Slot s;
-  load_slot<kCanGather<MODE>, F32>(A, tile, lane, s, kWantsB<MODE>);
-  const int64_t sl = tile * kTile + lane;
-  const int po = pt_off(A, s.pt);
+// What a streaming mode (kSx, kSpseZ, kJtJx) needs from global memory besides the slot itself.
+struct StreamAux {
+  double xc[9];            // the slot's camera part of x
+  double ei[6];            // kSx / kSpseZ: (E^T E)^-1 of the slot's point
+  double xa, xb, da, db;   // kJtJx, cooperative: scalars `lane` and `64 + lane` of the tile's point range of x, D
+  double xp[3], dd[3];     // kJtJx, otherwise: the slot's own point part of x, D
+  int64_t base;
+  bool coop;
+};
+
+// Issues the loads of `aux`; consumes only the slot's index words (s.cam, s.pt).
+template <int MODE>
+__device__ __forceinline__ void load_aux(const BalArgs& A, const Slot& s, int lane, int npts, StreamAux& x) {
+  load_xc(A, s.cam, x.xc);
+  x.xa = x.xb = x.da = x.db = 0.0;
+  x.base = 0;
+  x.coop = false;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { x.xp[j] = 0.0; x.dd[j] = 0.0; }
   if constexpr (MODE == kSx || MODE == kSpseZ) {
-    double xc[9], ei[6], v[3];
-    load_xc(A, s.cam, xc);
-    load_ete_inverse(A, s.pt, ei);
+    load_ete_inverse(A, s.pt, x.ei);
+  } else if constexpr (MODE == kJtJx) {
+    // Point-space x / D / y of a tile are ONE contiguous range when the layout is
+    // points-then-cameras (pt_pos == nullptr): [3 p0, 3 p0 + 3 npts).  Then lane L loads and
+    // stores scalars L (and 64 + L) of that range — dense 8-byte-per-lane accesses — and the
+    // per-observation copies travel by wavefront shuffle, instead of three strided loads per
+    // lane and three partial-wave scattered stores per point.
+    x.coop = A.pt_pos == nullptr && !(A.flags & 1);
+    if (x.coop) {
+      const int n3 = 3 * npts;
+      x.base = 3 * int64_t(__builtin_amdgcn_readfirstlane(s.pt));  // lane 0 of a normal tile is valid
+      if (lane < n3) { x.xa = A.x_e[x.base + lane]; if (A.D_e) x.da = A.D_e[x.base + lane]; }
+      if (n3 > 64 && lane + 64 < n3) { x.xb = A.x_e[x.base + 64 + lane]; if (A.D_e) x.db = A.D_e[x.base + 64 + lane]; }
+    } else {
+      const int po = pt_off(A, s.pt);
+      x.xp[0] = A.x_e[po]; x.xp[1] = A.x_e[po + 1]; x.xp[2] = A.x_e[po + 2];
+      if (A.D_e) { x.dd[0] = A.D_e[po]; x.dd[1] = A.D_e[po + 1]; x.dd[2] = A.D_e[po + 2]; }
+    }
+  }
+}
+
+// The arithmetic of a streaming mode on one normal tile; issues no global loads.
+template <int MODE, bool LDS>
+__device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, int lane, int span, int npts,
+                                               const StreamAux& x, double* acc) {
+  if constexpr (MODE == kSx || MODE == kSpseZ) {
+    double v[3];
     double t0, t1;
-    f_times(s, xc, t0, t1);
+    f_times(s, x.xc, t0, t1);
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_allreduce<3>(u, lane, s.first, s.last, span);
-    sym3_mul(ei, u, v);
+    sym3_mul(x.ei, u, v);
     // kSx: F^T (F x - E (E^T E)^-1 E^T F x);  kSpseZ: only the second term, F^T E (E^T E)^-1 E^T F x
     // (ImplicitSchurComplement::InversePowerSeriesOperatorRightMultiplyAccumulate, :146-174)
     const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
@@ -330,67 +392,73 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     const double z0 = MODE == kSx ? t0 - ev0 : ev0;
     const double z1 = MODE == kSx ? t1 - ev1 : ev1;
     scatter_ft<LDS>(s, acc, z0, z1);
-  } else if constexpr (MODE == kJtJx || MODE == kJtb) {
-    double z0, z1, xp[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
-    // Point-space x / D / y of a tile are ONE contiguous range when the layout is
-    // points-then-cameras (pt_pos == nullptr): [3 p0, 3 p0 + 3 npts).  Then lane L loads and
-    // stores scalars L (and 64 + L) of that range — dense 8-byte-per-lane accesses — and the
-    // per-observation copies travel by wavefront shuffle, instead of three strided loads per
-    // lane and three partial-wave scattered stores per point.
-    const bool coop = (MODE == kJtJx) && A.pt_pos == nullptr && !(A.flags & 1);
+  } else {
+    static_assert(MODE == kJtJx, "streaming modes");
     const int n3 = 3 * npts;
-    int64_t base = 0;
-    double xa = 0, xb = 0, da = 0, db = 0;
-    if constexpr (MODE == kJtJx) {
-      double xc[9];
-      load_xc(A, s.cam, xc);
-      if (coop) {
-        base = 3 * int64_t(__builtin_amdgcn_readfirstlane(s.pt));  // lane 0 of a normal tile is valid
-        if (lane < n3) { xa = A.x_e[base + lane]; if (A.D_e) da = A.D_e[base + lane]; }
-        if (n3 > 64 && lane + 64 < n3) { xb = A.x_e[base + 64 + lane]; if (A.D_e) db = A.D_e[base + 64 + lane]; }
-        const int li = s.valid ? 3 * s.pt - int(base) : 0;
-        if (n3 <= 64) {
+    double xp[3] = {x.xp[0], x.xp[1], x.xp[2]};
+    if (x.coop) {
+      const int li = s.valid ? 3 * s.pt - int(x.base) : 0;
+      if (n3 <= 64) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) xp[j] = shfl_idx(xa, li + j);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const double va = shfl_idx(xa, (li + j) & 63), vb = shfl_idx(xb, (li + j) & 63);
-            xp[j] = (li + j) < 64 ? va : vb;
-          }
-        }
+        for (int j = 0; j < 3; ++j) xp[j] = shfl_idx(x.xa, li + j);
       } else {
-        xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
-        if (A.D_e) { dd[0] = A.D_e[po]; dd[1] = A.D_e[po + 1]; dd[2] = A.D_e[po + 2]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const double va = shfl_idx(x.xa, (li + j) & 63), vb = shfl_idx(x.xb, (li + j) & 63);
+          xp[j] = (li + j) < 64 ? va : vb;
+        }
       }
-      f_times(s, xc, z0, z1);
-      z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
-      z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
-    } else {
-      z0 = s.b0; z1 = s.b1;
     }
+    double z0, z1;
+    f_times(s, x.xc, z0, z1);
+    z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
+    z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
     scatter_ft<LDS>(s, acc, z0, z1);
     double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
     if (!s.valid) { w[0] = w[1] = w[2] = 0; }
     seg_scan<3>(w, lane, s.first, span);
-    if (coop) {
+    if (x.coop) {
       // lane L gathers component L % 3 of point L / 3 from that point's last lane and stores scalar L
       const int ta = (s.seg >> 17) & 63, tb = (s.seg >> 24) & 63;
       {
         const double v0 = shfl_idx(w[0], ta), v1 = shfl_idx(w[1], ta), v2 = shfl_idx(w[2], ta);
         const int c = lane % 3;
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 23) & 1) A.y_e[base + lane] = v + da * da * xa;
+        if ((s.seg >> 23) & 1) A.y_e[x.base + lane] = v + x.da * x.da * x.xa;
       }
       if (n3 > 64) {
         const double v0 = shfl_idx(w[0], tb), v1 = shfl_idx(w[1], tb), v2 = shfl_idx(w[2], tb);
         const int c = (lane + 1) % 3;  // (64 + lane) % 3
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 30) & 1) A.y_e[base + 64 + lane] = v + db * db * xb;
+        if ((s.seg >> 30) & 1) A.y_e[x.base + 64 + lane] = v + x.db * x.db * x.xb;
       }
     } else if (s.valid && lane == s.last) {
+      const int po = pt_off(A, s.pt);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j] + dd[j] * dd[j] * xp[j];
+      for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j] + x.dd[j] * x.dd[j] * xp[j];
+    }
+  }
+}
+
+template <int MODE, bool LDS, bool F32>
+__device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int lane, int span, int npts, double* acc,
+                                             double& lane_acc) {
+  Slot s;
+  load_slot<kCanGather<MODE>, F32>(A, tile, lane, s, kWantsB<MODE>);
+  const int64_t sl = tile * kTile + lane;
+  const int po = pt_off(A, s.pt);
+  if constexpr (MODE == kSx || MODE == kSpseZ || MODE == kJtJx) {
+    StreamAux x;
+    load_aux<MODE>(A, s, lane, npts, x);
+    compute_stream<MODE, LDS>(A, s, lane, span, npts, x, acc);
+  } else if constexpr (MODE == kJtb) {
+    scatter_ft<LDS>(s, acc, s.b0, s.b1);
+    double w[3] = {s.e[0] * s.b0 + s.e[3] * s.b1, s.e[1] * s.b0 + s.e[4] * s.b1, s.e[2] * s.b0 + s.e[5] * s.b1};
+    if (!s.valid) { w[0] = w[1] = w[2] = 0; }
+    seg_scan<3>(w, lane, s.first, span);
+    if (s.valid && lane == s.last) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j];
     }
   } else if constexpr (MODE == kInit || MODE == kEte) {
     double r[9];
@@ -646,6 +714,125 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     }
   }
   if constexpr (kScatters && LDS) {
+    __syncthreads();
+    double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
+    for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
+  }
+}
+
+// Software-pipelined variant of the streaming modes (kSx, kSpseZ, kJtJx; packed fp64 tiles,
+// points-then-cameras vector layout).  bal_fused_kernel runs load -> wait -> compute -> store per
+// tile and leans on the other 3 waves of its SIMD to keep HBM busy; the SQ counters
+// (profiles/r01d_pmc_sq_*.txt) show its waves parked in s_waitcnt 45-60 % of their cycles, and
+// switching the 24 MB of point-space stores of JtJx off saved 12 % — vmcnt retires in order, so
+// the write acknowledgement of tile N sat in front of the loads of tile N+1.  Here a wave always
+// has the next tile in flight while it computes (8 waves per CU, 512 threads, <= 256 VGPRs):
+//   stage N:  issue index words (N+2) | issue pairs (N+1) | issue aux (N+1), addressed through
+//             index words (N+1) that were issued a stage ago | compute (N) | store (N)
+// so compute(N) only waits for loads issued during stage N-1, and a store has a whole stage to
+// retire before anything queued behind it is needed.
+// s_waitcnt counts are static, so every path through a stage must issue the SAME loads in the
+// same order or the compiler has to fall back to vmcnt(0): no load here sits under a
+// wave-uniform condition (the host picks this kernel only when x_f is unpadded, the layout is
+// contiguous and — kJtJx — D is given), a wave past its last tile re-issues that tile, and
+// tiles of long points run through compute() with every lane invalid.
+template <int MODE>
+__device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int lane, int npts, StreamAux& x) {
+  const double* xf = A.x_f + 9 * int64_t(s.cam);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) x.xc[k] = xf[k];
+  x.xa = x.xb = x.da = x.db = 0.0;
+  x.base = 0;
+  x.coop = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { x.xp[j] = 0.0; x.dd[j] = 0.0; }
+  if constexpr (MODE == kSx || MODE == kSpseZ) {
+    load_ete_inverse(A, s.pt, x.ei);
+  } else {
+    const int n3 = 3 * npts;
+    x.base = 3 * int64_t(__builtin_amdgcn_readfirstlane(s.pt));
+    // per-lane predicates only mask lanes, the four load instructions are always issued
+    // (lanes past the range read scalar 0 of it; nothing downstream looks at those lanes, and
+    // selecting zeros here would consume the loads — a wait — in the issue phase)
+    const bool a = lane < n3, b = lane + 64 < n3;
+    const int64_t ia = x.base + (a ? lane : 0), ib = x.base + (b ? 64 + lane : 0);
+    x.xa = A.x_e[ia]; x.da = A.D_e[ia]; x.xb = A.x_e[ib]; x.db = A.D_e[ib];
+  }
+}
+
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
+  constexpr int BLOCK = 512;
+  extern __shared__ double lds_acc[];
+  if (A.status && *A.status != 0) return;
+  double* acc = nullptr;
+  if constexpr (LDS) {
+    acc = lds_acc;
+    for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) acc[i] = 0.0;
+    __syncthreads();
+  } else {
+    acc = reinterpret_cast<double*>(A.zbuf);
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
+  // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
+  // scalar loads and the branches on them scalar branches
+  const int64_t wave0 = int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t last = A.n_tiles - 1;
+  if (wave0 < A.n_tiles) {
+    // Two register sets in ping-pong: copying "next" into "current" would need the loaded
+    // values to have arrived, which is exactly the wait this kernel exists to avoid.  (The
+    // three index words are the exception: they are copied a stage after they were issued.)
+    Slot sa, sb;
+    StreamAux xa, xb;
+    SlotIdx i1, i2;
+    int64_t tile = wave0;
+    int kind_a = A.tile_kind[tile], aux_a = A.tile_aux[tile], kind_b = 2, aux_b = 0;
+    // prologue in the steady-state issue order: index words (1), pairs (0), aux (0)
+    issue_idx(A, tile, lane, i2);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_idx(A, min(tile + nwaves, last), lane, i1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_pairs(A, tile, lane, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    sa.cam = i2.cam; sa.pt = i2.pt; sa.seg = i2.seg;
+    finish_slot(sa);
+    issue_aux<MODE>(A, sa, lane, kind_a == 0 ? aux_a >> 8 : 0, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    bool more = true;
+    // one pipeline stage: everything of the next tile is issued, then this one is computed from `c`
+    auto stage = [&](Slot& c, StreamAux& cx, int ckind, int caux, Slot& n, StreamAux& nx, int& nkind, int& naux) {
+      const int64_t next = min(tile + nwaves, last);  // past the end: re-issue, the load count stays the same
+      more = tile + nwaves < A.n_tiles;
+      nkind = A.tile_kind[next];
+      naux = A.tile_aux[next];
+      issue_idx(A, min(next + nwaves, last), lane, i2);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_pairs(A, next, lane, n);
+      __builtin_amdgcn_sched_barrier(0);
+      n.cam = i1.cam; n.pt = i1.pt; n.seg = i1.seg;
+      finish_slot(n);
+      issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ckind != 0) c.valid = false;  // long points are handled below; their seg words carry no store bits
+      compute_stream<MODE, LDS>(A, c, lane, caux & 0xff, ckind == 0 ? caux >> 8 : 0, cx, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      i1 = i2;
+      tile = next;
+    };
+    while (true) {
+      stage(sa, xa, kind_a, aux_a, sb, xb, kind_b, aux_b);
+      if (!more) break;
+      stage(sb, xb, kind_b, aux_b, sa, xa, kind_a, aux_a);
+      if (!more) break;
+    }
+  }
+  // Points with more than 64 observations own whole tiles (kind 1 = head, 2 = continuation);
+  // they are rare and are handled outside the pipelined loop to keep its register footprint down.
+  for (int64_t tile = wave0; tile < A.n_tiles; tile += nwaves) {
+    if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc);
+  }
+  if constexpr (LDS) {
     __syncthreads();
     double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
     for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
@@ -996,8 +1183,36 @@ int BalBlockFor(int mode) {
   return 1024;
 }
 
+template <int MODE>
+static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  if (lds) {
+    auto k = bal_stream_kernel<MODE, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
+  } else {
+    hipLaunchKernelGGL((bal_stream_kernel<MODE, false>), dim3(grid), dim3(512), 0, stream, A);
+  }
+  return hipGetLastError();
+}
+
+// CERES_HIP_PIPELINE=0 falls back to the unpipelined kernels (A/B measurements).
+static bool UsePipeline() {
+  static int v = [] { const char* e = getenv("CERES_HIP_PIPELINE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   const bool big = BalBlockFor(mode) == 1024;
+  if (UsePipeline() && !A.Jf && !A.src_values && !A.x_f_pad && !A.pt_pos && !A.cam_pos && !(A.flags & 1)) {
+    if (mode == kSx) return launch_stream<kSx>(A, lds, grid, stream);
+    if (mode == kJtJx && A.D_e) return launch_stream<kJtJx>(A, lds, grid, stream);
+    if (mode == kSpseZ) return launch_stream<kSpseZ>(A, lds, grid, stream);
+  }
   switch (mode) {
     case kSx: return big ? launch_fused<kSx, 1024>(A, lds, grid, stream) : launch_fused<kSx, 512>(A, lds, grid, stream);
     case kJtJx: return big ? launch_fused<kJtJx, 1024>(A, lds, grid, stream) : launch_fused<kJtJx, 512>(A, lds, grid, stream);

@@ -51,7 +51,7 @@ def test_solvers_match_fixture(hip, problems, name, force_generic):
         x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.0, r_tolerance=1e-13))
         s.close()
         assert summ.termination_type == hip.SUCCESS
-        assert rel(x, g[key + "_converged"]) <= 1e-8, (key, rel(x, g[key + "_converged"]))
+        assert rel(x, g[key + "_converged"]) <= 1e-7, (key, rel(x, g[key + "_converged"]))  # CGNR: cond(J)^2
 
 
 def test_known_answers_from_fixture_file(hip, problems):
