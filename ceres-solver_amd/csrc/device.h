@@ -227,5 +227,26 @@ hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
 // comm[slot] = sum over the shard's workgroups of partials[slot] for slot in [first, first+count)
 hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t stream);
 
+// ---- f4: BAL evaluator (kernels_evaluator.hip) ----
+struct BalEvalArgs {
+  int64_t n_rows = 0;                 // observations (= residual row blocks), grouped by point
+  const int32_t* row_cam = nullptr;
+  const int32_t* row_pt = nullptr;
+  const double2* row_obs = nullptr;   // observed pixel of the row
+  const double* state = nullptr;      // [3 n_p | 9 n_c]
+  int64_t cam_base = 0;               // 3 n_p
+  const double* scale = nullptr;      // Jacobi column scaling or nullptr
+  double* residuals = nullptr;        // 2 per row, or nullptr
+  double* values = nullptr;           // E cell at 6 r, F cell at 6 n_rows + 18 r
+  double* partials = nullptr;         // cost partial per workgroup (<= 2048)
+};
+hipError_t LaunchBalEvaluate(const BalEvalArgs& A, bool jacobian, int* nparts, hipStream_t stream);
+// delta = step .* scale, cand = x + delta; partials[0..g) = |x|^2, [g..2g) = |delta|^2 partial sums
+hipError_t LaunchBalCandidate(const double* x, const double* step, const double* scale, double* delta, double* cand, int64_t n,
+                              double* partials, int* nparts, hipStream_t stream);
+// partial maxima of |g_i / scale_i|
+hipError_t LaunchBalGradientMax(const double* g, const double* scale, int64_t n, double* partials, int* nparts, hipStream_t stream);
+hipError_t LaunchBalJacobiScale(const double* colnorm2, double* scale, int64_t n, hipStream_t stream);
+
 }  // namespace chip
 #endif

@@ -9,12 +9,15 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -1726,3 +1729,5 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
 }
 
 }  // extern "C"
+
+#include "bal_frontend.inc"

@@ -131,6 +131,44 @@ ABI = [
 _lib = None
 
 
+class CMinimizerOptions(ctypes.Structure):
+    _fields_ = [("max_num_iterations", c_int32), ("jacobi_scaling", c_int32), ("max_consecutive_invalid_steps", c_int32),
+                ("reserved", c_int32), ("initial_trust_region_radius", c_double), ("max_trust_region_radius", c_double),
+                ("min_trust_region_radius", c_double), ("min_lm_diagonal", c_double), ("max_lm_diagonal", c_double),
+                ("min_relative_decrease", c_double), ("eta", c_double), ("function_tolerance", c_double),
+                ("gradient_tolerance", c_double), ("parameter_tolerance", c_double)]
+
+
+class CIterationSummary(ctypes.Structure):
+    _fields_ = [("cost", c_double), ("cost_change", c_double), ("gradient_max_norm", c_double), ("step_norm", c_double),
+                ("relative_decrease", c_double), ("trust_region_radius", c_double), ("step_is_successful", c_int32),
+                ("step_is_valid", c_int32), ("linear_solver_iterations", c_int32), ("linear_solver_termination", c_int32)]
+
+
+MAX_LOGGED_ITERATIONS = 256
+
+
+class CMinimizerSummary(ctypes.Structure):
+    _fields_ = [("initial_cost", c_double), ("final_cost", c_double), ("num_successful_steps", c_int32),
+                ("num_unsuccessful_steps", c_int32), ("num_linear_solves", c_int32), ("termination_type", c_int32),
+                ("linear_solver_seconds", c_double), ("evaluation_seconds", c_double), ("total_seconds", c_double),
+                ("num_iterations_logged", c_int32), ("reserved", c_int32),
+                ("iterations", CIterationSummary * MAX_LOGGED_ITERATIONS), ("message", ctypes.c_char * 256)]
+
+
+ABI += [
+    ("ceres_hip_bal_create", c_void_p, [POINTER(COptions), c_int32, c_int32, c_int64, POINTER(c_int32), POINTER(c_int32), _DP]),
+    ("ceres_hip_bal_destroy", None, [c_void_p]),
+    ("ceres_hip_bal_last_error", c_char_p, [c_void_p]),
+    ("ceres_hip_bal_linear_solver", c_void_p, [c_void_p]),
+    ("ceres_hip_bal_sizes", c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    ("ceres_hip_bal_get_row_order", c_int32, [c_void_p, POINTER(c_int32)]),
+    ("ceres_hip_bal_evaluate", c_int32, [c_void_p, _DP, _DP, _DP, _DP, _DP]),
+    ("ceres_hip_minimizer_default_options", None, [POINTER(CMinimizerOptions)]),
+    ("ceres_hip_bal_minimize", c_int32, [c_void_p, POINTER(CMinimizerOptions), _DP, POINTER(CMinimizerSummary)]),
+]
+
+
 def load_library():
     """dlopen csrc/libceres_hip.so and bind every ABI symbol; raises if anything is missing."""
     global _lib
@@ -511,3 +549,91 @@ def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
     return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
             "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tail_a": (seg >> 17) & 63, "has_a": (seg >> 23) & 1,
             "tail_b": (seg >> 24) & 63, "has_b": (seg >> 30) & 1, "tile_kind": kind, "tile_aux": aux}
+
+
+CONVERGENCE, MINIMIZER_NO_CONVERGENCE, MINIMIZER_FAILURE = 0, 1, 2
+
+
+class BalProblem:
+    """Bundle adjustment in BAL form on the device: the Evaluator of the reduced,
+    Schur-ordered program (internal/ceres/evaluator.h:98-158) for the Snavely reprojection error
+    (examples/snavely_reprojection_error.h:53-105, examples/bal_problem.cc:75-135) and
+    TrustRegionMinimizer::Minimize around the linear solver `options` selects.
+
+    state = [3 doubles per point | 9 doubles per camera]; `state_from_bal` / `state_to_bal`
+    convert from the file order (cameras, then points)."""
+
+    def __init__(self, options: LinearSolverOptions, num_cameras, num_points, camera_index, point_index, observations):
+        self._lib = load_library()
+        self.options = options
+        self.num_cameras, self.num_points = int(num_cameras), int(num_points)
+        cam = np.ascontiguousarray(camera_index, dtype=np.int32)
+        pt = np.ascontiguousarray(point_index, dtype=np.int32)
+        obs = _f64(observations).reshape(-1)
+        self.num_observations = int(cam.shape[0])
+        if pt.shape[0] != self.num_observations or obs.shape[0] != 2 * self.num_observations:
+            raise ValueError("camera_index, point_index and observations disagree on the number of observations")
+        c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
+                     options.max_num_iterations, options.residual_reset_period, self.num_points, options.device,
+                     int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage,
+                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance)
+        self._h = self._lib.ceres_hip_bal_create(byref(c), self.num_cameras, self.num_points, self.num_observations,
+                                                 cam.ctypes.data_as(POINTER(c_int32)), pt.ctypes.data_as(POINTER(c_int32)),
+                                                 _p(obs))
+        if not self._h:
+            raise HipError(self._lib.ceres_hip_bal_last_error(None).decode())
+        n, m, v = c_int64(), c_int64(), c_int64()
+        self._check(self._lib.ceres_hip_bal_sizes(self._h, byref(n), byref(m), byref(v)))
+        self.num_parameters, self.num_residuals, self.num_jacobian_values = n.value, m.value, v.value
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HipError(f"ceres_hip error {rc}: {self._lib.ceres_hip_bal_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ceres_hip_bal_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def row_order(self):
+        out = np.empty(self.num_observations, dtype=np.int32)
+        self._check(self._lib.ceres_hip_bal_get_row_order(self._h, out.ctypes.data_as(POINTER(c_int32))))
+        return out
+
+    def state_from_bal(self, parameters):
+        """BAL file order (9 per camera, then 3 per point) -> state."""
+        a = _f64(parameters, 9 * self.num_cameras + 3 * self.num_points)
+        return np.concatenate([a[9 * self.num_cameras:9 * self.num_cameras + 3 * self.num_points], a[:9 * self.num_cameras]])
+
+    def state_to_bal(self, state):
+        a = _f64(state, self.num_parameters)
+        return np.concatenate([a[3 * self.num_points:], a[:3 * self.num_points]])
+
+    def evaluate(self, state, residuals=False, gradient=False, jacobian=False):
+        """Evaluator::Evaluate: returns (cost, residuals|None, gradient|None, jacobian values|None)."""
+        x = _f64(state, self.num_parameters)
+        cost = np.zeros(1)
+        r = np.empty(self.num_residuals) if residuals else None
+        g = np.empty(self.num_parameters) if gradient else None
+        v = np.empty(self.num_jacobian_values) if jacobian else None
+        self._check(self._lib.ceres_hip_bal_evaluate(self._h, _p(x), _p(cost), _p(r), _p(g), _p(v)))
+        return float(cost[0]), r, g, v
+
+    def minimize(self, state, **opts):
+        """TrustRegionMinimizer::Minimize (LEVENBERG_MARQUARDT).  Returns (state, CMinimizerSummary)."""
+        o = CMinimizerOptions()
+        self._lib.ceres_hip_minimizer_default_options(byref(o))
+        for k, val in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown minimizer option {k}")
+            setattr(o, k, val)
+        x = _f64(state, self.num_parameters).copy()
+        S = CMinimizerSummary()
+        self._check(self._lib.ceres_hip_bal_minimize(self._h, byref(o), _p(x), byref(S)))
+        return x, S

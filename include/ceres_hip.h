@@ -295,6 +295,79 @@ int ceres_hip_get_lm_diagonal(ceres_hip_solver* s, double* host_D);
  * host_values_out != NULL.  BlockSparseMatrix::ScaleColumns       I/block_sparse_matrix.cc:403-450 */
 int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, double* host_values_out);
 
+/* ---- the Evaluator side of the boundary for bundle adjustment in BAL form ----
+ * For the one cost function of bundle_adjuster (examples/snavely_reprojection_error.h:53-105,
+ * camera = angle-axis(3) translation(3) focal k1 k2, 2 residuals per observation) this replaces
+ * ceres::internal::Evaluator (I/evaluator.h:98-158: Evaluate(state, cost, residuals, gradient,
+ * jacobian), Plus) — ProgramEvaluator + autodiff Jets + BlockJacobianWriter in the reference —
+ * and TrustRegionMinimizer::Minimize with the Levenberg-Marquardt strategy
+ * (I/trust_region_minimizer.cc:72-845, I/levenberg_marquardt_strategy.cc:69-157) around the
+ * linear solvers above, with the Jacobian, the residuals and every vector of the loop resident
+ * in HBM: per iteration only a few scalars cross PCIe.
+ *
+ * The reduced program is Schur-ordered (I/reorder_program.cc:278-360): state = [3 doubles per
+ * point, points 0..n_p-1 | 9 doubles per camera], residual rows grouped by point, stable in
+ * observation order; the Jacobian has the BlockSparseMatrix layout BlockJacobianWriter produces
+ * for it (all E cells, 6 doubles per row, then all F cells, 18 per row), which
+ * ceres_hip_bal_get_structure describes.                                                     */
+typedef struct ceres_hip_bal ceres_hip_bal;
+/* `options` configures the linear solver (solver_type CGNR or ITERATIVE_SCHUR, preconditioner,
+ * iteration limits); num_eliminate_blocks is set to num_points.  BAL reader: examples/bal_problem.cc:75-135. */
+ceres_hip_bal* ceres_hip_bal_create(const ceres_hip_options* options, int32_t num_cameras, int32_t num_points,
+                                    int64_t num_observations, const int32_t* camera_index,
+                                    const int32_t* point_index, const double* observations);
+void ceres_hip_bal_destroy(ceres_hip_bal* p);
+const char* ceres_hip_bal_last_error(const ceres_hip_bal* p);
+/* The linear solver this problem drives (borrowed; operators, timing, info). */
+ceres_hip_solver* ceres_hip_bal_linear_solver(ceres_hip_bal* p);
+/* Evaluator::NumParameters / NumResiduals, and the number of Jacobian values (24 per observation). */
+int ceres_hip_bal_sizes(const ceres_hip_bal* p, int64_t* num_parameters, int64_t* num_residuals, int64_t* num_jacobian_values);
+/* row_observation[r] = index of the observation residual row block r belongs to. */
+int ceres_hip_bal_get_row_order(const ceres_hip_bal* p, int32_t* row_observation);
+/* Evaluator::Evaluate.  Host pointers; cost is required, the others may be NULL.  jacobian_values
+ * is UNSCALED; gradient = J^T residuals.  Leaves the evaluated point loaded in the linear solver
+ * (as ceres_hip_load_device would), so the ceres_hip_op_* entry points can be applied to it. */
+int ceres_hip_bal_evaluate(ceres_hip_bal* p, const double* state, double* cost, double* residuals, double* gradient,
+                           double* jacobian_values);
+/* Solver::Options of the trust-region loop (include/ceres/solver.h defaults in comments). */
+typedef struct ceres_hip_minimizer_options {
+  int32_t max_num_iterations;            /* 50 */
+  int32_t jacobi_scaling;                /* 1 */
+  int32_t max_consecutive_invalid_steps; /* max_num_consecutive_invalid_steps, 5 */
+  int32_t reserved;
+  double initial_trust_region_radius;    /* 1e4 */
+  double max_trust_region_radius;        /* 1e16 */
+  double min_trust_region_radius;        /* 1e-32 */
+  double min_lm_diagonal;                /* 1e-6 */
+  double max_lm_diagonal;                /* 1e32 */
+  double min_relative_decrease;          /* 1e-3 */
+  double eta;                            /* 1e-1 */
+  double function_tolerance;             /* 1e-6 */
+  double gradient_tolerance;             /* 1e-10 */
+  double parameter_tolerance;            /* 1e-8 */
+} ceres_hip_minimizer_options;
+void ceres_hip_minimizer_default_options(ceres_hip_minimizer_options* o);
+/* IterationSummary (include/ceres/iteration_callback.h), the fields the loop itself produces. */
+typedef struct ceres_hip_iteration_summary {
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+  int32_t step_is_successful, step_is_valid, linear_solver_iterations, linear_solver_termination;
+} ceres_hip_iteration_summary;
+#define CERES_HIP_MAX_LOGGED_ITERATIONS 256
+#define CERES_HIP_CONVERGENCE 0    /* TerminationType CONVERGENCE    */
+#define CERES_HIP_NO_CONVERGENCE_T 1 /* NO_CONVERGENCE */
+#define CERES_HIP_MINIMIZER_FAILURE 2 /* FAILURE */
+typedef struct ceres_hip_minimizer_summary {
+  double initial_cost, final_cost;
+  int32_t num_successful_steps, num_unsuccessful_steps, num_linear_solves, termination_type;
+  double linear_solver_seconds, evaluation_seconds, total_seconds;
+  int32_t num_iterations_logged, reserved;
+  ceres_hip_iteration_summary iterations[CERES_HIP_MAX_LOGGED_ITERATIONS];
+  char message[256];
+} ceres_hip_minimizer_summary;
+/* TrustRegionMinimizer::Minimize with LEVENBERG_MARQUARDT, monotonic steps.  state: host, in/out. */
+int ceres_hip_bal_minimize(ceres_hip_bal* p, const ceres_hip_minimizer_options* options, double* state,
+                           ceres_hip_minimizer_summary* summary);
+
 /* ---- timing for the roofline numbers --------------------------------------
  * Runs `iters` back-to-back launches of one operator on the solver's stream
  * with device-resident operands and brackets them with HIP events recorded on

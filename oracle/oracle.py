@@ -434,6 +434,20 @@ class BalProblem:
                                  arr(c.cell_value_pos, n_cells))
         return self.bs, self.nelim
 
+    def indices(self):
+        """(camera_index, point_index, observations[n, 2]) in observation (file) order."""
+        n = int(self.num_observations)
+        L = lib()
+        L.oracle_bal_camera_index.restype = POINTER(c_int32)
+        L.oracle_bal_point_index.restype = POINTER(c_int32)
+        L.oracle_bal_observations.restype = POINTER(c_double)
+        for f in (L.oracle_bal_camera_index, L.oracle_bal_point_index, L.oracle_bal_observations):
+            f.argtypes = [c_void_p]
+        cam = np.ctypeslib.as_array(L.oracle_bal_camera_index(self.h), shape=(n,)).copy()
+        pt = np.ctypeslib.as_array(L.oracle_bal_point_index(self.h), shape=(n,)).copy()
+        obs = np.ctypeslib.as_array(L.oracle_bal_observations(self.h), shape=(2 * n,)).copy().reshape(n, 2)
+        return cam, pt, obs
+
     def state(self):
         x = np.zeros(self.bs.num_cols)
         lib().oracle_bal_get_state(self.h, _dp(x))

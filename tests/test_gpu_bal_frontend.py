@@ -1,0 +1,130 @@
+"""the device Evaluator for BAL problems and the trust-region loop around the
+linear solvers, against the oracle's restatement (oracle/bal_harness.cc: dual-number Jacobians
+of the Snavely residual, TrustRegionMinimizer + LevenbergMarquardtStrategy)."""
+import numpy as np
+import pytest
+
+from test_gpu_operators import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(hip, oracle, nc, npts, nobs, seed, solver_type=5, pre=2, max_it=500, **gen):
+    op = oracle.BalProblem.generate(nc, npts, nobs, seed=seed, **gen)
+    bs, nelim = op.build_structure(True)
+    cam, pt, obs = op.indices()
+    o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=max_it)
+    gp = hip.BalProblem(o, op.num_cameras, op.num_points, cam, pt, obs)
+    return op, gp, bs, nelim
+
+
+def test_sizes_and_row_order_match_the_reduced_program(hip, oracle):
+    op, gp, bs, nelim = make_pair(hip, oracle, 6, 80, 400, seed=3)
+    assert (gp.num_parameters, gp.num_residuals, gp.num_jacobian_values) == (bs.num_cols, bs.num_rows, bs.num_nonzeros)
+    cam, pt, _ = op.indices()
+    order = gp.row_order()
+    assert sorted(order.tolist()) == list(range(op.num_observations))
+    assert np.all(np.diff(pt[order]) >= 0)                      # grouped by point ...
+    same = np.diff(pt[order]) == 0
+    assert np.all(np.diff(order)[same] > 0)                     # ... stable in observation order
+    # the structure the device built is the oracle's
+    gp.close()
+
+
+@pytest.mark.parametrize("seed,nc,npts,nobs", [(3, 6, 80, 400), (4, 20, 700, 4000), (5, 40, 3000, 14000)])
+def test_evaluate_matches_oracle_dual_numbers(hip, oracle, seed, nc, npts, nobs):
+    op, gp, bs, _ = make_pair(hip, oracle, nc, npts, nobs, seed)
+    x = op.state()
+    cost_o, res_o, vals_o = op.evaluate(x)
+    cost, res, grad, vals = gp.evaluate(x, residuals=True, gradient=True, jacobian=True)
+    assert abs(cost - cost_o) <= 1e-13 * cost_o
+    assert rel(res, res_o) <= 1e-13
+    # analytic Jacobian vs forward-mode duals of the same formula, entry by entry
+    assert np.max(np.abs(vals - vals_o) / (np.abs(vals_o) + 1e-9 * np.abs(vals_o).max())) <= 1e-9
+    assert rel(vals, vals_o) <= 1e-12
+    m = oracle.Matrix(bs, 0)
+    assert rel(grad, m.left_multiply(vals_o, res_o)) <= 1e-12
+    # cost only
+    c2, r2, g2, v2 = gp.evaluate(x)
+    assert c2 == cost and r2 is None and g2 is None and v2 is None
+    gp.close()
+
+
+def test_small_angle_branch_of_the_rotation(hip, oracle):
+    # angle-axis exactly zero: the first-order branch of AngleAxisRotatePoint (include/ceres/rotation.h:864-905)
+    op, gp, bs, _ = make_pair(hip, oracle, 5, 60, 250, seed=9)
+    x = op.state()
+    x[3 * op.num_points:3 * op.num_points + 3] = 0.0          # camera 0
+    x[3 * op.num_points + 18:3 * op.num_points + 21] = 0.0    # camera 2
+    cost_o, res_o, vals_o = op.evaluate(x)
+    cost, res, _, vals = gp.evaluate(x, residuals=True, jacobian=True)
+    assert abs(cost - cost_o) <= 1e-13 * cost_o and rel(res, res_o) <= 1e-13 and rel(vals, vals_o) <= 1e-12
+    gp.close()
+
+
+def test_state_conversion_round_trip(hip, oracle):
+    op, gp, bs, _ = make_pair(hip, oracle, 4, 30, 100, seed=1)
+    x = op.state()
+    np.testing.assert_array_equal(gp.state_from_bal(gp.state_to_bal(x)), x)
+    gp.close()
+
+
+def check_same_trajectory(Sa, Sb, cost_tol):
+    assert Sa.num_iterations_logged == Sb.num_iterations_logged, (Sa.num_iterations_logged, Sb.num_iterations_logged)
+    for i in range(Sa.num_iterations_logged):
+        a, b = Sa.iterations[i], Sb.iterations[i]
+        assert a.step_is_successful == b.step_is_successful and a.step_is_valid == b.step_is_valid, i
+        assert abs(a.linear_solver_iterations - b.linear_solver_iterations) <= 1, i
+        assert abs(a.cost - b.cost) <= cost_tol * abs(a.cost), (i, a.cost, b.cost)
+        assert abs(a.radius - b.trust_region_radius) <= 1e-6 * a.radius, i
+    assert abs(Sa.final_cost - Sb.final_cost) <= cost_tol * Sa.final_cost
+
+
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
+def test_minimize_follows_the_oracle_trust_region_loop(hip, oracle, solver_type, pre):
+    # same problem, same options: the oracle's loop with the oracle's linear solver vs the loop on the device.
+    # Inexact Newton (eta = 0.1): the iterates agree as far as the CG termination decisions do; costs to 1e-6.
+    op, gp, bs, nelim = make_pair(hip, oracle, 12, 800, 3600, seed=5, solver_type=solver_type, pre=pre)
+    if solver_type == 6:
+        op.build_structure(True)
+    x0 = op.state()
+    Sa = op.lm_solve(solver_type=solver_type, preconditioner=pre, max_it=500, max_num_iterations=12)
+    x, Sb = gp.minimize(x0, max_num_iterations=12)
+    assert Sb.initial_cost == pytest.approx(Sa.initial_cost, rel=1e-13)
+    check_same_trajectory(Sa, Sb, 1e-6)
+    assert Sb.final_cost < 0.5 * Sb.initial_cost
+    assert Sb.termination_type == Sa.termination
+    # the returned state is the one whose cost is reported
+    assert gp.evaluate(x)[0] == pytest.approx(Sb.final_cost, rel=1e-12)
+    assert rel(x, op.state()) <= 1e-5
+    gp.close()
+
+
+def test_minimize_with_rejected_steps_and_without_jacobi_scaling(hip, oracle):
+    # a huge initial radius makes the first steps overshoot: exercises the rejection path (reuse_diagonal,
+    # radius /= decrease_factor) on both sides
+    op, gp, bs, nelim = make_pair(hip, oracle, 10, 500, 2400, seed=11, param_noise=0.08)
+    x0 = op.state()
+    kw = dict(max_num_iterations=15, jacobi_scaling=0)
+    Sa = op.lm_solve(solver_type=5, preconditioner=2, max_it=500, initial_radius=1e12, **kw)
+    x, Sb = gp.minimize(x0, initial_trust_region_radius=1e12, **kw)
+    check_same_trajectory(Sa, Sb, 1e-5)
+    assert Sb.num_unsuccessful_steps == Sa.num_unsuccessful_steps
+    gp.close()
+
+
+def test_convergence_tests_terminate_like_the_oracle(hip, oracle):
+    op, gp, bs, nelim = make_pair(hip, oracle, 8, 300, 1500, seed=21, pixel_noise=0.0, param_noise=0.01)
+    x0 = op.state()
+    Sa = op.lm_solve(solver_type=5, preconditioner=2, max_it=500, max_num_iterations=50)
+    x, Sb = gp.minimize(x0, max_num_iterations=50)
+    assert Sb.termination_type == hip.CONVERGENCE == Sa.termination
+    assert Sb.message == Sa.message
+    assert abs(Sb.num_iterations_logged - Sa.num_iterations_logged) <= 1
+    gp.close()
+
+
+def test_create_rejects_bad_indices(hip):
+    o = hip.LinearSolverOptions(type=5, preconditioner_type=2, max_num_iterations=10)
+    with pytest.raises(hip.HipError):
+        hip.BalProblem(o, 2, 3, [0, 1, 2], [0, 1, 2], np.zeros(6))
