@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--minimizer-iterations", type=int, default=8,
+                    help="also run the device-resident trust-region loop (f4) for this many iterations and report it in `extra` (0: skip)")
     ap.add_argument("--both-solvers", type=int, default=1, help="also report the other solver in `extra` (N=1 only)")
     return ap.parse_args()
 
@@ -191,7 +193,7 @@ def main():
             traffic = rec.get(f"{args.workload}:{kind}")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": f"bal_fused_kernel<{'kJtJx' if kind == 'jtjx' else 'kSx'}> + bal_reduce_partials_kernel",
+    roofline = {"bound": "hbm", "kernel": f"bal_stream_kernel<{'kJtJx' if kind == 'jtjx' else 'kSx'}> + bal_reduce_partials_kernel",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                 "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(op_ms, 5)}
@@ -212,6 +214,29 @@ def main():
             extra[other]["schur_init_ms"] = round(s2.time_op(hs.TIMED_SCHUR_INIT, 10), 4)
             extra[other]["schur_jacobi_ms"] = round(s2.time_op(hs.TIMED_SCHUR_JACOBI, 10), 4)
         s2.close()
+    # ---- the whole trust-region loop on the device, for the record (N = 1) ----------
+    if world == 1 and args.minimizer_iterations > 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b > 40 * n_obs * 24:  # its own Jacobian, tiles and vectors next to the bench's
+            nc_, np_, cam_i, pt_i, obs_, par_ = pkg.problems.bal_scene(args.workload, seed=38401, skew=args.skew)
+            typ, pre = (hs.CGNR, hs.JACOBI) if args.solver == "cgnr" else (hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)
+            bp = hs.BalProblem(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
+                                                      device=local_rank), nc_, np_, cam_i, pt_i, obs_)
+            x0 = bp.state_from_bal(par_)
+            bp.minimize(x0, max_num_iterations=1)  # warm-up
+            _, Sm = bp.minimize(x0, max_num_iterations=args.minimizer_iterations)
+            nit = Sm.num_successful_steps + Sm.num_unsuccessful_steps
+            extra["trust_region_minimizer_on_device"] = {
+                "what": "ceres_hip_bal_minimize: Snavely evaluator (analytic Jacobian) + LM step + candidate evaluation per iteration, "
+                        f"{args.workload}-shaped synthetic scene, state and Jacobian resident in HBM",
+                "iterations": nit, "iterations_per_s": round(nit / Sm.total_seconds, 3) if Sm.total_seconds > 0 else None,
+                "ms_per_iteration": round(1e3 * Sm.total_seconds / max(nit, 1), 3),
+                "linear_solver_ms_per_iteration": round(1e3 * Sm.linear_solver_seconds / max(Sm.num_linear_solves, 1), 3),
+                "evaluation_ms_total": round(1e3 * Sm.evaluation_seconds, 3),
+                "initial_cost": Sm.initial_cost, "final_cost": Sm.final_cost, "successful_steps": Sm.num_successful_steps,
+                "cg_iterations": [Sm.iterations[i].linear_solver_iterations for i in range(1, Sm.num_iterations_logged)],
+                "termination": Sm.message.decode(errors="replace")}
+            bp.close()
     extra["solve_phases_ms"] = {k: round(getattr(timing, k), 4) for k in
                                 ("pack_ms", "setup_ms", "preconditioner_ms", "cg_ms", "back_substitute_ms", "total_ms")}
     extra["operator_launches_enqueued_last_step"] = int(timing.operator_applications)

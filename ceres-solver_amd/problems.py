@@ -464,3 +464,31 @@ def scene_values(prob: LinearProblem, n_cams: int, n_points: int, seed=38401, pi
     D = np.sqrt(np.clip(colnorm2(values), 1e-6, 1e32) / radius)
     prob.values, prob.b, prob.D = values, b, D
     return prob
+
+
+def bal_scene(shape="dubrovnik16", seed=38401, skew=0.0, num_cameras=None, num_points=None, num_observations=None,
+              pixel_noise=0.5, param_noise=0.02, chunk=400_000):
+    """A synthetic bundle-adjustment problem in BAL form (examples/bal_problem.cc:75-135) with the
+    observation graph of `synthetic_bal`: returns (num_cameras, num_points, camera_index, point_index,
+    observations (n,2), parameters) — parameters in BAL file order (9 per camera, then 3 per point),
+    perturbed away from the scene that generated the observations."""
+    prob = synthetic_bal(shape, layout="schur", seed=seed, skew=skew, num_cameras=num_cameras, num_points=num_points,
+                         num_observations=num_observations, with_values=False)
+    n_points = int(prob.num_eliminate_blocks)
+    n_cams = int(prob.bs.num_col_blocks - n_points)
+    pt = np.asarray(prob.point_of_row, dtype=np.int64)
+    cam = np.asarray(prob.camera_of_row, dtype=np.int64) - n_points
+    n_obs = pt.shape[0]
+    rng = np.random.default_rng(seed + 17)
+    cams_true, pts_true = _scene(rng, n_cams, n_points)
+    cams0 = cams_true.copy()
+    cams0[:, :3] += 0.02 * param_noise * rng.standard_normal((n_cams, 3))
+    cams0[:, 3:6] += 0.2 * param_noise * rng.standard_normal((n_cams, 3))
+    cams0[:, 6] *= 1.0 + 0.02 * param_noise * rng.standard_normal(n_cams)
+    pts0 = pts_true + param_noise * rng.standard_normal((n_points, 3))
+    obs = np.empty((n_obs, 2))
+    for lo in range(0, n_obs, chunk):
+        hi = min(n_obs, lo + chunk)
+        obs[lo:hi] = _snavely(cams_true[cam[lo:hi]], pts_true[pt[lo:hi]], False) + pixel_noise * rng.standard_normal((hi - lo, 2))
+    return n_cams, n_points, cam.astype(np.int32), pt.astype(np.int32), obs, np.concatenate([cams0.reshape(-1), pts0.reshape(-1)])
+
