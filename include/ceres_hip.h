@@ -301,7 +301,7 @@ int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, do
  * ceres::internal::Evaluator (I/evaluator.h:98-158: Evaluate(state, cost, residuals, gradient,
  * jacobian), Plus) — ProgramEvaluator + autodiff Jets + BlockJacobianWriter in the reference —
  * and TrustRegionMinimizer::Minimize with the Levenberg-Marquardt strategy
- * (I/trust_region_minimizer.cc:72-845, I/levenberg_marquardt_strategy.cc:69-157) around the
+ * (I/trust_region_minimizer.cc:68-845, I/levenberg_marquardt_strategy.cc:69-157) around the
  * linear solvers above, with the Jacobian, the residuals and every vector of the loop resident
  * in HBM: per iteration only a few scalars cross PCIe.
  *
@@ -309,7 +309,7 @@ int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, do
  * point, points 0..n_p-1 | 9 doubles per camera], residual rows grouped by point, stable in
  * observation order; the Jacobian has the BlockSparseMatrix layout BlockJacobianWriter produces
  * for it (all E cells, 6 doubles per row, then all F cells, 18 per row), which
- * ceres_hip_bal_get_structure describes.                                                     */
+ * is fully determined by ceres_hip_bal_get_row_order.                                                   */
 typedef struct ceres_hip_bal ceres_hip_bal;
 /* `options` configures the linear solver (solver_type CGNR or ITERATIVE_SCHUR, preconditioner,
  * iteration limits); num_eliminate_blocks is set to num_points.  BAL reader: examples/bal_problem.cc:75-135. */

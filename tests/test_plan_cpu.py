@@ -140,3 +140,20 @@ def test_packed_formulation_matches_oracle(oracle, problems):
     raw = raw.reshape(n_c, 9, 9)
     iu = np.triu_indices(9)
     np.testing.assert_allclose(blocks[:, iu[0], iu[1]], raw[:, iu[0], iu[1]], rtol=0, atol=1e-12 * np.abs(raw).max())
+
+
+def test_bal_scene_generator_is_a_consistent_bal_problem(problems):
+    # the front-end's input for SURVEY §8 f4 (bench.py, tests): indices in range, every point observed by
+    # distinct cameras, observations near the projection of the perturbed start (a solvable problem)
+    nc, npts, cam, pt, obs, par = problems.bal_scene(None, num_cameras=12, num_points=400, num_observations=1900, seed=7, skew=0.5)
+    assert (nc, npts) == (12, 400) and cam.shape == pt.shape == (1900,) and obs.shape == (1900, 2)
+    assert par.shape == (9 * nc + 3 * npts,)
+    assert cam.min() >= 0 and cam.max() < nc and pt.min() == 0 and pt.max() == npts - 1
+    pairs = set(zip(pt.tolist(), cam.tolist()))
+    assert len(pairs) == 1900
+    cams, pts = par[:9 * nc].reshape(nc, 9), par[9 * nc:].reshape(npts, 3)
+    proj = problems._snavely(cams[cam], pts[pt], False)
+    r = proj - obs
+    assert np.sqrt((r * r).mean()) < 60.0   # pixels: perturbed start, not garbage
+    again = problems.bal_scene(None, num_cameras=12, num_points=400, num_observations=1900, seed=7, skew=0.5)
+    np.testing.assert_array_equal(again[4], obs)
