@@ -22,7 +22,7 @@ namespace chip {
 
 constexpr int kTile = 64;           // observation slots per tile = one wavefront
 constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
-constexpr int kCamChunk = 512;      // observations per work item (one wavefront) of the camera-major kernels
+constexpr int kCamChunk = 512;      // max observations per work item (one wavefront) of the camera-major kernels
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
 
 // ---------------------------------------------------------------------------

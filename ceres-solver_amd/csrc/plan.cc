@@ -301,10 +301,13 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       P.cam_slot[q] = int32_t(s);
     }
   }
+  // Item size: kCamChunk at scale (>= 8192 items keep every CU busy); smaller problems get
+  // proportionally shorter items, down to one wavefront's worth, so that they too spread over the chip.
+  const int chunk = int(std::max<int64_t>(kTile, std::min<int64_t>(kCamChunk, ((P.n_obs / 8192 + kTile - 1) / kTile) * kTile)));
   for (int c = 0; c < P.n_cameras; ++c) {
     int b = P.cam_ptr[c];
     do {  // a camera without observations still gets one (empty) item so that D^2 is added
-      const int e = std::min(P.cam_ptr[c + 1], b + kCamChunk);
+      const int e = std::min(P.cam_ptr[c + 1], b + chunk);
       P.item_cam.push_back(c); P.item_begin.push_back(b); P.item_end.push_back(e);
       b = e;
     } while (b < P.cam_ptr[c + 1]);
