@@ -10,6 +10,8 @@ Two kinds of fixture:
   numbers the reference's unit tests (iterative_schur_complement_solver_test.cc:75-117,
   schur_eliminator_test.cc, implicit_schur_complement_test.cc) check its solvers against.
   These pin the oracle ("parity pinned", oracle/ceres_oracle.h header).
+* bal_evaluator_small.npz — a small BAL problem (indices, observations, state) with the oracle's
+  Snavely residuals and dual-number Jacobian at that state.
 * bal_*.npz — outputs of the pinned oracle on small seeded <2,3,9> problems (inputs are
   regenerated from the seed by ceres-solver_amd/problems.py; the file also stores a checksum of
   the inputs so that a generator change cannot silently re-define the fixture).  The -m gpu
@@ -83,9 +85,27 @@ def make_case(pkg, oracle, name):
     return p, out
 
 
+def make_evaluator_case(oracle):
+    """Snavely residuals and dual-number Jacobian (oracle/bal_harness.cc) of a small BAL problem at its
+    perturbed start, two cameras with zero rotation (first-order branch of AngleAxisRotatePoint)."""
+    op = oracle.BalProblem.generate(7, 120, 600, seed=77, skew=0.3)
+    bs, nelim = op.build_structure(True)
+    cam, pt, obs = op.indices()
+    x = op.state()
+    x[3 * op.num_points:3 * op.num_points + 3] = 0.0
+    x[3 * op.num_points + 27:3 * op.num_points + 30] = 0.0
+    cost, res, vals = op.evaluate(x)
+    return {"num_cameras": np.int64(op.num_cameras), "num_points": np.int64(op.num_points), "camera_index": cam,
+            "point_index": pt, "observations": obs, "state": x, "cost": np.float64(cost), "residuals": res,
+            "jacobian_values": vals}
+
+
 def main():
     pkg = entry.load_package()
     oracle = entry.load_oracle()
+    ev = make_evaluator_case(oracle)
+    np.savez_compressed(os.path.join(HERE, "bal_evaluator_small.npz"), **ev)
+    print("bal_evaluator_small", {k: np.asarray(v).shape for k, v in ev.items()})
     ka = {}
     for pid in (0, 2, 3, 4, 5, 6):
         p = pkg.problems.linear_least_squares_problem(pid)

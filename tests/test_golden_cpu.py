@@ -48,3 +48,13 @@ def test_oracle_reproduces_recorded_outputs(oracle, problems, name):
             continue
         tol = 1e-9 if k.endswith("_converged") else 1e-12
         assert rel(fresh[k], v) <= tol, (name, k, rel(fresh[k], v))
+
+
+def test_oracle_reproduces_recorded_evaluator_case(oracle):
+    import os
+    g = dict(np.load(os.path.join(G.GOLDEN, "bal_evaluator_small.npz")))
+    fresh = G.MAKER.make_evaluator_case(oracle)
+    np.testing.assert_array_equal(fresh["camera_index"], g["camera_index"])
+    np.testing.assert_array_equal(fresh["observations"], g["observations"])
+    assert abs(float(fresh["cost"]) - float(g["cost"])) <= 1e-14 * float(g["cost"])
+    assert rel(fresh["residuals"], g["residuals"]) <= 1e-14 and rel(fresh["jacobian_values"], g["jacobian_values"]) <= 1e-14

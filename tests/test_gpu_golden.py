@@ -63,3 +63,16 @@ def test_known_answers_from_fixture_file(hip, problems):
     x, _ = s.solve(p.values, p.b, hip.PerSolveOptions(D=None, q_tolerance=0.0, r_tolerance=1e-15))
     np.testing.assert_allclose(x, ka["0"]["x"], atol=1e-10)
     s.close()
+
+
+def test_bal_evaluator_matches_fixture(hip):
+    # the device Evaluator against recorded dual-number Jacobians, no oracle in the loop
+    import os
+    g = dict(np.load(os.path.join(G.GOLDEN, "bal_evaluator_small.npz")))
+    o = hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, max_num_iterations=50)
+    bp = hip.BalProblem(o, int(g["num_cameras"]), int(g["num_points"]), g["camera_index"], g["point_index"], g["observations"])
+    cost, res, grad, vals = bp.evaluate(g["state"], residuals=True, gradient=True, jacobian=True)
+    bp.close()
+    assert abs(cost - float(g["cost"])) <= 1e-13 * float(g["cost"])
+    assert rel(res, g["residuals"]) <= 1e-13
+    assert rel(vals, g["jacobian_values"]) <= 1e-12
