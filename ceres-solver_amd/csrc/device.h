@@ -139,6 +139,11 @@ hipError_t LaunchAddBlockDiagonalSquares(const GenStructure& G, int first_block,
 hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                 int add_f_diag, double* blocks, int64_t total_entries, hipStream_t stream);
 // Dense S (upper block triangle) and nothing else; rhs comes from the ISC path.
+// explicit Schur complement (f2): mirror the stored upper block triangle; y = S x; diagonal blocks of S
+hipError_t LaunchGenSymmetrizeDense(const GenStructure& G, double* lhs, hipStream_t stream);
+hipError_t LaunchGenDenseSymv(const double* S, int n, const double* x, double* y, const int* status, hipStream_t stream);
+hipError_t LaunchGenExtractDiagBlocks(const GenStructure& G, const double* S, const int64_t* diag_off_f, double* blocks,
+                                      hipStream_t stream);
 hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                double* lhs, hipStream_t stream);
 

@@ -321,6 +321,48 @@ __global__ __launch_bounds__(kB) void gen_add_diag_squares_kernel(GenStructure G
   blocks[(off[j - first_block] - off[0]) + int64_t(a) * n + a] += d * d;
 }
 
+// ---- explicit Schur complement, dense storage for small reduced systems ----
+// The eliminator fills block1 <= block2 only (as the reference does); mirror it so that S x is a plain
+// dense product (BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate,
+// I/block_random_access_sparse_matrix.cc:125-163, uses each stored block for both triangles).
+__global__ __launch_bounds__(kB) void gen_symmetrize_dense_kernel(GenStructure G, double* __restrict__ lhs) {
+  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
+  const int64_t n = G.ncf;
+  if (e >= n * n) return;
+  const int row = int(e / n), col = int(e % n);
+  if (G.col_block_of[G.nce + row] > G.col_block_of[G.nce + col]) lhs[e] = lhs[int64_t(col) * n + row];
+}
+
+// y = S x, one wavefront per row (S row-major n x n, symmetric)
+__global__ __launch_bounds__(kB) void gen_dense_symv_kernel(const double* __restrict__ S, int n, const double* __restrict__ x,
+                                                            double* __restrict__ y, const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int row = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const double* r = S + int64_t(row) * n;
+  double v = 0.0;
+  for (int j = lane; j < n; j += 64) v += r[j] * x[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  if (lane == 0) y[row] = v;
+}
+
+// blocks[j] = S(j, j) for the F column blocks (the SCHUR_JACOBI preconditioner of the explicit solver,
+// I/schur_complement_solver.cc:361-381); one thread per row of S
+__global__ __launch_bounds__(kB) void gen_extract_diag_blocks_kernel(GenStructure G, const double* __restrict__ S,
+                                                                     const int64_t* __restrict__ off, double* __restrict__ blocks) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= G.ncf) return;
+  const int j = G.col_block_of[G.nce + i];
+  const int nj = G.csz[j];
+  const int c0 = G.cpos[j] - G.nce;
+  const int a = i - c0;
+  double* o = blocks + (off[j - G.nelim] - off[0]) + int64_t(a) * nj;
+  const double* r = S + int64_t(i) * G.ncf + c0;
+  for (int b = 0; b < nj; ++b) o[b] = r[b];
+}
+
 inline unsigned blocks_for(int64_t n) { return unsigned((n + kB - 1) / kB); }
 
 }  // namespace
@@ -365,6 +407,20 @@ hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, cons
                                hipStream_t s) {
   const int64_t n = int64_t(G.ncf) * G.ncf;
   if (n > 0) hipLaunchKernelGGL(gen_schur_dense_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, ete_inv, D, lhs);
+  return hipGetLastError();
+}
+
+hipError_t LaunchGenSymmetrizeDense(const GenStructure& G, double* lhs, hipStream_t s) {
+  const int64_t n = int64_t(G.ncf) * G.ncf;
+  if (n > 0) hipLaunchKernelGGL(gen_symmetrize_dense_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, lhs);
+  return hipGetLastError();
+}
+hipError_t LaunchGenDenseSymv(const double* S, int n, const double* x, double* y, const int* status, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(gen_dense_symv_kernel, dim3((n + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, S, n, x, y, status);
+  return hipGetLastError();
+}
+hipError_t LaunchGenExtractDiagBlocks(const GenStructure& G, const double* S, const int64_t* diag_off_f, double* blocks, hipStream_t s) {
+  if (G.ncf > 0) hipLaunchKernelGGL(gen_extract_diag_blocks_kernel, dim3(blocks_for(G.ncf)), dim3(kB), 0, s, G, S, diag_off_f, blocks);
   return hipGetLastError();
 }
 

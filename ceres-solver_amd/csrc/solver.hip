@@ -87,6 +87,7 @@ struct ceres_hip_solver {
   double *tmp_rows = nullptr, *tmp_e = nullptr, *tmp_e2 = nullptr;
   // preconditioner blocks: F blocks (diag_off_f) for ITERATIVE_SCHUR, all blocks (diag_off_all) for CGNR
   double* precond = nullptr;
+  double* d_S = nullptr;          // explicit Schur complement, dense num_cols_f^2 (use_explicit_schur_complement)
   bool precond_valid = false;
   // SCHUR_POWER_SERIES_EXPANSION: blockdiag(F^T F + D_f^2)^-1 and two F-space temporaries
   double *ftf_inv = nullptr, *spse_a = nullptr, *spse_b = nullptr;
@@ -830,6 +831,51 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
       HIP_TRY(s, hipEventRecord(s->ev[6], st));
       return 0;
     }
+    if (s->opt.use_explicit_schur_complement) {
+      // SchurComplementSolver::SolveImpl (I/schur_complement_solver.cc:100-158) with
+      // SolveReducedLinearSystemUsingConjugateGradients (:337-408): S and rhs by elimination,
+      // SCHUR_JACOBI = inverted diagonal blocks OF S, CG on S, back-substitution only on SUCCESS.
+      const int64_t nf = h.num_cols_f;
+      // D_f^2 joins the diagonal once: on rank 0 when the elimination is sharded by point
+      HIP_TRY(s, LaunchGenSchurDense(s->G, s->values, s->etei, (s->world > 1 && s->rank != 0) ? nullptr : s->D, s->d_S, st));
+      if (s->world > 1) TRY(allreduce(s, s->d_S, size_t(nf * nf)));  // "reduced-system contributions combined via all-reduce"
+      HIP_TRY(s, LaunchGenSymmetrizeDense(s->G, s->d_S, st));
+      HIP_TRY(s, LaunchGenExtractDiagBlocks(s->G, s->d_S, s->G.diag_off_f, s->precond, st));
+      HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+      HIP_TRY(s, LaunchGenInvertBlocks(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->precond, s->d_fail_flag, st));
+      TRY(check_factorization(s, &bad));
+      if (bad) {
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+        return 0;
+      }
+      s->precond_valid = true;
+      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      HIP_TRY(s, hipMemcpyAsync(s->cg_rhs, s->rhs_f, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
+      CgSpec spec;
+      spec.n = nf;
+      spec.n_local = 0;
+      const int* status = &s->cg.S->status;
+      spec.apply = [s, status, nf](const double* in, double* out) -> int {
+        HIP_TRY(s, LaunchGenDenseSymv(s->d_S, int(nf), in, out, status, s->stream));
+        return 0;
+      };
+      spec.first_block = h.nelim;
+      spec.nblocks = h.ncb - h.nelim;
+      spec.col_begin = h.num_cols_e;
+      spec.diag_off = s->G.diag_off_f;
+      spec.blocks = s->precond;
+      TRY(run_cg(s, spec, q_tol, r_tol, summary));
+      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      if (summary->termination_type == CERES_HIP_SUCCESS) {
+        TRY(op_back_substitute(s, s->cg.x, x));
+      } else {  // x was zero-filled (:135), the reduced solution sits in its tail
+        HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols_e, st));
+        HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, s->cg.x, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
+      }
+      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      return 0;
+    }
     const bool spse_pre = pre == CERES_HIP_SCHUR_POWER_SERIES_EXPANSION;
     const int spse_iters = s->opt.max_num_spse_iterations > 0 ? s->opt.max_num_spse_iterations : 5;
     if (spse_pre || s->opt.use_spse_initialization) {
@@ -962,6 +1008,16 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
     fail(nullptr, CERES_HIP_E_UNSUPPORTED, "preconditioner_type %d is not available for solver_type %d", pre, o->solver_type);
     return nullptr;
   }
+  if (o->use_explicit_schur_complement) {
+    if (o->solver_type != CERES_HIP_ITERATIVE_SCHUR) {
+      fail(nullptr, CERES_HIP_E_INVALID, "use_explicit_schur_complement applies to ITERATIVE_SCHUR");
+      return nullptr;
+    }
+    if (pre != CERES_HIP_SCHUR_JACOBI || o->use_spse_initialization) {  // CHECK_EQ(preconditioner_type, SCHUR_JACOBI), I/schur_complement_solver.cc:353
+      fail(nullptr, CERES_HIP_E_UNSUPPORTED, "Only SCHUR_JACOBI is supported with use_explicit_schur_complement");
+      return nullptr;
+    }
+  }
   if (o->jacobian_storage != 0 && o->jacobian_storage != 1) {
     fail(nullptr, CERES_HIP_E_INVALID, "jacobian_storage must be 0 (fp64) or 1 (fp32 tiles)");
     return nullptr;
@@ -1024,11 +1080,15 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   }
   if (s->world > 1 && !h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "sharded runs need the Schur ordering");
   BuildBalPlan(h, true, &s->plan);
-  s->path = (s->plan.eligible && !s->opt.force_generic_path) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
   if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !s->plan.contiguous_layout)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "sharded <2,3,9> runs need points-then-cameras column order");
+
+  if (s->opt.use_explicit_schur_complement && h.num_cols_f > CERES_HIP_MAX_EXPLICIT_SCHUR_COLS)
+    return fail(s, CERES_HIP_E_UNSUPPORTED, "use_explicit_schur_complement stores S densely: %d reduced columns exceed the limit of %d",
+                h.num_cols_f, CERES_HIP_MAX_EXPLICIT_SCHUR_COLS);
 
   // ---- structure arrays ----
   GenStructure& G = s->G;
@@ -1057,6 +1117,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->lm_D, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->scalar_partials, size_t(kMaxVecGrid)));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
+  if (s->opt.use_explicit_schur_complement) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.r, size_t(cg_n)));

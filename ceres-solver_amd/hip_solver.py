@@ -47,7 +47,7 @@ class COptions(ctypes.Structure):
                 ("max_num_iterations", c_int32), ("residual_reset_period", c_int32), ("num_eliminate_blocks", c_int32),
                 ("device", c_int32), ("force_generic_path", c_int32), ("cg_check_interval", c_int32),
                 ("jacobian_storage", c_int32), ("max_num_spse_iterations", c_int32), ("use_spse_initialization", c_int32),
-                ("spse_tolerance", c_double), ("reserved", c_int32 * 2)]
+                ("spse_tolerance", c_double), ("use_explicit_schur_complement", c_int32), ("reserved", c_int32)]
 
 
 class CSummary(ctypes.Structure):
@@ -223,6 +223,7 @@ class LinearSolverOptions:
     max_num_spse_iterations: int = 5
     use_spse_initialization: bool = False
     spse_tolerance: float = 0.1
+    use_explicit_schur_complement: bool = False   # ITERATIVE_SCHUR on an explicitly formed (dense) S; SCHUR_JACOBI only
 
 
 @dataclass
@@ -273,7 +274,8 @@ class HipLinearSolver:
         c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
                      options.max_num_iterations, options.residual_reset_period, nelim, options.device,
                      int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage,
-                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance)
+                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance,
+                     int(options.use_explicit_schur_complement))
         self._h = self._lib.ceres_hip_create(byref(c))
         if not self._h:
             raise HipError(self._lib.ceres_hip_last_error(None).decode())
@@ -576,7 +578,8 @@ class BalProblem:
         c = COptions(options.type, options.preconditioner_type, options.min_num_iterations,
                      options.max_num_iterations, options.residual_reset_period, self.num_points, options.device,
                      int(options.force_generic_path), options.cg_check_interval, options.jacobian_storage,
-                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance)
+                     options.max_num_spse_iterations, int(options.use_spse_initialization), options.spse_tolerance,
+                     int(options.use_explicit_schur_complement))
         self._h = self._lib.ceres_hip_bal_create(byref(c), self.num_cameras, self.num_points, self.num_observations,
                                                  cam.ctypes.data_as(POINTER(c_int32)), pt.ctypes.data_as(POINTER(c_int32)),
                                                  _p(obs))

@@ -86,6 +86,10 @@ class LinearSolver {
     int max_num_iterations = 1;  // the reference's default (internal/ceres/linear_solver.h:165-166)
     int residual_reset_period = 10;
     std::vector<int> elimination_groups;
+    bool use_explicit_schur_complement = false;  // internal/ceres/linear_solver.h:187-190
+    int max_num_spse_iterations = 5;
+    bool use_spse_initialization = false;
+    double spse_tolerance = 0.1;
     int device = 0;  // not in the reference: HIP device ordinal
   };
   struct PerSolveOptions {
@@ -119,6 +123,10 @@ class HipLinearSolver final : public LinearSolver {
     o.residual_reset_period = options.residual_reset_period;
     o.num_eliminate_blocks = options.elimination_groups.empty() ? 0 : options.elimination_groups[0];
     o.device = options.device;
+    o.use_explicit_schur_complement = options.use_explicit_schur_complement ? 1 : 0;
+    o.max_num_spse_iterations = options.max_num_spse_iterations;
+    o.use_spse_initialization = options.use_spse_initialization ? 1 : 0;
+    o.spse_tolerance = options.spse_tolerance;
     handle_ = ceres_hip_create(&o);
     if (!handle_) throw std::runtime_error(std::string("ceres_hip_create: ") + ceres_hip_last_error(nullptr));
   }

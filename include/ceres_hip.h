@@ -118,8 +118,16 @@ typedef struct ceres_hip_options {
   int32_t max_num_spse_iterations; /* 0 -> 5 (the reference's default)                       */
   int32_t use_spse_initialization; /* start CG from the power-series estimate of S^-1 rhs    */
   double spse_tolerance;           /* for the initialisation; the preconditioner uses 0     */
-  int32_t reserved[2];
+  /* ITERATIVE_SCHUR with LinearSolver::Options::use_explicit_schur_complement:
+   * LinearSolver::Create then returns SparseSchurComplementSolver (I/linear_solver.cc:104-109), which
+   * forms S with SchurEliminator::Eliminate and runs SCHUR_JACOBI-preconditioned CG on it
+   * (SolveReducedLinearSystemUsingConjugateGradients, I/schur_complement_solver.cc:337-408).
+   * Here: S stored DENSE, so only for num_cols_f <= CERES_HIP_MAX_EXPLICIT_SCHUR_COLS;
+   * preconditioner_type must be SCHUR_JACOBI (the reference CHECKs the same).                */
+  int32_t use_explicit_schur_complement;
+  int32_t reserved;
 } ceres_hip_options;
+#define CERES_HIP_MAX_EXPLICIT_SCHUR_COLS 8192
 
 /* ---- LinearSolver::Summary (I/linear_solver.h:320-326) ------------------- */
 typedef struct ceres_hip_summary {
