@@ -97,6 +97,7 @@ struct ceres_hip_solver {
   CgBuffers cg;
   double* cg_rhs = nullptr;
   CgScalars* h_scalars = nullptr;  // pinned
+  double* h_pinned = nullptr;      // pinned scratch, 2 * kMaxVecGrid + 8 doubles (scalar read-backs of the LM step)
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
   // comm
   ncclComm_t comm = nullptr;
@@ -566,41 +567,42 @@ int op_squared_column_norm(ceres_hip_solver* s, double* out) {
 }
 
 // -(J x)'(b + J x / 2) into *host_out.
-int op_model_cost_change(ceres_hip_solver* s, const double* x, double* host_out) {
+// -(J x)'(b + J x / 2): enqueues the kernels; the result is the sum of `*nparts` doubles at
+// `*dev_parts` once the stream has drained (fixed summation order on the host: deterministic).
+int enqueue_model_cost_change(ceres_hip_solver* s, const double* x, const double** dev_parts, int* nparts) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
-  int nparts = 0;
   if (s->path == CERES_HIP_PATH_BAL) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e;
     A.scalar_out = s->scalar_partials;
-    nparts = std::min(s->fused_grid, kMaxVecGrid);
-    HIP_TRY(s, LaunchBalFused(kBalJx, A, false, nparts, st));
-  } else {
-    // model = J x ; partial sums of -model .* (b + model / 2)
-    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
-    HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, nullptr, st));
-    double* t2 = s->scratch_vec + h.num_cols;  // num_rows doubles
-    HIP_TRY(s, LaunchAxpby(-1.0, s->b, -0.5, s->tmp_rows, t2, h.num_rows, st));
-    HIP_TRY(s, LaunchDot(s->tmp_rows, t2, h.num_rows, s->scalar_partials, s->cg.comm, st));
-    double v = 0;
-    HIP_TRY(s, hipMemcpyAsync(&v, s->cg.comm, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(s, hipStreamSynchronize(st));
-    *host_out = v;
+    *nparts = std::min(s->fused_grid, kMaxVecGrid);
+    *dev_parts = s->scalar_partials;
+    HIP_TRY(s, LaunchBalFused(kBalJx, A, false, *nparts, st));
     return 0;
   }
-  std::vector<double> parts(nparts);
-  HIP_TRY(s, hipMemcpyAsync(parts.data(), s->scalar_partials, sizeof(double) * nparts, hipMemcpyDeviceToHost, st));
-  HIP_TRY(s, hipStreamSynchronize(st));
+  // model = J x ; partial sums of -model .* (b + model / 2)
+  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, nullptr, st));
+  double* t2 = s->scratch_vec + h.num_cols;  // num_rows doubles
+  HIP_TRY(s, LaunchAxpby(-1.0, s->b, -0.5, s->tmp_rows, t2, h.num_rows, st));
+  HIP_TRY(s, LaunchDot(s->tmp_rows, t2, h.num_rows, s->scalar_partials, s->cg.comm, st));
+  *nparts = 1;
+  *dev_parts = s->cg.comm;
+  return 0;
+}
+int op_model_cost_change(ceres_hip_solver* s, const double* x, double* host_out) {
+  const double* parts = nullptr;
+  int nparts = 0;
+  TRY(enqueue_model_cost_change(s, x, &parts, &nparts));
+  HIP_TRY(s, hipMemcpyAsync(s->h_pinned, parts, sizeof(double) * nparts, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
   double v = 0;
-  for (double p : parts) v += p;
+  for (int i = 0; i < nparts; ++i) v += s->h_pinned[i];
   *host_out = v;
   return 0;
 }
-
-// Sum a few host scalars over the ranks of a sharded run (rows are partitioned: every rank
-// holds a share of the model cost, and all ranks must take the same finite/non-finite branch).
 int allreduce_host_scalars(ceres_hip_solver* s, double* v, int n) {
   if (s->world <= 1) return 0;
   HIP_TRY(s, hipMemcpyAsync(s->cg.comm, v, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
@@ -1051,6 +1053,10 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
     return nullptr;
   }
   memset(s->h_scalars, 0, sizeof(CgScalars));
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_pinned), sizeof(double) * (2 * kMaxVecGrid + 8), hipHostMallocDefault) != hipSuccess) {
+    fail(nullptr, CERES_HIP_E_HIP, "hipHostMalloc failed");
+    return nullptr;
+  }
   return s.release();
 }
 
@@ -1061,6 +1067,7 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   if (s->comm) (void)ncclCommDestroy(s->comm);
   free_all(s);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
+  if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -1115,7 +1122,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->d_nonfinite, 1));
   TRY(dev_alloc(s, &s->lm_diag, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->lm_D, size_t(h.num_cols)));
-  TRY(dev_alloc(s, &s->scalar_partials, size_t(kMaxVecGrid)));
+  TRY(dev_alloc(s, &s->scalar_partials, size_t(2 * kMaxVecGrid)));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
   if (s->opt.use_explicit_schur_complement) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
@@ -1348,45 +1355,51 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   res->step_is_finite = 0;
   const int term = res->linear_solver.termination_type;
   if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) return 0;
+  // Finite check + negation and the model cost change are enqueued together and read back with ONE
+  // synchronisation (and, sharded, one all-reduce of {flag, cost}); a non-finite step makes the
+  // cost meaningless, it is then ignored.
   HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
   HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
-  int bad = 0;
-  HIP_TRY(s, hipMemcpyAsync(&bad, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+  // parts_local: this rank's share (summed over ranks); parts_shared: replicated quantities (counted once)
+  const double *parts_local = nullptr, *parts_shared = nullptr;
+  int n_local = 0, n_shared = 0;
+  if (!is_schur(s)) {
+    // CGNR: no pass over J is needed.  With y the CG solution (step = -y), g = J^T f and r = g - (J^T J + D^2) y
+    // the residual CG carries:  -(J step)'(f + J step / 2) = y.g - |J y|^2 / 2 = (y.g + y.r + |D y|^2) / 2.
+    if (s->world > 1) {  // the point part is sharded, the camera part replicated
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols_e, s->scalar_partials, &n_local, st));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, h.num_cols_e, h.num_cols, s->scalar_partials + kMaxVecGrid, &n_shared, st));
+      if (h.num_cols_e <= 0) n_local = 0;
+      if (h.num_cols <= h.num_cols_e) n_shared = 0;
+      parts_local = s->scalar_partials;
+      parts_shared = s->scalar_partials + kMaxVecGrid;
+    } else {
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st));
+      if (h.num_cols <= 0) n_shared = 0;
+      parts_shared = s->scalar_partials;
+    }
+  } else {
+    TRY(enqueue_model_cost_change(s, dx, &parts_local, &n_local));  // rows are sharded: every rank holds a share
+  }
+  double* hp = s->h_pinned;
+  int* h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
+  HIP_TRY(s, hipMemcpyAsync(h_flag, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (n_local > 0) HIP_TRY(s, hipMemcpyAsync(hp, parts_local, sizeof(double) * n_local, hipMemcpyDeviceToHost, st));
+  if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
   HIP_TRY(s, hipStreamSynchronize(st));
-  if (s->world > 1) { double b = bad; TRY(allreduce_host_scalars(s, &b, 1)); bad = b != 0.0; }
-  if (bad) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
+  double v[2] = {double(*h_flag != 0), 0.0};
+  for (int i = 0; i < n_local; ++i) v[1] += hp[i];
+  double shared = 0;
+  for (int i = 0; i < n_shared; ++i) shared += hp[kMaxVecGrid + i];
+  TRY(allreduce_host_scalars(s, v, 2));
+  if (v[0] != 0.0) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
     res->linear_solver.termination_type = CERES_HIP_FAILURE;
     snprintf(res->linear_solver.message, sizeof(res->linear_solver.message), "Failed to compute a finite step.");
     return 0;
   }
   res->step_is_finite = 1;
-  if (!is_schur(s)) {
-    // CGNR: no pass over J is needed.  With y the CG solution (step = -y), g = J^T f and r = g - (J^T J + D^2) y
-    // the residual CG carries:  -(J step)'(f + J step / 2) = y.g - |J y|^2 / 2 = (y.g + y.r + |D y|^2) / 2.
-    auto sum_range = [&](int64_t b, int64_t e, double* out) -> int {
-      *out = 0;
-      if (e <= b) return 0;
-      int nparts = 0;
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, b, e, s->scalar_partials, &nparts, st));
-      std::vector<double> parts(nparts);
-      HIP_TRY(s, hipMemcpyAsync(parts.data(), s->scalar_partials, sizeof(double) * nparts, hipMemcpyDeviceToHost, st));
-      HIP_TRY(s, hipStreamSynchronize(st));
-      for (double p : parts) *out += p;
-      return 0;
-    };
-    double local = 0, shared = 0;
-    if (s->world > 1) {  // the point part is sharded, the camera part replicated
-      TRY(sum_range(0, h.num_cols_e, &local));
-      TRY(allreduce_host_scalars(s, &local, 1));
-      TRY(sum_range(h.num_cols_e, h.num_cols, &shared));
-    } else {
-      TRY(sum_range(0, h.num_cols, &shared));
-    }
-    res->model_cost_change = 0.5 * (local + shared);
-    return 0;
-  }
-  TRY(op_model_cost_change(s, dx, &res->model_cost_change));
-  return allreduce_host_scalars(s, &res->model_cost_change, 1);
+  res->model_cost_change = is_schur(s) ? v[1] : 0.5 * (v[1] + shared);
+  return 0;
 }
 }  // namespace
 
