@@ -180,6 +180,7 @@ enum CgStatus {
   kCgFailAlpha = 7,
   kCgZeroRhs = 8,          // |b| = 0: x = 0, SUCCESS
   kCgInitialResidual = 9,  // min_num_iterations == 0 and |r0| <= tol
+  kCgSetupFailed = 10,     // the preconditioner blocks could not be factorized (flag checked by the init kernels, no host round trip)
 };
 
 struct CgScalars {
@@ -203,6 +204,7 @@ struct CgBuffers {
   double* partials = nullptr;  // 4 slots * kMaxVecGrid doubles
   double* comm = nullptr;      // 4 doubles
   CgScalars* S = nullptr;      // device
+  const int* setup_fail = nullptr;  // optional device flag: non-zero => CG starts in kCgSetupFailed
 };
 
 // z = M^-1 r (block-diagonal, or copy when blocks == nullptr) and partial r.z

@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_kernel(CgBuffers B, double 
     S.fail_dir = 0; S.fail_step = 0;
     if (S.norm_rhs == 0.0) S.status = kCgZeroRhs;
     else if (min_it == 0 && S.norm_r <= S.tol_r) S.status = kCgInitialResidual;
+    if (B.setup_fail && *B.setup_fail != 0) S.status = kCgSetupFailed;
   }
 }
 
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_from_guess_finish_kernel(Cg
   S.fail_dir = 0; S.fail_step = 0;
   if (S.norm_rhs == 0.0) S.status = kCgZeroRhs;  // the host zeroes x in that case
   else if (min_it == 0 && S.norm_r <= S.tol_r) S.status = kCgInitialResidual;
+  if (B.setup_fail && *B.setup_fail != 0) S.status = kCgSetupFailed;
 }
 
 // One thread per COLUMN BLOCK (not per scalar): the block's metadata is read once, its

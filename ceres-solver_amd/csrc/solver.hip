@@ -624,6 +624,7 @@ struct CgSpec {
   int first_block = 0, col_begin = 0, nblocks = 0, n_local_blocks = 0;
   const int64_t* diag_off = nullptr;
   const double* blocks = nullptr;                       // nullptr = IDENTITY
+  const int* setup_fail = nullptr;  // device flag raised by the preconditioner set-up; checked on the device by the CG init kernels
 };
 
 void fill_summary(const CgScalars& S, int device_status, ceres_hip_summary* out) {
@@ -656,6 +657,9 @@ void fill_summary(const CgScalars& S, int device_status, ceres_hip_summary* out)
     case kCgIndefinite:
       out->termination_type = CERES_HIP_NO_CONVERGENCE;
       snprintf(m, n, "Matrix is indefinite, no more progress can be made. p'q = %e.", S.pq); break;
+    case kCgSetupFailed:  // Preconditioner::Update returned false, I/iterative_schur_complement_solver.cc:113-121, I/cgnr_solver.cc:176-183
+      out->termination_type = CERES_HIP_FAILURE; out->num_iterations = 0;
+      snprintf(m, n, "Preconditioner update failed."); break;
     case kCgFailAlpha:
       out->termination_type = CERES_HIP_FAILURE;
       snprintf(m, n, "Numerical failure. alpha = rho / pq = %e, rho = %e, pq = %e.", S.alpha, S.rho_new, S.pq); break;
@@ -684,6 +688,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   B.n = spec.n;
   B.n_local = (s->world > 1) ? spec.n_local : 0;
   B.rhs = s->cg_rhs;
+  B.setup_fail = spec.setup_fail;
   auto grid_for = [](int64_t n, int cap) {
     int64_t g = (n + int64_t(kVecBlock) * 4 - 1) / (int64_t(kVecBlock) * 4);
     return int(std::max<int64_t>(1, std::min<int64_t>(g, cap)));
@@ -889,13 +894,18 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
         return 0;
       }
     }
+    // On the fused path the factorization flag of the preconditioner blocks is not read back here
+    // (a host round trip in front of CG): the CG init kernel looks at it and starts in kCgSetupFailed.
+    const bool defer_check = s->path == CERES_HIP_PATH_BAL;
     if (pre != CERES_HIP_IDENTITY && !spse_pre) {
       TRY(op_preconditioner(s, pre, s->precond, true));
-      TRY(check_factorization(s, &bad));
-      if (bad) {  // Preconditioner::Update returned false, :113-121
-        summary->termination_type = CERES_HIP_FAILURE;
-        snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
-        return 0;
+      if (!defer_check) {
+        TRY(check_factorization(s, &bad));
+        if (bad) {  // Preconditioner::Update returned false, :113-121
+          summary->termination_type = CERES_HIP_FAILURE;
+          snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+          return 0;
+        }
       }
       s->precond_valid = true;
     }
@@ -911,6 +921,7 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     spec.col_begin = h.num_cols_e;
     spec.diag_off = s->G.diag_off_f;
     spec.blocks = (pre == CERES_HIP_IDENTITY || spse_pre) ? nullptr : s->precond;
+    if (defer_check && spec.blocks) spec.setup_fail = s->d_fail_flag;
     if (spse_pre)  // tolerance 0: the preconditioner must stay fixed during CG (:178-186)
       spec.precondition = [s, spse_iters, status](const double* in, double* out) { return op_spse_apply(s, in, out, spse_iters, 0.0, status); };
     if (s->opt.use_spse_initialization) {  // :97-111
@@ -933,13 +944,16 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     if (pre == CERES_HIP_JACOBI) TRY(op_preconditioner(s, pre, s->precond, true));
     TRY(op_jtb(s, s->cg_rhs));
   }
+  const bool defer_check = s->path == CERES_HIP_PATH_BAL;  // see the ITERATIVE_SCHUR branch
   if (pre == CERES_HIP_JACOBI) {
-    bool bad = false;
-    TRY(check_factorization(s, &bad));
-    if (bad) {
-      summary->termination_type = CERES_HIP_FAILURE;
-      snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
-      return 0;
+    if (!defer_check) {
+      bool bad = false;
+      TRY(check_factorization(s, &bad));
+      if (bad) {
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+        return 0;
+      }
     }
     s->precond_valid = true;
   }
@@ -955,6 +969,7 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   spec.col_begin = 0;
   spec.diag_off = s->G.diag_off_all;
   spec.blocks = pre == CERES_HIP_JACOBI ? s->precond : nullptr;
+  if (defer_check && spec.blocks) spec.setup_fail = s->d_fail_flag;
   TRY(run_cg(s, spec, q_tol, r_tol, summary));
   HIP_TRY(s, hipEventRecord(s->ev[5], st));
   HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));

@@ -122,3 +122,26 @@ def test_indefinite_and_failure_paths(hip, problems):
     x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=None, q_tolerance=0.0, r_tolerance=1e-10))
     assert summ.termination_type == hip.FAILURE and np.isnan(x).all(), summ
     s.close()
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("solver_type,pre", [(6, 1), (5, 2)])
+def test_singular_preconditioner_block_is_a_failure(hip, problems, solver_type, pre, force_generic):
+    # Preconditioner::Update returning false ends the solve with FAILURE
+    # (iterative_schur_complement_solver.cc:113-121, cgnr_solver.cc:176-183).  One camera with an all-zero
+    # Jacobian and no regularisation: its JACOBI / SCHUR_JACOBI block is singular.  On the fused path the
+    # flag is consumed on the device by the CG init kernel (no host round trip before CG).
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=9, num_points=200, num_observations=900, seed=5)
+    cam0 = int(p.camera_of_row.min())
+    rows = np.nonzero(p.camera_of_row == cam0)[0]
+    fpos = p.bs.cell_value_pos[1::2][rows].astype(np.int64)
+    vals = p.values.copy()
+    vals[(fpos[:, None] + np.arange(18)[None, :]).reshape(-1)] = 0.0
+    s = make_solver(hip, p, solver_type, pre, force_generic, max_it=50)
+    x, summ = s.solve(vals, p.b, hip.PerSolveOptions(D=None, q_tolerance=0.0, r_tolerance=1e-10))
+    assert summ.termination_type == hip.FAILURE, summ
+    assert "Preconditioner update failed" in summ.message
+    # the instance stays usable
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-10))
+    assert summ.termination_type == hip.SUCCESS
+    s.close()
