@@ -541,10 +541,18 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
     seg_scan<3>(u, lane, s.first, span);
-    if (s.valid && lane == s.last) {
-      double v[3];
-      sym3_mul(ei, u, v);
-      A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2];
+    double v[3];
+    sym3_mul(ei, u, v);  // the point's solution on the last lane of its segment
+    if (s.valid && lane == s.last) { A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
+    if (A.scalar_out) {
+      // Model cost change of the trust-region step -x, fused: with m = J x of this observation
+      // (F z + E y, y broadcast from the segment's last lane), -(J step)'(f + J step / 2) = m'(f - m / 2).
+      // I/trust_region_minimizer.cc:420-438; saves the separate pass over J (kJx) per LM step.
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[j] = shfl_idx(v[j], s.last);
+      const double m0 = (s.b0 - t0) + s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+      const double m1 = (s.b1 - t1) + s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+      if (s.valid) lane_acc += m0 * (s.b0 - 0.5 * m0) + m1 * (s.b1 - 0.5 * m1);
     }
   }
 }
@@ -553,7 +561,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
 // Sweep 1 accumulates the per-point sums over all its tiles, sweep 2 (only where the
 // per-observation result depends on them) re-reads the tiles, which are L2-warm.
 template <int MODE, bool LDS, bool F32>
-__device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t tile, int nt, int lane, double* acc) {
+__device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t tile, int nt, int lane, double* acc, double& lane_acc) {
   Slot s;
   if constexpr (MODE == kColNorm) {
     double w[3] = {0, 0, 0};
@@ -587,6 +595,18 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     sym3_mul(ei, u, v);
     if constexpr (MODE == kBackSub) {
       if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
+      if (A.scalar_out) {  // fused model cost change: second sweep over the point's (L2-warm) tiles
+        for (int t = 0; t < nt; ++t) {
+          load_slot<false, F32>(A, tile + t, lane, s, true, false);
+          double xc[9];
+          load_xc(A, s.cam, xc);
+          double t0, t1;
+          f_times(s, xc, t0, t1);
+          const double m0 = t0 + s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+          const double m1 = t1 + s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+          if (s.valid) lane_acc += m0 * (s.b0 - 0.5 * m0) + m1 * (s.b1 - 0.5 * m1);
+        }
+      }
     } else {
       for (int t = 0; t < nt; ++t) {
         load_slot<false, F32>(A, tile + t, lane, s, false, false);
@@ -697,10 +717,10 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     } else {
       if (kind == 2) continue;
       if (kind == 0) process_tile<MODE, LDS, F32>(A, tile, lane, aux & 0xff, aux >> 8, acc, lane_acc);
-      else process_long_point<MODE, LDS, F32>(A, tile, aux, lane, acc);
+      else process_long_point<MODE, LDS, F32>(A, tile, aux, lane, acc, lane_acc);
     }
   }
-  if constexpr (MODE == kJx) {  // one partial per workgroup, summed in fixed order by the caller
+  if (MODE == kJx || (MODE == kBackSub && A.scalar_out)) {  // one partial per workgroup, summed in fixed order by the caller
     __shared__ double red[16];
     double v = lane_acc;
 #pragma unroll
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   // Points with more than 64 observations own whole tiles (kind 1 = head, 2 = continuation);
   // they are rare and are handled outside the pipelined loop to keep its register footprint down.
   for (int64_t tile = wave0; tile < A.n_tiles; tile += nwaves) {
-    if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc);
+    if (A.tile_kind[tile] == 1) { double unused = 0.0; process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, unused); }
   }
   if constexpr (LDS) {
     __syncthreads();

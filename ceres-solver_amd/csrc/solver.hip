@@ -64,6 +64,8 @@ struct ceres_hip_solver {
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
   bool have_lm_diag = false;
+  bool lm_want_model_cost = false;  // op_back_substitute also accumulates the model cost change (fused <2,3,9> path)
+  int backsub_cost_parts = 0;       // partials it left in scalar_partials
   bool lm_fuse_active = false;      // this step forms D inside the set-up kernels (no separate column-norm pass)
   ceres_hip_lm_options lm_opts{};
   double* d_camsq = nullptr;
@@ -364,6 +366,9 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_f = z; A.y_e = x;
+    // f1: the LM step wants the model cost change of -x; the kernel has J x in hand (one partial per workgroup)
+    s->backsub_cost_parts = 0;
+    if (s->lm_want_model_cost && z != nullptr) { A.scalar_out = s->scalar_partials; s->backsub_cost_parts = s->fused_grid; }
     HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
   } else {
     HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
@@ -1364,8 +1369,11 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   s->have_lm_diag = true;
   s->D = s->lm_D;
   s->have_D = true;
+  s->lm_want_model_cost = is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->fused_grid <= 2 * kMaxVecGrid;
+  s->backsub_cost_parts = 0;
   const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
   s->lm_fuse_active = false;
+  s->lm_want_model_cost = false;
   if (rc) return rc;
   res->step_is_finite = 0;
   const int term = res->linear_solver.termination_type;
@@ -1393,6 +1401,9 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
       if (h.num_cols <= 0) n_shared = 0;
       parts_shared = s->scalar_partials;
     }
+  } else if (s->backsub_cost_parts > 0) {  // the back-substitution kernel already formed it
+    parts_local = s->scalar_partials;
+    n_local = s->backsub_cost_parts;
   } else {
     TRY(enqueue_model_cost_change(s, dx, &parts_local, &n_local));  // rows are sharded: every rank holds a share
   }
