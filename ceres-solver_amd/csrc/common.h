@@ -67,6 +67,7 @@ struct BalPlan {
   std::vector<uint32_t> slot_seg;
   // per tile: 0 normal (tile_aux = longest track | #points<<8), 1 head of a long point (tile_aux = #tiles), 2 continuation
   std::vector<int32_t> tile_kind, tile_aux;
+  std::vector<int32_t> tile_pt0;  // point id of lane 0 of each tile (every tile's lane 0 is a valid slot)
   // camera-major lists
   std::vector<int32_t> cam_ptr;    // n_cameras+1
   std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major

@@ -32,7 +32,7 @@ struct BalArgs {
   float4* Jf_out = nullptr;
   double2* b_out = nullptr;
   const int32_t* slot_cam = nullptr;
-  const int32_t* slot_pt = nullptr;
+  const int32_t* tile_pt0 = nullptr;  // first point id of each tile (points of a tile are consecutive ids)
   const uint32_t* slot_seg = nullptr;
   const int32_t* tile_kind = nullptr;
   const int32_t* tile_aux = nullptr;

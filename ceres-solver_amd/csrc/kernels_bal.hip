@@ -102,11 +102,18 @@ struct Slot {
   bool valid;
 };
 
-__device__ __forceinline__ void finish_slot(Slot& s) {
+// Derives the fields of a slot from its segment word.  The point id is not stored per slot (it was:
+// 4 of 204 bytes per observation): points of a tile are consecutive ids starting at tile_pt0, so a
+// slot's point is pt0 + (number of segment heads at or below its lane) - 1.  Tiles of a long point
+// have one segment: every lane gets pt0.
+__device__ __forceinline__ void finish_slot(Slot& s, int lane, int pt0) {
   const uint32_t sg = s.seg;
   s.first = sg & 0xff;
   s.last = (sg >> 8) & 0xff;
   s.valid = (sg >> 16) & 1;
+  const unsigned long long heads = __ballot(s.valid && lane == s.first);
+  const int rank = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
+  s.pt = pt0 + rank;
   if (!s.valid) { s.cam = 0; s.pt = 0; }
 }
 
@@ -178,19 +185,17 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
     for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
   }
   s.cam = A.slot_cam[sl];
-  s.pt = A.slot_pt[sl];
   s.seg = A.slot_seg[sl];
-  finish_slot(s);
+  finish_slot(s, lane, A.tile_pt0[tile]);
 }
 
 // The software-pipelined streaming kernel splits a slot load in three, each of which only ISSUES
 // loads and consumes nothing: the index words (SlotIdx), the 12 pairs of a packed fp64 tile
 // (issue_pairs), and what is addressed THROUGH the index words (issue_aux, further down).
-struct SlotIdx { int cam, pt; uint32_t seg; };
+struct SlotIdx { int cam; uint32_t seg; };
 __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
   const int64_t sl = tile * kTile + lane;
   i.cam = A.slot_cam[sl];
-  i.pt = A.slot_pt[sl];
   i.seg = A.slot_seg[sl];
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
@@ -815,8 +820,8 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     __builtin_amdgcn_sched_barrier(0);
     issue_pairs(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
-    sa.cam = i2.cam; sa.pt = i2.pt; sa.seg = i2.seg;
-    finish_slot(sa);
+    sa.cam = i2.cam; sa.seg = i2.seg;
+    finish_slot(sa, lane, A.tile_pt0[tile]);
     issue_aux<MODE>(A, sa, lane, kind_a == 0 ? aux_a >> 8 : 0, xa);
     __builtin_amdgcn_sched_barrier(0);
     bool more = true;
@@ -830,8 +835,8 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       __builtin_amdgcn_sched_barrier(0);
       issue_pairs(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);
-      n.cam = i1.cam; n.pt = i1.pt; n.seg = i1.seg;
-      finish_slot(n);
+      n.cam = i1.cam; n.seg = i1.seg;
+      finish_slot(n, lane, A.tile_pt0[next]);
       issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
       __builtin_amdgcn_sched_barrier(0);
       if (ckind != 0) c.valid = false;  // long points are handled below; their seg words carry no store bits

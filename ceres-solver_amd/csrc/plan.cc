@@ -254,6 +254,8 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
     used += k;
   }
   P.n_tiles = int64_t(P.tile_kind.size());
+  P.tile_pt0.resize(P.n_tiles);
+  for (int64_t t = 0; t < P.n_tiles; ++t) P.tile_pt0[t] = P.slot_pt[t * kTile];
   // Normal tiles: tile_aux = longest track in the tile (bounds the segmented-scan steps).
   for (int64_t t = 0; t < P.n_tiles; ++t) {
     if (P.tile_kind[t] != 0) continue;

@@ -55,7 +55,7 @@ struct ceres_hip_solver {
   // structure on device
   GenStructure G;
   // BAL plan on device
-  int32_t *d_slot_epos = nullptr, *d_slot_fpos = nullptr, *d_slot_bpos = nullptr, *d_slot_cam = nullptr, *d_slot_pt = nullptr;
+  int32_t *d_slot_epos = nullptr, *d_slot_fpos = nullptr, *d_slot_bpos = nullptr, *d_slot_cam = nullptr, *d_tile_pt0 = nullptr;
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
@@ -174,7 +174,7 @@ bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HI
 BalArgs bal_args(ceres_hip_solver* s) {
   BalArgs A;
   A.J = s->d_J; A.Jf = s->d_Jf; A.b = s->d_bt;
-  A.slot_cam = s->d_slot_cam; A.slot_pt = s->d_slot_pt; A.slot_seg = s->d_slot_seg;
+  A.slot_cam = s->d_slot_cam; A.tile_pt0 = s->d_tile_pt0; A.slot_seg = s->d_slot_seg;
   A.tile_kind = s->d_tile_kind; A.tile_aux = s->d_tile_aux;
   A.n_tiles = s->plan.n_tiles; A.n_slots = s->plan.n_tiles * kTile;
   A.pt_pos = s->plan.contiguous_layout ? nullptr : s->d_pt_pos;
@@ -1168,7 +1168,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_slot_fpos, P.slot_fpos));
     TRY(dev_upload(s, &s->d_slot_bpos, P.slot_bpos));
     TRY(dev_upload(s, &s->d_slot_cam, P.slot_cam));
-    TRY(dev_upload(s, &s->d_slot_pt, P.slot_pt));
+    TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
     TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));
     TRY(dev_upload(s, &s->d_tile_aux, P.tile_aux));
