@@ -589,6 +589,14 @@ class BalProblem:
         self._check(self._lib.ceres_hip_bal_sizes(self._h, byref(n), byref(m), byref(v)))
         self.num_parameters, self.num_residuals, self.num_jacobian_values = n.value, m.value, v.value
 
+    @classmethod
+    def from_file(cls, options: LinearSolverOptions, filename):
+        """BALProblem(filename) (examples/bal_problem.cc:75-135).  Returns (problem, initial state)."""
+        from . import problems
+        nc, npts, cam, pt, obs, par = problems.read_bal(filename)
+        p = cls(options, nc, npts, cam, pt, obs)
+        return p, p.state_from_bal(par)
+
     def _check(self, rc):
         if rc != 0:
             raise HipError(f"ceres_hip error {rc}: {self._lib.ceres_hip_bal_last_error(self._h).decode()}")

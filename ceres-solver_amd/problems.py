@@ -492,3 +492,36 @@ def bal_scene(shape="dubrovnik16", seed=38401, skew=0.0, num_cameras=None, num_p
         obs[lo:hi] = _snavely(cams_true[cam[lo:hi]], pts_true[pt[lo:hi]], False) + pixel_noise * rng.standard_normal((hi - lo, 2))
     return n_cams, n_points, cam.astype(np.int32), pt.astype(np.int32), obs, np.concatenate([cams0.reshape(-1), pts0.reshape(-1)])
 
+
+def read_bal(filename):
+    """BAL text format (examples/bal_problem.cc:75-135): "num_cameras num_points num_observations", then one
+    "camera point x y" line per observation, then 9 doubles per camera and 3 per point, whitespace-separated.
+    Returns the tuple `bal_scene` returns: (num_cameras, num_points, camera_index, point_index, observations, parameters)."""
+    with open(filename, "rb") as f:
+        tok = np.array(f.read().split())
+    if tok.shape[0] < 3:
+        raise ValueError(f"{filename}: not a BAL file")
+    n_cams, n_points, n_obs = (int(t) for t in tok[:3])
+    need = 3 + 4 * n_obs + 9 * n_cams + 3 * n_points
+    if tok.shape[0] < need:
+        raise ValueError(f"{filename}: {tok.shape[0]} tokens, the header promises {need}")
+    body = tok[3:3 + 4 * n_obs].reshape(n_obs, 4)
+    cam = body[:, 0].astype(np.int64).astype(np.int32)
+    pt = body[:, 1].astype(np.int64).astype(np.int32)
+    obs = body[:, 2:].astype(np.float64)
+    params = tok[3 + 4 * n_obs:need].astype(np.float64)
+    if n_obs and (cam.min() < 0 or cam.max() >= n_cams or pt.min() < 0 or pt.max() >= n_points):
+        raise ValueError(f"{filename}: observation index out of range")
+    return n_cams, n_points, cam, pt, np.ascontiguousarray(obs), params
+
+
+def write_bal(filename, num_cameras, num_points, camera_index, point_index, observations, parameters):
+    """Inverse of `read_bal` (BALProblem::WriteToFile, examples/bal_problem.cc:137-167)."""
+    obs = np.asarray(observations, dtype=np.float64).reshape(-1, 2)
+    with open(filename, "w") as f:
+        f.write(f"{int(num_cameras)} {int(num_points)} {obs.shape[0]}\n")
+        for c, q, (x, y) in zip(np.asarray(camera_index).tolist(), np.asarray(point_index).tolist(), obs.tolist()):
+            f.write(f"{c} {q} {x:.16e} {y:.16e}\n")
+        for v in np.asarray(parameters, dtype=np.float64).tolist():
+            f.write(f"{v:.16e}\n")
+

@@ -128,3 +128,15 @@ def test_create_rejects_bad_indices(hip):
     o = hip.LinearSolverOptions(type=5, preconditioner_type=2, max_num_iterations=10)
     with pytest.raises(hip.HipError):
         hip.BalProblem(o, 2, 3, [0, 1, 2], [0, 1, 2], np.zeros(6))
+
+
+def test_problem_from_bal_file(hip, oracle, tmp_path):
+    op = oracle.BalProblem.generate(6, 90, 420, seed=13)
+    op.build_structure(True)
+    f = str(tmp_path / "problem.txt")
+    assert op.write(f) == 0
+    o = hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, max_num_iterations=100)
+    gp, x0 = hip.BalProblem.from_file(o, f)
+    np.testing.assert_allclose(x0, op.state(), rtol=1e-15)
+    assert gp.evaluate(x0)[0] == pytest.approx(op.evaluate(op.state())[0], rel=1e-13)
+    gp.close()

@@ -59,3 +59,26 @@ def test_lm_reduces_cost_with_both_solvers(oracle):
         costs[name] = S.final_cost
     # both solvers minimise the same function: final costs close (inexact Newton, so not identical)
     assert abs(costs["cgnr"] - costs["iterative_schur"]) < 0.05 * costs["cgnr"]
+
+
+def test_product_side_bal_reader_agrees_with_the_oracle_reader(oracle, problems, tmp_path):
+    # ceres-solver_amd/problems.py::read_bal / write_bal (examples/bal_problem.cc:75-167) vs oracle/bal_harness.cc
+    prob = oracle.BalProblem.generate(5, 40, 170, seed=8)
+    f = str(tmp_path / "a.txt")
+    assert prob.write(f) == 0
+    nc, npts, cam, pt, obs, par = problems.read_bal(f)
+    c0, p0, o0 = prob.indices()
+    assert (nc, npts) == (5, 40)
+    np.testing.assert_array_equal(cam, c0)
+    np.testing.assert_array_equal(pt, p0)
+    np.testing.assert_allclose(obs, o0, rtol=1e-15)
+    g = str(tmp_path / "b.txt")
+    problems.write_bal(g, nc, npts, cam, pt, obs, par)
+    back = oracle.BalProblem.read(g)
+    prob.build_structure(True)
+    back.build_structure(True)
+    np.testing.assert_allclose(back.state(), prob.state(), rtol=1e-15)
+    import pytest
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.txt").write_text("2 3 4\n0 0 1.0 2.0\n")
+        problems.read_bal(str(tmp_path / "bad.txt"))
