@@ -597,17 +597,6 @@ int enqueue_model_cost_change(ceres_hip_solver* s, const double* x, const double
   *dev_parts = s->cg.comm;
   return 0;
 }
-int op_model_cost_change(ceres_hip_solver* s, const double* x, double* host_out) {
-  const double* parts = nullptr;
-  int nparts = 0;
-  TRY(enqueue_model_cost_change(s, x, &parts, &nparts));
-  HIP_TRY(s, hipMemcpyAsync(s->h_pinned, parts, sizeof(double) * nparts, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  double v = 0;
-  for (int i = 0; i < nparts; ++i) v += s->h_pinned[i];
-  *host_out = v;
-  return 0;
-}
 int allreduce_host_scalars(ceres_hip_solver* s, double* v, int n) {
   if (s->world <= 1) return 0;
   HIP_TRY(s, hipMemcpyAsync(s->cg.comm, v, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
