@@ -58,7 +58,7 @@ struct BalArgs {
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
-  double2* zbuf = nullptr;       // [n_slots]      (cameras do not fit in LDS: z per slot, second pass by camera)
+  double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
@@ -95,7 +95,7 @@ hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItem
                                  const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, double* camsq,
                                  hipStream_t stream);
 hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double2* zbuf, double* out, const int* status,
+                                const int32_t* cam_slot, const double* zbuf, double* out, const int* status,
                                 hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             hipStream_t stream);

@@ -245,9 +245,9 @@ __device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], do
   for (int k = 0; k < 9; ++k) { t0 += s.f[k] * xc[k]; t1 += s.f[9 + k] * xc[k]; }
 }
 // Camera-space contribution F^T z of one observation.  LDS: nine ds_add_f64 into the
-// workgroup's accumulator.  Otherwise (cameras do not fit in LDS) only z is stored, 16 bytes
-// per slot, and bal_camera_apply_kernel forms F^T z camera by camera in a second pass —
-// global fp64 atomics on a few thousand hot addresses are an order of magnitude slower.
+// workgroup's accumulator.  Otherwise (cameras do not fit in LDS) the nine products are stored per
+// slot and bal_camera_apply_kernel sums them camera by camera in a second pass — global fp64
+// atomics on a few thousand hot addresses are an order of magnitude slower.
 template <bool LDS>
 __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
   if (!s.valid) return;
@@ -256,7 +256,12 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);  // ds_add_f64
   } else {
-    reinterpret_cast<double2*>(acc)[s.slot] = make_double2(z0, z1);
+    // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
+    // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
+    // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
+    double* w = acc + 9 * s.slot;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = s.f[k] * z0 + s.f[9 + k] * z1;
   }
 }
 
@@ -1076,7 +1081,7 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
                                                                const int32_t* __restrict__ cam_ptr,
                                                                const int32_t* __restrict__ cam_fpos,
                                                                const int32_t* __restrict__ cam_slot,
-                                                               const double2* __restrict__ zbuf,
+                                                               const double* __restrict__ zbuf,
                                                                double* __restrict__ out, const int* __restrict__ status) {
   if (status && *status != 0) return;
   const int lane = threadIdx.x & 63;
@@ -1088,10 +1093,9 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   for (int q = beg + lane; q < end; q += 64) {
-    const double* f = values + cam_fpos[q];
-    const double2 z = zbuf[cam_slot[q]];
+    const double* w = zbuf + 9 * int64_t(cam_slot[q]);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] += f[k] * z.x + f[9 + k] * z.y;
+    for (int k = 0; k < 9; ++k) acc[k] += w[k];
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -1341,7 +1345,7 @@ hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItem
 }
 
 hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double2* zbuf, double* out, const int* status,
+                                const int32_t* cam_slot, const double* zbuf, double* out, const int* status,
                                 hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
   hipLaunchKernelGGL(bal_camera_apply_kernel, dim3((items.count + 3) / 4), dim3(256), 0, stream, values, items, cam_ptr,

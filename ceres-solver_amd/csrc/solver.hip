@@ -73,7 +73,7 @@ struct ceres_hip_solver {
   double2 *d_J = nullptr, *d_bt = nullptr;
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
-  double2* d_zbuf = nullptr;
+  double* d_zbuf = nullptr;
   int bal_flags = 0;
   bool use_xpad = false;
   bool lds_mode = false;
@@ -1192,7 +1192,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
-    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? 1 : n_slots));
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(n_slots) * 9));
     TRY(dev_alloc(s, &s->d_xpad, size_t(10) * P.n_cameras));
     TRY(dev_alloc(s, &s->d_camsq, n9));
     {  // measured alternative (16-byte aligned padded camera gathers); off by default: no gain
