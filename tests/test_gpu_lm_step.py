@@ -22,13 +22,16 @@ def reference_step(oracle, hip, p, solver_type, pre, radius, eta, diag=None, max
     return step, s, -model @ (p.b + model / 2.0), D, diag
 
 
-CASES = [("bal_schur", 5, 2), ("bal_schur", 6, 1), ("bal_cgnr", 6, 1), ("general", 5, 2), ("general", 6, 1)]
+CASES = [("bal_schur", 5, 2), ("bal_schur", 6, 1), ("bal_cgnr", 6, 1), ("general", 5, 2), ("general", 6, 1),
+         ("bal_many_cameras", 5, 2), ("bal_many_cameras", 6, 1)]
 
 
 @pytest.mark.parametrize("kind,solver_type,pre", CASES)
 def test_lm_compute_step_matches_reference(hip, oracle, problems, kind, solver_type, pre):
     if kind == "bal_schur":
         p = problems.synthetic_bal(None, layout="schur", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
+    elif kind == "bal_many_cameras":  # > 2275 cameras: the camera accumulators leave LDS (per-slot F^T z + camera-major pass)
+        p = problems.synthetic_bal(None, layout="schur", num_cameras=2500, num_points=12000, num_observations=62000, seed=43, skew=0.4)
     elif kind == "bal_cgnr":
         p = problems.synthetic_bal(None, layout="cgnr", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
     else:
@@ -37,6 +40,8 @@ def test_lm_compute_step_matches_reference(hip, oracle, problems, kind, solver_t
         p.num_eliminate_blocks = 0
     s = make_solver(hip, p, solver_type, pre, max_it=500)
     assert s.info().kernel_path == (hip.PATH_GENERIC if kind == "general" else hip.PATH_BAL)
+    if kind != "general":
+        assert s.info().camera_accum_in_lds == (0 if kind == "bal_many_cameras" else 1)
     radius, eta = 1e4, 0.1
     step, summ, model_cost_change = s.lm_compute_step(p.values, p.b, radius, eta)
     ref_step, ref_summ, ref_mcc, ref_D, diag = reference_step(oracle, hip, p, solver_type, pre, radius, eta)
