@@ -157,3 +157,26 @@ def test_bal_scene_generator_is_a_consistent_bal_problem(problems):
     assert np.sqrt((r * r).mean()) < 60.0   # pixels: perturbed start, not garbage
     again = problems.bal_scene(None, num_cameras=12, num_points=400, num_observations=1900, seed=7, skew=0.5)
     np.testing.assert_array_equal(again[4], obs)
+
+
+@pytest.mark.parametrize("seed,nc,npts,nobs,skew", [(1, 12, 900, 4000, 0.0), (2, 300, 250, 9000, 0.0), (3, 60, 5000, 21000, 0.7)])
+def test_point_ids_are_recoverable_from_the_segment_words(problems, seed, nc, npts, nobs, skew):
+    # The kernels do not load a per-slot point id: finish_slot() (csrc/kernels_bal.hip) rebuilds it as
+    # tile_pt0 + (number of segment heads at or below the lane) - 1, tile_pt0 = point of lane 0.  Emulate
+    # that on the plan (normal tiles, and the one-segment tiles of long points) and compare with slot_pt.
+    p = problems.synthetic_bal(None, num_cameras=nc, num_points=npts, num_observations=nobs, seed=seed, skew=skew)
+    plan = plan_of(p)
+    nt = plan["n_tiles"]
+    valid = plan["valid"].astype(bool).reshape(nt, 64)
+    first = plan["seg_first"].astype(int).reshape(nt, 64)
+    pt = plan["slot_pt"].reshape(nt, 64)
+    lane = np.arange(64)[None, :]
+    assert valid[:, 0].all()                          # lane 0 of every tile is a valid slot
+    heads = valid & (first == lane)
+    rank = np.cumsum(heads, axis=1) - 1               # popcount(ballot(heads) & mask_le(lane)) - 1
+    rebuilt = pt[:, :1] + rank
+    assert np.array_equal(rebuilt[valid], pt[valid])
+    # valid slots are a prefix of the tile (no holes), so the heads seen below a lane are exactly its predecessors
+    assert (np.diff(valid.astype(int), axis=1) <= 0).all()
+    if nc >= 100:
+        assert (plan["tile_kind"] == 1).any()        # the long-point case is exercised
