@@ -406,7 +406,9 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
                                        (fuse && schur) ? s->d_camsq : nullptr, st));
       if (s->world > 1) {
         TRY(allreduce(s, out, size_t(len)));
-        if (D_f) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
+        if (fuse && schur) TRY(allreduce(s, s->d_camsq, size_t(9) * s->plan.n_cameras));  // column norms of the camera columns
+        // fused LM diagonal: D_f does not exist yet, bal_invert9_kernel forms it from the reduced sums and adds it
+        if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
       }
       if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), st));
     } else {
@@ -481,7 +483,8 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
                                      nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, st));
     const int64_t first = h.diag_off_all[h.nelim];
     TRY(allreduce(s, blocks + first, size_t(len - first)));
-    if (s->D) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
+    if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
+      HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
   }
   HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), st));
   return 0;
@@ -1349,8 +1352,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   // (the point block's own diagonal; the camera columns' norms in the camera-major pass): then D
   // is formed inside them and no separate column-norm pass runs.
   const bool fresh = !o->reuse_diagonal || !s->have_lm_diag;
-  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->world <= 1 &&
-                      s->opt.preconditioner_type != CERES_HIP_IDENTITY;
+  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->opt.preconditioner_type != CERES_HIP_IDENTITY;
   s->lm_opts = *o;
   if (fresh && !s->lm_fuse_active) TRY(op_squared_column_norm(s, s->lm_diag));
   if (!s->lm_fuse_active)

@@ -106,7 +106,7 @@ def test_scale_columns_and_column_norms(hip, oracle, problems, kind):
 
 @pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
 def test_lm_step_sharded_code_paths_in_loopback(hip, problems, solver_type, pre):
-    # world > 1 branches of the LM step (column norms via the generic kernel + all-reduce, model cost and
+    # world > 1 branches of the LM step (fused LM diagonal from all-reduced sums, model cost and
     # finite flag summed over ranks) through a 1-rank RCCL communicator: must equal the unsharded step
     p = problems.synthetic_bal(None, num_cameras=25, num_points=1500, num_observations=7000, seed=46)
     o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=300,
@@ -119,5 +119,12 @@ def test_lm_step_sharded_code_paths_in_loopback(hip, problems, solver_type, pre)
     assert rel(loop.lm_diagonal(), ref.lm_diagonal()) <= 1e-13
     assert a[1].termination_type == b[1].termination_type == hip.SUCCESS and a[1].num_iterations == b[1].num_iterations
     assert rel(b[0], a[0]) <= 1e-10 and abs(a[2] - b[2]) <= 1e-10 * abs(a[2])
+    # a rejected step (diagonal reused, radius halved) and a fresh one again: fused and unfused LM diagonals alternate
+    for radius, reuse in ((5e3, True), (2e4, False)):
+        a = ref.lm_compute_step(p.values * 1.25, p.b, radius, 0.1, reuse_diagonal=reuse)
+        b = loop.lm_compute_step(p.values * 1.25, p.b, radius, 0.1, reuse_diagonal=reuse)
+        assert rel(loop.lm_diagonal(), ref.lm_diagonal()) <= 1e-13
+        assert a[1].num_iterations == b[1].num_iterations
+        assert rel(b[0], a[0]) <= 1e-10 and abs(a[2] - b[2]) <= 1e-10 * abs(a[2])
     ref.close()
     loop.close()
