@@ -15,9 +15,12 @@ this path.
 
 Workload (config.workload): synthetic BAL-shaped Jacobian with Venice-1778's block counts
 (1778 cameras, 993923 points, 5001946 observations; SURVEY.md §8d generator, seed 38401) —
-the configuration BASELINE.json's targets are quoted on.  Default solver: CGNR + JACOBI,
-whose dominant kernel is the fused JtJx SpMV the metric names; `--solver iterative_schur`
-switches to ITERATIVE_SCHUR + SCHUR_JACOBI (dominant kernel: fused S·x).
+the configuration BASELINE.json's targets are quoted on.  Default solver: ITERATIVE_SCHUR +
+SCHUR_JACOBI (BASELINE.json configs[0] and [2]; dominant kernel: the fused implicit Schur product
+S·x); `--solver cgnr` switches to CGNR + JACOBI (dominant kernel: the fused JtJx SpMV).  With
+`--both-solvers 1` (default, N = 1) the other solver is measured in the same run: `extra` carries its
+step rate and the line carries BOTH rooflines (`roofline` for the timed solver's operator,
+`roofline_jtjx` / `roofline_sx` for the other).
 
 N > 1 (strong scaling): the SAME problem sharded by point across the ranks
 (ceres-solver_amd/partition.py); camera-space sums and the CGNR inner products go through
@@ -57,7 +60,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="venice1778", choices=["dubrovnik16", "ladybug1723", "venice1778"])
-    ap.add_argument("--solver", default="cgnr", choices=["cgnr", "iterative_schur"])
+    ap.add_argument("--solver", default="iterative_schur", choices=["cgnr", "iterative_schur"])
     ap.add_argument("--skew", type=float, default=0.6, help="power-law exponent of camera popularity")
     ap.add_argument("--step", default="lm_step", choices=["lm_step", "linear_solve"],
                     help="lm_step: LevenbergMarquardtStrategy::ComputeStep on the device (diag(J'J), D, Solve, finite check, "
@@ -199,6 +202,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(op_ms, 5)}
 
     # ---- the other solver, for the record (N = 1) -------------------------------------
+    roofline_other = None
     if world == 1 and args.both_solvers:
         other = "iterative_schur" if args.solver == "cgnr" else "cgnr"
         s2 = make_solver(hs, bs, nelim_local, other, local_rank)
@@ -208,6 +212,14 @@ def main():
         k2 = "sx" if other == "iterative_schur" else "jtjx"
         ms2 = s2.time_op(hs.TIMED_SX if k2 == "sx" else hs.TIMED_JTJX, args.kernel_iters)
         gb2 = algorithmic_bytes(k2, my_obs, my_points, n_cams) / (ms2 * 1e-3) / 1e9
+        roofline_other = {"bound": "hbm", "kernel": f"bal_stream_kernel<{'kJtJx' if k2 == 'jtjx' else 'kSx'}> + bal_reduce_partials_kernel",
+                          "achieved": round(gb2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBS, 4),
+                          "traffic": None, "algorithmic_bytes_per_launch": algorithmic_bytes(k2, my_obs, my_points, n_cams),
+                          "avg_launch_ms": round(ms2, 5)}
+        try:
+            roofline_other["traffic"] = json.load(open(pmc)).get(f"{args.workload}:{k2}")
+        except Exception:
+            pass
         extra[other] = {"steps_per_s": round(max(3, args.steps // 4) / e2, 3), "cg_iterations": it2[-1],
                         f"{k2}_GBs": round(gb2, 1), f"{k2}_frac_hbm": round(gb2 / HBM_PEAK_GBS, 4), f"{k2}_ms": round(ms2, 5)}
         if other == "iterative_schur":
@@ -313,6 +325,8 @@ def main():
                        "camera_accumulators_in_lds": bool(info.camera_accum_in_lds)},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
+        if roofline_other is not None:
+            line["roofline_jtjx" if args.solver == "iterative_schur" else "roofline_sx"] = roofline_other
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)

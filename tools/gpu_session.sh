@@ -9,8 +9,8 @@ cd $(dirname $0)/..
 REPO=$(pwd)
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -40 | tee $OUT/pytest_gpu_$TAG.log | grep -E "passed|failed"
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as e; e.smoke()" 2>&1 | tail -5 | tee $OUT/smoke_$TAG.log
-echo "== bench (cgnr)"; timeout 900 python bench.py --gpus 1 2> $OUT/bench_$TAG.err | tee $OUT/bench_$TAG.json | cut -c1-1500; tail -3 $OUT/bench_$TAG.err
-echo "== bench (iterative_schur)"; timeout 900 python bench.py --gpus 1 --solver iterative_schur --both-solvers 0 2> $OUT/bench_schur_$TAG.err | tee $OUT/bench_schur_$TAG.json | cut -c1-1200
+echo "== bench (default: iterative_schur)"; timeout 900 python bench.py --gpus 1 2> $OUT/bench_$TAG.err | tee $OUT/bench_$TAG.json | cut -c1-1500; tail -3 $OUT/bench_$TAG.err
+echo "== bench (cgnr)"; timeout 900 python bench.py --gpus 1 --solver cgnr --both-solvers 0 2> $OUT/bench_cgnr_$TAG.err | tee $OUT/bench_cgnr_$TAG.json | cut -c1-1200
 echo "== rocprofv3 kernel stats"
 cd /tmp && export TMPDIR=/tmp
 for SOLVER in cgnr iterative_schur; do
