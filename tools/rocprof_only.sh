@@ -1,4 +1,4 @@
-cd /root/repo; REPO=$(pwd); OUT=$REPO/gpurun_out; TAG=r01e
+cd /root/repo; REPO=$(pwd); OUT=$REPO/gpurun_out; TAG=${1:-r01f}
 cd /tmp && export TMPDIR=/tmp
 for SOLVER in cgnr iterative_schur; do
   rm -rf /tmp/prof_$SOLVER
