@@ -52,7 +52,7 @@ def build_host_driver(force=False, verbose=False):
     """The C++ host-side mirror of ceres::internal::LinearSolver + a small driver (g++, links the C ABI)."""
     if not os.path.exists(HOST_DRIVER_SRC):
         return None
-    deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), OUT]
+    deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), os.path.join(HERE, "host", "hip_bal_problem.h"), OUT]
     if force or _stale(HOST_DRIVER, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"), "-I", os.path.join(HERE, "host"),
                HOST_DRIVER_SRC, "-o", HOST_DRIVER, "-L", CSRC, "-lceres_hip", "-Wl,-rpath," + CSRC,

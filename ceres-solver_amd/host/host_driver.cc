@@ -6,10 +6,12 @@
 // case and exits non-zero on any mismatch.  Built by build.py with g++ against the C ABI.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 
 #include "hip_linear_solver.h"
+#include "hip_bal_problem.h"
 
 using namespace ceres_hip;
 
@@ -130,11 +132,37 @@ int RunCase(const char* name, BlockSparseMatrix* A, const std::vector<double>& b
 
 }  // namespace
 
-int main() {
+// host_driver <problem.txt> [max_num_iterations]: BALProblem + Evaluator + TrustRegionMinimizer through the C++ mirror
+int RunBalFile(const char* filename, int max_it) {
+  const BalData data = BalData::Read(filename);
+  LinearSolver::Options o;
+  o.type = ITERATIVE_SCHUR;
+  o.preconditioner_type = SCHUR_JACOBI;
+  o.min_num_iterations = 0;
+  o.max_num_iterations = 500;
+  HipBalProblem problem(o, data);
+  std::vector<double> x = data.State();
+  double cost0 = 0;
+  if (!problem.Evaluate(x.data(), &cost0, nullptr, nullptr, nullptr)) return 1;
+  ceres_hip_minimizer_options mo;
+  ceres_hip_minimizer_default_options(&mo);
+  mo.max_num_iterations = max_it;
+  const ceres_hip_minimizer_summary s = problem.Minimize(mo, x.data());
+  double cost1 = 0;
+  if (!problem.Evaluate(x.data(), &cost1, nullptr, nullptr, nullptr)) return 1;
+  std::printf("bal parameters=%d residuals=%d initial_cost=%.17g evaluated_initial=%.17g final_cost=%.17g evaluated_final=%.17g "
+              "successful=%d unsuccessful=%d termination=%d message=%s\n",
+              problem.NumParameters(), problem.NumResiduals(), s.initial_cost, cost0, s.final_cost, cost1, s.num_successful_steps,
+              s.num_unsuccessful_steps, s.termination_type, s.message);
+  return 0;
+}
+
+int main(int argc, char** argv) {
   if (ceres_hip_device_count() < 1) {
     std::printf("FAIL no gfx950 device visible (the library has no CPU path)\n");
     return 2;
   }
+  if (argc >= 2) return RunBalFile(argv[1], argc >= 3 ? std::atoi(argv[2]) : 10);
   int bad = 0, nelim = 0;
   std::vector<double> b, D;
   auto p2 = Problem2(&b, &D, &nelim);

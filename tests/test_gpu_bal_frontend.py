@@ -140,3 +140,30 @@ def test_problem_from_bal_file(hip, oracle, tmp_path):
     np.testing.assert_allclose(x0, op.state(), rtol=1e-15)
     assert gp.evaluate(x0)[0] == pytest.approx(op.evaluate(op.state())[0], rel=1e-13)
     gp.close()
+
+
+def test_cpp_host_mirror_of_the_bal_front_end(hip, oracle, tmp_path):
+    # ceres-solver_amd/host/hip_bal_problem.h through host_driver: BAL file -> Evaluate -> Minimize, the same
+    # numbers as the Python mirror produces over the same C ABI (also checks the struct layouts both bind)
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    op = oracle.BalProblem.generate(8, 250, 1200, seed=17)
+    op.build_structure(True)
+    f = str(tmp_path / "problem.txt")
+    assert op.write(f) == 0
+    exe = os.path.join(ROOT, "ceres-solver_amd", "host", "host_driver")
+    r = subprocess.run([exe, f, "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("bal ")][0]
+    kv = dict(re.findall(r"(\w+)=([^ ]+)", line))
+    o = hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, min_num_iterations=0, max_num_iterations=500)
+    gp, x0 = hip.BalProblem.from_file(o, f)
+    x, S = gp.minimize(x0, max_num_iterations=6)
+    gp.close()
+    assert int(kv["parameters"]) == gp.num_parameters and int(kv["residuals"]) == gp.num_residuals
+    assert float(kv["initial_cost"]) == pytest.approx(S.initial_cost, rel=1e-13) == pytest.approx(float(kv["evaluated_initial"]), rel=1e-13)
+    assert float(kv["final_cost"]) == pytest.approx(S.final_cost, rel=1e-9) and float(kv["evaluated_final"]) == pytest.approx(float(kv["final_cost"]), rel=1e-12)
+    assert int(kv["successful"]) == S.num_successful_steps and int(kv["termination"]) == S.termination_type
+    assert S.final_cost < 0.5 * S.initial_cost
