@@ -42,7 +42,6 @@ struct BalArgs {
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
   const double* x_e = nullptr;
   const double* x_f = nullptr;
-  const double* x_f_pad = nullptr;  // optional [n_cameras][10] copy of x_f (16-byte aligned gathers)
   int flags = 0;                    // reserved
   double* y_e = nullptr;
   const double* D_e = nullptr;  // nullptr => no regularisation on the point part
@@ -69,8 +68,6 @@ hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
                                    hipStream_t stream);
 hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
-hipError_t LaunchBalPadCameraVector(const double* x_f, const int32_t* cam_pos, int n_cameras, double* xpad,
-                                    const int* status, hipStream_t stream);
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
                                  const int* status, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,

@@ -224,18 +224,11 @@ __device__ __forceinline__ void sym3_mul(const double (&m)[6], const double (&u)
   v[2] = m[2] * u[0] + m[4] * u[1] + m[5] * u[2];
 }
 
-// The 9 camera scalars of a slot: from the 16-byte aligned padded copy ([camera][10],
-// 5 x dwordx4 per lane) when one was prepared, else 9 x 8-byte loads from the vector itself.
+// The 9 camera scalars of a slot (72 contiguous bytes; L2-resident for the camera counts that fit LDS).
 __device__ __forceinline__ void load_xc(const BalArgs& A, int cam, double (&xc)[9]) {
-  if (A.x_f_pad) {
-    const double2* q = reinterpret_cast<const double2*>(A.x_f_pad + 10 * int64_t(cam));
-    const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
-    xc[0] = a.x; xc[1] = a.y; xc[2] = b.x; xc[3] = b.y; xc[4] = c.x; xc[5] = c.y; xc[6] = d.x; xc[7] = d.y; xc[8] = e.x;
-  } else {
-    const int co = cam_off(A, cam);
+  const int co = cam_off(A, cam);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
-  }
+  for (int k = 0; k < 9; ++k) xc[k] = A.x_f[co + k];
 }
 
 // t = F * xc
@@ -921,15 +914,6 @@ __global__ __launch_bounds__(1024) void bal_stream_probe_kernel(const double2* _
   if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 16; ++i) s += sh[i]; out[blockIdx.x] = s; }
 }
 
-// xpad[c][0..8] = x_f[cam_pos[c] + 0..8], xpad[c][9] = 0
-__global__ void bal_pad_camera_vector_kernel(const double* __restrict__ x_f, const int32_t* __restrict__ cam_pos, int n_cameras,
-                                             double* __restrict__ xpad, const int* __restrict__ status) {
-  if (status && *status != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 10 * n_cameras) return;
-  const int c = i / 10, k = i % 10;
-  xpad[i] = k < 9 ? x_f[(cam_pos ? cam_pos[c] : 9 * c) + k] : 0.0;
-}
 
 // y_f += D_f^2 x_f over the camera scalars (after an all-reduce of the raw sums).
 __global__ void bal_add_f_diagonal_kernel(int n_f9, const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
@@ -1264,7 +1248,7 @@ static bool UsePipeline() {
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   const bool big = BalBlockFor(mode) == 1024;
-  if (UsePipeline() && !A.Jf && !A.src_values && !A.x_f_pad && !A.pt_pos && !A.cam_pos && !(A.flags & 1)) {
+  if (UsePipeline() && !A.Jf && !A.src_values && !A.pt_pos && !A.cam_pos && !(A.flags & 1)) {
     if (mode == kSx) return launch_stream<kSx>(A, lds, grid, stream);
     if (mode == kJtJx && A.D_e) return launch_stream<kJtJx>(A, lds, grid, stream);
     if (mode == kSpseZ) return launch_stream<kSpseZ>(A, lds, grid, stream);
@@ -1297,12 +1281,6 @@ hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, dou
   return hipGetLastError();
 }
 
-hipError_t LaunchBalPadCameraVector(const double* x_f, const int32_t* cam_pos, int n_cameras, double* xpad,
-                                    const int* status, hipStream_t stream) {
-  hipLaunchKernelGGL(bal_pad_camera_vector_kernel, dim3((10 * n_cameras + 255) / 256), dim3(256), 0, stream, x_f, cam_pos,
-                     n_cameras, xpad, status);
-  return hipGetLastError();
-}
 
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
                                  const int* status, hipStream_t stream) {

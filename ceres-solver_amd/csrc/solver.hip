@@ -72,10 +72,9 @@ struct ceres_hip_solver {
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
   double2 *d_J = nullptr, *d_bt = nullptr;
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
-  double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr, *d_xpad = nullptr;
+  double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
   double* d_zbuf = nullptr;
   int bal_flags = 0;
-  bool use_xpad = false;
   bool lds_mode = false;
   int fused_grid = 0;
 
@@ -254,10 +253,6 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_f = x;
-    if (s->use_xpad) {
-      HIP_TRY(s, LaunchBalPadCameraVector(x, A.cam_pos, s->plan.n_cameras, s->d_xpad, status, s->stream));
-      A.x_f_pad = s->d_xpad;
-    }
     return bal_scatter(s, kBalSx, A, x, y, true, status);
   }
   const double* v = s->values;
@@ -291,10 +286,6 @@ int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status) 
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
-    if (s->use_xpad) {
-      HIP_TRY(s, LaunchBalPadCameraVector(A.x_f, A.cam_pos, s->plan.n_cameras, s->d_xpad, status, st));
-      A.x_f_pad = s->d_xpad;
-    }
     return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status);
   }
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
@@ -1196,12 +1187,9 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
     TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(n_slots) * 9));
-    TRY(dev_alloc(s, &s->d_xpad, size_t(10) * P.n_cameras));
     TRY(dev_alloc(s, &s->d_camsq, n9));
-    {  // measured alternative (16-byte aligned padded camera gathers); off by default: no gain
-      const char* e = getenv("CERES_HIP_XPAD");
-      s->use_xpad = e && atoi(e) != 0;
-      e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
+    {
+      const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
       s->bal_flags = (e && atoi(e) == 0) ? 1 : 0;
     }
   } else {
