@@ -30,6 +30,7 @@ BAL_SHAPES = {
     "synthetic10M": (50000, 10_000_000, 30_000_000),
     # the 50 k-camera regime of synthetic10M at a tenth of its points (camera accumulators do not fit in LDS)
     "synthetic1M": (50000, 1_000_000, 3_000_000),
+    "synthetic10M": (50000, 10_000_000, 30_000_000),   # 10 M points x 3 observations, 50 k cameras, 5.76 GB of J
 }
 
 
