@@ -30,23 +30,45 @@ using Vec = std::vector<double>;
 // "sign" = kOperation (+1: +=, -1: -=, 0: =).  One generic loop nest each; the
 // reference's static-size/unrolled variants compute the same sums.
 // --------------------------------------------------------------------------
-inline void mat_vec(const double* A, int r, int c, const double* x, double* y, int sign) {
+// Each kernel exists once as a loop nest over compile-time sizes (R, C, ... > 0) or run-time sizes
+// (template argument 0); the public entry dispatches the sizes bundle adjustment produces (2x3, 2x9,
+// 3x3, 9x9, ...) to the compile-time instances, as the reference does with its template
+// specialisations (I/small_blas.h, I/schur_eliminator.cc).  Same loop order, same sums.
+template <int R, int C>
+inline void mat_vec_t(const double* A, int r_, int c_, const double* x, double* y, int sign) {
+  const int r = R ? R : r_, c = C ? C : c_;
   for (int i = 0; i < r; ++i) {
     double s = 0;
     for (int j = 0; j < c; ++j) s += A[i * c + j] * x[j];
     if (sign > 0) y[i] += s; else if (sign < 0) y[i] -= s; else y[i] = s;
   }
 }
-inline void mat_t_vec(const double* A, int r, int c, const double* x, double* y, int sign) {
+inline void mat_vec(const double* A, int r, int c, const double* x, double* y, int sign) {
+  if (r == 2 && c == 9) return mat_vec_t<2, 9>(A, r, c, x, y, sign);
+  if (r == 2 && c == 3) return mat_vec_t<2, 3>(A, r, c, x, y, sign);
+  if (r == 9 && c == 9) return mat_vec_t<9, 9>(A, r, c, x, y, sign);
+  if (r == 3 && c == 3) return mat_vec_t<3, 3>(A, r, c, x, y, sign);
+  mat_vec_t<0, 0>(A, r, c, x, y, sign);
+}
+template <int R, int C>
+inline void mat_t_vec_t(const double* A, int r_, int c_, const double* x, double* y, int sign) {
+  const int r = R ? R : r_, c = C ? C : c_;
   for (int j = 0; j < c; ++j) {
     double s = 0;
     for (int i = 0; i < r; ++i) s += A[i * c + j] * x[i];
     if (sign > 0) y[j] += s; else if (sign < 0) y[j] -= s; else y[j] = s;
   }
 }
+inline void mat_t_vec(const double* A, int r, int c, const double* x, double* y, int sign) {
+  if (r == 2 && c == 9) return mat_t_vec_t<2, 9>(A, r, c, x, y, sign);
+  if (r == 2 && c == 3) return mat_t_vec_t<2, 3>(A, r, c, x, y, sign);
+  mat_t_vec_t<0, 0>(A, r, c, x, y, sign);
+}
 // C[r0.., c0..] (op)= A^T B, A is ra x ca, B is ra x cb, C has row stride ldc.
-inline void mat_t_mat(const double* A, int ra, int ca, const double* B, int cb, double* C, int r0,
-                      int c0, int ldc, int sign) {
+template <int RA, int CA, int CB>
+inline void mat_t_mat_t(const double* A, int ra_, int ca_, const double* B, int cb_, double* C, int r0, int c0, int ldc,
+                        int sign) {
+  const int ra = RA ? RA : ra_, ca = CA ? CA : ca_, cb = CB ? CB : cb_;
   for (int i = 0; i < ca; ++i)
     for (int j = 0; j < cb; ++j) {
       double s = 0;
@@ -55,9 +77,22 @@ inline void mat_t_mat(const double* A, int ra, int ca, const double* B, int cb, 
       if (sign > 0) d += s; else if (sign < 0) d -= s; else d = s;
     }
 }
+inline void mat_t_mat(const double* A, int ra, int ca, const double* B, int cb, double* C, int r0,
+                      int c0, int ldc, int sign) {
+  if (ra == 2) {
+    if (ca == 9 && cb == 9) return mat_t_mat_t<2, 9, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+    if (ca == 3 && cb == 3) return mat_t_mat_t<2, 3, 3>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+    if (ca == 3 && cb == 9) return mat_t_mat_t<2, 3, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+    if (ca == 9 && cb == 3) return mat_t_mat_t<2, 9, 3>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  }
+  if (ra == 3 && ca == 9 && cb == 9) return mat_t_mat_t<3, 9, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  mat_t_mat_t<0, 0, 0>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+}
 // C[r0.., c0..] (op)= A B, A is ra x ca, B is ca x cb.
-inline void mat_mat(const double* A, int ra, int ca, const double* B, int cb, double* C, int r0,
-                    int c0, int ldc, int sign) {
+template <int RA, int CA, int CB>
+inline void mat_mat_t(const double* A, int ra_, int ca_, const double* B, int cb_, double* C, int r0, int c0, int ldc,
+                      int sign) {
+  const int ra = RA ? RA : ra_, ca = CA ? CA : ca_, cb = CB ? CB : cb_;
   for (int i = 0; i < ra; ++i)
     for (int j = 0; j < cb; ++j) {
       double s = 0;
@@ -65,6 +100,15 @@ inline void mat_mat(const double* A, int ra, int ca, const double* B, int cb, do
       double& d = C[(r0 + i) * ldc + c0 + j];
       if (sign > 0) d += s; else if (sign < 0) d -= s; else d = s;
     }
+}
+inline void mat_mat(const double* A, int ra, int ca, const double* B, int cb, double* C, int r0,
+                    int c0, int ldc, int sign) {
+  if (ra == 3 && ca == 3 && cb == 9) return mat_mat_t<3, 3, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  if (ra == 3 && ca == 3 && cb == 3) return mat_mat_t<3, 3, 3>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  if (ra == 2 && ca == 3 && cb == 3) return mat_mat_t<2, 3, 3>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  if (ra == 2 && ca == 3 && cb == 9) return mat_mat_t<2, 3, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  if (ra == 9 && ca == 3 && cb == 9) return mat_mat_t<9, 3, 9>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
+  mat_mat_t<0, 0, 0>(A, ra, ca, B, cb, C, r0, c0, ldc, sign);
 }
 
 // In-place inverse of an SPD matrix from its UPPER triangle via Cholesky and a

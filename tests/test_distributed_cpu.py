@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
             m = oracle.Matrix(sh.bs, sh.num_eliminate_blocks)
             v, b, D = sh.local_values(prob.values), sh.local_rows(prob.b), sh.local_cols(prob.D)
             for solver, pre in (("iterative_schur_solve", 2), ("iterative_schur_solve", 1), ("cgnr_solve", 1), ("cgnr_solve", 0)):
-                x, s = getattr(m, solver)(v, b, D, preconditioner=pre, max_it=MAX_IT, q_tol=0.0, r_tol=R_TOL[solver], allreduce=allreduce)
+                x, s = getattr(m, solver)(v, b, D, preconditioner=pre, max_it=MAX_IT, q_tol=-1.0, r_tol=R_TOL[solver], allreduce=allreduce)
                 out[(name, solver, pre)] = (sh.col_index, int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum()), x,
                                             s.termination_type, s.num_iterations)
         q.put((rank, out))
@@ -93,7 +93,7 @@ def test_sharded_solvers_match_single_rank(oracle, problems):
                        ("general", problems.random_schur_problem(num_e_blocks=14, num_f_blocks=5, num_no_e_rows=2, seed=6))):
         m = oracle.Matrix(prob.bs, prob.num_eliminate_blocks)
         for solver, pre in (("iterative_schur_solve", 2), ("iterative_schur_solve", 1), ("cgnr_solve", 1), ("cgnr_solve", 0)):
-            ref, sref = getattr(m, solver)(prob.values, prob.b, prob.D, preconditioner=pre, max_it=MAX_IT, q_tol=0.0, r_tol=R_TOL[solver])
+            ref, sref = getattr(m, solver)(prob.values, prob.b, prob.D, preconditioner=pre, max_it=MAX_IT, q_tol=-1.0, r_tol=R_TOL[solver])
             x = np.full(prob.num_cols, np.nan)
             cams = []
             for r in range(world):
