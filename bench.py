@@ -279,12 +279,13 @@ def main():
             return time.perf_counter() - t, xo_, so_
         # memory-bound sparse kernels do not scale to every core of a big host: probe a few thread
         # counts with one solve each, then spend the rest of the budget on the fastest
+        # (cheapest candidates first: on some boxes one step with every core takes 20+ s)
         probe = {}
-        for th in sorted({ncpu, max(1, ncpu // 4), min(ncpu, 16), 1}, reverse=True):
+        for th in dict.fromkeys([min(ncpu, 16), min(ncpu, 64), 1, ncpu]):
+            if probe and sum(probe.values()) > args.cpu_seconds / 2:
+                break
             oracle.set_num_threads(th)
             probe[th] = one()[0]
-            if sum(probe.values()) > args.cpu_seconds:
-                break
         cores = min(probe, key=probe.get)
         oracle.set_num_threads(cores)
         n_done, t0, cpu_iters = 0, time.perf_counter(), None
