@@ -18,6 +18,13 @@
  *   ceres_hip_solve                  LinearSolver::Solve(A, b, per_solve, x)    I/linear_solver.h:339-342
  *                                    = CgnrSolver::SolveImpl                    I/cgnr_solver.cc:146-207
  *                                    = IterativeSchurComplementSolver::SolveImpl I/iterative_schur_complement_solver.cc:64-157
+ *   ceres_hip_lm_compute_step*       LevenbergMarquardtStrategy::ComputeStep + the model cost change of
+ *                                    TrustRegionMinimizer::ComputeTrustRegionStep
+ *                                                                               I/levenberg_marquardt_strategy.cc:69-157
+ *   options.use_explicit_schur_complement   SparseSchurComplementSolver's CG path (f2)  I/schur_complement_solver.cc:337-408
+ *   SCHUR_POWER_SERIES_EXPANSION     PowerSeriesExpansionPreconditioner (f3)    I/power_series_expansion_preconditioner.cc:57-89
+ *   ceres_hip_bal_*                  Evaluator::Evaluate and TrustRegionMinimizer::Minimize for bundle
+ *                                    adjustment in BAL form (f4)                I/evaluator.h:116-124, I/trust_region_minimizer.cc:68-845
  *   ceres_hip_op_*                   the individual operators of SURVEY.md §8(a), exported so
  *                                    that parity tests and roofline runs can address them one
  *                                    at a time (file:line given next to each declaration).
