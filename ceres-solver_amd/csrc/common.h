@@ -24,6 +24,7 @@ constexpr int kTile = 64;           // observation slots per tile = one wavefron
 constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
 constexpr int kCamChunk = 512;      // max observations per work item (one wavefront) of the camera-major kernels
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
+constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
 
 // ---------------------------------------------------------------------------
 // Host-side analysis (plan.cc).  Pure C++, unit-testable without a GPU through

@@ -60,16 +60,18 @@ struct BalArgs {
   double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
+  double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
+// pq_out != nullptr: also partial x_f . y_f, one per workgroup (*n_pq of them; needs x_f)
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
-                                   hipStream_t stream);
+                                   double* pq_out, int* n_pq, hipStream_t stream);
 hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
-                                 const int* status, hipStream_t stream);
+                                 const int* status, double* pq_out, int* n_pq, hipStream_t stream);
 hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
                          const int32_t* slot_bpos, int64_t n_tiles, double2* J, float4* Jf, double2* bt, hipStream_t stream);
 // Fused LM diagonal of the camera columns, applied by bal_invert9_kernel (radius > 0 to enable).
@@ -185,6 +187,10 @@ struct CgScalars {
   double rho, rho_new, beta, pq, alpha, Q0, Q1, zeta, norm_r, norm_p, norm_q;
   int iter, status, min_it, max_it;
   int fail_dir, fail_step;  // failures staged by direction / step, committed by finalize
+  // Fused iteration (cg_update_kernel + cg_finalize_direction_kernel): rho_i and the Q0 that iteration i tests
+  // against live at index i & 1, so that no multi-workgroup kernel reads a scalar another workgroup of the same
+  // launch writes (iteration i reads [i & 1] and writes [(i + 1) & 1]).
+  double rho_pp[2], Q0_pp[2];
 };
 
 struct CgBuffers {
@@ -202,7 +208,12 @@ struct CgBuffers {
   double* comm = nullptr;      // 4 doubles
   CgScalars* S = nullptr;      // device
   const int* setup_fail = nullptr;  // optional device flag: non-zero => CG starts in kCgSetupFailed
+  // p.q of the current iteration as n_pq partial sums (written by the operator's own kernels where they have p and q
+  // in registers, otherwise by cg_dot_pq_kernel into slot 1); summed in index order by cg_update_kernel
+  const double* pq_parts = nullptr;
+  int n_pq = 0;
 };
+constexpr int kMaxPqParts = 2048;
 
 // z = M^-1 r (block-diagonal, or copy when blocks == nullptr) and partial r.z
 // slot 0 <- partial |rhs|^2
@@ -228,6 +239,14 @@ hipError_t LaunchCgStep(const CgBuffers& B, int reset, hipStream_t stream);
 hipError_t LaunchCgResidualReset(const CgBuffers& B, const double* tmp, hipStream_t stream);
 // termination tests in the reference's order (:273-302); iter++
 hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
+// Fused iteration, second half of iteration `it` (I/conjugate_gradients_solver.h:196-249 + :162-167 of the next one):
+// pq = sum(pq_parts), alpha; x += alpha p; unless reset: r -= alpha q, partial Q1 / |r|^2 -> slots 2, 3 and, block by block,
+// z = M^-1 r with partial r.z -> slot 0 (the next iteration's rho).  One thread per column block.
+hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
+                          const int64_t* diag_off, const double* blocks, int reset, int it, hipStream_t stream);
+// Fused: the termination tests of iteration `it` in the reference's order (:273-302) and, if CG goes on, the
+// direction of iteration it + 1: rho = sum(slot 0), beta = rho / rho_it, p = z + beta p (:167-191).
+hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t stream);
 // comm[slot] = sum over the shard's workgroups of partials[slot] for slot in [first, first+count)
 hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t stream);
 

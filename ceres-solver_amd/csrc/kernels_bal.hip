@@ -29,6 +29,9 @@
 //   kBackSub   ImplicitSchurComplement::BackSubstitute
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+
 #include "device.h"
 
 namespace chip {
@@ -379,7 +382,7 @@ __device__ __forceinline__ void load_aux(const BalArgs& A, const Slot& s, int la
 // The arithmetic of a streaming mode on one normal tile; issues no global loads.
 template <int MODE, bool LDS>
 __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, int lane, int span, int npts,
-                                               const StreamAux& x, double* acc) {
+                                               const StreamAux& x, double* acc, double& dot) {
   if constexpr (MODE == kSx || MODE == kSpseZ) {
     double v[3];
     double t0, t1;
@@ -427,18 +430,18 @@ __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, 
         const double v0 = shfl_idx(w[0], ta), v1 = shfl_idx(w[1], ta), v2 = shfl_idx(w[2], ta);
         const int c = lane % 3;
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 23) & 1) A.y_e[x.base + lane] = v + x.da * x.da * x.xa;
+        if ((s.seg >> 23) & 1) { const double yv = v + x.da * x.da * x.xa; A.y_e[x.base + lane] = yv; dot += x.xa * yv; }
       }
       if (n3 > 64) {
         const double v0 = shfl_idx(w[0], tb), v1 = shfl_idx(w[1], tb), v2 = shfl_idx(w[2], tb);
         const int c = (lane + 1) % 3;  // (64 + lane) % 3
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 30) & 1) A.y_e[x.base + 64 + lane] = v + x.db * x.db * x.xb;
+        if ((s.seg >> 30) & 1) { const double yv = v + x.db * x.db * x.xb; A.y_e[x.base + 64 + lane] = yv; dot += x.xb * yv; }
       }
     } else if (s.valid && lane == s.last) {
       const int po = pt_off(A, s.pt);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) A.y_e[po + j] = w[j] + x.dd[j] * x.dd[j] * xp[j];
+      for (int j = 0; j < 3; ++j) { const double yv = w[j] + x.dd[j] * x.dd[j] * xp[j]; A.y_e[po + j] = yv; dot += xp[j] * yv; }
     }
   }
 }
@@ -453,7 +456,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
   if constexpr (MODE == kSx || MODE == kSpseZ || MODE == kJtJx) {
     StreamAux x;
     load_aux<MODE>(A, s, lane, npts, x);
-    compute_stream<MODE, LDS>(A, s, lane, span, npts, x, acc);
+    compute_stream<MODE, LDS>(A, s, lane, span, npts, x, acc, lane_acc);
   } else if constexpr (MODE == kJtb) {
     scatter_ft<LDS>(s, acc, s.b0, s.b1);
     double w[3] = {s.e[0] * s.b0 + s.e[3] * s.b1, s.e[1] * s.b0 + s.e[4] * s.b1, s.e[2] * s.b0 + s.e[5] * s.b1};
@@ -652,6 +655,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
         double d = 0;
         if (MODE == kJtJx && A.D_e) { d = A.D_e[po + j]; d = d * d * xp[j]; }
         A.y_e[po + j] = w[j] + d;
+        if (MODE == kJtJx) lane_acc += xp[j] * (w[j] + d);  // x_e . y_e share of CG's p.q
       }
     }
   } else if constexpr (MODE == kInit || MODE == kEte || MODE == kCgnrInit) {
@@ -723,7 +727,8 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
       else process_long_point<MODE, LDS, F32>(A, tile, aux, lane, acc, lane_acc);
     }
   }
-  if (MODE == kJx || (MODE == kBackSub && A.scalar_out)) {  // one partial per workgroup, summed in fixed order by the caller
+  double* const scalar_dst = MODE == kJtJx ? A.pq_out : A.scalar_out;
+  if ((MODE == kJx || MODE == kBackSub || MODE == kJtJx) && scalar_dst) {  // one partial per workgroup, summed in fixed order by the caller
     __shared__ double red[16];
     double v = lane_acc;
 #pragma unroll
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     if (threadIdx.x == 0) {
       double t = 0;
       for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
-      A.scalar_out[blockIdx.x] = t;
+      scalar_dst[blockIdx.x] = t;
     }
   }
   if constexpr (kScatters && LDS) {
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     acc = reinterpret_cast<double*>(A.zbuf);
   }
   const int lane = threadIdx.x & 63;
+  double dot = 0.0;  // kJtJx: this lane's share of x_e . y_e
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
       __builtin_amdgcn_sched_barrier(0);
       if (ckind != 0) c.valid = false;  // long points are handled below; their seg words carry no store bits
-      compute_stream<MODE, LDS>(A, c, lane, caux & 0xff, ckind == 0 ? caux >> 8 : 0, cx, acc);
+      compute_stream<MODE, LDS>(A, c, lane, caux & 0xff, ckind == 0 ? caux >> 8 : 0, cx, acc, dot);
       __builtin_amdgcn_sched_barrier(0);
       i1 = i2;
       tile = next;
@@ -853,7 +859,19 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   // Points with more than 64 observations own whole tiles (kind 1 = head, 2 = continuation);
   // they are rare and are handled outside the pipelined loop to keep its register footprint down.
   for (int64_t tile = wave0; tile < A.n_tiles; tile += nwaves) {
-    if (A.tile_kind[tile] == 1) { double unused = 0.0; process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, unused); }
+    if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, dot);
+  }
+  if (MODE == kJtJx && A.pq_out) {  // one partial of x_e . y_e per workgroup
+    __shared__ double red[BLOCK / 64];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if (lane == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+      for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      A.pq_out[blockIdx.x] = t;
+    }
   }
   if constexpr (LDS) {
     __syncthreads();
@@ -864,31 +882,45 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
 
 // y_f[pos(i)] = sum over workgroup partials (+ D_f^2 x_f).  One thread per F scalar.
 // Workgroup = 64 consecutive scalars x 8 waves, wave w sums partials w, w+8, w+16, ...; the eight
-// wave sums are combined through LDS in a fixed order (deterministic).
+// wave sums are combined through LDS in a fixed order (deterministic).  A workgroup takes every
+// gridDim.x-th group of 64 scalars.  pq_out: also the partial inner product x_f . y_f of the scalars this
+// workgroup finished (CG's p.q, camera part: x_f and the finished y_f are both in registers here).
 __global__ __launch_bounds__(512) void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
                                            const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
                                            const double* __restrict__ x_f, double* __restrict__ y_f,
-                                           const int* __restrict__ status) {
+                                           const int* __restrict__ status, double* __restrict__ pq_out) {
   __shared__ double sh[8][64];
   if (status && *status != 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
-  double s0 = 0, s1 = 0;
-  if (i < n_f9) {
-    int w = wv;
-    for (; w + 8 < nparts; w += 16) {
-      s0 += partials[int64_t(w) * n_f9 + i];
-      s1 += partials[int64_t(w + 8) * n_f9 + i];
+  const int ngroups = (n_f9 + 63) / 64;
+  double dot = 0;
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int i = g * 64 + lane;
+    double s0 = 0, s1 = 0;
+    if (i < n_f9) {
+      int w = wv;
+      for (; w + 8 < nparts; w += 16) {
+        s0 += partials[int64_t(w) * n_f9 + i];
+        s1 += partials[int64_t(w + 8) * n_f9 + i];
+      }
+      if (w < nparts) s0 += partials[int64_t(w) * n_f9 + i];
     }
-    if (w < nparts) s0 += partials[int64_t(w) * n_f9 + i];
+    sh[wv][lane] = s0 + s1;
+    __syncthreads();
+    if (wv == 0 && i < n_f9) {
+      double s = ((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane])) + ((sh[4][lane] + sh[5][lane]) + (sh[6][lane] + sh[7][lane]));
+      const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
+      if (D_f) { const double d = D_f[o]; s += d * d * x_f[o]; }
+      y_f[o] = s;
+      if (pq_out) dot += x_f[o] * s;
+    }
+    __syncthreads();  // sh is reused by the next group
   }
-  sh[wv][lane] = s0 + s1;
-  __syncthreads();
-  if (wv != 0 || i >= n_f9) return;
-  double s = ((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane])) + ((sh[4][lane] + sh[5][lane]) + (sh[6][lane] + sh[7][lane]));
-  const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
-  if (D_f) { const double d = D_f[o]; s += d * d * x_f[o]; }
-  y_f[o] = s;
+  if (pq_out && wv == 0) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if (lane == 0) pq_out[blockIdx.x] = dot;
+  }
 }
 
 // HBM read-stream probe: the same tile walk and 16-byte-per-lane loads as the fused kernels,
@@ -915,16 +947,26 @@ __global__ __launch_bounds__(1024) void bal_stream_probe_kernel(const double2* _
 }
 
 
-// y_f += D_f^2 x_f over the camera scalars (after an all-reduce of the raw sums).
-__global__ void bal_add_f_diagonal_kernel(int n_f9, const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
+// y_f += D_f^2 x_f over the camera scalars (after an all-reduce of the raw sums); pq_out: partial x_f . y_f per workgroup.
+__global__ __launch_bounds__(256) void bal_add_f_diagonal_kernel(int n_f9, const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
                                           const double* __restrict__ x_f, double* __restrict__ y_f,
-                                          const int* __restrict__ status) {
+                                          const int* __restrict__ status, double* __restrict__ pq_out) {
+  __shared__ double red[4];
   if (status && *status != 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_f9) return;
-  const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
-  const double d = D_f[o];
-  y_f[o] += d * d * x_f[o];
+  double dot = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_f9; i += gridDim.x * 256) {
+    const int o = cam_pos ? cam_pos[i / 9] + i % 9 : i;
+    double y = y_f[o];
+    if (D_f) { const double d = D_f[o]; y += d * d * x_f[o]; y_f[o] = y; }
+    if (pq_out) dot += x_f[o] * y;
+  }
+  if (pq_out) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) pq_out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
 // Re-layout: caller's values (any cell.position) -> tiles.  One wavefront per tile.
@@ -1192,17 +1234,26 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
+// The dynamic-LDS ceiling is a per-device attribute of a kernel: set it once per (kernel, device), whichever
+// thread gets there first (one static mask per instantiation; devices 0..63).
+template <typename K>
+static hipError_t allow_max_lds(K k) {
+  static std::atomic<unsigned long long> done{0ull};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes)); e != hipSuccess) return e;
+  done.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
+
 template <int MODE, int BLOCK, bool F32>
 static hipError_t launch_fused2(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
     const size_t bytes = size_t(A.n_f9) * sizeof(double);
     auto k = bal_fused_kernel<MODE, true, BLOCK, F32>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(k); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   } else {
     hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK, F32>), dim3(grid), dim3(BLOCK), 0, stream, A);
@@ -1227,12 +1278,7 @@ template <int MODE>
 static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
     auto k = bal_stream_kernel<MODE, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes));
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    if (hipError_t e = allow_max_lds(k); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
   } else {
     hipLaunchKernelGGL((bal_stream_kernel<MODE, false>), dim3(grid), dim3(512), 0, stream, A);
@@ -1270,9 +1316,12 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
-                                   hipStream_t stream) {
-  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3((n_f9 + 63) / 64), dim3(512), 0, stream, partials, nparts,
-                     n_f9, cam_pos, D_f, x_f, y_f, status);
+                                   double* pq_out, int* n_pq, hipStream_t stream) {
+  const int grid = std::max(1, std::min((n_f9 + 63) / 64, kMaxVecGrid));
+  if (!x_f) pq_out = nullptr;
+  if (n_pq) *n_pq = pq_out ? grid : 0;
+  hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3(grid), dim3(512), 0, stream, partials, nparts,
+                     n_f9, cam_pos, D_f, x_f, y_f, status, pq_out);
   return hipGetLastError();
 }
 
@@ -1283,9 +1332,13 @@ hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, dou
 
 
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
-                                 const int* status, hipStream_t stream) {
-  hipLaunchKernelGGL(bal_add_f_diagonal_kernel, dim3((n_f9 + 255) / 256), dim3(256), 0, stream, n_f9, cam_pos, D_f,
-                     x_f, y_f, status);
+                                 const int* status, double* pq_out, int* n_pq, hipStream_t stream) {
+  const int grid = std::max(1, std::min((n_f9 + 255) / 256, kMaxVecGrid));
+  if (!x_f) pq_out = nullptr;
+  if (n_pq) *n_pq = pq_out ? grid : 0;
+  if (!D_f && !pq_out) return hipSuccess;
+  hipLaunchKernelGGL(bal_add_f_diagonal_kernel, dim3(grid), dim3(256), 0, stream, n_f9, cam_pos, D_f,
+                     x_f, y_f, status, pq_out);
   return hipGetLastError();
 }
 

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_kernel(CgBuffers B, double 
     S.q_tol = q_tol;
     S.rho = 1.0; S.rho_new = 1.0; S.beta = 0; S.pq = 0; S.alpha = 0;
     S.Q0 = 0.0;  // -x.(rhs + r) with x = 0
+    S.Q0_pp[0] = 0.0; S.Q0_pp[1] = 0.0; S.rho_pp[0] = 1.0; S.rho_pp[1] = 1.0;
     S.Q1 = 0; S.zeta = 0; S.norm_r = S.norm_rhs; S.norm_p = 0; S.norm_q = 0;
     S.iter = 1; S.min_it = min_it; S.max_it = max_it;
     S.status = kCgRunning;
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_init_from_guess_finish_kernel(Cg
   S.q_tol = q_tol;
   S.rho = 1.0; S.rho_new = 1.0; S.beta = 0; S.pq = 0; S.alpha = 0;
   S.Q0 = Q0; S.Q1 = 0; S.zeta = 0; S.norm_r = sqrt(rr); S.norm_p = 0; S.norm_q = 0;
+  S.Q0_pp[0] = Q0; S.Q0_pp[1] = Q0; S.rho_pp[0] = 1.0; S.rho_pp[1] = 1.0;
   S.iter = 1; S.min_it = min_it; S.max_it = max_it;
   S.status = kCgRunning;
   S.fail_dir = 0; S.fail_step = 0;
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_direction_kernel(CgBuffers B) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     B.S->rho_new = rho;
+    B.S->rho_pp[iter & 1] = rho;  // where the fused iteration kernels look for rho_iter
     B.S->beta = beta;
     // The status word itself is written only by cg_finalize (one workgroup): a
     // workgroup of THIS launch that starts late must not see it change.  Failures are
@@ -382,6 +385,163 @@ __global__ __launch_bounds__(kVecBlock) void cg_finalize_kernel(CgBuffers B) {
   if (norm_r <= S.tol_r && S.iter >= S.min_it) { S.status = kCgConvergedResidual; return; }
   if (S.iter >= S.max_it) { S.status = kCgMaxIterations; return; }
   S.iter += 1;
+}
+
+// ---- fused iteration (two kernels after the operator instead of five) ---------------------------------
+// Second half of iteration `it`: what cg_step_kernel does (pq, alpha, x += alpha p, r -= alpha q, partial Q1 and
+// |r|^2) and, in the same pass over r, what cg_precondition_kernel does for the NEXT iteration (z = M^-1 r, partial
+// r.z): a column block's r is in registers when its update is done.  q arrives in z and is replaced by M^-1 r.
+template <int N>
+__device__ __forceinline__ void update_block(const double* __restrict__ m, double alpha, const double* __restrict__ p,
+                                             const double* __restrict__ rhs, double* __restrict__ x, double* __restrict__ r,
+                                             double* __restrict__ z, double& q1, double& rr, double& rz) {
+  double rn[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const double xv = x[c] + alpha * p[c];
+    const double rv = r[c] - alpha * z[c];
+    x[c] = xv;
+    r[c] = rv;
+    rn[c] = rv;
+    q1 -= xv * (rhs[c] + rv);
+    rr += rv * rv;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    double t = 0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) t += m[a * N + c] * rn[c];
+    z[a] = t;
+    rz += rn[a] * t;
+  }
+}
+
+__global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenStructure G, int first_block, int col_begin, int nblocks,
+                                                              const int64_t* diag_off, const double* blocks, int reset, int it) {
+  __shared__ double sh[4];
+  CgScalars& S = *B.S;
+  if (S.status != 0) return;
+  const int staged = S.fail_dir;  // the direction of this iteration failed: forwarded to cg_finalize_direction_kernel
+  double v = 0;
+  if (!staged) for (int k = threadIdx.x; k < B.n_pq; k += kVecBlock) v += B.pq_parts[k];
+  const double pq = staged ? 1.0 : block_sum(v, sh);
+  const double rho = S.rho_pp[it & 1];
+  int fail = staged;
+  double alpha = 0;
+  if (!fail) {
+    if (pq <= 0 || isinf(pq)) fail = kCgIndefinite;
+    else { alpha = rho / pq; if (isinf(alpha)) fail = kCgFailAlpha; }
+  }
+  double q1 = 0, rr = 0, rz = 0;
+  if (!fail) {
+    const int64_t t0 = int64_t(blockIdx.x) * kVecBlock + threadIdx.x, step = int64_t(gridDim.x) * kVecBlock;
+    if (reset) {  // x only: r comes from the operator (cg_residual_reset_kernel), then cg_precondition_kernel
+      for (int64_t i = t0; i < B.n; i += step) B.x[i] += alpha * B.p[i];
+    } else if (!blocks) {  // IDENTITY: z = r
+      for (int64_t i = t0; i < B.n; i += step) {
+        const double xv = B.x[i] + alpha * B.p[i];
+        const double rv = B.r[i] - alpha * B.z[i];
+        B.x[i] = xv; B.r[i] = rv; B.z[i] = rv;
+        q1 -= xv * (B.rhs[i] + rv);
+        rr += rv * rv;
+      }
+      rz = rr;
+    } else {
+      for (int64_t q = t0; q < nblocks; q += step) {
+        const int j = first_block + int(q);
+        const int n = G.csz[j];
+        const int64_t pos = G.cpos[j] - col_begin;
+        const double* m = blocks + (diag_off[q] - diag_off[0]);
+        if (n == 3) update_block<3>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
+        else if (n == 9) update_block<9>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
+        else {
+          double rn[kMaxGenericBlock];
+          for (int c = 0; c < n; ++c) {
+            const double xv = B.x[pos + c] + alpha * B.p[pos + c];
+            const double rv = B.r[pos + c] - alpha * B.z[pos + c];
+            B.x[pos + c] = xv; B.r[pos + c] = rv; rn[c] = rv;
+            q1 -= xv * (B.rhs[pos + c] + rv);
+            rr += rv * rv;
+          }
+          for (int a = 0; a < n; ++a) {
+            double t = 0;
+            for (int c = 0; c < n; ++c) t += m[a * n + c] * rn[c];
+            B.z[pos + a] = t;
+            rz += rn[a] * t;
+          }
+        }
+      }
+    }
+  }
+  if (!reset) {
+    q1 = block_sum(q1, sh);
+    rr = block_sum(rr, sh);
+    rz = block_sum(rz, sh);
+    if (threadIdx.x == 0) {
+      B.partials[2 * kMaxVecGrid + blockIdx.x] = q1;
+      B.partials[3 * kMaxVecGrid + blockIdx.x] = rr;
+      B.partials[0 * kMaxVecGrid + blockIdx.x] = rz;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S.pq = pq;
+    S.alpha = alpha;
+    S.rho_new = rho;
+    S.fail_step = fail;
+  }
+}
+
+// Sum of one slot of workgroup partials; every thread gets it (same order in every workgroup: all agree bit for bit).
+__device__ __forceinline__ double slot_total(const CgBuffers& B, int slot, double* sh) {
+  const double* p = B.partials + slot * kMaxVecGrid;
+  double v = 0;
+  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) v += p[k];
+  return block_sum(v, sh);
+}
+
+// End of iteration `it`: cg_finalize_kernel's tests and, if CG continues, cg_direction_kernel for iteration it + 1.
+// Every workgroup derives the same decision from the same partial sums; workgroup 0 records it.  Scalars this
+// kernel both needs and produces (rho, Q0) are double-buffered by iteration parity, the iteration number is a launch
+// argument, and a workgroup that starts after the status word went terminal just returns (CG is over, p is dead).
+__global__ __launch_bounds__(kVecBlock) void cg_finalize_direction_kernel(CgBuffers B, int it) {
+  __shared__ double sh[4];
+  CgScalars& S = *B.S;
+  if (S.status != 0) return;
+  const int fail = S.fail_step;
+  if (fail != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.status = fail;
+    return;
+  }
+  const double Q1 = slot_total(B, 2, sh);
+  const double rr = slot_total(B, 3, sh);
+  const double rho = slot_total(B, 0, sh);
+  const double Q0 = S.Q0_pp[it & 1], rho_prev = S.rho_pp[it & 1];
+  const double norm_r = sqrt(rr);
+  const double zeta = it * (Q1 - Q0) / Q1;
+  int status = kCgRunning;
+  if (zeta < S.q_tol && it >= S.min_it) status = kCgConvergedZeta;
+  else if (norm_r <= S.tol_r && it >= S.min_it) status = kCgConvergedResidual;
+  else if (it >= S.max_it) status = kCgMaxIterations;
+  int fail_dir = 0;
+  double beta = 0.0;
+  if (status == kCgRunning) {
+    if (zero_or_inf(rho)) fail_dir = kCgFailRho;
+    else { beta = rho / rho_prev; if (zero_or_inf(beta)) fail_dir = kCgFailBeta; }
+    if (!fail_dir)
+      for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < B.n; i += int64_t(gridDim.x) * kVecBlock)
+        B.p[i] = B.z[i] + beta * B.p[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S.Q1 = Q1; S.zeta = zeta; S.norm_r = norm_r;
+    if (status == kCgConvergedZeta) { S.status = status; return; }   // Q0 keeps its value, as in the reference (:273-284)
+    S.Q0 = Q1;
+    S.Q0_pp[(it + 1) & 1] = Q1;
+    if (status != kCgRunning) { S.status = status; return; }
+    S.rho = rho_prev; S.rho_new = rho; S.beta = beta;
+    S.rho_pp[(it + 1) & 1] = rho;
+    S.fail_dir = fail_dir;
+    S.iter = it + 1;
+  }
 }
 
 __global__ __launch_bounds__(kVecBlock) void cg_collapse_kernel(CgBuffers B, int first_slot, int count) {
@@ -488,6 +648,15 @@ hipError_t LaunchCgResidualReset(const CgBuffers& B, const double* tmp, hipStrea
 }
 hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t s) {
   hipLaunchKernelGGL(cg_finalize_kernel, dim3(1), dim3(kVecBlock), 0, s, B);
+  return hipGetLastError();
+}
+hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
+                          const int64_t* diag_off, const double* blocks, int reset, int it, hipStream_t s) {
+  hipLaunchKernelGGL(cg_update_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, reset, it);
+  return hipGetLastError();
+}
+hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t s) {
+  hipLaunchKernelGGL(cg_finalize_direction_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, it);
   return hipGetLastError();
 }
 hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t s) {

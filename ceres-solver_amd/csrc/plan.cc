@@ -224,6 +224,7 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   };
   int64_t tile = -1;
   int used = kTile;  // slots used in the current tile (kTile forces a new one)
+  int npts_in_tile = 0;
   int idx = 0;
   for (int p = 0; p < P.n_points; ++p) {
     const int k = track[p];
@@ -243,7 +244,12 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       used = kTile;  // nothing shares a tile with a long point
       continue;
     }
-    if (used + k > kTile) { tile = new_tile(0, 0); used = 0; }
+    // A normal tile holds at most kMaxPointsPerTile points: the cooperative point-space path of the
+    // fused JtJx (kernels_bal.hip, compute_stream / issue_aux) gives lane L the scalars L and 64 + L of
+    // the tile's point range, i.e. 128 scalars = 42 whole points.  Only tiles full of 1- and
+    // 2-observation points ever reach the cap.
+    if (used + k > kTile || npts_in_tile == kMaxPointsPerTile) { tile = new_tile(0, 0); used = 0; npts_in_tile = 0; }
+    ++npts_in_tile;
     for (int l = 0; l < k; ++l) {
       const int i = order[idx++];
       const int64_t s = tile * kTile + used + l;

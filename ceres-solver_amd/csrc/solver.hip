@@ -97,6 +97,8 @@ struct ceres_hip_solver {
   // CG
   CgBuffers cg;
   double* cg_rhs = nullptr;
+  double* cg_pq_parts = nullptr;   // kMaxPqParts partial sums of p.q left by the operator's kernels
+  bool cg_fused = true;            // CERES_HIP_CG_FUSED=0: the five-kernel iteration (A/B measurements)
   CgScalars* h_scalars = nullptr;  // pinned
   double* h_pinned = nullptr;      // pinned scratch, 2 * kMaxVecGrid + 8 doubles (scalar read-backs of the LM step)
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
@@ -221,12 +223,16 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
 
 // Run one fused kernel that scatters into camera space and produce y_f.
 // add_diag: y_f += D_f^2 x_f (after the all-reduce when sharded).
+// pq / n_pq (optional, needs x_f): the kernels that hold x and the finished y in registers also leave the partial sums of
+// x . y (CG's p.q) in pq[0 .. *n_pq) — point part from the JtJx tile pass, camera part from the reduction.
 int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
-                const int* status) {
+                const int* status, double* pq = nullptr, int* n_pq = nullptr) {
   const int n9 = A.n_f9;
   const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
   const int32_t* cam_pos = A.cam_pos;
   A.status = status;
+  int n_first = 0;
+  if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
   HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
   if (!s->lds_mode) {  // second pass by camera over the z the fused kernel left per slot
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
@@ -235,25 +241,28 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
   const int nparts = s->lds_mode ? s->fused_grid : 1;
+  int n_second = 0;
   if (s->world <= 1) {
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, s->stream));
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   } else {
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, s->stream));
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream));
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
     TRY(allreduce(s, y_f, size_t(n9)));
-    if (D_f) HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, s->stream));
+    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   }
+  if (n_pq) *n_pq = n_first + n_second;
   return 0;
 }
 
 // y = S x on F-space vectors.  ImplicitSchurComplement::RightMultiplyAndAccumulate.
-int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
+int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status, double* pq = nullptr, int* n_pq = nullptr) {
   const HostStructure& h = s->hs;
+  if (n_pq) *n_pq = 0;
   if (s->path == CERES_HIP_PATH_BAL) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_f = x;
-    return bal_scatter(s, kBalSx, A, x, y, true, status);
+    return bal_scatter(s, kBalSx, A, x, y, true, status, pq, n_pq);
   }
   const double* v = s->values;
   hipStream_t st = s->stream;
@@ -279,14 +288,15 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
 }
 
 // y = (A^T A + D^2) x on full-space vectors.  CgnrLinearOperator (y zeroed by CG first).
-int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status) {
+int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status, double* pq = nullptr, int* n_pq = nullptr) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
+  if (n_pq) *n_pq = 0;
   if (s->path == CERES_HIP_PATH_BAL) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
-    return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status);
+    return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status, pq, n_pq);
   }
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
   HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, status, st));
@@ -607,6 +617,8 @@ struct CgSpec {
   int64_t n = 0;
   int64_t n_local = 0;                                  // sharded CGNR: E-space prefix
   std::function<int(const double*, double*)> apply;     // y = A x (assigns)
+  // optional: y = A x AND the partial sums of x . y into pq[0 .. *n_pq) (n_pq <= kMaxPqParts); *n_pq = 0 if not produced
+  std::function<int(const double*, double*, double*, int*)> apply_dot;
   std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
   bool x0_nonzero = false;                              // B.x holds an initial guess
   int first_block = 0, col_begin = 0, nblocks = 0, n_local_blocks = 0;
@@ -712,22 +724,54 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   s->h_scalars->status = kCgRunning;
   s->timing.operator_applications = 0;
   int it = 1;
+  // Fused iteration: operator (+ p.q where its kernels have p and q in registers) -> cg_update (alpha, x, r, M^-1 r)
+  // -> cg_finalize_direction (tests, beta, p): 2 launches after the operator instead of 5.  Needs a block-diagonal
+  // (or no) preconditioner and unsharded CG vectors (ITERATIVE_SCHUR's camera-space vectors are replicated: fine).
+  const bool fused = s->cg_fused && !spec.precondition && B.grid_e == 0;
+  auto precondition = [&]() -> int {
+    if (spec.precondition) {
+      TRY(spec.precondition(B.r, B.z));
+      HIP_TRY(s, LaunchCgDotSlot(B, B.r, B.z, 0, st));
+    } else {
+      HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.nblocks,
+                                      B.grid_e > 0 ? spec.n_local_blocks : 0, spec.diag_off, spec.blocks, st));
+    }
+    return 0;
+  };
+  if (fused) {  // iteration 1's z = M^-1 r0, rho_1 and p = z; later directions come out of cg_finalize_direction
+    TRY(precondition());
+    HIP_TRY(s, LaunchCgDirection(B, st));
+  }
   while (s->h_scalars->status == kCgRunning) {
     const int batch_end = std::min(max_it, it + interval - 1);
     for (; it <= batch_end; ++it) {
-      if (spec.precondition) {
-        TRY(spec.precondition(B.r, B.z));
-        HIP_TRY(s, LaunchCgDotSlot(B, B.r, B.z, 0, st));
-      } else {
-        HIP_TRY(s, LaunchCgPrecondition(B, s->G, spec.first_block, spec.col_begin, spec.nblocks,
-                                        B.grid_e > 0 ? spec.n_local_blocks : 0, spec.diag_off, spec.blocks, st));
+      const int reset = (it % reset_period == 0) ? 1 : 0;
+      if (fused) {
+        int n_pq = 0;
+        if (spec.apply_dot) TRY(spec.apply_dot(B.p, B.z, s->cg_pq_parts, &n_pq));
+        else TRY(spec.apply(B.p, B.z));
+        if (n_pq > 0) { B.pq_parts = s->cg_pq_parts; B.n_pq = n_pq; }
+        else {  // the operator did not leave p.q behind: one pass over p and q
+          HIP_TRY(s, LaunchCgDotPq(B, st));
+          B.pq_parts = B.partials + kMaxVecGrid; B.n_pq = B.grid;
+        }
+        HIP_TRY(s, LaunchCgUpdate(B, s->G, spec.first_block, spec.col_begin, spec.nblocks, spec.diag_off, spec.blocks, reset, it, st));
+        ++s->timing.operator_applications;
+        if (reset) {  // r = rhs - A x (:235-239), then the next iteration's z = M^-1 r
+          TRY(spec.apply(B.x, B.z));
+          HIP_TRY(s, LaunchCgResidualReset(B, B.z, st));
+          TRY(precondition());
+          ++s->timing.operator_applications;
+        }
+        HIP_TRY(s, LaunchCgFinalizeDirection(B, it, st));
+        continue;
       }
+      TRY(precondition());
       TRY(collapse_and_reduce(s, 0, 1));
       HIP_TRY(s, LaunchCgDirection(B, st));
       TRY(spec.apply(B.p, B.z));
       HIP_TRY(s, LaunchCgDotPq(B, st));
       TRY(collapse_and_reduce(s, 1, 1));
-      const int reset = (it % reset_period == 0) ? 1 : 0;
       HIP_TRY(s, LaunchCgStep(B, reset, st));
       ++s->timing.operator_applications;
       if (reset) {
@@ -803,6 +847,11 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   memset(summary, 0, sizeof(*summary));
   summary->residual_norm = -1.0;
   if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "Solve needs the residual vector b");
+  // D may have changed since the last solve on the same values (a rejected trust-region step retries with a
+  // smaller radius, bal_frontend.inc): everything cached that contains D is rebuilt, as
+  // ImplicitSchurComplement::Init / Preconditioner::Update do on every Solve.
+  s->ftf_inv_valid = false;
+  s->precond_valid = false;
   HIP_TRY(s, hipEventRecord(s->ev[2], st));
   if (is_schur(s)) {
     // IterativeSchurComplementSolver::SolveImpl, I/iterative_schur_complement_solver.cc:64-157
@@ -904,6 +953,8 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     spec.n_local = 0;  // camera space is replicated: no inner product crosses ranks
     const int* status = &s->cg.S->status;
     spec.apply = [s, status](const double* in, double* out) { return op_sx(s, in, out, status); };
+    if (s->path == CERES_HIP_PATH_BAL)
+      spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq) { return op_sx(s, in, out, status, pq, n_pq); };
     spec.first_block = h.nelim;
     spec.nblocks = h.ncb - h.nelim;
     spec.col_begin = h.num_cols_e;
@@ -951,6 +1002,8 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   spec.n_local = h.num_cols_e;  // sharded: first nelim column blocks are this rank's points
   const int* status = &s->cg.S->status;
   spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status); };
+  if (s->path == CERES_HIP_PATH_BAL && s->world <= 1)
+    spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq) { return op_jtjx(s, in, out, status, pq, n_pq); };
   spec.first_block = 0;
   spec.nblocks = h.ncb;
   spec.n_local_blocks = h.nelim;
@@ -1136,6 +1189,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->cg_rhs, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.partials, size_t(4 * kMaxVecGrid)));
   TRY(dev_alloc(s, &s->cg.comm, 4));
+  TRY(dev_alloc(s, &s->cg_pq_parts, size_t(kMaxPqParts)));
+  { const char* e = getenv("CERES_HIP_CG_FUSED"); s->cg_fused = !(e && atoi(e) == 0); }
   TRY(dev_alloc(s, &s->cg.S, 1));
   HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
   TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back())));
@@ -1455,6 +1510,7 @@ int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, do
   HIP_TRY(s, LaunchGenScaleColumns(s->G, s->own_values, s->scratch_vec, s->stream));
   s->packed = false;
   s->precond_valid = false;
+  s->ftf_inv_valid = false;
   if (host_values_out)
     HIP_TRY(s, hipMemcpyAsync(host_values_out, s->own_values, sizeof(double) * s->hs.values_extent, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1501,6 +1557,49 @@ int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) 
   HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, dx, dy, nullptr, s->stream));
   return down(s, y, dy, h.num_cols);
 }
+
+// ---- PartitionedMatrixView products (I/partitioned_matrix_view_impl.h:112-375) -----------------
+// E = the first cell of each of the first num_row_blocks_e rows, F = everything else; vectors are
+// indexed in the part's own column space (F: col_block_pos - num_cols_e), rows in the full row space.
+namespace {
+int pmv_product(ceres_hip_solver* s, int part, bool left, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  const size_t ncols = size_t(part == kE ? h.num_cols_e : h.num_cols_f);
+  const size_t nin = left ? size_t(h.num_rows) : ncols, nout = left ? ncols : size_t(h.num_rows);
+  // scratch_vec holds num_cols + num_rows doubles: column-space vector first, row-space vector behind it
+  double* dcol = s->scratch_vec;
+  double* drow = s->scratch_vec + h.num_cols;
+  double* dx = left ? drow : dcol;
+  double* dy = left ? dcol : drow;
+  TRY(up(s, dx, x, nin));
+  TRY(up(s, dy, y, nout));
+  if (left) HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, part, dx, dy, nullptr, s->stream));
+  else HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, part, dx, dy, nullptr, s->stream));
+  return down(s, y, dy, nout);
+}
+int pmv_block_diagonal(ceres_hip_solver* s, int part, double* blocks, int64_t capacity) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const HostStructure& h = s->hs;
+  const int64_t len = part == kE ? h.diag_off_e.back() : h.diag_off_f.back();
+  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
+  double* tmp = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * std::max<int64_t>(1, len)));
+  hipError_t e = LaunchGenBlockDiagonal(s->G, s->values, part, nullptr, tmp, len, s->stream);
+  int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "block diagonal kernel failed");
+  (void)hipFree(tmp);
+  return rc;
+}
+}  // namespace
+
+int ceres_hip_op_right_multiply_e(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kE, false, x, y); }
+int ceres_hip_op_right_multiply_f(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kF, false, x, y); }
+int ceres_hip_op_left_multiply_e(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kE, true, x, y); }
+int ceres_hip_op_left_multiply_f(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kF, true, x, y); }
+int ceres_hip_op_block_diagonal_ete(ceres_hip_solver* s, double* blocks, int64_t capacity) { return pmv_block_diagonal(s, kE, blocks, capacity); }
+int ceres_hip_op_block_diagonal_ftf(ceres_hip_solver* s, double* blocks, int64_t capacity) { return pmv_block_diagonal(s, kF, blocks, capacity); }
 
 int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x) {
   TRY(require_loaded(s));

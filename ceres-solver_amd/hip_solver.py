@@ -98,6 +98,12 @@ ABI = [
     ("ceres_hip_load_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("ceres_hip_op_right_multiply", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_left_multiply", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_right_multiply_e", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_right_multiply_f", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_left_multiply_e", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_left_multiply_f", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_op_block_diagonal_ete", c_int32, [c_void_p, _DP, c_int64]),
+    ("ceres_hip_op_block_diagonal_ftf", c_int32, [c_void_p, _DP, c_int64]),
     ("ceres_hip_op_squared_column_norm", c_int32, [c_void_p, _DP]),
     ("ceres_hip_op_jtjx", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_jtb", c_int32, [c_void_p, _DP]),
@@ -409,6 +415,30 @@ class HipLinearSolver:
 
     def left_multiply(self, x, y=None):
         return self._xy(self._lib.ceres_hip_op_left_multiply, x, self._info.num_cols, y)
+
+    # PartitionedMatrixView products (internal/ceres/partitioned_matrix_view_impl.h:112-375); all accumulate into y
+    def right_multiply_e(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_right_multiply_e, x, self._info.num_rows, y)
+
+    def right_multiply_f(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_right_multiply_f, x, self._info.num_rows, y)
+
+    def left_multiply_e(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_left_multiply_e, x, self._info.num_cols_e, y)
+
+    def left_multiply_f(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_left_multiply_f, x, self._info.num_cols_f, y)
+
+    def _block_diagonal(self, fn, sizes):
+        out = np.full(int((sizes.astype(np.int64) ** 2).sum()), np.nan)
+        self._check(fn(self._h, _p(out), out.shape[0]))
+        return out
+
+    def block_diagonal_ete(self):
+        return self._block_diagonal(self._lib.ceres_hip_op_block_diagonal_ete, self.bs.col_block_size[: self._info.num_e_blocks])
+
+    def block_diagonal_ftf(self):
+        return self._block_diagonal(self._lib.ceres_hip_op_block_diagonal_ftf, self.bs.col_block_size[self._info.num_e_blocks:])
 
     def squared_column_norm(self):
         out = np.zeros(self._info.num_cols)

@@ -241,6 +241,25 @@ def synthetic_bal(shape="dubrovnik16", layout="schur", seed=38401, skew=0.0, num
     # sort cameras inside each point so that rows look like a real BAL file
     order = np.lexsort((cam_of_obs, point_of_obs))
     cam_of_obs = cam_of_obs[order]
+    return _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_values)
+
+
+def bal_from_tracks(track_lengths, num_cameras, layout="schur", seed=0, with_values=True) -> LinearProblem:
+    """BAL-shaped <2,3,9> Jacobian with a GIVEN number of observations per point (any value >= 1, e.g. runs of
+    single-observation points, which the reference allows: an eliminated block needs >= 1 residual,
+    internal/ceres/reorder_program.cc:313-317); cameras of a point are distinct and random."""
+    rng = np.random.default_rng(seed)
+    k = np.asarray(track_lengths, dtype=np.int64)
+    if k.min() < 1 or k.max() > num_cameras:
+        raise ValueError("track lengths must lie in [1, num_cameras]")
+    point_of_obs = np.repeat(np.arange(k.shape[0], dtype=np.int64), k)
+    cam_of_obs = _distinct_cameras(rng, num_cameras, point_of_obs, None)
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    return _assemble_bal(rng, int(num_cameras), int(k.shape[0]), point_of_obs, cam_of_obs[order], layout, with_values)
+
+
+def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_values) -> LinearProblem:
+    n_obs = int(point_of_obs.shape[0])
     r = np.arange(n_obs, dtype=np.int64)
     if layout == "schur":
         col_sizes = np.concatenate([np.full(n_points, 3, np.int32), np.full(n_cams, 9, np.int32)])

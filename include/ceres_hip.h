@@ -219,6 +219,22 @@ int ceres_hip_load_device(ceres_hip_solver* s, const double* dev_values, const d
 int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y);
 /* y += A^T x    BlockSparseMatrix::LeftMultiplyAndAccumulate   I/block_sparse_matrix.cc:278-349 */
 int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y);
+/* PartitionedMatrixView<kRow,kE,kF> products: E = the first cell of each of the first
+ * num_row_blocks_e rows, F = all other cells.  x / y live in the part's own column space
+ * (E: num_cols_e doubles, F: num_cols_f doubles indexed at col_block_pos - num_cols_e), rows in the
+ * full row space; all four accumulate into y.
+ *   y += E x    RightMultiplyAndAccumulateE        I/partitioned_matrix_view_impl.h:112-139
+ *   y += F x    RightMultiplyAndAccumulateF        :141-190
+ *   y += E^T x  LeftMultiplyAndAccumulateE(Single|Multi)Threaded  :192-250
+ *   y += F^T x  LeftMultiplyAndAccumulateF(Single|Multi)Threaded  :252-375                       */
+int ceres_hip_op_right_multiply_e(ceres_hip_solver* s, const double* x, double* y);
+int ceres_hip_op_right_multiply_f(ceres_hip_solver* s, const double* x, double* y);
+int ceres_hip_op_left_multiply_e(ceres_hip_solver* s, const double* x, double* y);
+int ceres_hip_op_left_multiply_f(ceres_hip_solver* s, const double* x, double* y);
+/* blockdiag(E^T E) / blockdiag(F^T F), dense row-major blocks in column-block order (no D).
+ * UpdateBlockDiagonalEtE / UpdateBlockDiagonalFtF                  :446-658                       */
+int ceres_hip_op_block_diagonal_ete(ceres_hip_solver* s, double* blocks, int64_t capacity);
+int ceres_hip_op_block_diagonal_ftf(ceres_hip_solver* s, double* blocks, int64_t capacity);
 /* x[j] = |A_j|^2  BlockSparseMatrix::SquaredColumnNorm           I/block_sparse_matrix.cc:351-401 */
 int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x);
 /* y = (A^T A + D^2) x, one fused pass.  CgnrLinearOperator::RightMultiplyAndAccumulate

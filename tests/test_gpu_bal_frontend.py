@@ -103,11 +103,33 @@ def test_minimize_follows_the_oracle_trust_region_loop(hip, oracle, solver_type,
 def test_minimize_with_rejected_steps_and_without_jacobi_scaling(hip, oracle):
     # a huge initial radius makes the first steps overshoot: exercises the rejection path (reuse_diagonal,
     # radius /= decrease_factor) on both sides
-    op, gp, bs, nelim = make_pair(hip, oracle, 10, 500, 2400, seed=11, param_noise=0.08)
+    op, gp, bs, nelim = make_pair(hip, oracle, 10, 500, 2400, seed=7, param_noise=2.0)
     x0 = op.state()
     kw = dict(max_num_iterations=15, jacobi_scaling=0)
-    Sa = op.lm_solve(solver_type=5, preconditioner=2, max_it=500, initial_radius=1e12, **kw)
-    x, Sb = gp.minimize(x0, initial_trust_region_radius=1e12, **kw)
+    Sa = op.lm_solve(solver_type=5, preconditioner=2, max_it=500, initial_radius=1e16, **kw)
+    x, Sb = gp.minimize(x0, initial_trust_region_radius=1e16, **kw)
+    assert Sa.num_unsuccessful_steps >= 3, "the scenario must contain rejected steps"
+    check_same_trajectory(Sa, Sb, 1e-5)
+    assert Sb.num_unsuccessful_steps == Sa.num_unsuccessful_steps
+    gp.close()
+
+
+def test_minimize_spse_preconditioner_with_rejected_steps(hip, oracle):
+    # SCHUR_POWER_SERIES_EXPANSION needs blockdiag(F^T F + D_f^2)^-1, which contains D: a rejected step retries
+    # with a smaller radius (= a new D) on the SAME Jacobian, and the cached inverse must be rebuilt
+    # (ImplicitSchurComplement::Init recomputes it on every Solve).  With a stale inverse the CG iteration
+    # counts of the retries drift away from the oracle's.
+    op, gp, bs, nelim = make_pair(hip, oracle, 10, 500, 2400, seed=7, pre=hip.SCHUR_POWER_SERIES_EXPANSION, param_noise=2.0)
+    x0 = op.state()
+    m = oracle.Matrix(bs, nelim)
+
+    def solve(values, b, D, q_tol, r_tol):
+        x, summ = oracle.iterative_schur_solve_spse(m, values, b, D, preconditioner=3, min_it=0, max_it=500, q_tol=q_tol, r_tol=r_tol)
+        return x, summ.termination_type, summ.num_iterations
+    kw = dict(max_num_iterations=15, jacobi_scaling=0)
+    Sa = op.lm_solve(solve_fn=solve, initial_radius=1e16, **kw)
+    x, Sb = gp.minimize(x0, initial_trust_region_radius=1e16, **kw)
+    assert Sa.num_unsuccessful_steps >= 3, "the scenario must contain rejected steps"
     check_same_trajectory(Sa, Sb, 1e-5)
     assert Sb.num_unsuccessful_steps == Sa.num_unsuccessful_steps
     gp.close()

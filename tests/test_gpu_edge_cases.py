@@ -49,6 +49,49 @@ def test_single_point_and_exactly_one_tile(hip, oracle, problems):
         check_against_oracle(hip, oracle, p, hip.PATH_BAL)
 
 
+@pytest.mark.parametrize("layout", ["schur", "cgnr"])
+def test_tiles_full_of_single_observation_points(hip, oracle, problems, layout):
+    """Runs of one-observation points (allowed: >= 1 residual per eliminated block): a tile would hold up to 64
+    of them = 192 point-space scalars, but the cooperative point-space path of the fused JtJx covers 128
+    per tile, so the plan caps a tile at 42 points (csrc/plan.cc).  Operators AND solves against the oracle,
+    both solvers, in the contiguous (schur) layout that selects the pipelined kernels and in the cgnr layout."""
+    tracks = [1] * 700 + [2] * 60 + [1] * 130 + [3, 1, 1, 70, 1, 1] + [1] * 64 + [5] * 30
+    p = problems.bal_from_tracks(tracks, 90, layout=layout, seed=12)
+    rng = np.random.default_rng(1)
+    p.D = 0.5 + rng.random(p.bs.num_cols)   # one-observation points need D: their E^T E alone is singular
+    nelim = p.num_eliminate_blocks
+    m0 = oracle.Matrix(p.bs, 0)
+    s = make_solver(hip, p, hip.CGNR, hip.JACOBI, max_it=400)
+    assert s.info().kernel_path == hip.PATH_BAL
+    s.load(p.values, p.b, p.D)
+    x = rng.standard_normal(p.bs.num_cols)
+    Jx = m0.right_multiply(p.values, x)
+    want = m0.left_multiply(p.values, Jx) + p.D ** 2 * x
+    got = s.jtjx(x)
+    assert np.isfinite(got).all() and rel(got, want) <= 1e-12
+    y = rng.standard_normal(p.bs.num_cols)   # symmetry: the defect made the operator non-symmetric
+    assert abs(y @ got - x @ s.jtjx(y)) <= 1e-11 * abs(y @ got)
+    assert rel(s.jtb(), m0.left_multiply(p.values, p.b)) <= 1e-12
+    xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-12))
+    xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=400, q_tol=-1.0, r_tol=1e-12)
+    assert summ.termination_type == so.termination_type == hip.SUCCESS and rel(xs, xo) <= 1e-8
+    s.close()
+    if layout == "schur":
+        m = oracle.Matrix(p.bs, nelim)
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=400)
+        s.load(p.values, p.b, p.D)
+        isc = oracle.ImplicitSchurComplement(m)
+        isc.init(p.values, p.D, p.b)
+        s.schur_init()
+        xf = rng.standard_normal(m.num_cols_f)
+        assert rel(s.schur_rhs(), isc.rhs()) <= 1e-12 and rel(s.schur_sx(xf), isc.sx(xf)) <= 1e-12
+        assert rel(s.back_substitute(xf), isc.back_substitute(xf)) <= 1e-12
+        xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-12))
+        xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, min_it=0, max_it=400, q_tol=-1.0, r_tol=1e-12)
+        assert summ.termination_type == so.termination_type == hip.SUCCESS and rel(xs, xo) <= 1e-8
+        s.close()
+
+
 def test_generic_structures_with_odd_rows(hip, oracle, problems):
     from ceres_solver_amd import BlockStructure
     # a row block with no cells at all, 1-wide and 16-wide blocks, an E block seen by one row only

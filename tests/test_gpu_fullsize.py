@@ -1,7 +1,13 @@
-"""BASELINE.json's sizes on the GPU through size-independent properties (the oracle is too slow
-to be the checker at these sizes): linearity and symmetry of S and of J^T J + D^2, agreement of the
-fused <2,3,9> kernels with the generic multi-pass kernels, and the normal-equation residual of
-the returned step."""
+"""BASELINE.json's shapes at FULL size on the GPU, checked against the ORACLE (16 OpenMP threads: a whole
+Venice-shaped step takes it about a second), plus size-independent properties.
+
+  dubrovnik16  (16 / 22 106 / 83 718)        both solvers: every operator 1e-12, the LM-style eta = 0.1 solve
+  ladybug1723  (1723 / 156 502 / 678 718)    (iteration count +-1, step 1e-9 when the counts coincide), converged solve 1e-8
+  venice1778   (1778 / 993 923 / 5 001 946)  operators of BOTH solvers: S x, rhs, (E^T E)^-1, back-substitution,
+                                             SCHUR_JACOBI blocks, JtJx, J^T b, JACOBI blocks; eta = 0.1 solves
+  many cameras (50 000 cameras)              the regime of BASELINE.json configs[4] (camera accumulators do not fit
+                                             in LDS), scaled to 1.2 M observations: operators + solves, both solvers
+"""
 import numpy as np
 import pytest
 
@@ -9,10 +15,130 @@ from test_gpu_operators import make_solver, rel
 
 pytestmark = pytest.mark.gpu
 
+OP_TOL = 1e-12
+
+
+@pytest.fixture(scope="module", autouse=True)
+def oracle_threads(oracle):
+    import os
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))
+    yield
+    oracle.set_num_threads(1)
+
+
+def upper_blocks_err(mine, ref, n):
+    a, b = mine.reshape(-1, n, n), ref.reshape(-1, n, n)
+    iu = np.triu_indices(n)
+    return np.abs(a[:, iu[0], iu[1]] - b[:, iu[0], iu[1]]).max() / max(np.abs(b).max(), 1e-300)
+
+
+def check_schur_side(hip, oracle, p, expect_lds, solve=True):
+    rng = np.random.default_rng(0)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    info = s.info()
+    assert info.kernel_path == hip.PATH_BAL and info.camera_accum_in_lds == int(expect_lds)
+    s.load(p.values, p.b, p.D)
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    s.schur_init()
+    errs = {"rhs": rel(s.schur_rhs(), isc.rhs()), "ete_inverse": rel(s.ete_inverse(), isc.ete_inverse())}
+    xf = rng.standard_normal(m.num_cols_f)
+    errs["sx"] = rel(s.schur_sx(xf), isc.sx(xf))
+    errs["back_substitute"] = rel(s.back_substitute(xf), isc.back_substitute(xf))
+    s.schur_jacobi_update()
+    inv, raw = m.schur_jacobi(p.values, p.D)
+    errs["schur_jacobi_raw"] = upper_blocks_err(s.preconditioner_blocks(not_inverted=True), raw, 9)
+    s.schur_jacobi_update()
+    errs["schur_jacobi_inv"] = rel(s.preconditioner_blocks(), inv)
+    for k, v in errs.items():
+        assert v <= OP_TOL, (k, v)
+    if solve:
+        # the call LevenbergMarquardtStrategy makes: eta = 0.1, r_tolerance = -1
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+        xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+        assert summ.termination_type == so.termination_type == hip.SUCCESS
+        assert abs(summ.num_iterations - so.num_iterations) <= 1, (summ, so)
+        if summ.num_iterations == so.num_iterations:
+            assert rel(x, xo) <= 1e-9, rel(x, xo)
+    s.close()
+    return m
+
+
+def check_cgnr_side(hip, oracle, p, expect_lds, solve=True):
+    rng = np.random.default_rng(1)
+    m0 = oracle.Matrix(p.bs, 0)
+    s = make_solver(hip, p, hip.CGNR, hip.JACOBI, max_it=500)
+    info = s.info()
+    assert info.kernel_path == hip.PATH_BAL and info.camera_accum_in_lds == int(expect_lds)
+    s.load(p.values, p.b, p.D)
+    x = rng.standard_normal(p.bs.num_cols)
+    want = m0.left_multiply(p.values, m0.right_multiply(p.values, x)) + p.D ** 2 * x
+    errs = {"jtjx": rel(s.jtjx(x), want), "jtb": rel(s.jtb(), m0.left_multiply(p.values, p.b)),
+            "squared_column_norm": rel(s.squared_column_norm(), m0.squared_column_norm(p.values))}
+    s.block_jacobi_update()
+    inv, raw = m0.block_jacobi(p.values, p.D)
+    errs["block_jacobi_inv"] = rel(s.preconditioner_blocks(), inv)
+    for k, v in errs.items():
+        assert v <= OP_TOL, (k, v)
+    if solve:
+        xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+        xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+        assert summ.termination_type == so.termination_type == hip.SUCCESS
+        assert abs(summ.num_iterations - so.num_iterations) <= 1, (summ, so)
+        if summ.num_iterations == so.num_iterations:
+            assert rel(xs, xo) <= 1e-9, rel(xs, xo)
+    s.close()
+
 
 @pytest.fixture(scope="module")
 def ladybug(problems):
     return problems.synthetic_bal("ladybug1723", layout="schur", seed=38401, skew=0.6)
+
+
+@pytest.fixture(scope="module")
+def venice(problems):
+    return problems.synthetic_bal("venice1778", layout="schur", seed=38401, skew=0.6)
+
+
+def test_dubrovnik16_full_shape_against_the_oracle(hip, oracle, problems):
+    p = problems.synthetic_bal("dubrovnik16", layout="schur", seed=38401, skew=0.6)
+    assert p.bs.num_row_blocks == 83718
+    check_schur_side(hip, oracle, p, True)
+    check_cgnr_side(hip, oracle, p, True)
+    # the row-sequential layout CGNR gets from BlockJacobianWriter (BASELINE configs[1])
+    q = problems.synthetic_bal("dubrovnik16", layout="cgnr", seed=38401, skew=0.6)
+    check_cgnr_side(hip, oracle, q, True)
+
+
+def test_ladybug1723_full_shape_against_the_oracle(hip, oracle, ladybug):
+    assert ladybug.bs.num_row_blocks == 678718
+    m = check_schur_side(hip, oracle, ladybug, True)
+    check_cgnr_side(hip, oracle, ladybug, True)
+    # converged solve (rung 3 of the ladder): vs the oracle 1e-8
+    s = make_solver(hip, ladybug, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    x, summ = s.solve(ladybug.values, ladybug.b, hip.PerSolveOptions(D=ladybug.D, q_tolerance=-1.0, r_tolerance=1e-12))
+    xo, so = m.iterative_schur_solve(ladybug.values, ladybug.b, ladybug.D, preconditioner=2, min_it=0, max_it=500, q_tol=-1.0, r_tol=1e-12)
+    assert summ.termination_type == so.termination_type == hip.SUCCESS and rel(x, xo) <= 1e-8
+    s.close()
+
+
+def test_venice1778_full_shape_schur_operators_against_the_oracle(hip, oracle, venice):
+    assert venice.bs.num_row_blocks == 5001946
+    check_schur_side(hip, oracle, venice, True)
+
+
+def test_venice1778_full_shape_cgnr_operators_against_the_oracle(hip, oracle, venice):
+    check_cgnr_side(hip, oracle, venice, True)
+
+
+def test_many_camera_regime_against_the_oracle(hip, oracle, problems):
+    # 50 000 cameras: 3.6 MB of camera accumulators per workgroup do not fit the 160 KB LDS; the kernels take their
+    # camera-major second pass (BASELINE.json configs[4] at 1/25 of its observations)
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=50000, num_points=400000, num_observations=1200000,
+                               seed=38401, skew=0.6)
+    check_schur_side(hip, oracle, p, False)
+    check_cgnr_side(hip, oracle, p, False)
 
 
 def test_ladybug_shape_fused_vs_generic(hip, ladybug):
@@ -57,7 +183,8 @@ def test_ladybug_shape_step_satisfies_normal_equations(hip, ladybug):
     c.close()
 
 
-def test_venice_shape_cgnr_properties_and_solve(hip, problems):
+def test_venice_shape_cgnr_layout_properties_and_solve(hip, oracle, problems):
+    # the row-sequential (interleaved) layout at full size: non-contiguous point / camera columns
     p = problems.synthetic_bal("venice1778", layout="cgnr", seed=38401, skew=0.6)
     p.num_eliminate_blocks = 0
     s = make_solver(hip, p, hip.CGNR, hip.JACOBI, max_it=30, min_it=0)
@@ -68,6 +195,8 @@ def test_venice_shape_cgnr_properties_and_solve(hip, problems):
     n = info.num_cols
     x, y = rng.standard_normal(n), rng.standard_normal(n)
     Ax, Ay = s.jtjx(x), s.jtjx(y)
+    m0 = oracle.Matrix(p.bs, 0)
+    assert rel(Ax, m0.left_multiply(p.values, m0.right_multiply(p.values, x)) + p.D ** 2 * x) <= OP_TOL
     assert rel(s.jtjx(0.5 * x + 4.0 * y), 0.5 * Ax + 4.0 * Ay) <= 1e-12
     assert abs(y @ Ax - x @ Ay) <= 1e-11 * abs(y @ Ax)
     # x^T (J^T J + D^2) x = |J x|^2 + |D x|^2 with J x from the plain (generic) SpMV

@@ -39,6 +39,12 @@ def check_plan_invariants(p, plan):
         assert aux[t] & 0xff == longest and aux[t] >> 8 == len(np.unique(pts))
         # lane L owns scalars L and 64 + L of the tile's point range: tail lanes of points L/3, (64+L)/3
         upts = np.unique(pts)
+        # ... so a tile's point range must fit the 128 scalars two-per-lane ownership covers, and every one of
+        # its 3 * npts scalars must have a store bit (a tile of 43+ one-observation points would silently lose
+        # the tail of its point range in the cooperative JtJx path)
+        assert 3 * len(upts) <= 128 and len(upts) <= 42
+        owned = sorted([L for L in range(64) if plan["has_a"][sl][L]] + [64 + L for L in range(64) if plan["has_b"][sl][L]])
+        assert owned == list(range(3 * len(upts)))
         tails = [np.flatnonzero(v & (pt[sl] == q))[-1] for q in upts]
         for L in range(64):
             for off, has, tail in ((0, plan["has_a"][sl][L], plan["tail_a"][sl][L]), (64, plan["has_b"][sl][L], plan["tail_b"][sl][L])):
@@ -80,6 +86,19 @@ def test_plan_long_points(problems):
     plan = plan_of(p)
     track = check_plan_invariants(p, plan)
     assert (plan["tile_kind"] == 1).sum() == (track > 64).sum()
+
+
+def test_plan_caps_points_per_tile(problems):
+    # runs of one-observation points: without the cap a tile would take up to 64 of them (192 point-space scalars)
+    tracks = [1] * 500 + [2] * 40 + [1] * 90 + [3, 1, 1, 70, 1, 1] + [1] * 64
+    p = problems.bal_from_tracks(tracks, 80, seed=4)
+    plan = plan_of(p)
+    check_plan_invariants(p, plan)
+    per_tile = [len(np.unique(plan["slot_pt"][t * 64:t * 64 + 64][plan["valid"][t * 64:t * 64 + 64].astype(bool)]))
+                for t in np.flatnonzero(plan["tile_kind"] == 0)]
+    assert max(per_tile) == 42
+    p = problems.bal_from_tracks(tracks, 80, layout="cgnr", seed=4)
+    check_plan_invariants(p, plan_of(p))
 
 
 def test_plan_rejections(problems):
