@@ -88,8 +88,25 @@ def make_solver(hs, bs, nelim, solver, device, comm=None, storage=0):
     typ, pre = (hs.CGNR, hs.JACOBI) if solver == "cgnr" else (hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)
     o = hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                residual_reset_period=10, elimination_groups=[nelim], device=device, jacobian_storage=storage)
-    kw = {} if comm is None else dict(comm_id=comm[0], rank=comm[1], world_size=comm[2])
-    s = hs.HipLinearSolver(o, **kw)
+    if comm is None:
+        s = hs.HipLinearSolver(o)
+    else:
+        # RCCL communicator (any message size) + the one-shot peer-to-peer all-reduce over hipIpc / xGMI for the
+        # latency-bound camera-space sums of a step (<= 81 doubles per camera); CERES_HIP_P2P=0 leaves RCCL alone.
+        kw = dict(comm_id=comm[0], rank=comm[1], world_size=comm[2])
+        if comm[3] is not None:
+            f = bs.col_block_size[nelim:].astype(np.int64)
+            kw.update(p2p_exchange=comm[3], p2p_max_elements=int(max((f * f).sum(), f.sum(), 2)))
+        s = hs.HipLinearSolver(o, **kw)
+        if comm[3] is not None:  # agree on the verdict of the self-test: all ranks use the peer-to-peer path, or none does
+            import torch
+            import torch.distributed as dist
+            ok = torch.tensor([1 if s.p2p_selftest() else 0], device=f"cuda:{device}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm[1] == 0:
+                    print(f"bench.py: peer-to-peer all-reduce unavailable ({s.p2p_error}); using RCCL", file=sys.stderr)
+                s.p2p_disable()
     s.set_structure(bs)
     return s
 
@@ -155,7 +172,13 @@ def main():
         if rank == 0:
             idt = torch.tensor(list(hs.comm_unique_id()), dtype=torch.uint8, device=dev)
         dist.broadcast(idt, 0)
-        comm = (bytes(idt.cpu().tolist()), rank, world)
+
+        def p2p_exchange(mine):
+            t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return [bytes(o.cpu().tolist()) for o in out]
+        comm = (bytes(idt.cpu().tolist()), rank, world, p2p_exchange if os.environ.get("CERES_HIP_P2P", "1") != "0" else None)
     prob = None
     if many_cameras:
         # configs[4]: 5.76 GB of Jacobian values.  The observation graph is generated on the host (numpy, the

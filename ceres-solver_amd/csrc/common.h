@@ -73,6 +73,7 @@ struct BalPlan {
   std::vector<int32_t> cam_ptr;    // n_cameras+1
   std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major
   std::vector<int32_t> cam_slot;   // slot of each observation, camera-major
+  std::vector<int32_t> slot_crank; // inverse of cam_slot: camera-major rank of each slot's observation (-1 = padding)
   // work items of the camera-block kernel: (camera, [begin,end) in the camera-major list)
   std::vector<int32_t> item_cam, item_begin, item_end;
   int max_track = 0, max_camera_degree = 0;

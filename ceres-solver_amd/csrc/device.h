@@ -60,6 +60,9 @@ struct BalArgs {
   double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
+  // camera-major placement of what the camera-major second passes read (nullptr: slot-major, gathered through cam_slot):
+  const int32_t* mo_crank = nullptr;  // kInit writes M_o at [crank][4] -> bal_camera_blocks_kernel streams it
+  const int32_t* z_crank = nullptr;   // cameras-not-in-LDS mode: F^T z at [crank][9] -> bal_camera_apply_kernel streams it
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
@@ -242,13 +245,29 @@ hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
 // Fused iteration, second half of iteration `it` (I/conjugate_gradients_solver.h:196-249 + :162-167 of the next one):
 // pq = sum(pq_parts), alpha; x += alpha p; unless reset: r -= alpha q, partial Q1 / |r|^2 -> slots 2, 3 and, block by block,
 // z = M^-1 r with partial r.z -> slot 0 (the next iteration's rho).  One thread per column block.
+// nine_from: blocks [nine_from, nblocks) of the range are all 9 wide (handled nine lanes per block); nblocks if unknown.
 hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
-                          const int64_t* diag_off, const double* blocks, int reset, int it, hipStream_t stream);
+                          const int64_t* diag_off, const double* blocks, int reset, int it, int nine_from, hipStream_t stream);
 // Fused: the termination tests of iteration `it` in the reference's order (:273-302) and, if CG goes on, the
 // direction of iteration it + 1: rho = sum(slot 0), beta = rho / rho_it, p = z + beta p (:167-191).
 hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t stream);
 // comm[slot] = sum over the shard's workgroups of partials[slot] for slot in [first, first+count)
 hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t stream);
+
+// out[0] = (*flag != 0), out[1] = sum of parts[0 .. n) (one workgroup, fixed order)
+hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t stream);
+
+// ---- one-shot peer-to-peer all-reduce (kernels_cg.hip) ----
+constexpr int kP2pMaxWorld = 8;   // one node: 8 GPUs on the xGMI mesh
+constexpr int kP2pChunk = 2048;   // doubles per workgroup
+struct P2pPeers {
+  double* slots[kP2pMaxWorld];               // rank q's receive slots [2][world][cap], as mapped into THIS process
+  unsigned long long* flags[kP2pMaxWorld];   // rank q's arrival flags [2][world][chunks_cap]
+};
+// out = sum over ranks of in (n <= cap; in may alias out).  `epoch` counts this communicator's all-reduces from 1.
+hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
+                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, double timeout_seconds,
+                              hipStream_t stream);
 
 // ---- f4: BAL evaluator (kernels_evaluator.hip) ----
 struct BalEvalArgs {

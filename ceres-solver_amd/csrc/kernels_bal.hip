@@ -100,6 +100,7 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
+  int64_t zslot;  // where this slot's per-observation output for the camera-major pass goes (slot, or its camera-major rank)
   uint32_t seg;
   int cam, pt, first, last;
   bool valid;
@@ -189,17 +190,21 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
   }
   s.cam = A.slot_cam[sl];
   s.seg = A.slot_seg[sl];
+  s.zslot = A.z_crank ? A.z_crank[sl] : sl;
   finish_slot(s, lane, A.tile_pt0[tile]);
 }
 
 // The software-pipelined streaming kernel splits a slot load in three, each of which only ISSUES
 // loads and consumes nothing: the index words (SlotIdx), the 12 pairs of a packed fp64 tile
 // (issue_pairs), and what is addressed THROUGH the index words (issue_aux, further down).
-struct SlotIdx { int cam; uint32_t seg; };
+struct SlotIdx { int cam; uint32_t seg; int crank; };
+template <bool LDS>
 __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
   const int64_t sl = tile * kTile + lane;
   i.cam = A.slot_cam[sl];
   i.seg = A.slot_seg[sl];
+  i.crank = -1;
+  if constexpr (!LDS) { if (A.z_crank) i.crank = A.z_crank[sl]; }  // kernel-uniform: one more index word per slot in that mode
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
@@ -255,7 +260,7 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
     // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
     // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
     // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
-    double* w = acc + 9 * s.slot;
+    double* w = acc + 9 * s.zslot;
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = s.f[k] * z0 + s.f[9 + k] * z1;
   }
@@ -332,7 +337,8 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     double q0[3], q1[3];
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
-    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * sl);  // [slot][4]: m00 m01 m11 pad, 32 B per slot
+    // [slot][4] (or, camera-major, [rank][4]): m00 m01 m11 pad, 32 B per observation
+    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * (A.mo_crank ? int64_t(A.mo_crank[sl]) : sl));
     mo[0] = make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]));
     mo[1] = make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0);
   }
@@ -818,13 +824,14 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     int64_t tile = wave0;
     int kind_a = A.tile_kind[tile], aux_a = A.tile_aux[tile], kind_b = 2, aux_b = 0;
     // prologue in the steady-state issue order: index words (1), pairs (0), aux (0)
-    issue_idx(A, tile, lane, i2);
+    issue_idx<LDS>(A, tile, lane, i2);
     __builtin_amdgcn_sched_barrier(0);
-    issue_idx(A, min(tile + nwaves, last), lane, i1);
+    issue_idx<LDS>(A, min(tile + nwaves, last), lane, i1);
     __builtin_amdgcn_sched_barrier(0);
     issue_pairs(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
     sa.cam = i2.cam; sa.seg = i2.seg;
+    sa.zslot = (!LDS && A.z_crank) ? int64_t(i2.crank) : sa.slot;
     finish_slot(sa, lane, A.tile_pt0[tile]);
     issue_aux<MODE>(A, sa, lane, kind_a == 0 ? aux_a >> 8 : 0, xa);
     __builtin_amdgcn_sched_barrier(0);
@@ -835,11 +842,12 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       more = tile + nwaves < A.n_tiles;
       nkind = A.tile_kind[next];
       naux = A.tile_aux[next];
-      issue_idx(A, min(next + nwaves, last), lane, i2);
+      issue_idx<LDS>(A, min(next + nwaves, last), lane, i2);
       __builtin_amdgcn_sched_barrier(0);
       issue_pairs(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);
       n.cam = i1.cam; n.seg = i1.seg;
+      n.zslot = (!LDS && A.z_crank) ? int64_t(i1.crank) : n.slot;
       finish_slot(n, lane, A.tile_pt0[next]);
       issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
       __builtin_amdgcn_sched_barrier(0);
@@ -1047,7 +1055,7 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
     for (int k = 0; k < 9; ++k) { f0[k] = f[k]; f1[k] = f[9 + k]; }
     double m00 = 1.0, m01 = 0.0, m11 = 1.0;
     if constexpr (SCHUR) {
-      const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
+      const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot ? cam_slot[q] : q));  // nullptr: M_o is camera-major
       const double2 a = mo[0], b = mo[1];
       m00 = a.x; m01 = a.y; m11 = b.x;
       if (camsq) {  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
@@ -1119,7 +1127,7 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   for (int q = beg + lane; q < end; q += 64) {
-    const double* w = zbuf + 9 * int64_t(cam_slot[q]);
+    const double* w = zbuf + 9 * int64_t(cam_slot ? cam_slot[q] : q);  // nullptr: the per-observation F^T z were written camera-major
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] += w[k];
   }

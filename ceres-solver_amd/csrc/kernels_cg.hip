@@ -22,6 +22,8 @@
 // enqueue a batch of iterations and poll the word only every few iterations.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device.h"
 
 namespace chip {
@@ -416,8 +418,13 @@ __device__ __forceinline__ void update_block(const double* __restrict__ m, doubl
   }
 }
 
+// Column blocks [nine_from, nblocks) are all 9 wide (the camera blocks): workgroups [grid_a, gridDim.x) take them with NINE
+// LANES PER BLOCK (7 blocks per wavefront, lane a of a group owns row a: its 72-byte row of M and the block's 648 bytes
+// are contiguous across the group, r travels by shuffle) instead of one thread per block walking 81 strided entries —
+// with 1778 cameras that thread-per-block tail alone took 15 us.  Blocks [0, nine_from) stay one thread per block.
 __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenStructure G, int first_block, int col_begin, int nblocks,
-                                                              const int64_t* diag_off, const double* blocks, int reset, int it) {
+                                                              const int64_t* diag_off, const double* blocks, int reset, int it,
+                                                              int nine_from, int grid_a) {
   __shared__ double sh[4];
   CgScalars& S = *B.S;
   if (S.status != 0) return;
@@ -446,8 +453,35 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
         rr += rv * rv;
       }
       rz = rr;
+    } else if (int(blockIdx.x) >= grid_a) {
+      const int lane = threadIdx.x & 63;
+      const int g = lane / 9, a = lane - 9 * g;
+      const int n9 = nblocks - nine_from;
+      const int64_t wave = int64_t(int(blockIdx.x) - grid_a) * (kVecBlock / 64) + (threadIdx.x >> 6);
+      const int64_t nwaves = int64_t(int(gridDim.x) - grid_a) * (kVecBlock / 64);
+      for (int64_t base = wave * 7; base < n9; base += nwaves * 7) {
+        const bool active = g < 7 && base + g < n9;
+        const int64_t q = nine_from + (active ? base + g : base);
+        const int64_t i = G.cpos[first_block + q] - col_begin + (active ? a : 0);
+        const double* m = blocks + (diag_off[q] - diag_off[0]) + (active ? 9 * a : 0);
+        double mr[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) mr[c] = m[c];
+        const double xv = B.x[i] + alpha * B.p[i];
+        const double rv = B.r[i] - alpha * B.z[i];
+        double t = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) t += mr[c] * __shfl(rv, 9 * (g < 7 ? g : 0) + c, 64);
+        if (active) {
+          B.x[i] = xv; B.r[i] = rv; B.z[i] = t;
+          q1 -= xv * (B.rhs[i] + rv);
+          rr += rv * rv;
+          rz += rv * t;
+        }
+      }
     } else {
-      for (int64_t q = t0; q < nblocks; q += step) {
+      const int64_t stepa = int64_t(grid_a) * kVecBlock;
+      for (int64_t q = t0; q < nine_from; q += stepa) {
         const int j = first_block + int(q);
         const int n = G.csz[j];
         const int64_t pos = G.cpos[j] - col_begin;
@@ -651,8 +685,14 @@ hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
-                          const int64_t* diag_off, const double* blocks, int reset, int it, hipStream_t s) {
-  hipLaunchKernelGGL(cg_update_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, reset, it);
+                          const int64_t* diag_off, const double* blocks, int reset, int it, int nine_from, hipStream_t s) {
+  nine_from = std::max(0, std::min(nine_from, nblocks));
+  const int n9 = nblocks - nine_from;
+  int grid_a = B.grid;  // workgroups of the one-thread-per-block part
+  if (n9 > 0) grid_a = nine_from == 0 ? 0 : std::max(1, B.grid - std::max(1, std::min(B.grid / 2, (n9 + 111) / 112)));
+  if (n9 > 0 && grid_a >= B.grid) { nine_from = nblocks; grid_a = B.grid; }  // a single workgroup: no room to split
+  hipLaunchKernelGGL(cg_update_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, reset, it,
+                     nine_from, grid_a);
   return hipGetLastError();
 }
 hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t s) {
@@ -664,4 +704,97 @@ hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipSt
   return hipGetLastError();
 }
 
+}  // namespace chip
+
+namespace chip {
+namespace {
+// out[0] = (*flag != 0), out[1] = sum(parts[0 .. n)) in a fixed order: what a sharded LM step all-reduces at its end
+// (finite-step flag, this rank's share of the model cost change) without a host round trip in front of the collective.
+__global__ __launch_bounds__(kVecBlock) void collect_scalars_kernel(const int* flag, const double* parts, int n, double* out) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (int k = threadIdx.x; k < n; k += kVecBlock) v += parts[k];
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) { out[0] = (*flag != 0) ? 1.0 : 0.0; out[1] = v; }
+}
+}  // namespace
+hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(collect_scalars_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out);
+  return hipGetLastError();
+}
+}  // namespace chip
+
+// ---- one-shot peer-to-peer all-reduce (the <= few-MB camera-space sums of a sharded solve) ----
+// RCCL's small-message all-reduce costs tens of microseconds; the vectors summed here (9 or 81 doubles per camera)
+// are latency-bound, and a step issues several.  Every rank owns one fine-grained buffer mapped by all peers
+// (hipIpc handles exchanged by the host once): receive slots [parity][source rank][capacity] and arrival
+// flags [parity][source rank][chunk].  One kernel, one workgroup per 2048-element chunk, no grid barrier:
+//   push   : the chunk of `in` is written into the slot [epoch & 1][my rank] of EVERY rank (its own included),
+//            system-scope release, then the chunk's flag at every rank is set to `epoch`;
+//   wait   : lane q of the workgroup spins (system-scope acquire loads, s_sleep, wall-clock timeout) on the flag
+//            that source rank q sets in MY buffer;
+//   reduce : out = sum over source ranks in rank order of MY slots — every rank adds the same numbers in the same
+//            order, so all ranks end with identical bits (ITERATIVE_SCHUR's replicated CG state relies on it).
+// Slots are double-buffered by epoch parity: a writer reaching epoch e + 2 has completed epoch e + 1, which needed
+// every peer's epoch e + 1 flag, which a peer sets only after its epoch e kernel (the reader of the slot) finished.
+namespace chip {
+namespace {
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n,
+                                                            P2pPeers P, int rank, int world, unsigned long long epoch,
+                                                            int64_t cap, int chunks_cap, int* error_flag, long long timeout_ticks) {
+  const int parity = int(epoch & 1ull);
+  const int c = blockIdx.x;
+  const int64_t lo = int64_t(c) * kP2pChunk;
+  constexpr int kPer = kP2pChunk / 256;
+  double v[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int64_t i = lo + threadIdx.x + 256 * k;
+    v[k] = i < n ? in[i] : 0.0;
+  }
+  for (int q = 0; q < world; ++q) {
+    double* dst = P.slots[q] + (int64_t(parity) * world + rank) * cap;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int64_t i = lo + threadIdx.x + 256 * k;
+      if (i < n) dst[i] = v[k];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (int(threadIdx.x) < world) {
+    const int q = threadIdx.x;
+    __hip_atomic_store(P.flags[q] + (int64_t(parity) * world + rank) * chunks_cap + c, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long* f = P.flags[rank] + (int64_t(parity) * world + q) * chunks_cap + c;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (wall_clock64() - t0 > timeout_ticks) { atomicExch(error_flag, 1); break; }  // a peer never arrived: do not hang the GPU
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  const double* mine = P.slots[rank] + int64_t(parity) * world * cap;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int64_t i = lo + threadIdx.x + 256 * k;
+    if (i < n) {
+      double s = 0.0;
+      for (int q = 0; q < world; ++q) s += mine[q * cap + i];
+      out[i] = s;
+    }
+  }
+}
+}  // namespace
+
+hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
+                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, double timeout_seconds,
+                              hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int grid = int((n + kP2pChunk - 1) / kP2pChunk);
+  const long long ticks = (long long)(timeout_seconds * 1e8);  // wall_clock64 counts at 100 MHz
+  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(grid), dim3(256), 0, stream, in, out, n, peers, rank, world, epoch, cap, chunks_cap,
+                     error_flag, ticks);
+  return hipGetLastError();
+}
 }  // namespace chip

@@ -300,6 +300,7 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   }
   P.cam_fpos.resize(P.n_obs);
   P.cam_slot.resize(P.n_obs);
+  P.slot_crank.assign(size_t(P.n_tiles) * kTile, -1);
   {
     std::vector<int32_t> cur(P.cam_ptr.begin(), P.cam_ptr.end() - 1);
     for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
@@ -307,6 +308,7 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       const int q = cur[P.slot_cam[s]]++;
       P.cam_fpos[q] = P.slot_fpos[s];
       P.cam_slot[q] = int32_t(s);
+      P.slot_crank[s] = q;  // inverse: where the slot's observation sits in the camera-major list
     }
   }
   // Item size: kCamChunk at scale (>= 8192 items keep every CU busy); smaller problems get

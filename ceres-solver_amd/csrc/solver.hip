@@ -58,7 +58,8 @@ struct ceres_hip_solver {
   int32_t *d_slot_epos = nullptr, *d_slot_fpos = nullptr, *d_slot_bpos = nullptr, *d_slot_cam = nullptr, *d_tile_pt0 = nullptr;
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
-  int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
+  int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr, *d_slot_crank = nullptr;
+  bool mo_cam_major = false, z_cam_major = false;  // what the camera-major passes read is WRITTEN camera-major (CERES_HIP_MO_CAM / CERES_HIP_Z_CAM)
   CamItems cam_items;
   // f1: LM step state
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
@@ -99,12 +100,23 @@ struct ceres_hip_solver {
   double* cg_rhs = nullptr;
   double* cg_pq_parts = nullptr;   // kMaxPqParts partial sums of p.q left by the operator's kernels
   bool cg_fused = true;            // CERES_HIP_CG_FUSED=0: the five-kernel iteration (A/B measurements)
+  int nine_wide_from = 0;          // column blocks [nine_wide_from, ncb) are all 9 wide (BAL: the cameras)
   CgScalars* h_scalars = nullptr;  // pinned
   double* h_pinned = nullptr;      // pinned scratch, 2 * kMaxVecGrid + 8 doubles (scalar read-backs of the LM step)
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
-  // comm
+  // comm: RCCL communicator and / or the one-shot peer-to-peer all-reduce over hipIpc-mapped buffers
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  bool p2p = false;                 // peers connected
+  void* p2p_base = nullptr;         // this rank's buffer: [flags | slots]
+  size_t p2p_bytes = 0;
+  int64_t p2p_cap = 0;              // doubles per slot
+  int p2p_chunks_cap = 0;
+  P2pPeers p2p_peers{};
+  void* p2p_opened[kP2pMaxWorld] = {};
+  unsigned long long p2p_epoch = 0;
+  int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived
+  double p2p_timeout_s = 10.0;
   ceres_hip_solve_timing timing{};
 };
 
@@ -161,8 +173,20 @@ void free_all(ceres_hip_solver* s) {
   s->device_bytes = 0;
 }
 
+// Sum over ranks, in place, on the solver's stream.  Messages that fit the peer-to-peer slots (everything a solve
+// sums: 9 or 81 doubles per camera) go through the one-shot kernel; longer ones are cut into slot-sized pieces, or
+// go to RCCL when a communicator exists.
 int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
   if (s->world <= 1 || n == 0) return 0;
+  if (s->p2p && (int64_t(n) <= s->p2p_cap || !s->comm)) {
+    for (size_t off = 0; off < n; off += size_t(s->p2p_cap)) {
+      const int64_t len = int64_t(std::min<size_t>(size_t(s->p2p_cap), n - off));
+      HIP_TRY(s, LaunchP2pAllReduce(dev + off, dev + off, len, s->p2p_peers, s->rank, s->world, ++s->p2p_epoch, s->p2p_cap,
+                                    s->p2p_chunks_cap, s->d_comm_error, s->p2p_timeout_s, s->stream));
+    }
+    return 0;
+  }
+  if (!s->comm) return fail(s, CERES_HIP_E_COMM, "world_size > 1 but no communicator is connected");
   NCCL_TRY(s, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, s->comm, s->stream));
   return 0;
 }
@@ -182,6 +206,8 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
+  if (s->mo_cam_major) A.mo_crank = s->d_slot_crank;
+  if (s->z_cam_major && !s->lds_mode) A.z_crank = s->d_slot_crank;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -236,7 +262,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
   if (!s->lds_mode) {  // second pass by camera over the z the fused kernel left per slot
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
-    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_zbuf,
+    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->z_cam_major ? nullptr : s->d_cam_slot, s->d_zbuf,
                                     s->d_global_acc, status, s->stream));
   }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
@@ -402,7 +428,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));
       const bool fuse = s->lm_fuse_active && invert;
       if (fuse && schur) HIP_TRY(s, hipMemsetAsync(s->d_camsq, 0, sizeof(double) * 9 * s->plan.n_cameras, st));
-      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_Mo,
+      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->mo_cam_major ? nullptr : s->d_cam_slot, s->d_Mo,
                                        (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
                                        (fuse && schur) ? s->d_camsq : nullptr, st));
       if (s->world > 1) {
@@ -601,15 +627,6 @@ int enqueue_model_cost_change(ceres_hip_solver* s, const double* x, const double
   *dev_parts = s->cg.comm;
   return 0;
 }
-int allreduce_host_scalars(ceres_hip_solver* s, double* v, int n) {
-  if (s->world <= 1) return 0;
-  HIP_TRY(s, hipMemcpyAsync(s->cg.comm, v, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
-  TRY(allreduce(s, s->cg.comm, size_t(n)));
-  HIP_TRY(s, hipMemcpyAsync(v, s->cg.comm, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
-}
-
 // ---------------------------------------------------------------------------
 // Conjugate gradients driver (I/conjugate_gradients_solver.h:108-306).
 // ---------------------------------------------------------------------------
@@ -669,10 +686,18 @@ void fill_summary(const CgScalars& S, int device_status, ceres_hip_summary* out)
   }
 }
 
+int check_comm_error(ceres_hip_solver* s) {  // after a stream synchronisation
+  if (!s->p2p) return 0;
+  int flag = 0;
+  HIP_TRY(s, hipMemcpy(&flag, s->d_comm_error, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) return fail(s, CERES_HIP_E_COMM, "peer-to-peer all-reduce timed out after %.1f s: a rank did not arrive", s->p2p_timeout_s);
+  return 0;
+}
+
 int poll_scalars(ceres_hip_solver* s) {
   HIP_TRY(s, hipMemcpyAsync(s->h_scalars, s->cg.S, sizeof(CgScalars), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
+  return check_comm_error(s);
 }
 
 int collapse_and_reduce(ceres_hip_solver* s, int first_slot, int count) {
@@ -755,7 +780,8 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
           HIP_TRY(s, LaunchCgDotPq(B, st));
           B.pq_parts = B.partials + kMaxVecGrid; B.n_pq = B.grid;
         }
-        HIP_TRY(s, LaunchCgUpdate(B, s->G, spec.first_block, spec.col_begin, spec.nblocks, spec.diag_off, spec.blocks, reset, it, st));
+        HIP_TRY(s, LaunchCgUpdate(B, s->G, spec.first_block, spec.col_begin, spec.nblocks, spec.diag_off, spec.blocks, reset, it,
+                                  s->nine_wide_from - spec.first_block, st));
         ++s->timing.operator_applications;
         if (reset) {  // r = rhs - A x (:235-239), then the next iteration's z = M^-1 r
           TRY(spec.apply(B.x, B.z));
@@ -1121,6 +1147,9 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   (void)hipSetDevice(s->opt.device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->comm) (void)ncclCommDestroy(s->comm);
+  for (int q = 0; q < kP2pMaxWorld; ++q) if (s->p2p_opened[q]) (void)hipIpcCloseMemHandle(s->p2p_opened[q]);
+  if (s->p2p_base) (void)hipFree(s->p2p_base);
+  if (s->d_comm_error) (void)hipFree(s->d_comm_error);
   free_all(s);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -1142,6 +1171,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     if (!h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "rows are not ordered for a Schur solver: E rows must come first, grouped by E block (I/reorder_program.cc:278-360)");
   }
   if (s->world > 1 && !h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "sharded runs need the Schur ordering");
+  s->nine_wide_from = h.ncb;
+  while (s->nine_wide_from > 0 && h.csz[s->nine_wide_from - 1] == 9) --s->nine_wide_from;
   BuildBalPlan(h, true, &s->plan);
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
@@ -1215,6 +1246,9 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_cam_ptr, P.cam_ptr));
     TRY(dev_upload(s, &s->d_cam_fpos, P.cam_fpos));
     TRY(dev_upload(s, &s->d_cam_slot, P.cam_slot));
+    TRY(dev_upload(s, &s->d_slot_crank, P.slot_crank));
+    { const char* e = getenv("CERES_HIP_MO_CAM"); s->mo_cam_major = e ? atoi(e) != 0 : false; }
+    { const char* e = getenv("CERES_HIP_Z_CAM"); s->z_cam_major = e ? atoi(e) != 0 : false; }
     {
       int32_t *ic = nullptr, *ib = nullptr, *ie = nullptr;
       TRY(dev_upload(s, &ic, P.item_cam));
@@ -1294,6 +1328,101 @@ int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_I
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   NCCL_TRY(s, ncclCommInitRank(&s->comm, world, u, rank));
+  return 0;
+}
+
+// ---- peer-to-peer communicator ---------------------------------------------------------------
+// Step 1 (every rank): allocate this rank's receive buffer and hand out its hipIpc handle.
+int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world, int64_t max_elements,
+                               uint8_t handle_out[CERES_HIP_IPC_HANDLE_BYTES]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == CERES_HIP_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  if (!s || !handle_out || world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world || max_elements < 1) return CERES_HIP_E_INVALID;
+  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_p2p_prepare before ceres_hip_set_structure");
+  if (s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "peer-to-peer buffer already prepared");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  s->rank = rank; s->world = world;
+  s->p2p_cap = ((max_elements + kP2pChunk - 1) / kP2pChunk) * kP2pChunk;
+  s->p2p_chunks_cap = int(s->p2p_cap / kP2pChunk);
+  const size_t flag_bytes = ((size_t(2) * world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
+  s->p2p_bytes = flag_bytes + size_t(2) * world * size_t(s->p2p_cap) * sizeof(double);
+  // fine-grained: writes arriving from another device (or another XCD's L2) must be visible to this rank's loads.
+  // CERES_HIP_P2P_COARSE=1 (or a runtime that cannot export a fine-grained allocation) falls back to hipMalloc; the
+  // kernel's system-scope release / acquire fences are what a same-device pair of ranks then relies on.
+  hipIpcMemHandle_t h;
+  const char* coarse = getenv("CERES_HIP_P2P_COARSE");
+  bool ok = false;
+  if (!(coarse && atoi(coarse) != 0)) {
+    if (hipExtMallocWithFlags(&s->p2p_base, s->p2p_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      if (hipIpcGetMemHandle(&h, s->p2p_base) == hipSuccess) ok = true;
+      else { (void)hipFree(s->p2p_base); s->p2p_base = nullptr; }
+    }
+    (void)hipGetLastError();
+  }
+  if (!ok) {
+    HIP_TRY(s, hipMalloc(&s->p2p_base, s->p2p_bytes));
+    HIP_TRY(s, hipIpcGetMemHandle(&h, s->p2p_base));
+  }
+  HIP_TRY(s, hipMemset(s->p2p_base, 0, s->p2p_bytes));
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error), sizeof(int)));
+  HIP_TRY(s, hipMemset(s->d_comm_error, 0, sizeof(int)));
+  HIP_TRY(s, hipDeviceSynchronize());
+  { const char* e = getenv("CERES_HIP_P2P_TIMEOUT"); if (e && atof(e) > 0) s->p2p_timeout_s = atof(e); }
+  memcpy(handle_out, &h, sizeof(h));
+  return 0;
+}
+
+// Step 2 (every rank, after the host gathered all handles in rank order): map the peers' buffers.
+int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles) {
+  if (!s || !all_handles) return CERES_HIP_E_INVALID;
+  if (!s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_p2p_prepare first");
+  if (s->p2p) return fail(s, CERES_HIP_E_INVALID, "peers already connected");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  const size_t flag_bytes = ((size_t(2) * s->world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
+  for (int q = 0; q < s->world; ++q) {
+    void* base = s->p2p_base;
+    if (q != s->rank) {
+      hipIpcMemHandle_t h;
+      memcpy(&h, all_handles + size_t(q) * CERES_HIP_IPC_HANDLE_BYTES, sizeof(h));
+      HIP_TRY(s, hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+      s->p2p_opened[q] = base;
+    }
+    s->p2p_peers.flags[q] = reinterpret_cast<unsigned long long*>(base);
+    s->p2p_peers.slots[q] = reinterpret_cast<double*>(static_cast<char*>(base) + flag_bytes);
+  }
+  s->p2p = true;
+  return 0;
+}
+
+// One round trip through the peer-to-peer all-reduce: sum of {rank + 1, 1} over ranks must be {w (w + 1) / 2, w}.
+// A collective: every rank calls it.  Non-zero (with the communicator left disabled) if a peer did not arrive in
+// CERES_HIP_P2P_SELFTEST_TIMEOUT seconds (default 5) or the sums are wrong; callers then agree (e.g. by an RCCL
+// all-reduce of the verdict) and fall back to RCCL with ceres_hip_comm_p2p_disable on every rank.
+int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
+  if (!s || !s->p2p) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  double *d = nullptr, h[2] = {double(s->rank + 1), 1.0};
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), 2 * sizeof(double)));
+  const double keep = s->p2p_timeout_s;
+  { const char* e = getenv("CERES_HIP_P2P_SELFTEST_TIMEOUT"); s->p2p_timeout_s = (e && atof(e) > 0) ? atof(e) : 5.0; }
+  int rc = 0;
+  if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  if (!rc) rc = allreduce(s, d, 2);
+  if (!rc && hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  if (!rc) rc = check_comm_error(s);
+  s->p2p_timeout_s = keep;
+  (void)hipFree(d);
+  const double w = double(s->world);
+  if (!rc && (h[0] != w * (w + 1.0) / 2.0 || h[1] != w)) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: got {%g, %g} for world %d", h[0], h[1], s->world);
+  if (rc) s->p2p = false;
+  return rc;
+}
+
+// Stop using the peer-to-peer path (all-reduces go to RCCL, which must then be connected).
+int ceres_hip_comm_p2p_disable(ceres_hip_solver* s) {
+  if (!s) return CERES_HIP_E_INVALID;
+  s->p2p = false;
+  if (s->d_comm_error) { HIP_TRY(s, hipSetDevice(s->opt.device)); HIP_TRY(s, hipMemset(s->d_comm_error, 0, sizeof(int))); }
   return 0;
 }
 
@@ -1443,15 +1572,26 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   }
   double* hp = s->h_pinned;
   int* h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
-  HIP_TRY(s, hipMemcpyAsync(h_flag, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (n_local > 0) HIP_TRY(s, hipMemcpyAsync(hp, parts_local, sizeof(double) * n_local, hipMemcpyDeviceToHost, st));
+  double v[2] = {0.0, 0.0};
+  if (s->world > 1) {
+    // sharded: {flag, this rank's share of the cost} are summed over ranks ON THE DEVICE, then read back once
+    HIP_TRY(s, LaunchCollectScalars(s->d_nonfinite, parts_local, n_local, s->cg.comm, st));
+    TRY(allreduce(s, s->cg.comm, 2));
+    HIP_TRY(s, hipMemcpyAsync(hp, s->cg.comm, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+  } else {
+    HIP_TRY(s, hipMemcpyAsync(h_flag, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (n_local > 0) HIP_TRY(s, hipMemcpyAsync(hp, parts_local, sizeof(double) * n_local, hipMemcpyDeviceToHost, st));
+  }
   if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
   HIP_TRY(s, hipStreamSynchronize(st));
-  double v[2] = {double(*h_flag != 0), 0.0};
-  for (int i = 0; i < n_local; ++i) v[1] += hp[i];
+  TRY(check_comm_error(s));
+  if (s->world > 1) { v[0] = hp[0]; v[1] = hp[1]; }
+  else {
+    v[0] = double(*h_flag != 0);
+    for (int i = 0; i < n_local; ++i) v[1] += hp[i];
+  }
   double shared = 0;
   for (int i = 0; i < n_shared; ++i) shared += hp[kMaxVecGrid + i];
-  TRY(allreduce_host_scalars(s, v, 2));
   if (v[0] != 0.0) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
     res->linear_solver.termination_type = CERES_HIP_FAILURE;
     snprintf(res->linear_solver.message, sizeof(res->linear_solver.message), "Failed to compute a finite step.");

@@ -31,6 +31,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 PATH_GENERIC, PATH_BAL = 0, 1
 TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_ERROR"}
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 
 (TIMED_JTJX, TIMED_SX, TIMED_SCHUR_INIT, TIMED_SCHUR_JACOBI, TIMED_BACK_SUBSTITUTE, TIMED_PACK, TIMED_BLOCK_JACOBI, TIMED_COPY,
  TIMED_READ_STREAM, TIMED_CGNR_SETUP) = range(1, 11)
@@ -92,6 +93,10 @@ ABI = [
     ("ceres_hip_get_info", c_int32, [c_void_p, POINTER(CInfo)]),
     ("ceres_hip_comm_get_unique_id", c_int32, [POINTER(c_uint8)]),
     ("ceres_hip_comm_init", c_int32, [c_void_p, POINTER(c_uint8), c_int32, c_int32]),
+    ("ceres_hip_comm_p2p_prepare", c_int32, [c_void_p, c_int32, c_int32, c_int64, POINTER(c_uint8)]),
+    ("ceres_hip_comm_p2p_connect", c_int32, [c_void_p, POINTER(c_uint8)]),
+    ("ceres_hip_comm_p2p_selftest", c_int32, [c_void_p]),
+    ("ceres_hip_comm_p2p_disable", c_int32, [c_void_p]),
     ("ceres_hip_solve", c_int32, [c_void_p, _DP, _DP, _DP, c_double, c_double, _DP, POINTER(CSummary)]),
     ("ceres_hip_solve_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, POINTER(CSummary)]),
     ("ceres_hip_load", c_int32, [c_void_p, _DP, _DP, _DP]),
@@ -273,7 +278,10 @@ class HipLinearSolver:
     """
 
     def __init__(self, options: LinearSolverOptions, comm_id: Optional[bytes] = None, rank: int = 0,
-                 world_size: int = 1, loopback_world: int = 0):
+                 world_size: int = 1, loopback_world: int = 0, p2p_exchange=None, p2p_max_elements: int = 0):
+        """comm_id: RCCL unique id (ceres_hip_comm_init).  p2p_exchange: callable(bytes) -> list of every rank's bytes in
+        rank order (e.g. a torch.distributed all_gather); connects the one-shot peer-to-peer all-reduce for vectors of
+        up to p2p_max_elements doubles (81 * number of F blocks covers a solve)."""
         self._lib = load_library()
         self.options = options
         nelim = options.elimination_groups[0] if options.elimination_groups else 0
@@ -286,9 +294,43 @@ class HipLinearSolver:
         if not self._h:
             raise HipError(self._lib.ceres_hip_last_error(None).decode())
         self.bs = None
-        if world_size > 1:
+        self._values_extent = None
+        if world_size > 1 and comm_id is not None:
             buf = (c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(comm_id)
             self._check(self._lib.ceres_hip_comm_init(self._h, buf, rank, world_size))
+        self.p2p_ok = False
+        self.p2p_error = ""
+        if world_size > 1 and p2p_exchange is not None:
+            # every step is collective: a rank that fails still takes part in the exchange, and reports through p2p_ok
+            mine = (c_uint8 * IPC_HANDLE_BYTES)()
+            ok = self._lib.ceres_hip_comm_p2p_prepare(self._h, rank, world_size, int(p2p_max_elements), mine) == 0
+            if not ok:
+                self.p2p_error = self._lib.ceres_hip_last_error(self._h).decode()
+            handles = p2p_exchange(bytes(mine))
+            if len(handles) != world_size or any(len(h) != IPC_HANDLE_BYTES for h in handles):
+                raise HipError("p2p_exchange must return one 64-byte handle per rank")
+            if ok:
+                allh = (c_uint8 * (IPC_HANDLE_BYTES * world_size)).from_buffer_copy(b"".join(handles))
+                ok = self._lib.ceres_hip_comm_p2p_connect(self._h, allh) == 0
+                if not ok:
+                    self.p2p_error = self._lib.ceres_hip_last_error(self._h).decode()
+            self.p2p_ok = ok
+            if not ok and comm_id is None:
+                raise HipError("peer-to-peer communicator failed and there is no RCCL communicator: " + self.p2p_error)
+
+    def p2p_selftest(self) -> bool:
+        """Collective: one all-reduce of known values through the peer-to-peer path."""
+        if not self.p2p_ok:
+            return False
+        rc = self._lib.ceres_hip_comm_p2p_selftest(self._h)
+        if rc != 0:
+            self.p2p_error = self._lib.ceres_hip_last_error(self._h).decode()
+            self.p2p_ok = False
+        return rc == 0
+
+    def p2p_disable(self):
+        self._check(self._lib.ceres_hip_comm_p2p_disable(self._h))
+        self.p2p_ok = False
         if loopback_world > 1:  # debug: sharded code paths on one GPU (see include/ceres_hip.h)
             self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
 
@@ -320,6 +362,7 @@ class HipLinearSolver:
         self._cbs = bs.as_ctypes()
         self._check(self._lib.ceres_hip_set_structure(self._h, byref(self._cbs)))
         self._info = self.info()
+        self._values_extent = bs.values_extent()  # O(num_cells) to compute: once, not per solve
 
     def info(self) -> CInfo:
         i = CInfo()
@@ -331,7 +374,7 @@ class HipLinearSolver:
         """LinearSolver::Solve.  Returns (x, Summary).  x is pre-poisoned with NaN like the
         caller does (internal/ceres/levenberg_marquardt_strategy.cc:110)."""
         n = self._info
-        values = _f64(values, self.bs.values_extent(), "values")
+        values = _f64(values, self._values_extent, "values")
         b = _f64(b, n.num_rows, "b")
         D = _f64(per_solve_options.D, n.num_cols, "D")
         x = np.full(n.num_cols, np.nan)
@@ -360,7 +403,7 @@ class HipLinearSolver:
         """LevenbergMarquardtStrategy::ComputeStep + the model-cost bookkeeping of
         TrustRegionMinimizer::ComputeTrustRegionStep.  Returns (step, Summary, model_cost_change)."""
         n = self._info
-        values = _f64(values, self.bs.values_extent(), "values")
+        values = _f64(values, self._values_extent, "values")
         residuals = _f64(residuals, n.num_rows, "residuals")
         o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), 0)
         r = CLmResult()
@@ -386,7 +429,7 @@ class HipLinearSolver:
 
     def scale_columns(self, scale):
         scale = _f64(scale, self._info.num_cols, "scale")
-        out = np.full(self.bs.values_extent(), np.nan)
+        out = np.full(self._values_extent, np.nan)
         self._check(self._lib.ceres_hip_op_scale_columns(self._h, _p(scale), _p(out)))
         return out
 
@@ -398,7 +441,7 @@ class HipLinearSolver:
     # -- operator level ----------------------------------------------------
     def load(self, values, b=None, D=None):
         n = self._info
-        self._keep = (_f64(values, self.bs.values_extent(), "values"), _f64(b, n.num_rows, "b"), _f64(D, n.num_cols, "D"))
+        self._keep = (_f64(values, self._values_extent, "values"), _f64(b, n.num_rows, "b"), _f64(D, n.num_cols, "D"))
         self._check(self._lib.ceres_hip_load(self._h, *map(_p, self._keep)))
 
     def load_device(self, d_values: int, d_b: int = 0, d_D: int = 0):

@@ -15,6 +15,7 @@ and synthetic BAL-shaped block-sparse Jacobians.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -230,6 +231,31 @@ def synthetic_bal(shape="dubrovnik16", layout="schur", seed=38401, skew=0.0, num
     n_cams, n_points, n_obs = BAL_SHAPES[shape] if shape else (num_cameras, num_points, num_observations)
     if num_cameras is not None:
         n_cams, n_points, n_obs = num_cameras, num_points, num_observations
+    # Optional on-disk cache (CERES_HIP_PROBLEM_CACHE=<dir>): the generator is deterministic, and a GPU-box session that
+    # runs bench.py / the tools several times should not spend 20 s of numpy per run on the same Venice-shaped problem.
+    cache_dir = os.environ.get("CERES_HIP_PROBLEM_CACHE")
+    cache = None
+    if cache_dir and n_obs >= 500_000:
+        cache = os.path.join(cache_dir, f"bal_{layout}_{seed}_{skew}_{n_cams}_{n_points}_{n_obs}_{int(with_values)}.npz")
+        if os.path.exists(cache):
+            z = np.load(cache)
+            bs = BlockStructure(*(z[k] for k in ("rsz", "rpos", "csz", "cpos", "rptr", "ccol", "cval")))
+            D = z["D"] if with_values else None
+            return LinearProblem(bs, z["values"], z["b"], D, int(z["nelim"]), {}, z["cam"], z["pt"])
+    p = _generate_bal(n_cams, n_points, n_obs, layout, seed, skew, with_values)
+    if cache:
+        try:
+            os.makedirs(cache_dir, exist_ok=True)
+            b_ = p.bs
+            np.savez(cache, rsz=b_.row_block_size, rpos=b_.row_block_pos, csz=b_.col_block_size, cpos=b_.col_block_pos, rptr=b_.row_cell_ptr,
+                     ccol=b_.cell_col_block, cval=b_.cell_value_pos, values=p.values, b=p.b, D=p.D if p.D is not None else np.zeros(0),
+                     nelim=p.num_eliminate_blocks, cam=p.camera_of_row, pt=p.point_of_row)
+        except OSError:
+            pass
+    return p
+
+
+def _generate_bal(n_cams, n_points, n_obs, layout, seed, skew, with_values) -> LinearProblem:
     rng = np.random.default_rng(seed)
     k = _track_lengths(rng, n_cams, n_points, n_obs)
     point_of_obs = np.repeat(np.arange(n_points, dtype=np.int64), k)

@@ -190,6 +190,23 @@ int ceres_hip_comm_get_unique_id(uint8_t id[CERES_HIP_UNIQUE_ID_BYTES]);
 int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_ID_BYTES],
                         int32_t rank, int32_t world_size);
 
+/* Alternative (or additional) communicator: a one-shot peer-to-peer all-reduce over buffers mapped with hipIpc
+ * — xGMI between the GPUs of a node, plain device memory between two ranks that share one GPU.  The sums a
+ * sharded solve exchanges are 9 or 81 doubles per camera: latency-bound, several per step, so the collective is a
+ * single kernel (push to every peer, flag, wait, sum in rank order = identical bits on every rank) instead of an
+ * RCCL call.  Step 1: every rank calls _prepare (before set_structure) with the largest vector it will sum
+ * (81 * num_f_blocks covers a solve) and receives a 64-byte hipIpc handle; the host gathers the handles of all
+ * ranks in rank order by any means; step 2: every rank calls _connect.  With both communicators present, messages
+ * longer than max_elements go to RCCL; with only this one they are cut into pieces.  world_size <= 8.       */
+#define CERES_HIP_IPC_HANDLE_BYTES 64
+int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world_size, int64_t max_elements,
+                               uint8_t handle_out[CERES_HIP_IPC_HANDLE_BYTES]);
+int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles /* world_size x 64 bytes */);
+/* Collective self-test (one all-reduce of known values, 5 s timeout): non-zero leaves the path disabled on this rank;
+ * ranks then agree on the verdict out of band and call _disable everywhere if any failed (RCCL takes over).       */
+int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s);
+int ceres_hip_comm_p2p_disable(ceres_hip_solver* s);
+
 /* ---- the boundary call ----------------------------------------------------
  * LinearSolver::Solve (I/linear_solver.h:339-342).  values: num_nonzeros
  * doubles in the caller's layout; b: num_rows; D: num_cols or NULL

@@ -1,0 +1,82 @@
+"""Worker process of tests/test_gpu_multirank.py: ONE RANK of a sharded solve, product code only
+(ceres-solver_amd through the C ABI).  Ranks may share a GPU: the one-shot peer-to-peer all-reduce maps its
+peers' buffers with hipIpc, which works between processes on the same device as well as across xGMI.
+
+Protocol with the parent over a multiprocessing connection: ("exchange", bytes) -> list of every rank's bytes;
+("done", results) ends the rank; ("error", text) on failure."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+
+def run_rank(rank, world, conn, device, scenario):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.setdefault("CERES_HIP_P2P_TIMEOUT", "20")
+    try:
+        import torch  # noqa: F401  (before the HIP library: see hip_solver.load_library)
+        import __graft_entry__ as entry
+        pkg = entry.load_package()
+        hs = pkg.hip_solver
+        from ceres_solver_amd import partition
+        hs.load_library()
+
+        def exchange(mine):
+            conn.send(("exchange", mine))
+            return conn.recv()
+
+        out = {}
+        for name, kw in scenario:
+            kind = kw["kind"]
+            if kind == "bal":
+                prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),
+                                                  num_cameras=kw["nc"], num_points=kw["np"], num_observations=kw["no"])
+            else:
+                prob = pkg.problems.random_schur_problem(num_e_blocks=kw["ne"], num_f_blocks=kw["nf"], num_no_e_rows=2, seed=kw["seed"])
+            sh = partition.shard_by_point(prob.bs, prob.num_eliminate_blocks, world, rank)
+            v, b, D = sh.local_values(prob.values), sh.local_rows(prob.b), sh.local_cols(prob.D)
+            n_f_blocks = sh.bs.num_col_blocks - sh.num_eliminate_blocks
+            fsz = sh.bs.col_block_size[sh.num_eliminate_blocks:].astype(np.int64)
+            max_elems = int(max((fsz ** 2).sum(), fsz.sum(), 2))
+            for solver_type, pre in kw["solvers"]:
+                o = hs.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=kw.get("max_it", 400),
+                                           elimination_groups=[sh.num_eliminate_blocks], device=device,
+                                           force_generic_path=bool(kw.get("force_generic", False)))
+                s = hs.HipLinearSolver(o, rank=rank, world_size=world, p2p_exchange=exchange, p2p_max_elements=max_elems)
+                assert s.p2p_selftest(), s.p2p_error
+                s.set_structure(sh.bs)
+                info = s.info()
+                rec = {"path": int(info.kernel_path), "world": int(info.world_size), "rank": int(info.rank),
+                       "col_index": sh.col_index, "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum())}
+                # (1) converged solve
+                x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=-1.0, r_tolerance=1e-12))
+                rec["converged"] = (x, summ.termination_type, summ.num_iterations)
+                # (2) the call LM makes
+                x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=0.1, r_tolerance=-1.0))
+                rec["lm_style"] = (x, summ.termination_type, summ.num_iterations)
+                # (3) the whole LM step on the device (f1), incl. the all-reduced {finite flag, model cost}
+                step, summ, mcc = s.lm_compute_step(v, b, 1e4, 0.1)
+                rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc)
+                # (4) operators that sum over ranks
+                if solver_type == hs.ITERATIVE_SCHUR:
+                    s.load(v, b, D)
+                    s.schur_init()
+                    xf = np.random.default_rng(5).standard_normal(info.num_cols_f)
+                    rec["rhs"] = s.schur_rhs()
+                    rec["sx"] = s.schur_sx(xf)
+                    s.schur_jacobi_update()
+                    rec["precond"] = s.preconditioner_blocks()
+                else:
+                    s.load(v, b, D)
+                    xx = np.random.default_rng(6).standard_normal(prob.bs.num_cols)[sh.col_index]
+                    rec["jtjx"] = s.jtjx(xx)
+                    rec["jtb"] = s.jtb()
+                s.close()
+                out[(name, solver_type, pre)] = rec
+        conn.send(("done", out))
+    except Exception:
+        conn.send(("error", traceback.format_exc()))
+    finally:
+        conn.close()

@@ -51,8 +51,8 @@ def check_schur_side(hip, oracle, p, expect_lds, solve=True):
     errs["schur_jacobi_raw"] = upper_blocks_err(s.preconditioner_blocks(not_inverted=True), raw, 9)
     s.schur_jacobi_update()
     errs["schur_jacobi_inv"] = rel(s.preconditioner_blocks(), inv)
-    for k, v in errs.items():
-        assert v <= OP_TOL, (k, v)
+    for k, v in errs.items():  # inverted blocks carry their condition number: 1e-11
+        assert v <= (1e-11 if k.endswith("_inv") else OP_TOL), (k, v)
     if solve:
         # the call LevenbergMarquardtStrategy makes: eta = 0.1, r_tolerance = -1
         x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
@@ -79,8 +79,8 @@ def check_cgnr_side(hip, oracle, p, expect_lds, solve=True):
     s.block_jacobi_update()
     inv, raw = m0.block_jacobi(p.values, p.D)
     errs["block_jacobi_inv"] = rel(s.preconditioner_blocks(), inv)
-    for k, v in errs.items():
-        assert v <= OP_TOL, (k, v)
+    for k, v in errs.items():  # inverted blocks carry their condition number: 1e-11, like the reference's inverse checks
+        assert v <= (1e-11 if k.endswith("_inv") else OP_TOL), (k, v)
     if solve:
         xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
         xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)

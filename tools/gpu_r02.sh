@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-2 GPU-box session (run through gpurun).  usage: tools/gpu_r02.sh TAG stage [stage ...]
+# stages: probe pytest smoke bench bench_cgnr bench10m bench10m_fp32 longcg small rocprof rocprof10m
+TAG=$1; shift
+REPO=$(cd $(dirname $0)/.. && pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd $REPO
+export CERES_HIP_PROBLEM_CACHE=/tmp/ceres_problem_cache
+for STAGE in "$@"; do
+  echo "===== $STAGE ($(date +%T))"
+  case $STAGE in
+    probe) bash tools/probe.sh | tee $OUT/probe_$TAG.txt ;;
+    pytest) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -60 | tee $OUT/pytest_gpu_$TAG.log | tail -15 ;;
+    pytest_all) timeout 2400 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -80 | tee $OUT/pytest_gpu_$TAG.log | tail -25 ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as e; e.smoke()" 2>&1 | tail -5 | tee $OUT/smoke_$TAG.log ;;
+    bench) timeout 900 python bench.py --gpus 1 2> $OUT/bench_$TAG.err | tee $OUT/bench_$TAG.json | cut -c1-1800; tail -3 $OUT/bench_$TAG.err ;;
+    bench_cgnr) timeout 900 python bench.py --gpus 1 --solver cgnr --both-solvers 0 --minimizer-iterations 0 --host-boundary-steps 0 2> $OUT/bench_cgnr_$TAG.err | tee $OUT/bench_cgnr_$TAG.json | cut -c1-1200; tail -3 $OUT/bench_cgnr_$TAG.err ;;
+    bench10m) timeout 1500 python bench.py --gpus 1 --workload synthetic10M --steps 10 --cpu-seconds 30 2> $OUT/bench_synthetic10M_fp64_$TAG.err | tee $OUT/bench_synthetic10M_fp64_$TAG.json | cut -c1-1800; tail -3 $OUT/bench_synthetic10M_fp64_$TAG.err ;;
+    bench10m_fp32) timeout 1500 python bench.py --gpus 1 --workload synthetic10M --storage fp32 --steps 10 --no-cpu-baseline 2> $OUT/bench_synthetic10M_fp32_$TAG.err | tee $OUT/bench_synthetic10M_fp32_$TAG.json | cut -c1-1500; tail -3 $OUT/bench_synthetic10M_fp32_$TAG.err ;;
+    bench1m) timeout 900 python bench.py --gpus 1 --workload synthetic1M --steps 20 --no-cpu-baseline 2> $OUT/bench_synthetic1M_$TAG.err | tee $OUT/bench_synthetic1M_$TAG.json | cut -c1-1500; tail -3 $OUT/bench_synthetic1M_$TAG.err ;;
+    longcg)
+      for F in 0 1; do CERES_HIP_CG_FUSED=$F timeout 600 python tools/gpu_long_cg.py 30 2>&1 | tail -1 | tee -a $OUT/longcg_$TAG.jsonl; done ;;
+    small)
+      for WL in dubrovnik16 ladybug1723; do for F in 0 1; do
+        echo -n "$WL fused=$F " | tee -a $OUT/small_$TAG.txt
+        CERES_HIP_CG_FUSED=$F timeout 600 python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --minimizer-iterations 0 --host-boundary-steps 0 2>/dev/null \
+          | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('ms_per_step','value')} | {'cg_its': d['config']['cg_iterations_per_step'], 'cgnr': d['extra'].get('cgnr',{}).get('ms_per_step'), 'sx_ms': d['roofline']['avg_launch_ms'], 'phases': d['extra']['solve_phases_ms']}))" | tee -a $OUT/small_$TAG.txt
+      done; done ;;
+    rocprof)
+      cd /tmp && export TMPDIR=/tmp
+      for SOLVER in iterative_schur cgnr; do
+        rm -rf /tmp/prof_$SOLVER
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SOLVER -o $SOLVER -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --both-solvers 0 --minimizer-iterations 0 --host-boundary-steps 0 --solver $SOLVER > $OUT/rocprof_bench_${SOLVER}_$TAG.json 2> $OUT/rocprof_${SOLVER}_$TAG.err
+        F=$(find /tmp/prof_$SOLVER -name "*kernel_stats.csv" | head -1)
+        [ -n "$F" ] && cp $F $OUT/kernel_stats_${SOLVER}_venice_$TAG.csv && head -14 $F | cut -c1-220
+      done
+      cd $REPO ;;
+    rocprof10m)
+      cd /tmp && export TMPDIR=/tmp
+      rm -rf /tmp/prof_10m
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_10m -o s10m -- python $REPO/bench.py --workload synthetic10M --steps 5 --warmup 2 --no-cpu-baseline --both-solvers 1 > $OUT/rocprof_bench_synthetic10M_$TAG.json 2> $OUT/rocprof_synthetic10M_$TAG.err
+      F=$(find /tmp/prof_10m -name "*kernel_stats.csv" | head -1)
+      [ -n "$F" ] && cp $F $OUT/kernel_stats_synthetic10M_$TAG.csv && head -14 $F | cut -c1-220
+      cd $REPO ;;
+    *) echo "unknown stage $STAGE" ;;
+  esac
+done
+echo "===== done ($(date +%T))"
