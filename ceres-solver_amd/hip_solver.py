@@ -317,6 +317,8 @@ class HipLinearSolver:
             self.p2p_ok = ok
             if not ok and comm_id is None:
                 raise HipError("peer-to-peer communicator failed and there is no RCCL communicator: " + self.p2p_error)
+        if loopback_world > 1:  # debug: sharded code paths on one GPU (see include/ceres_hip.h)
+            self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
 
     def p2p_selftest(self) -> bool:
         """Collective: one all-reduce of known values through the peer-to-peer path."""
@@ -331,8 +333,6 @@ class HipLinearSolver:
     def p2p_disable(self):
         self._check(self._lib.ceres_hip_comm_p2p_disable(self._h))
         self.p2p_ok = False
-        if loopback_world > 1:  # debug: sharded code paths on one GPU (see include/ceres_hip.h)
-            self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
 
     # -- plumbing ----------------------------------------------------------
     def _check(self, rc):

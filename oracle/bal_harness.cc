@@ -106,6 +106,29 @@ struct oracle_bal {
 
 extern "C" {
 
+// The evaluator's building blocks, exported so that tests can pin them to what the reference's own tests expect of
+// the functions they restate (internal/ceres/rotation_test.cc:1809-1900: AngleAxisRotatePoint == the product with
+// AngleAxisToRotationMatrix, also for |angle_axis| ~ 1e-16 and exactly 0).
+void oracle_angle_axis_rotate_points(int64_t n, const double* angle_axis, const double* pts, double* out) {
+  for (int64_t i = 0; i < n; ++i) angle_axis_rotate<double>(angle_axis + 3 * i, pts + 3 * i, out + 3 * i);
+}
+// residual (2) and its Jacobian (2 x 9 camera | 2 x 3 point, row-major) of SnavelyReprojectionError for n (camera, point,
+// observation) triples, by forward-mode duals of the same formula (examples/snavely_reprojection_error.h:53-105)
+void oracle_snavely_batch(int64_t n, const double* cams, const double* pts, const double* obs, double* residuals, double* jac_cam,
+                          double* jac_pt) {
+  for (int64_t i = 0; i < n; ++i) {
+    Dual c[9], q[3], r[2];
+    for (int k = 0; k < 9; ++k) c[k] = Dual(cams[9 * i + k], k);
+    for (int k = 0; k < 3; ++k) q[k] = Dual(pts[3 * i + k], 9 + k);
+    snavely<Dual>(c, q, obs[2 * i], obs[2 * i + 1], r);
+    for (int a = 0; a < 2; ++a) {
+      residuals[2 * i + a] = r[a].v;
+      if (jac_cam) for (int k = 0; k < 9; ++k) jac_cam[18 * i + 9 * a + k] = r[a].d[k];
+      if (jac_pt) for (int k = 0; k < 3; ++k) jac_pt[6 * i + 3 * a + k] = r[a].d[9 + k];
+    }
+  }
+}
+
 int oracle_bal_num_cameras(const oracle_bal* p) { return p->nc; }
 int oracle_bal_num_points(const oracle_bal* p) { return p->np; }
 int64_t oracle_bal_num_observations(const oracle_bal* p) { return p->no; }

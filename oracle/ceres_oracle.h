@@ -197,6 +197,12 @@ int oracle_bal_build_structure(oracle_bal* p, int schur_ordering, oracle_block_s
 /* state: num_cols doubles in the structure's column order.                   */
 void oracle_bal_get_state(const oracle_bal* p, double* state);
 void oracle_bal_set_state(oracle_bal* p, const double* state);
+/* AngleAxisRotatePoint (include/ceres/rotation.h:864-905) on n (angle_axis, point) pairs; and the Snavely residual with
+ * its 2x9 | 2x3 Jacobian by dual numbers (examples/snavely_reprojection_error.h:53-105).  For pinning tests. */
+void oracle_angle_axis_rotate_points(int64_t n, const double* angle_axis, const double* pts, double* out);
+void oracle_snavely_batch(int64_t n, const double* cams, const double* pts, const double* obs, double* residuals,
+                          double* jac_cam, double* jac_pt);
+
 /* residuals (2/obs, row order) and, if values != NULL, the Jacobian values in the
  * structure's layout; returns cost = 1/2 |r|^2.                              */
 double oracle_bal_evaluate(const oracle_bal* p, const double* state, double* residuals,

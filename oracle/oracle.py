@@ -122,6 +122,8 @@ def lib():
         L.oracle_isc_compute_ftf_inverse.argtypes = [c_void_p]
         L.oracle_isc_power_series_operator.argtypes = [c_void_p, dp, dp]
         L.oracle_isc_spse_apply.argtypes = [c_void_p, dp, dp, c_int, c_double]
+        L.oracle_angle_axis_rotate_points.argtypes = [c_int64, dp, dp, dp]
+        L.oracle_snavely_batch.argtypes = [c_int64, dp, dp, dp, dp, dp, dp]
         L.oracle_bal_generate.restype = c_void_p
         L.oracle_bal_generate.argtypes = [c_int, c_int, c_int64, c_double, c_double, c_double, c_uint64]
         L.oracle_bal_read.restype = c_void_p
@@ -157,6 +159,22 @@ def _dp(a):
 
 def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def angle_axis_rotate_points(angle_axis, pts):
+    aa, pts = _f64(angle_axis).reshape(-1, 3), _f64(pts).reshape(-1, 3)
+    out = np.empty_like(pts)
+    lib().oracle_angle_axis_rotate_points(aa.shape[0], _dp(aa), _dp(pts), _dp(out))
+    return out
+
+
+def snavely_batch(cams, pts, obs):
+    """(residuals (n,2), d/dcamera (n,2,9), d/dpoint (n,2,3)) of the Snavely reprojection error."""
+    cams, pts, obs = _f64(cams).reshape(-1, 9), _f64(pts).reshape(-1, 3), _f64(obs).reshape(-1, 2)
+    n = cams.shape[0]
+    r, jc, jp = np.empty((n, 2)), np.empty((n, 2, 9)), np.empty((n, 2, 3))
+    lib().oracle_snavely_batch(n, _dp(cams), _dp(pts), _dp(obs), _dp(r), _dp(jc), _dp(jp))
+    return r, jc, jp
 
 
 def set_num_threads(n):

@@ -27,6 +27,19 @@ for STAGE in "$@"; do
         CERES_HIP_CG_FUSED=$F timeout 600 python bench.py --workload $WL --steps 200 --warmup 20 --no-cpu-baseline --minimizer-iterations 0 --host-boundary-steps 0 2>/dev/null \
           | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('ms_per_step','value')} | {'cg_its': d['config']['cg_iterations_per_step'], 'cgnr': d['extra'].get('cgnr',{}).get('ms_per_step'), 'sx_ms': d['roofline']['avg_launch_ms'], 'phases': d['extra']['solve_phases_ms']}))" | tee -a $OUT/small_$TAG.txt
       done; done ;;
+    ab_mo)   # M_o written camera-major by kInit vs gathered through cam_slot (Venice shape)
+      for V in 0 1; do echo -n "MO_CAM=$V " | tee -a $OUT/ab_mo_$TAG.jsonl; CERES_HIP_MO_CAM=$V timeout 600 python tools/kernel_times.py venice1778 2>/dev/null | tail -1 | tee -a $OUT/ab_mo_$TAG.jsonl; done ;;
+    ab_z)    # per-observation F^T z written camera-major vs gathered (50 k cameras, 3 M observations)
+      for V in 0 1; do echo -n "Z_CAM=$V " | tee -a $OUT/ab_z_$TAG.jsonl; CERES_HIP_Z_CAM=$V CERES_HIP_MO_CAM=$V timeout 600 python tools/kernel_times.py synthetic1M 2>/dev/null | tail -1 | tee -a $OUT/ab_z_$TAG.jsonl; done ;;
+    rocprof_small)
+      cd /tmp && export TMPDIR=/tmp
+      for WL in ladybug1723 dubrovnik16; do
+        rm -rf /tmp/prof_$WL
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$WL -o $WL -- python $REPO/bench.py --workload $WL --steps 200 --warmup 10 --no-cpu-baseline --both-solvers 0 --minimizer-iterations 0 --host-boundary-steps 0 > $OUT/rocprof_bench_${WL}_$TAG.json 2> $OUT/rocprof_${WL}_$TAG.err
+        F=$(find /tmp/prof_$WL -name "*kernel_stats.csv" | head -1)
+        [ -n "$F" ] && cp $F $OUT/kernel_stats_${WL}_$TAG.csv && head -22 $F | cut -c1-200
+      done
+      cd $REPO ;;
     rocprof)
       cd /tmp && export TMPDIR=/tmp
       for SOLVER in iterative_schur cgnr; do
