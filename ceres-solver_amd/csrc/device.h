@@ -60,9 +60,10 @@ struct BalArgs {
   double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
-  // camera-major placement of what the camera-major second passes read (nullptr: slot-major, gathered through cam_slot):
-  const int32_t* mo_crank = nullptr;  // kInit writes M_o at [crank][4] -> bal_camera_blocks_kernel streams it
-  const int32_t* z_crank = nullptr;   // cameras-not-in-LDS mode: F^T z at [crank][9] -> bal_camera_apply_kernel streams it
+  // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
+  const double* copy_src = nullptr;
+  double* copy_dst = nullptr;
+  int copy_n = 0;
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
@@ -91,16 +92,26 @@ struct CamItems {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;
   int count = 0;
 };
-// blocks must be zeroed by the caller (items of one camera are combined with atomics).
-hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
-                                 const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, double* camsq,
-                                 hipStream_t stream);
+// Per-camera 9x9 blocks in two steps: every item (<= kCamChunk observations of one camera) leaves 45 upper-triangle sums + 9
+// column square sums in parts[item][kCamPart]; the items of a camera (cam_item_ptr) are then added in list order either by
+// LaunchBalCameraFinish (raw sums to memory, + D_f^2 if given) or by the load phase of LaunchBalInvert9 (CamGather).
+constexpr int kCamPart = 54;
+hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
+                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream);
+hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
+                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream);
+struct CamGather {
+  const double* parts = nullptr;          // nullptr: the blocks are already assembled in memory
+  const int32_t* cam_item_ptr = nullptr;
+  const double* D_f = nullptr;            // added squared to the diagonal (indexed through cam_pos)
+  const int32_t* cam_pos = nullptr;
+  int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
+};
 hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
                                 const int32_t* cam_slot, const double* zbuf, double* out, const int* status,
                                 hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
-                            hipStream_t stream);
+                            const CamGather& gather, hipStream_t stream);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------
 struct GenStructure {
@@ -248,6 +259,9 @@ hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
 // nine_from: blocks [nine_from, nblocks) of the range are all 9 wide (handled nine lanes per block); nblocks if unknown.
 hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
                           const int64_t* diag_off, const double* blocks, int reset, int it, int nine_from, hipStream_t stream);
+// Start of a solve with x0 = 0 in two launches: LaunchCgUpdate(..., it = 0) [x = 0, r = rhs, z = M^-1 r, partial |rhs|^2 and r.z] and
+// LaunchCgBegin [scalars as LaunchCgInit sets them, p = z] — instead of rhs-norm, init, precondition, direction.
+hipError_t LaunchCgBegin(const CgBuffers& B, double q_tol, double r_tol, int min_it, int max_it, hipStream_t stream);
 // Fused: the termination tests of iteration `it` in the reference's order (:273-302) and, if CG goes on, the
 // direction of iteration it + 1: rho = sum(slot 0), beta = rho / rho_it, p = z + beta p (:167-191).
 hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t stream);

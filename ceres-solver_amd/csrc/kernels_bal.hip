@@ -100,7 +100,6 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
-  int64_t zslot;  // where this slot's per-observation output for the camera-major pass goes (slot, or its camera-major rank)
   uint32_t seg;
   int cam, pt, first, last;
   bool valid;
@@ -190,21 +189,17 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
   }
   s.cam = A.slot_cam[sl];
   s.seg = A.slot_seg[sl];
-  s.zslot = A.z_crank ? A.z_crank[sl] : sl;
   finish_slot(s, lane, A.tile_pt0[tile]);
 }
 
 // The software-pipelined streaming kernel splits a slot load in three, each of which only ISSUES
 // loads and consumes nothing: the index words (SlotIdx), the 12 pairs of a packed fp64 tile
 // (issue_pairs), and what is addressed THROUGH the index words (issue_aux, further down).
-struct SlotIdx { int cam; uint32_t seg; int crank; };
-template <bool LDS>
+struct SlotIdx { int cam; uint32_t seg; };
 __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
   const int64_t sl = tile * kTile + lane;
   i.cam = A.slot_cam[sl];
   i.seg = A.slot_seg[sl];
-  i.crank = -1;
-  if constexpr (!LDS) { if (A.z_crank) i.crank = A.z_crank[sl]; }  // kernel-uniform: one more index word per slot in that mode
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
@@ -260,7 +255,7 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
     // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
     // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
     // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
-    double* w = acc + 9 * s.zslot;
+    double* w = acc + 9 * s.slot;
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = s.f[k] * z0 + s.f[9 + k] * z1;
   }
@@ -337,8 +332,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     double q0[3], q1[3];
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
-    // [slot][4] (or, camera-major, [rank][4]): m00 m01 m11 pad, 32 B per observation
-    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * (A.mo_crank ? int64_t(A.mo_crank[sl]) : sl));
+    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * sl);  // [slot][4]: m00 m01 m11 pad, 32 B per slot
     mo[0] = make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]));
     mo[1] = make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0);
   }
@@ -720,6 +714,10 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   }
   const int lane = threadIdx.x & 63;
   double lane_acc = 0.0;
+  if constexpr (MODE == kBackSub) {  // y_f = z (:238-242), a few KB: no separate copy launch
+    if (A.copy_dst)
+      for (int i = blockIdx.x * BLOCK + threadIdx.x; i < A.copy_n; i += gridDim.x * BLOCK) A.copy_dst[i] = A.copy_src[i];
+  }
   const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   for (int64_t tile = wave; tile < A.n_tiles; tile += nwaves) {
@@ -824,14 +822,13 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     int64_t tile = wave0;
     int kind_a = A.tile_kind[tile], aux_a = A.tile_aux[tile], kind_b = 2, aux_b = 0;
     // prologue in the steady-state issue order: index words (1), pairs (0), aux (0)
-    issue_idx<LDS>(A, tile, lane, i2);
+    issue_idx(A, tile, lane, i2);
     __builtin_amdgcn_sched_barrier(0);
-    issue_idx<LDS>(A, min(tile + nwaves, last), lane, i1);
+    issue_idx(A, min(tile + nwaves, last), lane, i1);
     __builtin_amdgcn_sched_barrier(0);
     issue_pairs(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
     sa.cam = i2.cam; sa.seg = i2.seg;
-    sa.zslot = (!LDS && A.z_crank) ? int64_t(i2.crank) : sa.slot;
     finish_slot(sa, lane, A.tile_pt0[tile]);
     issue_aux<MODE>(A, sa, lane, kind_a == 0 ? aux_a >> 8 : 0, xa);
     __builtin_amdgcn_sched_barrier(0);
@@ -842,12 +839,11 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       more = tile + nwaves < A.n_tiles;
       nkind = A.tile_kind[next];
       naux = A.tile_aux[next];
-      issue_idx<LDS>(A, min(next + nwaves, last), lane, i2);
+      issue_idx(A, min(next + nwaves, last), lane, i2);
       __builtin_amdgcn_sched_barrier(0);
       issue_pairs(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);
       n.cam = i1.cam; n.seg = i1.seg;
-      n.zslot = (!LDS && A.z_crank) ? int64_t(i1.crank) : n.slot;
       finish_slot(n, lane, A.tile_pt0[next]);
       issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
       __builtin_amdgcn_sched_barrier(0);
@@ -1024,24 +1020,21 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // combined with global_atomic_add_f64 into a zeroed output (rounding-level order effects
 // only there).
 
-// Per-camera 9x9 blocks: sum of F^T M F (+ D^2), with M = I (JACOBI: block diagonal of
-// F^T F) or M = I - E (E^T E)^-1 E^T read from [slot][4] (SCHUR_JACOBI: the diagonal blocks
-// SchurEliminator::Eliminate writes into a block-diagonal lhs).  `blocks` must be zeroed.
+// Per-camera 9x9 blocks: sum of F^T M F, with M = I (JACOBI: block diagonal of F^T F) or M = I - E (E^T E)^-1 E^T read
+// from [slot][4] (SCHUR_JACOBI: the diagonal blocks SchurEliminator::Eliminate writes into a block-diagonal lhs).
+// Every ITEM leaves its 45 upper-triangle sums (and, SCHUR, the 9 column square sums of F) in parts[item][kCamPart]:
+// no atomics, no zeroed output, and the per-camera combination (bal_camera_finish_kernel, or the load phase of
+// bal_invert9_kernel) adds the items of a camera in a fixed order — bit-reproducible.  The first version combined split
+// cameras with global fp64 atomics: 81 per item, which on a problem with few cameras (Dubrovnik: 16) or small items
+// (Ladybug) cost several times the pass itself (55 / 105 us, profiles/r02b_kernel_stats_*).
 template <bool SCHUR>
-__global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __restrict__ values, CamItems items,
-                                                                const int32_t* __restrict__ cam_ptr,
-                                                                const int32_t* __restrict__ cam_fpos,
-                                                                const int32_t* __restrict__ cam_slot,
-                                                                const double* __restrict__ Mo,
-                                                                const double* __restrict__ D_f,
-                                                                const int32_t* __restrict__ cam_pos,
-                                                                const int64_t* __restrict__ cam_diag_off,
-                                                                double* __restrict__ blocks,
-                                                                double* __restrict__ camsq) {
+__global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __restrict__ values, CamItems items,
+                                                               const int32_t* __restrict__ cam_fpos,
+                                                               const int32_t* __restrict__ cam_slot,
+                                                               const double* __restrict__ Mo, double* __restrict__ parts) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= items.count) return;
-  const int c = items.cam[item];
   const int beg = items.begin[item], end = items.end[item];
   double acc[45], sq[9];
 #pragma unroll
@@ -1055,13 +1048,11 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
     for (int k = 0; k < 9; ++k) { f0[k] = f[k]; f1[k] = f[9 + k]; }
     double m00 = 1.0, m01 = 0.0, m11 = 1.0;
     if constexpr (SCHUR) {
-      const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot ? cam_slot[q] : q));  // nullptr: M_o is camera-major
+      const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
       const double2 a = mo[0], b = mo[1];
       m00 = a.x; m01 = a.y; m11 = b.x;
-      if (camsq) {  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sq[k] += f0[k] * f0[k] + f1[k] * f1[k];
-      }
+      for (int k = 0; k < 9; ++k) sq[k] += f0[k] * f0[k] + f1[k] * f1[k];  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
     }
     int idx = 0;
 #pragma unroll
@@ -1072,41 +1063,65 @@ __global__ __launch_bounds__(256) void bal_camera_blocks_kernel(const double* __
       for (int bb = a; bb < 9; ++bb) acc[idx++] += g0 * f0[bb] + g1 * f1[bb];
     }
   }
+  double* out = parts + int64_t(item) * kCamPart;
 #pragma unroll
   for (int i = 0; i < 45; ++i) {
     double v = acc[i];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    acc[i] = v;
+    if (lane == i) out[i] = v;   // every lane holds every sum; lane i stores entry i: 360 contiguous bytes per item
   }
-  // lanes 0..44 each own one upper-triangle entry (static register index via a select chain
-  // would be long: go through LDS-free broadcast instead — every lane holds all 45 sums)
-  const bool first = beg == cam_ptr[c];
-  const bool single = first && end == cam_ptr[c + 1];
-  if (SCHUR && camsq) {
+  if constexpr (SCHUR) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       double v = sq[k];
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (lane == k) { if (single) camsq[9 * int64_t(c) + k] = v; else unsafeAtomicAdd(&camsq[9 * int64_t(c) + k], v); }
+      if (lane == 45 + k) out[45 + k] = v;
     }
   }
-  double* out = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c);
-  const int dpos = cam_pos ? cam_pos[c] : 9 * c;
-  int idx = 0;
+}
+
+// Row `i` of camera c's block from the per-item partial sums (packed upper triangle: entry (a, b), a <= b, at a (19 - a) / 2 + b - a),
+// items of a camera in list order; sqsum = the camera's column-i square sum (SCHUR items only).
+__device__ __forceinline__ void gather_camera_row(const double* __restrict__ parts, int item_lo, int item_hi, int i, double (&row)[9],
+                                                  double& sqsum, bool want_sq) {
 #pragma unroll
-  for (int a = 0; a < 9; ++a) {
+  for (int k = 0; k < 9; ++k) row[k] = 0.0;
+  sqsum = 0.0;
+  for (int it = item_lo; it < item_hi; ++it) {
+    const double* p = parts + int64_t(it) * kCamPart;
 #pragma unroll
-    for (int bb = a; bb < 9; ++bb, ++idx) {
-      if (lane == (idx & 63)) {
-        double v = acc[idx];
-        if (a == bb && D_f && first) { const double d = D_f[dpos + a]; v += d * d; }
-        if (single) { out[a * 9 + bb] = v; if (a != bb) out[bb * 9 + a] = v; }
-        else { unsafeAtomicAdd(&out[a * 9 + bb], v); if (a != bb) unsafeAtomicAdd(&out[bb * 9 + a], v); }
-      }
+    for (int k = 0; k < 9; ++k) {
+      const int a = k < i ? k : i, b = k < i ? i : k;
+      row[k] += p[a * (19 - a) / 2 + (b - a)];
     }
+    if (want_sq) sqsum += p[45 + i];
   }
+}
+
+// blocks[c] = sum of the camera's items (full symmetric 9x9) + D_f^2 on the diagonal if D_f != nullptr; camsq likewise.
+// Nine lanes per camera, seven cameras per wavefront.  Used when the raw sums are needed in memory (sharded all-reduce,
+// not_inverted read-back); otherwise bal_invert9_kernel gathers the items itself.
+__global__ __launch_bounds__(64) void bal_camera_finish_kernel(const double* __restrict__ parts, const int32_t* __restrict__ cam_item_ptr,
+                                                               const double* __restrict__ D_f, const int32_t* __restrict__ cam_pos,
+                                                               const int64_t* __restrict__ cam_diag_off, double* __restrict__ blocks,
+                                                               double* __restrict__ camsq, int n_cameras) {
+  const int lane = threadIdx.x;
+  const int grp = lane / 9, i = lane - 9 * grp;
+  const int c = blockIdx.x * 7 + grp;
+  if (grp >= 7 || c >= n_cameras) return;
+  double row[9], sqsum;
+  gather_camera_row(parts, cam_item_ptr[c], cam_item_ptr[c + 1], i, row, sqsum, camsq != nullptr);
+  if (D_f) {
+    const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) if (k == i) row[k] += d * d;
+  }
+  double* out = blocks + (cam_diag_off ? cam_diag_off[c] : int64_t(81) * c) + 9 * i;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[k] = row[k];
+  if (camsq) camsq[9 * int64_t(c) + i] = sqsum;
 }
 
 // y_c = sum over the camera's observations of F_o^T z_o, z from the per-slot buffer written by
@@ -1127,7 +1142,7 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   for (int q = beg + lane; q < end; q += 64) {
-    const double* w = zbuf + 9 * int64_t(cam_slot ? cam_slot[q] : q);  // nullptr: the per-observation F^T z were written camera-major
+    const double* w = zbuf + 9 * int64_t(cam_slot[q]);
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] += w[k];
   }
@@ -1158,7 +1173,7 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 // I/block_random_access_diagonal_matrix.cc:106-127); one thread per camera, as this kernel first
 // was, ran a ~1000-instruction dependent chain with 648-byte strided accesses: 31 us for 1778 cameras.
 __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
-                                                         int n_cameras, int* fail_flag, LmFuse lm) {
+                                                         int n_cameras, int* fail_flag, LmFuse lm, CamGather gather) {
   const int lane = threadIdx.x;
   const int grp = lane / 9, i = lane - 9 * grp;  // lane 63 idles
   const int c = blockIdx.x * 7 + grp;
@@ -1166,15 +1181,29 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
   const int cc = active ? c : 0;
   const int g0 = 9 * (grp < 7 ? grp : 0);        // first lane of the group
   double* a = blocks + (cam_diag_off ? cam_diag_off[cc] : int64_t(81) * cc);
-  double row[9];
+  double row[9], sq_from_items = 0.0;
+  if (gather.parts) {  // the blocks are still per-item partial sums: combine them here (bal_camera_items_kernel)
+    if (active) {
+      gather_camera_row(gather.parts, gather.cam_item_ptr[c], gather.cam_item_ptr[c + 1], i, row, sq_from_items, gather.want_sq != 0);
+      if (gather.D_f) {
+        const double d = gather.D_f[(gather.cam_pos ? gather.cam_pos[c] : 9 * c) + i];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) row[k] = active ? a[i * 9 + k] : (k == i ? 1.0 : 0.0);
+        for (int k = 0; k < 9; ++k) if (k == i) row[k] += d * d;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = (k == i ? 1.0 : 0.0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) row[k] = active ? a[i * 9 + k] : (k == i ? 1.0 : 0.0);
+  }
   if (lm.radius > 0.0 && active) {  // fused LM diagonal of the camera columns: d = clamp(diag(F^T F)), D^2 = d / radius
     const int o = lm.cam_pos ? lm.cam_pos[c] : 9 * c;
     double dii = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) if (k == i) dii = row[k];
-    const double v = lm.camsq ? lm.camsq[9 * int64_t(c) + i] : dii;
+    const double v = lm.camsq ? lm.camsq[9 * int64_t(c) + i] : ((gather.parts && gather.want_sq) ? sq_from_items : dii);
     const double d = fmin(fmax(v, lm.min_d), lm.max_d), q = d / lm.radius;
     lm.diag_f[o + i] = d;
     lm.D_f[o + i] = sqrt(q);
@@ -1363,23 +1392,24 @@ hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* s
 }
 
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
-                            hipStream_t stream) {
-  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 6) / 7), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm);
+                            const CamGather& gather, hipStream_t stream) {
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 6) / 7), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
   return hipGetLastError();
 }
 
-hipError_t LaunchBalCameraBlocks(bool schur, const double* values, const CamItems& items, const int32_t* cam_ptr,
-                                 const int32_t* cam_fpos, const int32_t* cam_slot, const double* Mo, const double* D_f,
-                                 const int32_t* cam_pos, const int64_t* cam_diag_off, double* blocks, double* camsq,
-                                 hipStream_t stream) {
+hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
+                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
   const dim3 grid((items.count + 3) / 4);
-  if (schur)
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
-                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks, camsq);
-  else
-    hipLaunchKernelGGL((bal_camera_blocks_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_ptr, cam_fpos,
-                       cam_slot, Mo, D_f, cam_pos, cam_diag_off, blocks, camsq);
+  if (schur) hipLaunchKernelGGL((bal_camera_items_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  else hipLaunchKernelGGL((bal_camera_items_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
+                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream) {
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_camera_finish_kernel, dim3((n_cameras + 6) / 7), dim3(64), 0, stream, parts, cam_item_ptr, D_f, cam_pos,
+                                        cam_diag_off, blocks, camsq, n_cameras);
   return hipGetLastError();
 }
 

@@ -45,6 +45,17 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 */) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// Three sums at once (one pair of barriers instead of three).
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* sh /* >= 12 */) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[w] = a; sh[4 + w] = b; sh[8 + w] = c; }
+  __syncthreads();
+  a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  c = (sh[8] + sh[9]) + (sh[10] + sh[11]);
+}
+
 struct Span { int64_t i, end, step; };
 
 // Element range of this thread: workgroups [0, grid_e) stride over the shard
@@ -393,15 +404,15 @@ __global__ __launch_bounds__(kVecBlock) void cg_finalize_kernel(CgBuffers B) {
 // Second half of iteration `it`: what cg_step_kernel does (pq, alpha, x += alpha p, r -= alpha q, partial Q1 and
 // |r|^2) and, in the same pass over r, what cg_precondition_kernel does for the NEXT iteration (z = M^-1 r, partial
 // r.z): a column block's r is in registers when its update is done.  q arrives in z and is replaced by M^-1 r.
-template <int N>
+template <int N, bool START>
 __device__ __forceinline__ void update_block(const double* __restrict__ m, double alpha, const double* __restrict__ p,
                                              const double* __restrict__ rhs, double* __restrict__ x, double* __restrict__ r,
                                              double* __restrict__ z, double& q1, double& rr, double& rz) {
   double rn[N];
 #pragma unroll
   for (int c = 0; c < N; ++c) {
-    const double xv = x[c] + alpha * p[c];
-    const double rv = r[c] - alpha * z[c];
+    const double xv = START ? 0.0 : x[c] + alpha * p[c];
+    const double rv = START ? rhs[c] : r[c] - alpha * z[c];
     x[c] = xv;
     r[c] = rv;
     rn[c] = rv;
@@ -422,22 +433,28 @@ __device__ __forceinline__ void update_block(const double* __restrict__ m, doubl
 // LANES PER BLOCK (7 blocks per wavefront, lane a of a group owns row a: its 72-byte row of M and the block's 648 bytes
 // are contiguous across the group, r travels by shuffle) instead of one thread per block walking 81 strided entries —
 // with 1778 cameras that thread-per-block tail alone took 15 us.  Blocks [0, nine_from) stay one thread per block.
+// START: the same pass as the first kernel of a solve with x0 = 0 (:130-167): x = 0, r = rhs, z = M^-1 r, partial |rhs|^2 -> slot 3
+// and r.z -> slot 0; cg_begin_kernel turns those into the scalars and p = z.
+template <bool START>
 __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenStructure G, int first_block, int col_begin, int nblocks,
                                                               const int64_t* diag_off, const double* blocks, int reset, int it,
                                                               int nine_from, int grid_a) {
-  __shared__ double sh[4];
+  __shared__ double sh[12];
   CgScalars& S = *B.S;
-  if (S.status != 0) return;
-  const int staged = S.fail_dir;  // the direction of this iteration failed: forwarded to cg_finalize_direction_kernel
-  double v = 0;
-  if (!staged) for (int k = threadIdx.x; k < B.n_pq; k += kVecBlock) v += B.pq_parts[k];
-  const double pq = staged ? 1.0 : block_sum(v, sh);
-  const double rho = S.rho_pp[it & 1];
-  int fail = staged;
-  double alpha = 0;
-  if (!fail) {
-    if (pq <= 0 || isinf(pq)) fail = kCgIndefinite;
-    else { alpha = rho / pq; if (isinf(alpha)) fail = kCgFailAlpha; }
+  double pq = 0, rho = 0, alpha = 0;
+  int fail = 0;
+  if constexpr (!START) {
+    if (S.status != 0) return;
+    const int staged = S.fail_dir;  // the direction of this iteration failed: forwarded to cg_finalize_direction_kernel
+    double v = 0;
+    if (!staged) for (int k = threadIdx.x; k < B.n_pq; k += kVecBlock) v += B.pq_parts[k];
+    pq = staged ? 1.0 : block_sum(v, sh);
+    rho = S.rho_pp[it & 1];
+    fail = staged;
+    if (!fail) {
+      if (pq <= 0 || isinf(pq)) fail = kCgIndefinite;
+      else { alpha = rho / pq; if (isinf(alpha)) fail = kCgFailAlpha; }
+    }
   }
   double q1 = 0, rr = 0, rz = 0;
   if (!fail) {
@@ -446,8 +463,8 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
       for (int64_t i = t0; i < B.n; i += step) B.x[i] += alpha * B.p[i];
     } else if (!blocks) {  // IDENTITY: z = r
       for (int64_t i = t0; i < B.n; i += step) {
-        const double xv = B.x[i] + alpha * B.p[i];
-        const double rv = B.r[i] - alpha * B.z[i];
+        const double xv = START ? 0.0 : B.x[i] + alpha * B.p[i];
+        const double rv = START ? B.rhs[i] : B.r[i] - alpha * B.z[i];
         B.x[i] = xv; B.r[i] = rv; B.z[i] = rv;
         q1 -= xv * (B.rhs[i] + rv);
         rr += rv * rv;
@@ -467,8 +484,8 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
         double mr[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) mr[c] = m[c];
-        const double xv = B.x[i] + alpha * B.p[i];
-        const double rv = B.r[i] - alpha * B.z[i];
+        const double xv = START ? 0.0 : B.x[i] + alpha * B.p[i];
+        const double rv = START ? B.rhs[i] : B.r[i] - alpha * B.z[i];
         double t = 0;
 #pragma unroll
         for (int c = 0; c < 9; ++c) t += mr[c] * __shfl(rv, 9 * (g < 7 ? g : 0) + c, 64);
@@ -486,13 +503,13 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
         const int n = G.csz[j];
         const int64_t pos = G.cpos[j] - col_begin;
         const double* m = blocks + (diag_off[q] - diag_off[0]);
-        if (n == 3) update_block<3>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
-        else if (n == 9) update_block<9>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
+        if (n == 3) update_block<3, START>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
+        else if (n == 9) update_block<9, START>(m, alpha, B.p + pos, B.rhs + pos, B.x + pos, B.r + pos, B.z + pos, q1, rr, rz);
         else {
           double rn[kMaxGenericBlock];
           for (int c = 0; c < n; ++c) {
-            const double xv = B.x[pos + c] + alpha * B.p[pos + c];
-            const double rv = B.r[pos + c] - alpha * B.z[pos + c];
+            const double xv = START ? 0.0 : B.x[pos + c] + alpha * B.p[pos + c];
+            const double rv = START ? B.rhs[pos + c] : B.r[pos + c] - alpha * B.z[pos + c];
             B.x[pos + c] = xv; B.r[pos + c] = rv; rn[c] = rv;
             q1 -= xv * (B.rhs[pos + c] + rv);
             rr += rv * rv;
@@ -508,16 +525,14 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
     }
   }
   if (!reset) {
-    q1 = block_sum(q1, sh);
-    rr = block_sum(rr, sh);
-    rz = block_sum(rz, sh);
+    block_sum3(q1, rr, rz, sh);
     if (threadIdx.x == 0) {
       B.partials[2 * kMaxVecGrid + blockIdx.x] = q1;
       B.partials[3 * kMaxVecGrid + blockIdx.x] = rr;
       B.partials[0 * kMaxVecGrid + blockIdx.x] = rz;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (!START && blockIdx.x == 0 && threadIdx.x == 0) {
     S.pq = pq;
     S.alpha = alpha;
     S.rho_new = rho;
@@ -525,12 +540,36 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
   }
 }
 
-// Sum of one slot of workgroup partials; every thread gets it (same order in every workgroup: all agree bit for bit).
-__device__ __forceinline__ double slot_total(const CgBuffers& B, int slot, double* sh) {
-  const double* p = B.partials + slot * kMaxVecGrid;
-  double v = 0;
-  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) v += p[k];
-  return block_sum(v, sh);
+// Second and last kernel of the start of a solve (x0 = 0): the scalars cg_init_kernel sets, from the partial sums cg_update_kernel<START>
+// left (|rhs|^2 in slot 3, r.z in slot 0), and the direction of iteration 1, p = z (:175-177).  Same discipline as
+// cg_finalize_direction_kernel: every workgroup derives the same decision, workgroup 0 records it.
+__global__ __launch_bounds__(kVecBlock) void cg_begin_kernel(CgBuffers B, double q_tol, double r_tol, int min_it, int max_it) {
+  __shared__ double sh[12];
+  double nn = 0, rho = 0, unused = 0;
+  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) { nn += B.partials[3 * kMaxVecGrid + k]; rho += B.partials[0 * kMaxVecGrid + k]; }
+  block_sum3(nn, rho, unused, sh);
+  const double norm_rhs = sqrt(nn);
+  const double tol_r = r_tol * norm_rhs;
+  int status = kCgRunning;
+  if (norm_rhs == 0.0) status = kCgZeroRhs;
+  else if (min_it == 0 && norm_rhs <= tol_r) status = kCgInitialResidual;
+  if (B.setup_fail && *B.setup_fail != 0) status = kCgSetupFailed;
+  int fail_dir = 0;
+  if (status == kCgRunning) {
+    if (zero_or_inf(rho)) fail_dir = kCgFailRho;
+    else
+      for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < B.n; i += int64_t(gridDim.x) * kVecBlock) B.p[i] = B.z[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    CgScalars& S = *B.S;
+    S.norm_rhs = norm_rhs; S.tol_r = tol_r; S.q_tol = q_tol;
+    S.rho = 1.0; S.rho_new = rho; S.beta = 0; S.pq = 0; S.alpha = 0;
+    S.Q0 = 0.0; S.Q1 = 0; S.zeta = 0; S.norm_r = norm_rhs; S.norm_p = 0; S.norm_q = 0;
+    S.Q0_pp[0] = 0.0; S.Q0_pp[1] = 0.0; S.rho_pp[0] = 1.0; S.rho_pp[1] = rho;
+    S.iter = 1; S.min_it = min_it; S.max_it = max_it;
+    S.fail_dir = fail_dir; S.fail_step = 0;
+    S.status = status;
+  }
 }
 
 // End of iteration `it`: cg_finalize_kernel's tests and, if CG continues, cg_direction_kernel for iteration it + 1.
@@ -538,7 +577,7 @@ __device__ __forceinline__ double slot_total(const CgBuffers& B, int slot, doubl
 // kernel both needs and produces (rho, Q0) are double-buffered by iteration parity, the iteration number is a launch
 // argument, and a workgroup that starts after the status word went terminal just returns (CG is over, p is dead).
 __global__ __launch_bounds__(kVecBlock) void cg_finalize_direction_kernel(CgBuffers B, int it) {
-  __shared__ double sh[4];
+  __shared__ double sh[12];
   CgScalars& S = *B.S;
   if (S.status != 0) return;
   const int fail = S.fail_step;
@@ -546,9 +585,13 @@ __global__ __launch_bounds__(kVecBlock) void cg_finalize_direction_kernel(CgBuff
     if (blockIdx.x == 0 && threadIdx.x == 0) S.status = fail;
     return;
   }
-  const double Q1 = slot_total(B, 2, sh);
-  const double rr = slot_total(B, 3, sh);
-  const double rho = slot_total(B, 0, sh);
+  double Q1 = 0, rr = 0, rho = 0;
+  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) {  // same order in every workgroup: all agree bit for bit
+    Q1 += B.partials[2 * kMaxVecGrid + k];
+    rr += B.partials[3 * kMaxVecGrid + k];
+    rho += B.partials[0 * kMaxVecGrid + k];
+  }
+  block_sum3(Q1, rr, rho, sh);
   const double Q0 = S.Q0_pp[it & 1], rho_prev = S.rho_pp[it & 1];
   const double norm_r = sqrt(rr);
   const double zeta = it * (Q1 - Q0) / Q1;
@@ -691,8 +734,16 @@ hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_b
   int grid_a = B.grid;  // workgroups of the one-thread-per-block part
   if (n9 > 0) grid_a = nine_from == 0 ? 0 : std::max(1, B.grid - std::max(1, std::min(B.grid / 2, (n9 + 111) / 112)));
   if (n9 > 0 && grid_a >= B.grid) { nine_from = nblocks; grid_a = B.grid; }  // a single workgroup: no room to split
-  hipLaunchKernelGGL(cg_update_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, reset, it,
-                     nine_from, grid_a);
+  if (it == 0)  // start of a solve
+    hipLaunchKernelGGL((cg_update_kernel<true>), dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, 0, 0,
+                       nine_from, grid_a);
+  else
+    hipLaunchKernelGGL((cg_update_kernel<false>), dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, reset, it,
+                       nine_from, grid_a);
+  return hipGetLastError();
+}
+hipError_t LaunchCgBegin(const CgBuffers& B, double q_tol, double r_tol, int min_it, int max_it, hipStream_t s) {
+  hipLaunchKernelGGL(cg_begin_kernel, dim3(B.grid), dim3(kVecBlock), 0, s, B, q_tol, r_tol, min_it, max_it);
   return hipGetLastError();
 }
 hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t s) {

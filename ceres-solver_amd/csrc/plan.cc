@@ -300,7 +300,6 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   }
   P.cam_fpos.resize(P.n_obs);
   P.cam_slot.resize(P.n_obs);
-  P.slot_crank.assign(size_t(P.n_tiles) * kTile, -1);
   {
     std::vector<int32_t> cur(P.cam_ptr.begin(), P.cam_ptr.end() - 1);
     for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
@@ -308,12 +307,13 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       const int q = cur[P.slot_cam[s]]++;
       P.cam_fpos[q] = P.slot_fpos[s];
       P.cam_slot[q] = int32_t(s);
-      P.slot_crank[s] = q;  // inverse: where the slot's observation sits in the camera-major list
     }
   }
-  // Item size: kCamChunk at scale (>= 8192 items keep every CU busy); smaller problems get
-  // proportionally shorter items, down to one wavefront's worth, so that they too spread over the chip.
-  const int chunk = int(std::max<int64_t>(kTile, std::min<int64_t>(kCamChunk, ((P.n_obs / 8192 + kTile - 1) / kTile) * kTile)));
+  // Item size: kCamChunk at scale; smaller problems get shorter items so that they too spread over the chip, but never
+  // fewer than 256 observations (4 per lane): an item ends in a 54-value wavefront reduction, and items of 64-128
+  // observations spent more time reducing than accumulating.
+  const int chunk = int(std::max<int64_t>(256, std::min<int64_t>(kCamChunk, ((P.n_obs / 8192 + kTile - 1) / kTile) * kTile)));
+  P.cam_item_ptr.assign(P.n_cameras + 1, 0);
   for (int c = 0; c < P.n_cameras; ++c) {
     int b = P.cam_ptr[c];
     do {  // a camera without observations still gets one (empty) item so that D^2 is added
@@ -321,6 +321,7 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       P.item_cam.push_back(c); P.item_begin.push_back(b); P.item_end.push_back(e);
       b = e;
     } while (b < P.cam_ptr[c + 1]);
+    P.cam_item_ptr[c + 1] = int32_t(P.item_cam.size());  // the items of a camera are consecutive
   }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
   P.eligible = true;

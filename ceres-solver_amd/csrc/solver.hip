@@ -58,12 +58,14 @@ struct ceres_hip_solver {
   int32_t *d_slot_epos = nullptr, *d_slot_fpos = nullptr, *d_slot_bpos = nullptr, *d_slot_cam = nullptr, *d_tile_pt0 = nullptr;
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
-  int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr, *d_slot_crank = nullptr;
-  bool mo_cam_major = false, z_cam_major = false;  // what the camera-major passes read is WRITTEN camera-major (CERES_HIP_MO_CAM / CERES_HIP_Z_CAM)
+  int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   CamItems cam_items;
+  int32_t* d_cam_item_ptr = nullptr;
+  double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
   // f1: LM step state
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
+  bool fail_flag_clean = false, nonfinite_clean = false;  // cleared together at the start of a solve: the per-operator memsets are skipped once
   bool have_lm_diag = false;
   bool lm_want_model_cost = false;  // op_back_substitute also accumulates the model cost change (fused <2,3,9> path)
   int backsub_cost_parts = 0;       // partials it left in scalar_partials
@@ -206,8 +208,6 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
-  if (s->mo_cam_major) A.mo_crank = s->d_slot_crank;
-  if (s->z_cam_major && !s->lds_mode) A.z_crank = s->d_slot_crank;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -262,7 +262,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
   if (!s->lds_mode) {  // second pass by camera over the z the fused kernel left per slot
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
-    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->z_cam_major ? nullptr : s->d_cam_slot, s->d_zbuf,
+    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_zbuf,
                                     s->d_global_acc, status, s->stream));
   }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
@@ -396,7 +396,9 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
     // f1: the LM step wants the model cost change of -x; the kernel has J x in hand (one partial per workgroup)
     s->backsub_cost_parts = 0;
     if (s->lm_want_model_cost && z != nullptr) { A.scalar_out = s->scalar_partials; s->backsub_cost_parts = s->fused_grid; }
+    if (h.num_cols_f > 0 && z != nullptr) { A.copy_src = z; A.copy_dst = x + h.num_cols_e; A.copy_n = h.num_cols_f; }
     HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
+    return 0;
   } else {
     HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
     if (h.num_cols_f > 0) HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kF, z, s->tmp_rows, nullptr, st));
@@ -418,26 +420,33 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
-  HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  if (!s->fail_flag_clean) HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  s->fail_flag_clean = false;
   if (is_schur(s)) {
     const int nf = h.ncb - h.nelim;
     const int64_t len = h.diag_off_f.back();
     if (s->path == CERES_HIP_PATH_BAL) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
-      // raw sums first (no diagonal) so that a sharded run can add them up
-      HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));
       const bool fuse = s->lm_fuse_active && invert;
-      if (fuse && schur) HIP_TRY(s, hipMemsetAsync(s->d_camsq, 0, sizeof(double) * 9 * s->plan.n_cameras, st));
-      HIP_TRY(s, LaunchBalCameraBlocks(schur, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->mo_cam_major ? nullptr : s->d_cam_slot, s->d_Mo,
-                                       (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
-                                       (fuse && schur) ? s->d_camsq : nullptr, st));
-      if (s->world > 1) {
-        TRY(allreduce(s, out, size_t(len)));
-        if (fuse && schur) TRY(allreduce(s, s->d_camsq, size_t(9) * s->plan.n_cameras));  // column norms of the camera columns
-        // fused LM diagonal: D_f does not exist yet, bal_invert9_kernel forms it from the reduced sums and adds it
-        if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
+      HIP_TRY(s, LaunchBalCameraItems(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
+      if (s->world <= 1 && invert) {
+        // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
+        CamGather g;
+        g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.want_sq = (fuse && schur) ? 1 : 0;
+        g.D_f = fuse ? nullptr : D_f;
+        HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
+      } else {
+        // raw sums in memory first (no diagonal when sharded: the ranks' sums are added up, then D_f^2 joins once)
+        HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
+                                         (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st));
+        if (s->world > 1) {
+          TRY(allreduce(s, out, size_t(len)));
+          if (fuse && schur) TRY(allreduce(s, s->d_camsq, size_t(9) * s->plan.n_cameras));  // column norms of the camera columns
+          // fused LM diagonal: D_f does not exist yet, bal_invert9_kernel forms it from the reduced sums and adds it
+          if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
+        }
+        if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), CamGather(), st));
       }
-      if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), st));
     } else {
       if (type == CERES_HIP_SCHUR_JACOBI) {
         HIP_TRY(s, LaunchGenSchurJacobi(s->G, s->values, s->etei, s->D, s->world > 1 ? 0 : 1, out, len, st));
@@ -461,11 +470,12 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     A.D_e = s->D;
     A.point_blocks = out;
     A.pt_diag_off = s->d_pt_diag_off;
-    HIP_TRY(s, hipMemsetAsync(out, 0, sizeof(double) * len, st));  // camera blocks are accumulated with atomics
     HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
-    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     D_f, s->plan.contiguous_layout ? nullptr : s->d_cam_pos, s->d_cam_diag_off, out, nullptr, st));
-    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), st));
+    HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
+    CamGather g;
+    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.D_f = D_f;
+    g.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
     return 0;
   }
   HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kAll, s->world > 1 ? nullptr : s->D, out, len, st));
@@ -488,8 +498,8 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   hipStream_t st = s->stream;
   const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
   const int64_t len = h.diag_off_all.back();
-  if (jacobi) HIP_TRY(s, hipMemsetAsync(blocks, 0, sizeof(double) * len, st));  // camera blocks use atomics
-  HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  if (!s->fail_flag_clean) HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+  s->fail_flag_clean = false;
   BalArgs A = bal_args(s);
   A.etei = nullptr;
   A.D_e = s->D;
@@ -500,20 +510,22 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   TRY(bal_scatter(s, kBalCgnrInit, A, nullptr, rhs + h.num_cols_e, false, nullptr));
   if (!jacobi) return 0;
   const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
   if (s->world <= 1) {
-    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     s->lm_fuse_active ? nullptr : D_f, cam_pos, s->d_cam_diag_off, blocks, nullptr, st));
-  } else {
-    // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
-    // behind the point blocks in the Schur-ordered layout a sharded run requires)
-    HIP_TRY(s, LaunchBalCameraBlocks(false, s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, nullptr,
-                                     nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, st));
-    const int64_t first = h.diag_off_all[h.nelim];
-    TRY(allreduce(s, blocks + first, size_t(len - first)));
-    if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
-      HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
+    CamGather g;
+    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.cam_pos = cam_pos;
+    g.D_f = s->lm_fuse_active ? nullptr : D_f;  // fused LM diagonal: bal_invert9_kernel forms D_f from the block's own diagonal and adds it
+    HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
+    return 0;
   }
-  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), st));
+  // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
+  // behind the point blocks in the Schur-ordered layout a sharded run requires)
+  HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, s->plan.n_cameras, st));
+  const int64_t first = h.diag_off_all[h.nelim];
+  TRY(allreduce(s, blocks + first, size_t(len - first)));
+  if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
+    HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
+  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), CamGather(), st));
   return 0;
 }
 
@@ -638,6 +650,7 @@ struct CgSpec {
   std::function<int(const double*, double*, double*, int*)> apply_dot;
   std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
   bool x0_nonzero = false;                              // B.x holds an initial guess
+  const double* rhs = nullptr;                          // right-hand side (nullptr: s->cg_rhs)
   int first_block = 0, col_begin = 0, nblocks = 0, n_local_blocks = 0;
   const int64_t* diag_off = nullptr;
   const double* blocks = nullptr;                       // nullptr = IDENTITY
@@ -712,10 +725,12 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   CgBuffers& B = s->cg;
   B.n = spec.n;
   B.n_local = (s->world > 1) ? spec.n_local : 0;
-  B.rhs = s->cg_rhs;
+  B.rhs = spec.rhs ? spec.rhs : s->cg_rhs;
   B.setup_fail = spec.setup_fail;
+  // one element per thread until the cap: the short camera-space vectors of ITERATIVE_SCHUR (16 k doubles) are
+  // latency-bound, and more, shorter workgroups finish sooner than 16 long ones
   auto grid_for = [](int64_t n, int cap) {
-    int64_t g = (n + int64_t(kVecBlock) * 4 - 1) / (int64_t(kVecBlock) * 4);
+    int64_t g = (n + int64_t(kVecBlock) - 1) / int64_t(kVecBlock);
     return int(std::max<int64_t>(1, std::min<int64_t>(g, cap)));
   };
   if (B.n_local > 0) {
@@ -734,6 +749,16 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   const bool adaptive = s->opt.cg_check_interval <= 0;
   int interval = adaptive ? 2 : s->opt.cg_check_interval;
 
+  // Fused iteration: operator (+ p.q where its kernels have p and q in registers) -> cg_update (alpha, x, r, M^-1 r)
+  // -> cg_finalize_direction (tests, beta, p): 2 launches after the operator instead of 5.  Needs a block-diagonal
+  // (or no) preconditioner and unsharded CG vectors (ITERATIVE_SCHUR's camera-space vectors are replicated: fine).
+  const bool fused = s->cg_fused && !spec.precondition && B.grid_e == 0;
+  const bool fused_start = fused && !spec.x0_nonzero;  // x0 = 0: the whole start of the solve is two launches
+  if (fused_start) {
+    HIP_TRY(s, LaunchCgUpdate(B, s->G, spec.first_block, spec.col_begin, spec.nblocks, spec.diag_off, spec.blocks, 0, 0,
+                              s->nine_wide_from - spec.first_block, st));
+    HIP_TRY(s, LaunchCgBegin(B, q_tol, r_tol, min_it, max_it, st));
+  } else {
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
   TRY(collapse_and_reduce(s, 0, 1));
   if (spec.x0_nonzero) {  // r = rhs - A x0, Q0 = -x0.(rhs + r)   (:138-159)
@@ -744,15 +769,12 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   } else {
     HIP_TRY(s, LaunchCgInit(B, q_tol, r_tol, min_it, max_it, st));
   }
+  }
   // No poll here: if |b| = 0 or r0 already meets the tolerance the status word is set and the
   // first batch below is a string of no-ops; the first poll comes after it.
   s->h_scalars->status = kCgRunning;
   s->timing.operator_applications = 0;
   int it = 1;
-  // Fused iteration: operator (+ p.q where its kernels have p and q in registers) -> cg_update (alpha, x, r, M^-1 r)
-  // -> cg_finalize_direction (tests, beta, p): 2 launches after the operator instead of 5.  Needs a block-diagonal
-  // (or no) preconditioner and unsharded CG vectors (ITERATIVE_SCHUR's camera-space vectors are replicated: fine).
-  const bool fused = s->cg_fused && !spec.precondition && B.grid_e == 0;
   auto precondition = [&]() -> int {
     if (spec.precondition) {
       TRY(spec.precondition(B.r, B.z));
@@ -763,7 +785,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
     }
     return 0;
   };
-  if (fused) {  // iteration 1's z = M^-1 r0, rho_1 and p = z; later directions come out of cg_finalize_direction
+  if (fused && !fused_start) {  // iteration 1's z = M^-1 r0, rho_1 and p = z; later directions come out of cg_finalize_direction
     TRY(precondition());
     HIP_TRY(s, LaunchCgDirection(B, st));
   }
@@ -878,6 +900,9 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   // ImplicitSchurComplement::Init / Preconditioner::Update do on every Solve.
   s->ftf_inv_valid = false;
   s->precond_valid = false;
+  HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), st));  // finite-step flag + factorization flag, adjacent
+  s->fail_flag_clean = true;
+  s->nonfinite_clean = true;
   HIP_TRY(s, hipEventRecord(s->ev[2], st));
   if (is_schur(s)) {
     // IterativeSchurComplementSolver::SolveImpl, I/iterative_schur_complement_solver.cc:64-157
@@ -973,8 +998,8 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
       s->precond_valid = true;
     }
     HIP_TRY(s, hipEventRecord(s->ev[4], st));
-    HIP_TRY(s, hipMemcpyAsync(s->cg_rhs, s->rhs_f, sizeof(double) * h.num_cols_f, hipMemcpyDeviceToDevice, st));
     CgSpec spec;
+    spec.rhs = s->rhs_f;  // CG only reads it: no copy into cg_rhs
     spec.n = h.num_cols_f;
     spec.n_local = 0;  // camera space is replicated: no inner product crosses ranks
     const int* status = &s->cg.S->status;
@@ -990,7 +1015,7 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     if (spse_pre)  // tolerance 0: the preconditioner must stay fixed during CG (:178-186)
       spec.precondition = [s, spse_iters, status](const double* in, double* out) { return op_spse_apply(s, in, out, spse_iters, 0.0, status); };
     if (s->opt.use_spse_initialization) {  // :97-111
-      TRY(op_spse_apply(s, s->cg_rhs, s->cg.x, spse_iters, s->opt.spse_tolerance, nullptr));
+      TRY(op_spse_apply(s, s->rhs_f, s->cg.x, spse_iters, s->opt.spse_tolerance, nullptr));
       spec.x0_nonzero = true;
     }
     TRY(run_cg(s, spec, q_tol, r_tol, summary));
@@ -1205,11 +1230,15 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->own_D, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->own_x, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->scratch_vec, size_t(h.num_cols) + size_t(h.num_rows)));
-  TRY(dev_alloc(s, &s->d_fail_flag, 1));
-  TRY(dev_alloc(s, &s->d_nonfinite, 1));
+
   TRY(dev_alloc(s, &s->lm_diag, size_t(h.num_cols)));
   TRY(dev_alloc(s, &s->lm_D, size_t(h.num_cols)));
-  TRY(dev_alloc(s, &s->scalar_partials, size_t(2 * kMaxVecGrid)));
+  // [0, 2 kMaxVecGrid) partial sums, then two int flags in one double: one memset clears both flags, one D2H copy at the
+  // end of an LM step brings {model-cost partials, finite-step flag} back
+  TRY(dev_alloc(s, &s->scalar_partials, size_t(2 * kMaxVecGrid + 2)));
+  s->d_nonfinite = reinterpret_cast<int*>(s->scalar_partials + 2 * kMaxVecGrid);
+  s->d_fail_flag = s->d_nonfinite + 1;
+  HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), s->stream));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
   if (s->opt.use_explicit_schur_complement) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
@@ -1246,9 +1275,6 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_cam_ptr, P.cam_ptr));
     TRY(dev_upload(s, &s->d_cam_fpos, P.cam_fpos));
     TRY(dev_upload(s, &s->d_cam_slot, P.cam_slot));
-    TRY(dev_upload(s, &s->d_slot_crank, P.slot_crank));
-    { const char* e = getenv("CERES_HIP_MO_CAM"); s->mo_cam_major = e ? atoi(e) != 0 : false; }
-    { const char* e = getenv("CERES_HIP_Z_CAM"); s->z_cam_major = e ? atoi(e) != 0 : false; }
     {
       int32_t *ic = nullptr, *ib = nullptr, *ie = nullptr;
       TRY(dev_upload(s, &ic, P.item_cam));
@@ -1256,6 +1282,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       TRY(dev_upload(s, &ie, P.item_end));
       s->cam_items.cam = ic; s->cam_items.begin = ib; s->cam_items.end = ie;
       s->cam_items.count = int(P.item_cam.size());
+      TRY(dev_upload(s, &s->d_cam_item_ptr, P.cam_item_ptr));
+      TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * kCamPart));
     }
     std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
     for (int p = 0; p < P.n_points; ++p) pdo[p] = h.diag_off_all[P.pt_block[p]];
@@ -1544,7 +1572,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   // Finite check + negation and the model cost change are enqueued together and read back with ONE
   // synchronisation (and, sharded, one all-reduce of {flag, cost}); a non-finite step makes the
   // cost meaningless, it is then ignored.
-  HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
+  if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
+  s->nonfinite_clean = false;
   HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
   // parts_local: this rank's share (summed over ranks); parts_shared: replicated quantities (counted once)
   const double *parts_local = nullptr, *parts_shared = nullptr;
@@ -1578,20 +1607,34 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     HIP_TRY(s, LaunchCollectScalars(s->d_nonfinite, parts_local, n_local, s->cg.comm, st));
     TRY(allreduce(s, s->cg.comm, 2));
     HIP_TRY(s, hipMemcpyAsync(hp, s->cg.comm, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
-  } else {
-    HIP_TRY(s, hipMemcpyAsync(h_flag, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (n_local > 0) HIP_TRY(s, hipMemcpyAsync(hp, parts_local, sizeof(double) * n_local, hipMemcpyDeviceToHost, st));
   }
-  if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
+  // unsharded: the partial sums and the flag word live in one buffer (scalar_partials | flags): ONE copy brings them back
+  const double* sp = s->scalar_partials;
+  auto inside = [&](const double* q, int n) { return n == 0 || (q >= sp && q + n <= sp + 2 * kMaxVecGrid); };
+  const bool one_copy = s->world <= 1 && inside(parts_local, n_local) && inside(parts_shared, n_shared);
+  double* hl = hp;                  // host images of the two partial lists
+  double* hsh = hp + kMaxVecGrid;
+  if (one_copy) {
+    HIP_TRY(s, hipMemcpyAsync(hp, sp, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, st));
+    h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
+    if (n_local > 0) hl = hp + (parts_local - sp);
+    if (n_shared > 0) hsh = hp + (parts_shared - sp);
+  } else {
+    if (s->world <= 1) {
+      HIP_TRY(s, hipMemcpyAsync(h_flag, s->d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+      if (n_local > 0) HIP_TRY(s, hipMemcpyAsync(hp, parts_local, sizeof(double) * n_local, hipMemcpyDeviceToHost, st));
+    }
+    if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(s, hipStreamSynchronize(st));
   TRY(check_comm_error(s));
   if (s->world > 1) { v[0] = hp[0]; v[1] = hp[1]; }
   else {
     v[0] = double(*h_flag != 0);
-    for (int i = 0; i < n_local; ++i) v[1] += hp[i];
+    for (int i = 0; i < n_local; ++i) v[1] += hl[i];
   }
   double shared = 0;
-  for (int i = 0; i < n_shared; ++i) shared += hp[kMaxVecGrid + i];
+  for (int i = 0; i < n_shared; ++i) shared += hsh[i];
   if (v[0] != 0.0) {  // "Linear solver failure. Failed to compute a finite step."  :124-128
     res->linear_solver.termination_type = CERES_HIP_FAILURE;
     snprintf(res->linear_solver.message, sizeof(res->linear_solver.message), "Failed to compute a finite step.");

@@ -28,9 +28,13 @@ for STAGE in "$@"; do
           | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({k: d[k] for k in ('ms_per_step','value')} | {'cg_its': d['config']['cg_iterations_per_step'], 'cgnr': d['extra'].get('cgnr',{}).get('ms_per_step'), 'sx_ms': d['roofline']['avg_launch_ms'], 'phases': d['extra']['solve_phases_ms']}))" | tee -a $OUT/small_$TAG.txt
       done; done ;;
     ab_mo)   # M_o written camera-major by kInit vs gathered through cam_slot (Venice shape)
-      for V in 0 1; do echo -n "MO_CAM=$V " | tee -a $OUT/ab_mo_$TAG.jsonl; CERES_HIP_MO_CAM=$V timeout 600 python tools/kernel_times.py venice1778 2>/dev/null | tail -1 | tee -a $OUT/ab_mo_$TAG.jsonl; done ;;
+      for V in 0 1; do echo -n "MO_CAM=$V " | tee -a $OUT/ab_mo_$TAG.jsonl; CERES_HIP_MO_CAM=$V timeout 600 python tools/kernel_times.py venice1778 2>$OUT/ab_mo_$TAG.err | tail -1 | tee -a $OUT/ab_mo_$TAG.jsonl; done ;;
     ab_z)    # per-observation F^T z written camera-major vs gathered (50 k cameras, 3 M observations)
       for V in 0 1; do echo -n "Z_CAM=$V " | tee -a $OUT/ab_z_$TAG.jsonl; CERES_HIP_Z_CAM=$V CERES_HIP_MO_CAM=$V timeout 600 python tools/kernel_times.py synthetic1M 2>/dev/null | tail -1 | tee -a $OUT/ab_z_$TAG.jsonl; done ;;
+    ktimes)  # per-operator times, Venice shape
+      timeout 600 python tools/kernel_times.py venice1778 2>$OUT/ktimes_$TAG.err | tail -1 | tee -a $OUT/ktimes_$TAG.jsonl; tail -3 $OUT/ktimes_$TAG.err ;;
+    ktimes1m)
+      timeout 600 python tools/kernel_times.py synthetic1M 2>$OUT/ktimes1m_$TAG.err | tail -1 | tee -a $OUT/ktimes1m_$TAG.jsonl; tail -3 $OUT/ktimes1m_$TAG.err ;;
     rocprof_small)
       cd /tmp && export TMPDIR=/tmp
       for WL in ladybug1723 dubrovnik16; do
