@@ -30,7 +30,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #include "device.h"
 
@@ -1174,17 +1175,38 @@ __global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __r
 // was, ran a ~1000-instruction dependent chain with 648-byte strided accesses: 31 us for 1778 cameras.
 __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
                                                          int n_cameras, int* fail_flag, LmFuse lm, CamGather gather) {
+  __shared__ double csum[kCamPart];
   const int lane = threadIdx.x;
   const int grp = lane / 9, i = lane - 9 * grp;  // lane 63 idles
-  const int c = blockIdx.x * 7 + grp;
-  const bool active = grp < 7 && c < n_cameras;
+  // assembled blocks: seven cameras per wavefront; per-item partial sums (gather.parts): ONE camera per wavefront, whose
+  // 54 lanes first add up the camera's items entry by entry (coalesced 432-byte rows), then lanes 0..8 take the rows
+  const bool gathering = gather.parts != nullptr;
+  const int c = gathering ? int(blockIdx.x) : int(blockIdx.x) * 7 + grp;
+  const bool active = (gathering ? grp == 0 : grp < 7) && c < n_cameras;
   const int cc = active ? c : 0;
-  const int g0 = 9 * (grp < 7 ? grp : 0);        // first lane of the group
+  const int g0 = 9 * ((!gathering && grp < 7) ? grp : 0);        // first lane of the group
   double* a = blocks + (cam_diag_off ? cam_diag_off[cc] : int64_t(81) * cc);
   double row[9], sq_from_items = 0.0;
-  if (gather.parts) {  // the blocks are still per-item partial sums: combine them here (bal_camera_items_kernel)
+  if (gathering) {  // the blocks are still per-item partial sums: combine them here (bal_camera_items_kernel)
+    const int item_lo = gather.cam_item_ptr[blockIdx.x], item_hi = gather.cam_item_ptr[blockIdx.x + 1];
+    if (lane < kCamPart) {
+      double s0 = 0.0, s1 = 0.0;
+      int it = item_lo;
+      for (; it + 1 < item_hi; it += 2) {
+        s0 += gather.parts[int64_t(it) * kCamPart + lane];
+        s1 += gather.parts[int64_t(it + 1) * kCamPart + lane];
+      }
+      if (it < item_hi) s0 += gather.parts[int64_t(it) * kCamPart + lane];
+      csum[lane] = s0 + s1;
+    }
+    __syncthreads();
     if (active) {
-      gather_camera_row(gather.parts, gather.cam_item_ptr[c], gather.cam_item_ptr[c + 1], i, row, sq_from_items, gather.want_sq != 0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int ra = k < i ? k : i, rb = k < i ? i : k;
+        row[k] = csum[ra * (19 - ra) / 2 + (rb - ra)];
+      }
+      sq_from_items = csum[45 + i];
       if (gather.D_f) {
         const double d = gather.D_f[(gather.cam_pos ? gather.cam_pos[c] : 9 * c) + i];
 #pragma unroll
@@ -1271,17 +1293,24 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-// The dynamic-LDS ceiling is a per-device attribute of a kernel: set it once per (kernel, device), whichever
-// thread gets there first (one static mask per instantiation; devices 0..63).
-template <typename K>
-static hipError_t allow_max_lds(K k) {
-  static std::atomic<unsigned long long> done{0ull};
+// The dynamic-LDS ceiling is a per-device attribute of a kernel: set it once per (kernel, device), whichever thread
+// gets there first.  Keyed by the kernel's ADDRESS (all kernels here share one function type, so a static per
+// template instantiation would be shared between them).
+static hipError_t allow_max_lds(const void* kernel) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, unsigned long long> done;  // kernel -> mask of devices 0..63
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
   const unsigned long long bit = 1ull << (dev & 63);
-  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-  if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(kMaxLdsBytes)); e != hipSuccess) return e;
-  done.fetch_or(bit, std::memory_order_release);
+  std::lock_guard<std::mutex> lock(mu);
+  unsigned long long& mask = done[kernel];
+  if (mask & bit) return hipSuccess;
+  // static + dynamic LDS must fit the CU's 160 KB: kernels with a few bytes of static __shared__ (cross-wave reductions) get that much less
+  hipFuncAttributes fa;
+  if (hipError_t e = hipFuncGetAttributes(&fa, kernel); e != hipSuccess) return e;
+  const int dyn = int(kMaxLdsBytes) - int(fa.sharedSizeBytes);
+  if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); e != hipSuccess) return e;
+  mask |= bit;
   return hipSuccess;
 }
 
@@ -1290,7 +1319,7 @@ static hipError_t launch_fused2(const BalArgs& A, bool lds, int grid, hipStream_
   if (lds) {
     const size_t bytes = size_t(A.n_f9) * sizeof(double);
     auto k = bal_fused_kernel<MODE, true, BLOCK, F32>;
-    if (hipError_t e = allow_max_lds(k); e != hipSuccess) return e;
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   } else {
     hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK, F32>), dim3(grid), dim3(BLOCK), 0, stream, A);
@@ -1315,7 +1344,7 @@ template <int MODE>
 static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
     auto k = bal_stream_kernel<MODE, true>;
-    if (hipError_t e = allow_max_lds(k); e != hipSuccess) return e;
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
   } else {
     hipLaunchKernelGGL((bal_stream_kernel<MODE, false>), dim3(grid), dim3(512), 0, stream, A);
@@ -1393,7 +1422,7 @@ hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* s
 
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             const CamGather& gather, hipStream_t stream) {
-  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3((n_cameras + 6) / 7), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3(gather.parts ? n_cameras : (n_cameras + 6) / 7), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
   return hipGetLastError();
 }
 
