@@ -24,6 +24,8 @@ constexpr int kTile = 64;           // observation slots per tile = one wavefron
 constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
 constexpr int kCamChunk = 512;      // max observations per work item (one wavefront) of the camera-major kernels
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
+constexpr size_t kLdsBytesPerCu = 160 * 1024;  // LDS per CU on gfx950
+constexpr int kZUnit = 64;             // max entries of one work unit of the chunked camera-major pass (cameras not in LDS)
 constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
 
 // ---------------------------------------------------------------------------
@@ -76,6 +78,15 @@ struct BalPlan {
   // work items of the camera-block kernel: (camera, [begin,end) in the camera-major list)
   std::vector<int32_t> item_cam, item_begin, item_end;
   std::vector<int32_t> cam_item_ptr;  // n_cameras+1: items [cam_item_ptr[c], cam_item_ptr[c+1]) belong to camera c
+  // Cameras whose 9-double accumulators do not fit in LDS (more than ~2270): the tile pass leaves F^T z per slot and a
+  // camera-major pass sums it.  Both can run CHUNK by chunk of tiles through a ring buffer (plan.cc: default one chunk).
+  bool cameras_in_lds = true;
+  int64_t z_ring_slots = 0;                  // slots of the largest chunk = size of the per-slot ring buffer
+  std::vector<int32_t> zc_tile_ptr;          // n_chunks+1 tile boundaries (never inside a long point)
+  std::vector<int32_t> zc_unit_ptr;          // n_chunks+1 into the unit arrays
+  std::vector<int32_t> zu_cam, zu_begin, zu_end;  // unit = <= kZUnit entries of ONE camera inside ONE chunk; [begin, end) into zc_slot
+  std::vector<int32_t> zu_shared;            // 1: the camera has more units in this chunk (combine with atomics), 0: plain read-modify-write
+  std::vector<int32_t> zc_slot;              // per entry: slot index RELATIVE to its chunk's first slot; chunk-major, camera-major inside
   int max_track = 0, max_camera_degree = 0;
 };
 

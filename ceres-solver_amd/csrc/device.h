@@ -37,6 +37,10 @@ struct BalArgs {
   const int32_t* tile_kind = nullptr;
   const int32_t* tile_aux = nullptr;
   int64_t n_tiles = 0, n_slots = 0;
+  // tiles this launch walks: [tile_begin, tile_end); tile_end = 0 means all.  Chunked launches (cameras not in LDS) write their
+  // per-slot F^T z into a ring buffer indexed by slot - z_slot0.
+  int64_t tile_begin = 0, tile_end = 0, z_slot0 = 0;
+  int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)
   const int32_t* pt_pos = nullptr;   // nullptr => 3*p
   const int32_t* cam_pos = nullptr;  // nullptr => 9*c   (relative to the F base pointer)
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
@@ -107,9 +111,13 @@ struct CamGather {
   const int32_t* cam_pos = nullptr;
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
 };
-hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double* zbuf, double* out, const int* status,
-                                hipStream_t stream);
+// Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].
+struct ZUnits {
+  const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr, *shared = nullptr;  // units [first, first + count)
+  const int32_t* slot = nullptr;                                                       // entry -> ring-relative slot
+  int first = 0, count = 0;
+};
+hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             const CamGather& gather, hipStream_t stream);
 

@@ -101,6 +101,7 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
+  int64_t zrel;   // slot - A.z_slot0: where the slot's F^T z goes in the (chunk) ring when cameras are not in LDS
   uint32_t seg;
   int cam, pt, first, last;
   bool valid;
@@ -134,6 +135,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
                                           bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
   s.slot = sl;
+  s.zrel = sl - A.z_slot0;
   s.b0 = 0.0; s.b1 = 0.0;
   if (CAN_GATHER && A.src_values && may_gather) {
     const int ep = A.slot_epos[sl], fp = A.slot_fpos[sl];
@@ -204,6 +206,7 @@ __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int la
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
+  s.zrel = s.slot - A.z_slot0;
   s.b0 = 0.0; s.b1 = 0.0;
   const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
   double2 p[kPairsPerSlot];
@@ -247,8 +250,8 @@ __device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], do
 // atomics on a few thousand hot addresses are an order of magnitude slower.
 template <bool LDS>
 __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
-  if (!s.valid) return;
   if constexpr (LDS) {
+    if (!s.valid) return;
     const int base = 9 * s.cam;
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);  // ds_add_f64
@@ -256,9 +259,23 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
     // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
     // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
     // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
-    double* w = acc + 9 * s.slot;
+    // A lane storing its own 72-byte record would issue nine 8-byte stores at a 72-byte stride: 576 partial-line write
+    // requests per tile, and it is the L2's request rate, not its bytes, that such stores exhaust (the per-slot output cost as
+    // much as reading the 200 B / slot tile stream).  The tile's 64 x 9 doubles are one contiguous 4.6 KB range, so the wave
+    // transposes them through a private LDS strip and stores nine fully coalesced 512-byte rows.
+    __shared__ double zstage[16][kTile * 9];  // one strip per wave of the (<= 1024-thread) workgroup; only LDS = false kernels carry it
+    // nothing to store for a tile with no valid slot: the pipelined kernel runs the tiles of long points through here with every
+    // lane masked, and their real values are written later by whichever wave owns the point's head tile — zeros from here could land after them
+    if (__ballot(s.valid) == 0ull) return;
+    double* st = zstage[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = s.f[k] * z0 + s.f[9 + k] * z1;
+    for (int k = 0; k < 9; ++k) st[lane * 9 + k] = s.valid ? s.f[k] * z0 + s.f[9 + k] * z1 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double* w = acc + 9 * (s.zrel - lane);  // the tile's first slot in the ring (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) w[kTile * j + lane] = st[kTile * j + lane];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -721,7 +738,8 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   }
   const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
-  for (int64_t tile = wave; tile < A.n_tiles; tile += nwaves) {
+  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
+  for (int64_t tile = A.tile_begin + wave; tile < tile_end; tile += nwaves) {
     const int kind = A.tile_kind[tile];
     const int aux = A.tile_aux[tile];
     if constexpr (MODE == kJx) {
@@ -743,6 +761,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     if (threadIdx.x == 0) {
       double t = 0;
       for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      if (MODE == kJtJx && A.pq_accumulate) t += scalar_dst[blockIdx.x];
       scalar_dst[blockIdx.x] = t;
     }
   }
@@ -811,9 +830,10 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
-  const int64_t wave0 = int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-  const int64_t last = A.n_tiles - 1;
-  if (wave0 < A.n_tiles) {
+  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
+  const int64_t wave0 = A.tile_begin + int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t last = tile_end - 1;
+  if (wave0 < tile_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
     // values to have arrived, which is exactly the wait this kernel exists to avoid.  (The
     // three index words are the exception: they are copied a stage after they were issued.)
@@ -837,7 +857,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     // one pipeline stage: everything of the next tile is issued, then this one is computed from `c`
     auto stage = [&](Slot& c, StreamAux& cx, int ckind, int caux, Slot& n, StreamAux& nx, int& nkind, int& naux) {
       const int64_t next = min(tile + nwaves, last);  // past the end: re-issue, the load count stays the same
-      more = tile + nwaves < A.n_tiles;
+      more = tile + nwaves < tile_end;
       nkind = A.tile_kind[next];
       naux = A.tile_aux[next];
       issue_idx(A, min(next + nwaves, last), lane, i2);
@@ -863,7 +883,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   }
   // Points with more than 64 observations own whole tiles (kind 1 = head, 2 = continuation);
   // they are rare and are handled outside the pipelined loop to keep its register footprint down.
-  for (int64_t tile = wave0; tile < A.n_tiles; tile += nwaves) {
+  for (int64_t tile = wave0; tile < tile_end; tile += nwaves) {
     if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, dot);
   }
   if (MODE == kJtJx && A.pq_out) {  // one partial of x_e . y_e per workgroup
@@ -875,6 +895,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     if (threadIdx.x == 0) {
       double t = 0;
       for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      if (A.pq_accumulate) t += A.pq_out[blockIdx.x];
       A.pq_out[blockIdx.x] = t;
     }
   }
@@ -1125,43 +1146,41 @@ __global__ __launch_bounds__(64) void bal_camera_finish_kernel(const double* __r
   if (camsq) camsq[9 * int64_t(c) + i] = sqsum;
 }
 
-// y_c = sum over the camera's observations of F_o^T z_o, z from the per-slot buffer written by
-// the fused kernel in its non-LDS mode.  Output: contiguous [9c + k], zeroed by the caller.
-__global__ __launch_bounds__(256) void bal_camera_apply_kernel(const double* __restrict__ values, CamItems items,
-                                                               const int32_t* __restrict__ cam_ptr,
-                                                               const int32_t* __restrict__ cam_fpos,
-                                                               const int32_t* __restrict__ cam_slot,
-                                                               const double* __restrict__ zbuf,
-                                                               double* __restrict__ out, const int* __restrict__ status) {
+// Camera-major pass of ONE CHUNK of tiles when the camera accumulators do not fit in LDS: the tile pass of the chunk left
+// F_o^T z_o (9 doubles) per slot in a ring buffer that is small enough to still be in the Infinity Cache; a unit = up to kZUnit
+// entries of one camera inside the chunk.  Nine lanes per unit (lane k sums component k: the 72 bytes of an entry are one
+// contiguous access of the group), seven units per wavefront, four entries in flight per lane.  A camera covered by a single
+// unit in this chunk is updated with a plain read-modify-write (chunks run one after the other on the stream); split cameras
+// (more than kZUnit observations inside one chunk: the popular ones) combine with global_atomic_add_f64.
+__global__ __launch_bounds__(256) void bal_camera_chunk_kernel(ZUnits U, const double* __restrict__ ring, double* __restrict__ acc,
+                                                               const int* __restrict__ status) {
   if (status && *status != 0) return;
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= items.count) return;
-  const int c = items.cam[item];
-  const int beg = items.begin[item], end = items.end[item];
-  double acc[9];
+  const int g = lane / 9, k = lane - 9 * g;
+  const int64_t u = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 7 + g;
+  if (g >= 7 || u >= U.count) return;
+  const int unit = U.first + int(u);
+  const int c = U.cam[unit], beg = U.begin[unit], end = U.end[unit];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int e = beg;
+  for (; e + 7 < end; e += 8) {  // eight index words, then eight entries in flight
+    int a[8];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  for (int q = beg + lane; q < end; q += 64) {
-    const double* w = zbuf + 9 * int64_t(cam_slot[q]);
+    for (int i = 0; i < 8; ++i) a[i] = U.slot[e + i];
+    double v[8];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] += w[k];
+    for (int i = 0; i < 8; ++i) v[i] = ring[9 * int64_t(a[i]) + k];
+    s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
   }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    acc[k] = v;
+  for (; e + 3 < end; e += 4) {
+    const int a0 = U.slot[e], a1 = U.slot[e + 1], a2 = U.slot[e + 2], a3 = U.slot[e + 3];
+    s0 += ring[9 * int64_t(a0) + k]; s1 += ring[9 * int64_t(a1) + k]; s2 += ring[9 * int64_t(a2) + k]; s3 += ring[9 * int64_t(a3) + k];
   }
-  const bool single = beg == cam_ptr[c] && end == cam_ptr[c + 1];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    if (lane == k) {
-      if (single) out[9 * int64_t(c) + k] = acc[k];
-      else unsafeAtomicAdd(&out[9 * int64_t(c) + k], acc[k]);
-    }
-  }
+  for (; e < end; ++e) s0 += ring[9 * int64_t(U.slot[e]) + k];
+  const double v = (s0 + s1) + (s2 + s3);
+  double* dst = acc + 9 * int64_t(c) + k;
+  if (U.shared[unit]) unsafeAtomicAdd(dst, v);
+  else *dst += v;
 }
 
 // In-place inverse of the 9x9 SPD camera blocks from their upper triangle (Cholesky +
@@ -1442,12 +1461,10 @@ hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_pt
   return hipGetLastError();
 }
 
-hipError_t LaunchBalCameraApply(const double* values, const CamItems& items, const int32_t* cam_ptr, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double* zbuf, double* out, const int* status,
-                                hipStream_t stream) {
-  if (items.count == 0) return hipSuccess;
-  hipLaunchKernelGGL(bal_camera_apply_kernel, dim3((items.count + 3) / 4), dim3(256), 0, stream, values, items, cam_ptr,
-                     cam_fpos, cam_slot, zbuf, out, status);
+hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream) {
+  if (units.count == 0) return hipSuccess;
+  const int waves = (units.count + 6) / 7;
+  hipLaunchKernelGGL(bal_camera_chunk_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, units, ring, acc, status);
   return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 // 64 observations, which is what lets the fused kernels do every per-point
 // reduction with wavefront shuffles and no inter-workgroup traffic.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "common.h"
@@ -324,6 +325,51 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
     P.cam_item_ptr[c + 1] = int32_t(P.item_cam.size());  // the items of a camera are consecutive
   }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
+
+  // Chunked camera-major pass for camera counts beyond the LDS accumulators.
+  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 512;
+  if (!P.cameras_in_lds) {
+    // Default: ONE chunk (the whole problem).  Chunks sized for the Infinity Cache (64-128 MiB of per-slot output) were
+    // measured and do not pay on this kernel pair (profiles/r02g_chunk_sweep_synthetic1M.txt: the tile pass is not limited by
+    // the HBM write-back of the ring, and the camera-major pass is latency-bound on its gathers either way), although a
+    // streaming write -> read-back hand-off of that size does stay in the cache (profiles/r02_infinity_cache_handoff_probe.txt).
+    // CERES_HIP_Z_CHUNK_MIB=<n> bounds the ring to n MiB (memory-constrained runs; the chunked path is covered by tests).
+    int64_t chunk_mib = 0;
+    if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
+    const int64_t want_tiles = chunk_mib > 0 ? std::max<int64_t>(1, chunk_mib * (int64_t(1) << 20) / (int64_t(kTile) * 72)) : P.n_tiles;
+    P.zc_tile_ptr.assign(1, 0);
+    for (int64_t t = 0; t < P.n_tiles;) {
+      int64_t e = std::min<int64_t>(P.n_tiles, t + want_tiles);
+      while (e < P.n_tiles && P.tile_kind[e] == 2) ++e;  // keep a long point's tiles together
+      P.zc_tile_ptr.push_back(int32_t(e));
+      P.z_ring_slots = std::max<int64_t>(P.z_ring_slots, (e - t) * kTile);
+      t = e;
+    }
+    const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
+    P.zc_slot.resize(P.n_obs);
+    P.zc_unit_ptr.assign(1, 0);
+    std::vector<int32_t> count(P.n_cameras + 1), cur(P.n_cameras);
+    int64_t base = 0;  // entries emitted so far
+    for (int k = 0; k < n_chunks; ++k) {
+      const int64_t s0 = int64_t(P.zc_tile_ptr[k]) * kTile, s1 = int64_t(P.zc_tile_ptr[k + 1]) * kTile;
+      std::fill(count.begin(), count.end(), 0);
+      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) ++count[P.slot_cam[s] + 1];
+      for (int c = 0; c < P.n_cameras; ++c) {
+        const int n = count[c + 1];
+        count[c + 1] += count[c];
+        cur[c] = count[c];
+        for (int b = 0; b < n; b += kZUnit) {
+          P.zu_cam.push_back(c);
+          P.zu_begin.push_back(int32_t(base + count[c] + b));
+          P.zu_end.push_back(int32_t(base + count[c] + std::min(n, b + kZUnit)));
+          P.zu_shared.push_back(n > kZUnit ? 1 : 0);
+        }
+      }
+      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) P.zc_slot[base + cur[P.slot_cam[s]]++] = int32_t(s - s0);
+      base += count[P.n_cameras];
+      P.zc_unit_ptr.push_back(int32_t(P.zu_cam.size()));
+    }
+  }
   P.eligible = true;
 }
 

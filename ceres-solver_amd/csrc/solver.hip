@@ -62,6 +62,8 @@ struct ceres_hip_solver {
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
+  ZUnits zunits;                   // chunked camera-major pass (cameras not in LDS): all chunks' units
+  int chunk_grid = 0;              // workgroups of one chunk's tile pass
   // f1: LM step state
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
@@ -258,12 +260,27 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   const int32_t* cam_pos = A.cam_pos;
   A.status = status;
   int n_first = 0;
-  if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
-  HIP_TRY(s, LaunchBalFused(mode, A, s->lds_mode, s->fused_grid, s->stream));
-  if (!s->lds_mode) {  // second pass by camera over the z the fused kernel left per slot
+  if (s->lds_mode) {
+    if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
+    HIP_TRY(s, LaunchBalFused(mode, A, true, s->fused_grid, s->stream));
+  } else {
+    // cameras do not fit in LDS: chunk by chunk, the tile pass leaves F^T z per slot in a ring that is still in the Infinity
+    // Cache when the chunk's camera-major pass adds it into the camera sums
+    const BalPlan& P = s->plan;
+    if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->chunk_grid; }
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
-    HIP_TRY(s, LaunchBalCameraApply(s->values, s->cam_items, s->d_cam_ptr, s->d_cam_fpos, s->d_cam_slot, s->d_zbuf,
-                                    s->d_global_acc, status, s->stream));
+    const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
+    for (int k = 0; k < n_chunks; ++k) {
+      A.tile_begin = P.zc_tile_ptr[k];
+      A.tile_end = P.zc_tile_ptr[k + 1];
+      A.z_slot0 = int64_t(P.zc_tile_ptr[k]) * kTile;
+      A.pq_accumulate = k > 0 ? 1 : 0;
+      HIP_TRY(s, LaunchBalFused(mode, A, false, s->chunk_grid, s->stream));
+      ZUnits U = s->zunits;
+      U.first = P.zc_unit_ptr[k];
+      U.count = P.zc_unit_ptr[k + 1] - P.zc_unit_ptr[k];
+      HIP_TRY(s, LaunchBalCameraChunk(U, s->d_zbuf, s->d_global_acc, status, s->stream));
+    }
   }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
   const int nparts = s->lds_mode ? s->fused_grid : 1;
@@ -1297,13 +1314,23 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
     const size_t n9 = size_t(9) * P.n_cameras;
-    s->lds_mode = n9 * sizeof(double) <= kMaxLdsBytes - 512;
+    s->lds_mode = P.cameras_in_lds;
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
     const int64_t tiles_per_wg = 512 / kTile;
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
-    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(n_slots) * 9));
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_slots) * 9));  // ring of ONE chunk's per-slot F^T z
+    if (!s->lds_mode) {
+      int32_t *uc = nullptr, *ub = nullptr, *ue = nullptr, *us = nullptr, *zs = nullptr;
+      TRY(dev_upload(s, &uc, P.zu_cam)); TRY(dev_upload(s, &ub, P.zu_begin)); TRY(dev_upload(s, &ue, P.zu_end));
+      TRY(dev_upload(s, &us, P.zu_shared)); TRY(dev_upload(s, &zs, P.zc_slot));
+      s->zunits.cam = uc; s->zunits.begin = ub; s->zunits.end = ue; s->zunits.shared = us; s->zunits.slot = zs;
+      // a chunk's tile pass: every wave should see a few tiles (the pipelined kernel has a prologue), at most 4 workgroups per CU
+      const int64_t chunk_tiles = P.z_ring_slots / kTile;
+      // (the pipelined kernel keeps 8 waves per CU resident: one workgroup per CU, no second round with a ragged tail)
+      s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
+    }
     TRY(dev_alloc(s, &s->d_camsq, n9));
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones

@@ -35,6 +35,16 @@ for STAGE in "$@"; do
       timeout 600 python tools/kernel_times.py venice1778 2>$OUT/ktimes_$TAG.err | tail -1 | tee -a $OUT/ktimes_$TAG.jsonl; tail -3 $OUT/ktimes_$TAG.err ;;
     ktimes1m)
       timeout 600 python tools/kernel_times.py synthetic1M 2>$OUT/ktimes1m_$TAG.err | tail -1 | tee -a $OUT/ktimes1m_$TAG.jsonl; tail -3 $OUT/ktimes1m_$TAG.err ;;
+    rocprof1m)
+      cd /tmp && export TMPDIR=/tmp
+      for MIB in ${CHUNKS:-64}; do
+        rm -rf /tmp/prof_1m
+        CERES_HIP_Z_CHUNK_MIB=$MIB timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_1m -o s1m -- python $REPO/bench.py --workload synthetic1M --steps 10 --warmup 2 --no-cpu-baseline --both-solvers 0 > $OUT/rocprof_bench_synthetic1M_${MIB}_$TAG.json 2> $OUT/rocprof_synthetic1M_$TAG.err
+        F=$(find /tmp/prof_1m -name "*kernel_stats.csv" | head -1)
+        echo "--- chunk MiB $MIB"; python -c "import json;d=json.loads(open('$OUT/rocprof_bench_synthetic1M_${MIB}_$TAG.json').read());print('sx_ms',d['roofline']['avg_launch_ms'],'step',d['ms_per_step'])"
+        [ -n "$F" ] && cp $F $OUT/kernel_stats_synthetic1M_${MIB}_$TAG.csv && head -8 $F | cut -c1-160
+      done
+      cd $REPO ;;
     rocprof_small)
       cd /tmp && export TMPDIR=/tmp
       for WL in ladybug1723 dubrovnik16; do
