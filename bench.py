@@ -101,9 +101,11 @@ def make_solver(hs, bs, nelim, solver, device, comm=None, storage=0):
         if comm[3] is not None:  # agree on the verdict of the self-test: all ranks use the peer-to-peer path, or none does
             import torch
             import torch.distributed as dist
-            ok = torch.tensor([1 if s.p2p_selftest() else 0], device=f"cuda:{device}")
+            ok = torch.tensor([1 if s.p2p_selftest() else 0], device=comm[4])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
+                if comm[0] is None:
+                    raise SystemExit(f"bench.py: peer-to-peer all-reduce failed ({s.p2p_error}) and there is no RCCL communicator")
                 if comm[1] == 0:
                     print(f"bench.py: peer-to-peer all-reduce unavailable ({s.p2p_error}); using RCCL", file=sys.stderr)
                 s.p2p_disable()
@@ -149,12 +151,22 @@ def main():
     hs.load_library()
     if hs.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no gfx950 device visible (there is no CPU path)")
+    # CERES_HIP_BENCH_ONE_GPU=1: every rank on device 0, torch.distributed over gloo, the solver's collectives over the
+    # peer-to-peer path alone (RCCL refuses two ranks on one device).  A VALIDATION mode for a one-GPU box: it runs the
+    # whole N > 1 code path of this file and of the library; its timings mean nothing.
+    one_gpu = os.environ.get("CERES_HIP_BENCH_ONE_GPU", "0") == "1" and world > 1
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    cdev = torch.device("cpu") if one_gpu else dev   # where tensors of torch.distributed collectives live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -168,17 +180,18 @@ def main():
     storage = 1 if args.storage == "fp32" else 0
     comm = None
     if world > 1:
-        idt = torch.zeros(hs.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt = torch.tensor(list(hs.comm_unique_id()), dtype=torch.uint8, device=dev)
+        idt = torch.zeros(hs.UNIQUE_ID_BYTES, dtype=torch.uint8, device=cdev)
+        if rank == 0 and not one_gpu:
+            idt = torch.tensor(list(hs.comm_unique_id()), dtype=torch.uint8, device=cdev)
         dist.broadcast(idt, 0)
 
         def p2p_exchange(mine):
-            t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+            t = torch.tensor(list(mine), dtype=torch.uint8, device=cdev)
             out = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(out, t)
             return [bytes(o.cpu().tolist()) for o in out]
-        comm = (bytes(idt.cpu().tolist()), rank, world, p2p_exchange if os.environ.get("CERES_HIP_P2P", "1") != "0" else None)
+        use_p2p = one_gpu or os.environ.get("CERES_HIP_P2P", "1") != "0"
+        comm = (None if one_gpu else bytes(idt.cpu().tolist()), rank, world, p2p_exchange if use_p2p else None, cdev)
     prob = None
     if many_cameras:
         # configs[4]: 5.76 GB of Jacobian values.  The observation graph is generated on the host (numpy, the
@@ -208,9 +221,9 @@ def main():
         for c in range(9):
             diag.index_add_(0, cam_cols + c, f2[:, c].contiguous())
         if dist is not None:
-            cam_part = diag[3 * nelim_local:].clone()
+            cam_part = diag[3 * nelim_local:].to(cdev)
             dist.all_reduce(cam_part)
-            diag[3 * nelim_local:] = cam_part
+            diag[3 * nelim_local:] = cam_part.to(dev)
         tD = torch.sqrt(torch.clamp(diag, 1e-6, 1e32) / RADIUS)
         del diag, e2, f2, pt_cols, cam_cols
     else:
@@ -234,7 +247,7 @@ def main():
     # ---- timed region: K LM linear solves, inputs resident in HBM -------------------
     elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync, args.step)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = solver.last_timing()
@@ -278,7 +291,7 @@ def main():
         extra["device_copy_GBs"] = round(2 * 8 * min(int(info.num_nonzeros), int(info.num_tiles) * 64 * 24) / (copy_ms * 1e-3) / 1e9, 1)
         extra["read_stream_probe_GBs"] = round(int(info.num_tiles) * 12288 / (solver.time_op(hs.TIMED_READ_STREAM, 10) * 1e-3) / 1e9, 1)
     if dist is not None:
-        t = torch.tensor([achieved], dtype=torch.float64, device=dev)
+        t = torch.tensor([achieved], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)  # aggregate GB/s over ranks, each on its shard
         achieved = float(t.item())
     traffic, traffic_source = pmc_traffic(kind) if world == 1 else (None, None)
@@ -449,7 +462,9 @@ def main():
                                 "model cost change, all on the device" if args.step == "lm_step" else "LinearSolver::Solve"),
                        "eta": 0.1, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
                        "termination": hs.TERMINATION_NAMES[last.termination_type],
-                       "parallelism": f"points sharded over {world} GPU(s), all-reduce of camera space"
+                       "parallelism": (f"points sharded over {world} rank(s), camera-space sums by " +
+                                       ("the one-shot peer-to-peer all-reduce (hipIpc / xGMI)" if solver.p2p_ok else "RCCL all-reduce") +
+                                       (" — ONE-GPU VALIDATION MODE, timings meaningless" if one_gpu else ""))
                        if world > 1 else "1 GPU", "inputs_resident_in_hbm": True, "step_finite": step_ok,
                        "jacobian_storage": "fp32 tiles, fp64 arithmetic (accuracy mode, not parity)" if storage else "fp64",
                        "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",

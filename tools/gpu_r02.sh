@@ -35,6 +35,11 @@ for STAGE in "$@"; do
       timeout 600 python tools/kernel_times.py venice1778 2>$OUT/ktimes_$TAG.err | tail -1 | tee -a $OUT/ktimes_$TAG.jsonl; tail -3 $OUT/ktimes_$TAG.err ;;
     ktimes1m)
       timeout 600 python tools/kernel_times.py synthetic1M 2>$OUT/ktimes1m_$TAG.err | tail -1 | tee -a $OUT/ktimes1m_$TAG.jsonl; tail -3 $OUT/ktimes1m_$TAG.err ;;
+    bench_n2)  # the N > 1 code path of bench.py and of the library with two ranks on ONE GPU (validation only: timings meaningless)
+      for WL in ${WLS:-ladybug1723 synthetic1M}; do for SV in iterative_schur cgnr; do
+        echo "--- $WL $SV"
+        CERES_HIP_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload $WL --solver $SV --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_n2_${WL}_${SV}_$TAG.err | tee $OUT/bench_n2_${WL}_${SV}_$TAG.json | cut -c1-900; tail -2 $OUT/bench_n2_${WL}_${SV}_$TAG.err
+      done; done ;;
     rocprof1m)
       cd /tmp && export TMPDIR=/tmp
       for MIB in ${CHUNKS:-64}; do
