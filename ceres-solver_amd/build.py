@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libceres_hip.so")
-SOURCES = ["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal.hip", "kernels_evaluator.hip", "solver.hip"]
+SOURCES = ["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal.hip", "kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"]
 HEADERS = ["common.h", "device.h", "bal_frontend.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
 HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")
 HOST_DRIVER = os.path.join(HERE, "host", "host_driver")

@@ -90,6 +90,24 @@ struct BalPlan {
   int max_track = 0, max_camera_degree = 0;
 };
 
+// Storage of an EXPLICIT Schur complement: what SparseSchurComplementSolver::InitStorage builds
+// (I/schur_complement_solver.cc:224-290) — the set of block pairs (i <= j) of F blocks that share a chunk (or an E-free
+// row), as a BlockRandomAccessSparseMatrix (I/block_random_access_sparse_matrix.cc:51-110: cells of a block row are
+// consecutive, each cell row-major n_i x n_j) — plus, per pair, the list of (chunk, cell of block i, cell of block j)
+// contributions, so that SchurEliminator::Eliminate becomes a gather per stored block: deterministic, no atomics, no mutexes.
+struct SchurStorage {
+  int nf = 0;
+  std::vector<int32_t> pair_i, pair_j;      // F-relative block ids, sorted by (i, j), i <= j; every (i, i) is present
+  std::vector<int64_t> pair_off;            // npairs + 1 value offsets
+  std::vector<int32_t> row_ptr;             // nf + 1: pairs whose first block is i
+  std::vector<int32_t> col_ptr, col_pair;   // nf + 1 / list: pairs (j, i) with j < i, per second block i (the transpose half)
+  std::vector<int64_t> trip_ptr;            // npairs + 1
+  std::vector<int32_t> trip_e, trip_k1, trip_k2;  // E block of the chunk (-1: an E-free row), cell of block i, cell of block j
+  std::vector<int32_t> cell_row;            // row block of every cell
+  int64_t num_values() const { return pair_off.empty() ? 0 : pair_off.back(); }
+};
+void BuildSchurStorage(const HostStructure& hs, SchurStorage* out);
+
 // Fills hs from the ABI structure; returns "" or an error message.
 std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs);
 // Decides whether the fused <2,3,9> path applies and, if so, builds the packing plan.

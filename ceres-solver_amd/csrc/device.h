@@ -168,6 +168,25 @@ hipError_t LaunchGenExtractDiagBlocks(const GenStructure& G, const double* S, co
 hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                double* lhs, hipStream_t stream);
 
+// ---- explicit Schur complement solvers (kernels_schur.hip) ------------------
+struct SchurPairs {  // device image of SchurStorage (common.h)
+  int npairs = 0;
+  const int32_t *pair_i = nullptr, *pair_j = nullptr, *row_ptr = nullptr, *col_ptr = nullptr, *col_pair = nullptr;
+  const int64_t *pair_off = nullptr, *trip_ptr = nullptr;
+  const int32_t *trip_e = nullptr, *trip_k1 = nullptr, *trip_k2 = nullptr, *cell_row = nullptr;
+};
+// S (block-sparse, upper block triangle) = SchurEliminator::Eliminate; D may be nullptr (then no D_f^2 on the diagonal)
+hipError_t LaunchSchurSparseEliminate(const GenStructure& G, const SchurPairs& P, const double* values, const double* ete_inv,
+                                      const double* D, double* S, hipStream_t stream);
+// y (+)= S x   BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate
+hipError_t LaunchSchurSparseSymv(const GenStructure& G, const SchurPairs& P, const double* S, const double* x, double* y,
+                                 const int* status, int accumulate, hipStream_t stream);
+hipError_t LaunchSchurSparseDiag(const GenStructure& G, const SchurPairs& P, const double* S, const int64_t* diag_off_f, double* blocks,
+                                 int64_t total, hipStream_t stream);
+// dense SPD n x n, upper triangle authoritative: in-place factor (L in the lower triangle), then x <- A^-1 x
+hipError_t LaunchDenseCholesky(double* A, int n, int* fail_flag, hipStream_t stream);
+hipError_t LaunchDenseCholeskySolve(const double* A, int n, double* x, hipStream_t stream);
+
 // ---- vector kernels + device-resident CG (kernels_cg.hip) ------------------
 hipError_t LaunchSet(double* x, double v, int64_t n, hipStream_t stream);
 hipError_t LaunchAxpby(double a, const double* x, double b, const double* y, double* z, int64_t n, hipStream_t stream);

@@ -373,4 +373,71 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   P.eligible = true;
 }
 
+void BuildSchurStorage(const HostStructure& h, SchurStorage* out) {
+  SchurStorage& S = *out;
+  S = SchurStorage();
+  S.nf = h.ncb - h.nelim;
+  S.cell_row.resize(h.ncells);
+  for (int i = 0; i < h.nrb; ++i)
+    for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) S.cell_row[k] = i;
+  struct Trip { int64_t key; int32_t e, k1, k2; };
+  std::vector<Trip> trips;
+  const int64_t nf = S.nf;
+  auto add = [&](int e, int k1, int k2) {
+    const int b1 = h.ccol[k1] - h.nelim, b2 = h.ccol[k2] - h.nelim;
+    if (b1 > b2) return;  // upper block triangle only (I/schur_eliminator_impl.h:548-565); equal blocks keep both orders
+    trips.push_back({int64_t(b1) * nf + b2, e, k1, k2});
+  };
+  std::vector<int32_t> cells;
+  // chunks: all F cells of the rows of one E block, every ordered pair of them
+  for (int e = 0; e < h.nelim; ++e) {
+    cells.clear();
+    for (int i = h.chunk_start[e]; i < h.chunk_start[e] + h.chunk_size[e]; ++i)
+      for (int k = h.rptr[i] + 1; k < h.rptr[i + 1]; ++k) cells.push_back(k);
+    for (int k1 : cells) for (int k2 : cells) add(e, k1, k2);
+  }
+  // E-free rows go into the Schur complement as plain outer products (:274-290)
+  for (int i = 0; i < h.nrb; ++i) {
+    if (h.row_e_block[i] >= 0) continue;
+    for (int k1 = h.rptr[i]; k1 < h.rptr[i + 1]; ++k1)
+      for (int k2 = h.rptr[i]; k2 < h.rptr[i + 1]; ++k2) add(-1, k1, k2);
+  }
+  std::stable_sort(trips.begin(), trips.end(), [](const Trip& a, const Trip& b) { return a.key < b.key; });
+  // pairs = diagonal pairs (always present, :231-234) merged with the keys that occur
+  size_t t = 0;
+  S.row_ptr.assign(S.nf + 1, 0);
+  S.pair_off.push_back(0);
+  S.trip_ptr.push_back(0);
+  for (int i = 0; i < S.nf; ++i) {
+    S.row_ptr[i] = int32_t(S.pair_i.size());
+    bool diag_done = false;
+    auto emit = [&](int j) {
+      S.pair_i.push_back(i);
+      S.pair_j.push_back(j);
+      S.pair_off.push_back(S.pair_off.back() + int64_t(h.csz[h.nelim + i]) * h.csz[h.nelim + j]);
+      while (t < trips.size() && trips[t].key == int64_t(i) * nf + j) {
+        S.trip_e.push_back(trips[t].e); S.trip_k1.push_back(trips[t].k1); S.trip_k2.push_back(trips[t].k2);
+        ++t;
+      }
+      S.trip_ptr.push_back(int64_t(S.trip_e.size()));
+    };
+    while (t < trips.size() && trips[t].key / nf == i) {
+      const int j = int(trips[t].key % nf);
+      if (!diag_done && j > i) { emit(i); diag_done = true; continue; }
+      if (j == i) diag_done = true;
+      emit(j);
+    }
+    if (!diag_done) emit(i);
+  }
+  S.row_ptr[S.nf] = int32_t(S.pair_i.size());
+  // transpose half: for block i the pairs (j, i), j < i
+  S.col_ptr.assign(S.nf + 1, 0);
+  const int np = int(S.pair_i.size());
+  for (int p = 0; p < np; ++p) if (S.pair_i[p] != S.pair_j[p]) ++S.col_ptr[S.pair_j[p] + 1];
+  for (int i = 0; i < S.nf; ++i) S.col_ptr[i + 1] += S.col_ptr[i];
+  S.col_pair.resize(S.col_ptr[S.nf]);
+  std::vector<int32_t> cur(S.col_ptr.begin(), S.col_ptr.end() - 1);
+  for (int p = 0; p < np; ++p) if (S.pair_i[p] != S.pair_j[p]) S.col_pair[cur[S.pair_j[p]]++] = p;
+}
+
 }  // namespace chip

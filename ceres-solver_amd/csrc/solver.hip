@@ -93,7 +93,10 @@ struct ceres_hip_solver {
   double *tmp_rows = nullptr, *tmp_e = nullptr, *tmp_e2 = nullptr;
   // preconditioner blocks: F blocks (diag_off_f) for ITERATIVE_SCHUR, all blocks (diag_off_all) for CGNR
   double* precond = nullptr;
-  double* d_S = nullptr;          // explicit Schur complement, dense num_cols_f^2 (use_explicit_schur_complement)
+  double* d_S = nullptr;          // explicit Schur complement: dense num_cols_f^2 (DENSE_SCHUR, sharded explicit), or block-sparse values
+  bool sparse_S = false;          // use_explicit_schur_complement on one rank: BlockRandomAccessSparseMatrix storage
+  SchurStorage schur_storage;
+  SchurPairs schur_pairs;
   bool precond_valid = false;
   // SCHUR_POWER_SERIES_EXPANSION: blockdiag(F^T F + D_f^2)^-1 and two F-space temporaries
   double *ftf_inv = nullptr, *spse_a = nullptr, *spse_b = nullptr;
@@ -195,7 +198,9 @@ int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
   return 0;
 }
 
-bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HIP_ITERATIVE_SCHUR; }
+bool is_dense_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HIP_DENSE_SCHUR; }
+// solvers built on the E | F partition (ImplicitSchurComplement / SchurEliminator state, camera-space CG vectors)
+bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HIP_ITERATIVE_SCHUR || is_dense_schur(s); }
 
 // ---------------------------------------------------------------------------
 // Operators.  All take device pointers and enqueue on s->stream.
@@ -943,7 +948,76 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
       HIP_TRY(s, hipEventRecord(s->ev[6], st));
       return 0;
     }
+    if (is_dense_schur(s)) {
+      // DenseSchurComplementSolver (I/schur_complement_solver.cc:163-222): S dense by elimination, Cholesky of its upper
+      // triangle (DenseCholesky::FactorAndSolve), back-substitution on SUCCESS.
+      const int64_t nf = h.num_cols_f;
+      HIP_TRY(s, LaunchGenSchurDense(s->G, s->values, s->etei, (s->world > 1 && s->rank != 0) ? nullptr : s->D, s->d_S, st));
+      if (s->world > 1) TRY(allreduce(s, s->d_S, size_t(nf * nf)));
+      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+      HIP_TRY(s, LaunchDenseCholesky(s->d_S, int(nf), s->d_fail_flag, st));
+      TRY(check_factorization(s, &bad));
+      summary->num_iterations = 1;
+      if (bad) {  // EigenDenseCholesky::Factorize, I/dense_cholesky.cc
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "Eigen failure. Unable to perform dense Cholesky factorization.");
+        return 0;
+      }
+      HIP_TRY(s, hipMemcpyAsync(s->cg.x, s->rhs_f, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(s, LaunchDenseCholeskySolve(s->d_S, int(nf), s->cg.x, st));
+      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      summary->termination_type = CERES_HIP_SUCCESS;
+      snprintf(summary->message, sizeof(summary->message), "Success.");
+      TRY(op_back_substitute(s, s->cg.x, x));
+      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      return 0;
+    }
+    if (s->sparse_S) {
+      // SparseSchurComplementSolver with use_explicit_schur_complement: S in BlockRandomAccessSparseMatrix storage
+      // (InitStorage's block pairs), SchurEliminator::Eliminate as a gather per stored block, SCHUR_JACOBI = inverted
+      // diagonal blocks OF S, CG with SymmetricRightMultiplyAndAccumulate, back-substitution only on SUCCESS
+      // (I/schur_complement_solver.cc:100-158, 224-290, 337-408).
+      const int64_t nf = h.num_cols_f;
+      HIP_TRY(s, LaunchSchurSparseEliminate(s->G, s->schur_pairs, s->values, s->etei, s->D, s->d_S, st));
+      HIP_TRY(s, LaunchSchurSparseDiag(s->G, s->schur_pairs, s->d_S, s->G.diag_off_f, s->precond, h.diag_off_f.back(), st));
+      HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
+      HIP_TRY(s, LaunchGenInvertBlocks(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->precond, s->d_fail_flag, st));
+      TRY(check_factorization(s, &bad));
+      if (bad) {
+        summary->termination_type = CERES_HIP_FAILURE;
+        snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+        return 0;
+      }
+      s->precond_valid = true;
+      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      CgSpec spec;
+      spec.rhs = s->rhs_f;
+      spec.n = nf;
+      spec.n_local = 0;
+      const int* status = &s->cg.S->status;
+      spec.apply = [s, status](const double* in, double* out) -> int {
+        HIP_TRY(s, LaunchSchurSparseSymv(s->G, s->schur_pairs, s->d_S, in, out, status, 0, s->stream));
+        return 0;
+      };
+      spec.first_block = h.nelim;
+      spec.nblocks = h.ncb - h.nelim;
+      spec.col_begin = h.num_cols_e;
+      spec.diag_off = s->G.diag_off_f;
+      spec.blocks = s->precond;
+      TRY(run_cg(s, spec, q_tol, r_tol, summary));
+      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      if (summary->termination_type == CERES_HIP_SUCCESS) {
+        TRY(op_back_substitute(s, s->cg.x, x));
+      } else {  // x was zero-filled (:135), the reduced solution sits in its tail
+        HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols_e, st));
+        HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, s->cg.x, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
+      }
+      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      return 0;
+    }
     if (s->opt.use_explicit_schur_complement) {
+      // sharded runs keep S DENSE (one all-reduce of the ranks' contributions):
       // SchurComplementSolver::SolveImpl (I/schur_complement_solver.cc:100-158) with
       // SolveReducedLinearSystemUsingConjugateGradients (:337-408): S and rhs by elimination,
       // SCHUR_JACOBI = inverted diagonal blocks OF S, CG on S, back-substitution only on SUCCESS.
@@ -1122,12 +1196,13 @@ const char* ceres_hip_last_error(const ceres_hip_solver* s) { return s ? s->err.
 
 ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
   if (!o) { fail(nullptr, CERES_HIP_E_INVALID, "options == NULL"); return nullptr; }
-  if (o->solver_type != CERES_HIP_CGNR && o->solver_type != CERES_HIP_ITERATIVE_SCHUR) {
-    fail(nullptr, CERES_HIP_E_UNSUPPORTED, "solver_type %d is not CGNR or ITERATIVE_SCHUR", o->solver_type);
+  if (o->solver_type != CERES_HIP_CGNR && o->solver_type != CERES_HIP_ITERATIVE_SCHUR && o->solver_type != CERES_HIP_DENSE_SCHUR) {
+    fail(nullptr, CERES_HIP_E_UNSUPPORTED, "solver_type %d is not CGNR, ITERATIVE_SCHUR or DENSE_SCHUR", o->solver_type);
     return nullptr;
   }
   const int pre = o->preconditioner_type;
-  const bool pre_ok = o->solver_type == CERES_HIP_CGNR ? (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI)
+  const bool pre_ok = o->solver_type == CERES_HIP_DENSE_SCHUR ? true  // a direct solver: the field is ignored
+                      : o->solver_type == CERES_HIP_CGNR ? (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI)
                                                        : (pre == CERES_HIP_IDENTITY || pre == CERES_HIP_JACOBI || pre == CERES_HIP_SCHUR_JACOBI ||
                                                           pre == CERES_HIP_SCHUR_POWER_SERIES_EXPANSION);
   if (!pre_ok) {  // CgnrSolver's ctor LOG(FATAL)s on the same condition, I/cgnr_solver.cc:119-128
@@ -1216,14 +1291,17 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   s->nine_wide_from = h.ncb;
   while (s->nine_wide_from > 0 && h.csz[s->nine_wide_from - 1] == 9) --s->nine_wide_from;
   BuildBalPlan(h, true, &s->plan);
-  s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !is_dense_schur(s)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
   if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !s->plan.contiguous_layout)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "sharded <2,3,9> runs need points-then-cameras column order");
 
-  if (s->opt.use_explicit_schur_complement && h.num_cols_f > CERES_HIP_MAX_EXPLICIT_SCHUR_COLS)
-    return fail(s, CERES_HIP_E_UNSUPPORTED, "use_explicit_schur_complement stores S densely: %d reduced columns exceed the limit of %d",
+  // explicit S: block-sparse (BlockRandomAccessSparseMatrix) on one rank; dense for DENSE_SCHUR and for sharded runs (one all-reduce of S)
+  s->sparse_S = s->opt.use_explicit_schur_complement && !is_dense_schur(s) && s->world <= 1;
+  const bool dense_S = is_dense_schur(s) || (s->opt.use_explicit_schur_complement && !s->sparse_S);
+  if (dense_S && h.num_cols_f > CERES_HIP_MAX_EXPLICIT_SCHUR_COLS)
+    return fail(s, CERES_HIP_E_UNSUPPORTED, "a dense Schur complement of %d reduced columns exceeds the limit of %d",
                 h.num_cols_f, CERES_HIP_MAX_EXPLICIT_SCHUR_COLS);
 
   // ---- structure arrays ----
@@ -1257,7 +1335,26 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   s->d_fail_flag = s->d_nonfinite + 1;
   HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), s->stream));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
-  if (s->opt.use_explicit_schur_complement) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
+  if (dense_S) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
+  if (s->sparse_S) {
+    SchurStorage& Q = s->schur_storage;
+    BuildSchurStorage(h, &Q);
+    SchurPairs& P = s->schur_pairs;
+    P.npairs = int(Q.pair_i.size());
+    int32_t* q32 = nullptr; int64_t* q64 = nullptr;
+    TRY(dev_upload(s, &q32, Q.pair_i)); P.pair_i = q32;
+    TRY(dev_upload(s, &q32, Q.pair_j)); P.pair_j = q32;
+    TRY(dev_upload(s, &q32, Q.row_ptr)); P.row_ptr = q32;
+    TRY(dev_upload(s, &q32, Q.col_ptr)); P.col_ptr = q32;
+    TRY(dev_upload(s, &q32, Q.col_pair)); P.col_pair = q32;
+    TRY(dev_upload(s, &q64, Q.pair_off)); P.pair_off = q64;
+    TRY(dev_upload(s, &q64, Q.trip_ptr)); P.trip_ptr = q64;
+    TRY(dev_upload(s, &q32, Q.trip_e)); P.trip_e = q32;
+    TRY(dev_upload(s, &q32, Q.trip_k1)); P.trip_k1 = q32;
+    TRY(dev_upload(s, &q32, Q.trip_k2)); P.trip_k2 = q32;
+    TRY(dev_upload(s, &q32, Q.cell_row)); P.cell_row = q32;
+    TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(Q.num_values()))));
+  }
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.r, size_t(cg_n)));
@@ -1983,6 +2080,39 @@ int ceres_hip_op_schur_eliminate_dense(ceres_hip_solver* s, double* lhs, double*
   if (rc) return rc;
   if (rhs && s->have_b) return down(s, rhs, s->rhs_f, size_t(n));
   return 0;
+}
+
+// ---- explicit Schur complement in BlockRandomAccessSparseMatrix storage (use_explicit_schur_complement, one rank) ----
+int ceres_hip_schur_storage_info(const ceres_hip_solver* s, int64_t* num_block_pairs, int64_t* num_values) {
+  if (!s || !s->have_structure || !s->sparse_S) return CERES_HIP_E_INVALID;
+  if (num_block_pairs) *num_block_pairs = int64_t(s->schur_storage.pair_i.size());
+  if (num_values) *num_values = s->schur_storage.num_values();
+  return 0;
+}
+
+int ceres_hip_op_schur_eliminate_sparse(ceres_hip_solver* s, int32_t* pair_i, int32_t* pair_j, int64_t* pair_offset, double* values,
+                                        int64_t pair_capacity, int64_t value_capacity) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!s->sparse_S) return fail(s, CERES_HIP_E_INVALID, "create the solver with use_explicit_schur_complement = 1 (one rank)");
+  const SchurStorage& Q = s->schur_storage;
+  const int64_t np = int64_t(Q.pair_i.size());
+  if (pair_capacity < np || value_capacity < Q.num_values()) return fail(s, CERES_HIP_E_INVALID, "capacity too small");
+  TRY(op_schur_init(s, false));
+  HIP_TRY(s, LaunchSchurSparseEliminate(s->G, s->schur_pairs, s->values, s->etei, s->D, s->d_S, s->stream));
+  for (int64_t p = 0; p < np; ++p) { pair_i[p] = Q.pair_i[p]; pair_j[p] = Q.pair_j[p]; pair_offset[p] = Q.pair_off[p]; }
+  return down(s, values, s->d_S, size_t(Q.num_values()));
+}
+
+int ceres_hip_op_schur_symmetric_multiply(ceres_hip_solver* s, const double* x, double* y) {
+  TRY(require_loaded(s));
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  if (!s->sparse_S) return fail(s, CERES_HIP_E_INVALID, "create the solver with use_explicit_schur_complement = 1 (one rank)");
+  const int n = s->hs.num_cols_f;
+  TRY(up(s, s->cg.p, x, n));
+  TRY(up(s, s->cg.z, y, n));
+  HIP_TRY(s, LaunchSchurSparseSymv(s->G, s->schur_pairs, s->d_S, s->cg.p, s->cg.z, nullptr, 1, s->stream));
+  return down(s, y, s->cg.z, n);
 }
 
 int ceres_hip_op_eliminator_back_substitute(ceres_hip_solver* s, const double* z, double* x) {

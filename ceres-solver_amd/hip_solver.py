@@ -25,7 +25,7 @@ import numpy as np
 from .block_structure import BlockStructure, CBlockStructure
 
 # enum values equal the reference's (include/ceres/types.h:57-141, internal/ceres/linear_solver.h:57-74)
-ITERATIVE_SCHUR, CGNR = 5, 6
+DENSE_SCHUR, ITERATIVE_SCHUR, CGNR = 3, 5, 6
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 PATH_GENERIC, PATH_BAL = 0, 1
@@ -124,6 +124,9 @@ ABI = [
     ("ceres_hip_get_preconditioner_blocks", c_int32, [c_void_p, c_int32, _DP, c_int64]),
     ("ceres_hip_op_precond_apply", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_schur_eliminate_dense", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_schur_storage_info", c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    ("ceres_hip_op_schur_eliminate_sparse", c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), _DP, c_int64, c_int64]),
+    ("ceres_hip_op_schur_symmetric_multiply", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_eliminator_back_substitute", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_op_dot", c_int32, [c_void_p, _DP, _DP, c_int64, _DP]),
     ("ceres_hip_op_axpby", c_int32, [c_void_p, c_double, _DP, c_double, _DP, c_int64, _DP]),
@@ -552,6 +555,20 @@ class HipLinearSolver:
         lhs, rhs = np.full(n * n, np.nan), (np.full(n, np.nan) if want_rhs else None)
         self._check(self._lib.ceres_hip_op_schur_eliminate_dense(self._h, _p(lhs), _p(rhs)))
         return lhs.reshape(n, n), rhs
+
+    def schur_eliminate_sparse(self):
+        """(pair_i, pair_j, pair_offset, values) of the explicit Schur complement in BlockRandomAccessSparseMatrix storage."""
+        npairs, nvals = c_int64(), c_int64()
+        self._check(self._lib.ceres_hip_schur_storage_info(self._h, byref(npairs), byref(nvals)))
+        pi, pj = np.zeros(npairs.value, np.int32), np.zeros(npairs.value, np.int32)
+        off, vals = np.zeros(npairs.value, np.int64), np.full(nvals.value, np.nan)
+        ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
+        self._check(self._lib.ceres_hip_op_schur_eliminate_sparse(self._h, ip(pi), ip(pj), off.ctypes.data_as(POINTER(c_int64)), _p(vals),
+                                                                  npairs.value, nvals.value))
+        return pi, pj, off, vals
+
+    def schur_symmetric_multiply(self, x, y=None):
+        return self._xy(self._lib.ceres_hip_op_schur_symmetric_multiply, x, self._info.num_cols_f, y)
 
     def eliminator_back_substitute(self, z):
         x = np.full(self._info.num_cols, np.nan)

@@ -66,6 +66,7 @@ extern "C" {
  * solver_type         ceres::LinearSolverType          include/ceres/types.h:57-91
  * preconditioner_type ceres::PreconditionerType        include/ceres/types.h:93-141
  * termination_type    LinearSolverTerminationType      I/linear_solver.h:57-74     */
+#define CERES_HIP_DENSE_SCHUR 3 /* DenseSchurComplementSolver: dense S, Cholesky; num_cols_f <= CERES_HIP_MAX_EXPLICIT_SCHUR_COLS */
 #define CERES_HIP_ITERATIVE_SCHUR 5
 #define CERES_HIP_CGNR 6
 
@@ -129,7 +130,8 @@ typedef struct ceres_hip_options {
    * LinearSolver::Create then returns SparseSchurComplementSolver (I/linear_solver.cc:104-109), which
    * forms S with SchurEliminator::Eliminate and runs SCHUR_JACOBI-preconditioned CG on it
    * (SolveReducedLinearSystemUsingConjugateGradients, I/schur_complement_solver.cc:337-408).
-   * Here: S stored DENSE, so only for num_cols_f <= CERES_HIP_MAX_EXPLICIT_SCHUR_COLS;
+   * Here: on one rank S is stored block-sparse like the reference's BlockRandomAccessSparseMatrix (any size that fits in
+   * HBM); a sharded run stores it DENSE (num_cols_f <= CERES_HIP_MAX_EXPLICIT_SCHUR_COLS) and all-reduces it.
    * preconditioner_type must be SCHUR_JACOBI (the reference CHECKs the same).                */
   int32_t use_explicit_schur_complement;
   int32_t reserved;
@@ -302,6 +304,18 @@ int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y);
  * like the reference (I/schur_eliminator_impl.h:184-311,548-565).  Generic
  * kernels; meant for the small/explicit-S callers.         */
 int ceres_hip_op_schur_eliminate_dense(ceres_hip_solver* s, double* lhs, double* rhs);
+/* The explicit Schur complement of a solver created with use_explicit_schur_complement = 1 (one rank): the lhs
+ * SparseSchurComplementSolver::InitStorage allocates (I/schur_complement_solver.cc:224-290) in the storage of
+ * BlockRandomAccessSparseMatrix (I/block_random_access_sparse_matrix.cc:51-110) — block pairs (i <= j, F-relative ids,
+ * sorted; every (i, i) present), each a row-major n_i x n_j cell at pair_offset.
+ *   _storage_info            counts
+ *   _op_schur_eliminate_sparse  SchurEliminator::Eliminate into that lhs (incl. D_f^2); returns pairs, offsets, values
+ *   _op_schur_symmetric_multiply  y += S x from the stored upper block triangle
+ *                            BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate  :125-163            */
+int ceres_hip_schur_storage_info(const ceres_hip_solver* s, int64_t* num_block_pairs, int64_t* num_values);
+int ceres_hip_op_schur_eliminate_sparse(ceres_hip_solver* s, int32_t* pair_i, int32_t* pair_j, int64_t* pair_offset,
+                                        double* values, int64_t pair_capacity, int64_t value_capacity);
+int ceres_hip_op_schur_symmetric_multiply(ceres_hip_solver* s, const double* x, double* y);
 /* SchurEliminator::BackSubstitute                                I/schur_eliminator_impl.h:314-380 */
 int ceres_hip_op_eliminator_back_substitute(ceres_hip_solver* s, const double* z, double* x);
 
