@@ -73,8 +73,9 @@ class BlockSparseMatrix {
 };
 
 // Values equal ceres::LinearSolverType / PreconditionerType / LinearSolverTerminationType.
-enum LinearSolverType { ITERATIVE_SCHUR = CERES_HIP_ITERATIVE_SCHUR, CGNR = CERES_HIP_CGNR };
-enum PreconditionerType { IDENTITY = CERES_HIP_IDENTITY, JACOBI = CERES_HIP_JACOBI, SCHUR_JACOBI = CERES_HIP_SCHUR_JACOBI };
+enum LinearSolverType { DENSE_SCHUR = CERES_HIP_DENSE_SCHUR, ITERATIVE_SCHUR = CERES_HIP_ITERATIVE_SCHUR, CGNR = CERES_HIP_CGNR };
+enum PreconditionerType { IDENTITY = CERES_HIP_IDENTITY, JACOBI = CERES_HIP_JACOBI, SCHUR_JACOBI = CERES_HIP_SCHUR_JACOBI,
+                          SCHUR_POWER_SERIES_EXPANSION = CERES_HIP_SCHUR_POWER_SERIES_EXPANSION };
 enum class LinearSolverTerminationType { SUCCESS = 0, NO_CONVERGENCE = 1, FAILURE = 2, FATAL_ERROR = 3 };
 
 class LinearSolver {

@@ -112,6 +112,28 @@ def linear_least_squares_problem(problem_id: int) -> LinearProblem:
     raise ValueError(f"no block-sparse problem with id {problem_id}")
 
 
+def block_sparse_test_matrix(matrix_id: int):
+    """The three hand-written matrices of the reference's BlockSparseMatrix tests (CreateTestMatrixFromId,
+    internal/ceres/block_sparse_matrix_test.cc:50-146) WITH the dense form its comments spell out: a 2-cell block-diagonal
+    layout, a row with two cells, and the E|F-split value ordering (cells of the left submatrix before the right one).
+    Returns (BlockStructure, values, dense)."""
+    if matrix_id == 0:
+        bs = BlockStructure.from_rows([2, 3, 1], [(2, [(0, 0)]), (2, [(1, 4)])])
+        dense = [[1, 2, 0, 0, 0, 0], [3, 4, 0, 0, 0, 0], [0, 0, 5, 6, 7, 0], [0, 0, 8, 9, 10, 0]]
+        n = 10
+    elif matrix_id == 1:
+        bs = BlockStructure.from_rows([2, 1, 2, 1], [(2, [(0, 0), (2, 4)]), (1, [(1, 8)])])
+        dense = [[1, 2, 0, 5, 6, 0], [3, 4, 0, 7, 8, 0], [0, 0, 9, 0, 0, 0]]
+        n = 9
+    elif matrix_id == 2:
+        bs = BlockStructure.from_rows([2, 1, 2, 1], [(2, [(0, 0), (2, 5)]), (1, [(1, 4), (3, 9)])])
+        dense = [[1, 2, 0, 6, 7, 0], [3, 4, 0, 8, 9, 0], [0, 0, 5, 0, 0, 10]]
+        n = 10
+    else:
+        raise ValueError(matrix_id)
+    return bs, np.arange(1, n + 1, dtype=np.float64), np.array(dense, dtype=np.float64)
+
+
 def random_schur_problem(num_e_blocks=7, num_f_blocks=5, max_rows_per_e=4, num_no_e_rows=3,
                          block_sizes=(1, 2, 3, 4), static_sizes=None, seed=0, shuffle_values=True,
                          with_D=True) -> LinearProblem:

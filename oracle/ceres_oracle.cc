@@ -200,6 +200,10 @@ struct oracle_matrix {
   std::vector<int> diag_offset_f;   // offset of each F block's dense block in a block-diagonal store
   std::vector<int> diag_offset_all; // same over all column blocks
   std::vector<int> diag_offset_e;
+  // F column blocks cut into contiguous ranges of nearly equal cell counts: the work units of the column-major loops
+  // (camera degrees are heavily skewed; the reference balances its ParallelFor the same way, by cumulative nnz,
+  // I/partitioned_matrix_view_impl.h:89-103)
+  std::vector<int> f_ranges;
 };
 
 extern "C" {
@@ -261,6 +265,19 @@ oracle_matrix* oracle_matrix_create(const oracle_block_structure* bs, int num_el
       m->trow[p] = i;
       m->tcell[p] = k;
     }
+  {
+    const int nf = m->ncb - m->nelim;
+    const int want = std::max(1, std::min(nf, 1024));
+    const int64_t total = m->tptr[m->ncb] - m->tptr[m->nelim];
+    m->f_ranges.assign(1, m->nelim);
+    for (int k = 1; k < want; ++k) {
+      const int64_t target = m->tptr[m->nelim] + total * k / want;
+      int j = int(std::lower_bound(m->tptr.begin() + m->nelim, m->tptr.begin() + m->ncb, target) - m->tptr.begin());
+      j = std::max(j, m->f_ranges.back());
+      if (j > m->f_ranges.back() && j < m->ncb) m->f_ranges.push_back(j);
+    }
+    m->f_ranges.push_back(m->ncb);
+  }
   // Chunks: maximal runs of rows sharing their first (E) block.
   if (m->nelim > 0) {
     int r = 0;
@@ -433,12 +450,14 @@ void oracle_left_multiply_f(const oracle_matrix* m, const double* v, const doubl
     }
     return;
   }
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
-  for (int j = m->nelim; j < m->ncb; ++j)
-    for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
-      const int i = m->trow[t], k = m->tcell[t];
-      mat_t_vec(v + m->cval[k], m->rsz[i], m->csz[j], x + m->rpos[i], y + m->cpos[j] - m->num_cols_e, 1);
-    }
+  const int n_ranges = int(m->f_ranges.size()) - 1;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+  for (int rg = 0; rg < n_ranges; ++rg)
+    for (int j = m->f_ranges[rg]; j < m->f_ranges[rg + 1]; ++j)
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
+        const int i = m->trow[t], k = m->tcell[t];
+        mat_t_vec(v + m->cval[k], m->rsz[i], m->csz[j], x + m->rpos[i], y + m->cpos[j] - m->num_cols_e, 1);
+      }
 }
 // UpdateBlockDiagonalEtE, :446-523
 void oracle_block_diagonal_ete(const oracle_matrix* m, const double* v, double* blocks) {
@@ -455,13 +474,15 @@ void oracle_block_diagonal_ete(const oracle_matrix* m, const double* v, double* 
 // UpdateBlockDiagonalFtF, :530-658
 void oracle_block_diagonal_ftf(const oracle_matrix* m, const double* v, double* blocks) {
   std::fill(blocks, blocks + m->diag_offset_f.back(), 0.0);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
-  for (int j = m->nelim; j < m->ncb; ++j)
-    for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
-      const int i = m->trow[t], k = m->tcell[t];
-      mat_t_mat(v + m->cval[k], m->rsz[i], m->csz[j], v + m->cval[k], m->csz[j],
-                blocks + m->diag_offset_f[j - m->nelim], 0, 0, m->csz[j], 1);
-    }
+  const int n_ranges = int(m->f_ranges.size()) - 1;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+  for (int rg = 0; rg < n_ranges; ++rg)
+    for (int j = m->f_ranges[rg]; j < m->f_ranges[rg + 1]; ++j)
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
+        const int i = m->trow[t], k = m->tcell[t];
+        mat_t_mat(v + m->cval[k], m->rsz[i], m->csz[j], v + m->cval[k], m->csz[j],
+                  blocks + m->diag_offset_f[j - m->nelim], 0, 0, m->csz[j], 1);
+      }
 }
 
 int oracle_invert_psd(int n, double* a) { return invert_spd_upper(n, a); }
@@ -635,12 +656,17 @@ void oracle_isc_back_substitute(oracle_isc* s, const double* z, double* x) {
 // --------------------------------------------------------------------------
 namespace {
 
+// The reference guards every lhs cell with a mutex (I/schur_eliminator_impl.h:557,689,710).  With a block-diagonal lhs
+// (SCHUR_JACOBI) every thread hammers the same few thousand 9x9 cells and the locks — and the cache lines behind them —
+// stop the loop from scaling past ~16 threads.  `private_copy` gives each thread its own zeroed image of the diagonal
+// store (a few MB), no locks, and the images are added up afterwards: same sums, a fair multi-core baseline.
 struct Lhs {
   const oracle_matrix* m;
   bool diagonal;
   double* data;
+  bool use_locks = true;
   std::vector<omp_lock_t> locks;
-  Lhs(const oracle_matrix* mm, bool d, double* p) : m(mm), diagonal(d), data(p), locks(1021) {
+  Lhs(const oracle_matrix* mm, bool d, double* p, bool with_locks = true) : m(mm), diagonal(d), data(p), use_locks(with_locks), locks(with_locks ? 1021 : 1) {
     for (auto& l : locks) omp_init_lock(&l);
   }
   ~Lhs() { for (auto& l : locks) omp_destroy_lock(&l); }
@@ -649,7 +675,7 @@ struct Lhs {
     if (diagonal) {
       if (b1 != b2) return nullptr;
       *r = 0; *c = 0; *stride = m->csz[m->nelim + b1];
-      *lock = &locks[b1 % locks.size()];
+      *lock = use_locks ? &locks[b1 % locks.size()] : nullptr;
       return data + m->diag_offset_f[b1];
     }
     *r = m->lhs_row_layout[b1]; *c = m->lhs_row_layout[b2]; *stride = m->num_cols_f;
@@ -665,16 +691,16 @@ void row_outer_product(const oracle_matrix* m, const double* v, int row, int fir
     const int b1 = m->ccol[a] - m->nelim, s1 = m->csz[m->ccol[a]];
     int r, c, stride; omp_lock_t* lock;
     if (double* p = lhs->cell(b1, b1, &r, &c, &stride, &lock)) {
-      omp_set_lock(lock);
+      if (lock) omp_set_lock(lock);
       mat_t_mat(v + m->cval[a], m->rsz[row], s1, v + m->cval[a], s1, p, r, c, stride, 1);
-      omp_unset_lock(lock);
+      if (lock) omp_unset_lock(lock);
     }
     for (int bb = a + 1; bb < m->rptr[row + 1]; ++bb) {
       const int b2 = m->ccol[bb] - m->nelim, s2 = m->csz[m->ccol[bb]];
       if (double* p = lhs->cell(b1, b2, &r, &c, &stride, &lock)) {
-        omp_set_lock(lock);
+        if (lock) omp_set_lock(lock);
         mat_t_mat(v + m->cval[a], m->rsz[row], s1, v + m->cval[bb], s2, p, r, c, stride, 1);
-        omp_unset_lock(lock);
+        if (lock) omp_unset_lock(lock);
       }
     }
   }
@@ -703,9 +729,28 @@ void schur_eliminate(const oracle_matrix* m, const double* v, const double* b, c
   std::vector<omp_lock_t> rhs_locks(nf);
   for (auto& l : rhs_locks) omp_init_lock(&l);
 
+  // thread-private images of the (block-diagonal) lhs and of the rhs: see struct Lhs
+  const bool private_copy = diagonal_only && g_threads > 1;
+  std::vector<Vec> lhs_priv, rhs_priv;
+  if (private_copy) {
+    lhs_priv.assign(g_threads, Vec());
+    rhs_priv.assign(g_threads, Vec());
+  }
+  Lhs* const shared_lhs = &lhs;
 #pragma omp parallel num_threads(g_threads)
   {
     Vec buffer(m->buffer_size), scratch(m->buffer_size), ete, g, inv_g, sj;
+    Lhs* lhs_ptr = shared_lhs;
+    double* rhs_t = rhs;
+    std::unique_ptr<Lhs> mine;
+    if (private_copy) {
+      const int tid = omp_get_thread_num();
+      lhs_priv[tid].assign(size_t(lhs_len), 0.0);
+      mine.reset(new Lhs(m, true, lhs_priv[tid].data(), false));
+      lhs_ptr = mine.get();
+      if (rhs) { rhs_priv[tid].assign(size_t(m->num_cols_f), 0.0); rhs_t = rhs_priv[tid].data(); }
+    }
+    Lhs& lhs = *lhs_ptr;
 #pragma omp for schedule(dynamic, 16)
     for (int ci = 0; ci < int(m->chunks.size()); ++ci) {
       const auto& ch = m->chunks[ci];
@@ -737,9 +782,9 @@ void schur_eliminate(const oracle_matrix* m, const double* v, const double* b, c
           mat_vec(v + m->cval[k0], rs, es, inv_g.data(), sj.data(), -1);
           for (int k = k0 + 1; k < m->rptr[row + 1]; ++k) {
             const int blk = m->ccol[k] - m->nelim;
-            omp_set_lock(&rhs_locks[blk]);
-            mat_t_vec(v + m->cval[k], rs, m->csz[m->ccol[k]], sj.data(), rhs + m->lhs_row_layout[blk], 1);
-            omp_unset_lock(&rhs_locks[blk]);
+            if (!private_copy) omp_set_lock(&rhs_locks[blk]);
+            mat_t_vec(v + m->cval[k], rs, m->csz[m->ccol[k]], sj.data(), rhs_t + m->lhs_row_layout[blk], 1);
+            if (!private_copy) omp_unset_lock(&rhs_locks[blk]);
           }
         }
       }
@@ -751,10 +796,26 @@ void schur_eliminate(const oracle_matrix* m, const double* v, const double* b, c
           const int b2 = it2->first - m->nelim, s2 = m->csz[it2->first];
           int r, c, stride; omp_lock_t* lock;
           if (double* p = lhs.cell(b1, b2, &r, &c, &stride, &lock)) {
-            omp_set_lock(lock);
+            if (lock) omp_set_lock(lock);
             mat_mat(scratch.data(), s1, es, buffer.data() + it2->second, s2, p, r, c, stride, -1);
-            omp_unset_lock(lock);
+            if (lock) omp_unset_lock(lock);
           }
+        }
+      }
+    }
+    if (private_copy) {  // add the images up (implicit barrier of the omp for above: every image is complete)
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < lhs_len; ++i) {
+        double t = 0;
+        for (int th = 0; th < g_threads; ++th) if (!lhs_priv[th].empty()) t += lhs_priv[th][size_t(i)];
+        lhs_data[i] += t;
+      }
+      if (rhs) {
+#pragma omp for schedule(static)
+        for (int i = 0; i < m->num_cols_f; ++i) {
+          double t = 0;
+          for (int th = 0; th < g_threads; ++th) if (!rhs_priv[th].empty()) t += rhs_priv[th][size_t(i)];
+          rhs[i] += t;
         }
       }
     }

@@ -145,3 +145,23 @@ def test_detect_structure_of_the_product(hip, oracle, problems):
         assert got == want, (name, got)
         assert got == oracle.Matrix(bs, nelim).detect_structure(), name
         s.close()
+
+
+@pytest.mark.parametrize("matrix_id", [0, 1, 2])
+def test_block_sparse_matrix_layouts_ka6_on_the_device(hip, problems, matrix_id):
+    """The reference's hand-written BlockSparseMatrix matrices (block_sparse_matrix_test.cc:50-146; dense forms from its
+    comments) through the PRODUCT's operators: y += A x, y += A^T x, |A_j|^2 and (J^T J + D^2) x."""
+    bs, values, dense = problems.block_sparse_test_matrix(matrix_id)
+    o = hip.LinearSolverOptions(type=hip.CGNR, preconditioner_type=hip.JACOBI, max_num_iterations=20)
+    s = hip.HipLinearSolver(o)
+    s.set_structure(bs)
+    rng = np.random.default_rng(matrix_id)
+    D = 0.5 + rng.random(bs.num_cols)
+    s.load(values, rng.standard_normal(bs.num_rows), D)
+    x, y0 = rng.standard_normal(bs.num_cols), rng.standard_normal(bs.num_rows)
+    np.testing.assert_allclose(s.right_multiply(x, y0), y0 + dense @ x, rtol=0, atol=1e-13)
+    z, c0 = rng.standard_normal(bs.num_rows), rng.standard_normal(bs.num_cols)
+    np.testing.assert_allclose(s.left_multiply(z, c0), c0 + dense.T @ z, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(s.squared_column_norm(), (dense * dense).sum(0), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(s.jtjx(x), dense.T @ (dense @ x) + D * D * x, rtol=0, atol=1e-12)
+    s.close()

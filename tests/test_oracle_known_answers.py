@@ -103,3 +103,21 @@ def test_solvers_match_dense_qr(oracle, problems, pid):
     for pre in (0, 1):
         x, s = m.cgnr_solve(p.values, p.b, p.D, preconditioner=pre, max_it=4 * p.num_cols, r_tol=1e-14)
         assert np.linalg.norm(x - ref) < 1e-10 * max(1.0, np.linalg.norm(ref)), (pre, s)
+
+
+@pytest.mark.parametrize("matrix_id", [0, 1, 2])
+def test_block_sparse_matrix_layouts_ka6(oracle, problems, matrix_id):
+    """KA-6: the reference's hand-written BlockSparseMatrix test matrices (block_sparse_matrix_test.cc:50-146) — any
+    cell.position order, incl. the E|F-split ordering of id 2 — reproduce the dense matrices its comments give, through
+    ToDenseMatrix, Right/LeftMultiplyAndAccumulate (tested there against the dense product, :225-263) and SquaredColumnNorm."""
+    bs, values, dense = problems.block_sparse_test_matrix(matrix_id)
+    assert (bs.num_rows, bs.num_cols, bs.num_nonzeros) == (dense.shape[0], dense.shape[1], values.shape[0])
+    m = oracle.Matrix(bs, 0)
+    np.testing.assert_array_equal(m.to_dense(values), dense)
+    np.testing.assert_array_equal(bs.to_dense(values), dense)
+    rng = np.random.default_rng(matrix_id)
+    x, y0 = rng.standard_normal(bs.num_cols), rng.standard_normal(bs.num_rows)
+    np.testing.assert_allclose(m.right_multiply(values, x, y0), y0 + dense @ x, rtol=0, atol=1e-14)
+    z, c0 = rng.standard_normal(bs.num_rows), rng.standard_normal(bs.num_cols)
+    np.testing.assert_allclose(m.left_multiply(values, z, c0), c0 + dense.T @ z, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(m.squared_column_norm(values), (dense * dense).sum(0), rtol=0, atol=1e-14)
