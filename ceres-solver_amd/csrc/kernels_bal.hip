@@ -1049,6 +1049,13 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // bal_invert9_kernel) adds the items of a camera in a fixed order — bit-reproducible.  The first version combined split
 // cameras with global fp64 atomics: 81 per item, which on a problem with few cameras (Dubrovnik: 16) or small items
 // (Ladybug) cost several times the pass itself (55 / 105 us, profiles/r02b_kernel_stats_*).
+// Loads: every lane reads "its" 144-byte cell (18 loads of 8 bytes).  tools/probes/gather_probe.hip shows what that access
+// shape costs in isolation — 720 MB of cells fetched as 2.1-3.8 GB (FETCH_SIZE), 630-1340 us, whatever the order of the cells:
+// consecutive load instructions of a wave revisit the same 64 lines and the L1 (a dozen waves per CU) has lost them in between
+// (profiles/r02l_gather_probe_fetch_size_calibration.txt).  This kernel's few, register-heavy waves keep the over-fetch near
+// 2.2x.  Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
+// per cell into an LDS strip and each lane picking its observation up from there — one line request per line, but load ->
+// LDS -> compute serialise inside an iteration and the wave count drops with the 36 KB of LDS per workgroup.
 template <bool SCHUR>
 __global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __restrict__ values, CamItems items,
                                                                const int32_t* __restrict__ cam_fpos,

@@ -35,6 +35,23 @@ for STAGE in "$@"; do
       timeout 600 python tools/kernel_times.py venice1778 2>$OUT/ktimes_$TAG.err | tail -1 | tee -a $OUT/ktimes_$TAG.jsonl; tail -3 $OUT/ktimes_$TAG.err ;;
     ktimes1m)
       timeout 600 python tools/kernel_times.py synthetic1M 2>$OUT/ktimes1m_$TAG.err | tail -1 | tee -a $OUT/ktimes1m_$TAG.jsonl; tail -3 $OUT/ktimes1m_$TAG.err ;;
+    gather)  # what a camera-major gather of 144-byte cells costs + what FETCH_SIZE reports for it (known useful bytes)
+      timeout 300 ./tools/probes/gather_probe | tee $OUT/gather_probe_$TAG.txt
+      cd /tmp && export TMPDIR=/tmp
+      for T in order0_w16 order1_w16 order2_w16 order2_w8; do
+        rm -rf /tmp/pmc_g
+        timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_g -o g -- $REPO/tools/probes/gather_probe $T > /dev/null 2>&1
+        F=$(find /tmp/pmc_g -name "*counter_collection.csv" | head -1)
+        [ -n "$F" ] && python3 - "$F" $T <<'PY' | tee -a $OUT/gather_probe_$TAG.txt
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r.get("Counter_Name") == "FETCH_SIZE" and "gather_kernel" in r.get("Kernel_Name", "")]
+vals = [float(r["Counter_Value"]) for r in rows]
+if vals:
+    v = sum(vals) / len(vals)
+    print(f"{sys.argv[2]}: FETCH_SIZE per launch = {v:.0f} (KiB => {v * 1024 / 1e6:.1f} MB as reported, {2 * v * 1024 / 1e6:.1f} MB doubled); useful = {5001946 * 144 / 1e6:.1f} MB; dispatches {len(vals)}")
+PY
+      done
+      cd $REPO ;;
     bench_n2)  # the N > 1 code path of bench.py and of the library with two ranks on ONE GPU (validation only: timings meaningless)
       for WL in ${WLS:-ladybug1723 synthetic1M}; do for SV in iterative_schur cgnr; do
         echo "--- $WL $SV"
