@@ -292,7 +292,7 @@ enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCg
 template <int MODE>
 constexpr bool kWantsB = (MODE == kJtb || MODE == kInit || MODE == kBackSub || MODE == kCgnrInit || MODE == kJx);
 template <int MODE>
-constexpr bool kCanGather = (MODE == kInit || MODE == kCgnrInit || MODE == kColNorm);
+constexpr bool kCanGather = (MODE == kInit || MODE == kCgnrInit || MODE == kColNorm || MODE == kJtb);
 
 // E^T E (packed symmetric) of one slot.
 __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
@@ -1049,11 +1049,10 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // bal_invert9_kernel) adds the items of a camera in a fixed order — bit-reproducible.  The first version combined split
 // cameras with global fp64 atomics: 81 per item, which on a problem with few cameras (Dubrovnik: 16) or small items
 // (Ladybug) cost several times the pass itself (55 / 105 us, profiles/r02b_kernel_stats_*).
-// Loads: every lane reads "its" 144-byte cell (18 loads of 8 bytes).  tools/probes/gather_probe.hip shows what that access
-// shape costs in isolation — 720 MB of cells fetched as 2.1-3.8 GB (FETCH_SIZE), 630-1340 us, whatever the order of the cells:
-// consecutive load instructions of a wave revisit the same 64 lines and the L1 (a dozen waves per CU) has lost them in between
-// (profiles/r02l_gather_probe_fetch_size_calibration.txt).  This kernel's few, register-heavy waves keep the over-fetch near
-// 2.2x.  Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
+// Loads: every lane reads "its" 144-byte cell (18 loads of 8 bytes, all issued before the first use).  A naive lane-per-cell
+// gather LOOP with half a million lanes in flight (tools/probes/gather_probe.hip) fetches 3-5x its useful bytes by FETCH_SIZE,
+// whatever the order of the cells (profiles/r02l_gather_probe_fetch_size_calibration.txt); this kernel's few, register-heavy
+// waves stay near 2.2x (1.9 GB for 0.88 GB of F and M_o on the Venice shape).  Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
 // per cell into an LDS strip and each lane picking its observation up from there — one line request per line, but load ->
 // LDS -> compute serialise inside an iteration and the wave count drops with the 36 KB of LDS per workgroup.
 template <bool SCHUR>
@@ -1394,7 +1393,7 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
   switch (mode) {
     case kSx: return big ? launch_fused<kSx, 1024>(A, lds, grid, stream) : launch_fused<kSx, 512>(A, lds, grid, stream);
     case kJtJx: return big ? launch_fused<kJtJx, 1024>(A, lds, grid, stream) : launch_fused<kJtJx, 512>(A, lds, grid, stream);
-    case kJtb: return big ? launch_fused<kJtb, 1024>(A, lds, grid, stream) : launch_fused<kJtb, 512>(A, lds, grid, stream);
+    case kJtb: return (big && !A.src_values) ? launch_fused<kJtb, 1024>(A, lds, grid, stream) : launch_fused<kJtb, 512>(A, lds, grid, stream);
     case kInit: return launch_fused<kInit, 512>(A, lds, grid, stream);
     case kEte: return big ? launch_fused<kEte, 1024>(A, false, grid, stream) : launch_fused<kEte, 512>(A, false, grid, stream);
     case kBackSub: return big ? launch_fused<kBackSub, 1024>(A, false, grid, stream) : launch_fused<kBackSub, 512>(A, false, grid, stream);

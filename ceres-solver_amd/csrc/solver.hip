@@ -361,9 +361,9 @@ int op_jtb(ceres_hip_solver* s, double* y) {
   hipStream_t st = s->stream;
   if (!s->have_b) return fail(s, CERES_HIP_E_INVALID, "no residual vector loaded");
   if (s->path == CERES_HIP_PATH_BAL) {
-    TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.y_e = y;
+    use_gather_if_unpacked(s, A);  // first pass over freshly loaded values (the evaluator's gradient): fused with the re-layout
     return bal_scatter(s, kBalJtb, A, nullptr, y + h.num_cols_e, false, nullptr);
   }
   HIP_TRY(s, hipMemsetAsync(y, 0, sizeof(double) * h.num_cols, st));
@@ -1567,6 +1567,26 @@ int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
   const double w = double(s->world);
   if (!rc && (h[0] != w * (w + 1.0) / 2.0 || h[1] != w)) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: got {%g, %g} for world %d", h[0], h[1], s->world);
   if (rc) s->p2p = false;
+  return rc;
+}
+
+// Collective timing probe: `iters` back-to-back all-reduces of n doubles on the solver's stream (whichever path allreduce()
+// takes for that size), HIP events around them; average microseconds per all-reduce.  For the latency budget of DESIGN.md §5.
+int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t iters, double* avg_us) {
+  if (!s || !avg_us || n < 1 || iters < 1 || s->world < 2) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  double* d = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(double)));
+  HIP_TRY(s, hipMemsetAsync(d, 0, size_t(n) * sizeof(double), s->stream));
+  int rc = 0;
+  for (int w = 0; w < 3 && !rc; ++w) rc = allreduce(s, d, size_t(n));
+  if (!rc && hipEventRecord(s->ev[8], s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  for (int i = 0; i < iters && !rc; ++i) rc = allreduce(s, d, size_t(n));
+  if (!rc && hipEventRecord(s->ev[9], s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+  if (!rc) rc = check_comm_error(s);
+  if (!rc) *avg_us = 1e3 * double(elapsed(s->ev[8], s->ev[9])) / iters;
+  (void)hipFree(d);
   return rc;
 }
 

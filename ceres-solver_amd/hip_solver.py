@@ -97,6 +97,7 @@ ABI = [
     ("ceres_hip_comm_p2p_connect", c_int32, [c_void_p, POINTER(c_uint8)]),
     ("ceres_hip_comm_p2p_selftest", c_int32, [c_void_p]),
     ("ceres_hip_comm_p2p_disable", c_int32, [c_void_p]),
+    ("ceres_hip_debug_allreduce_timing", c_int32, [c_void_p, c_int64, c_int32, _DP]),
     ("ceres_hip_solve", c_int32, [c_void_p, _DP, _DP, _DP, c_double, c_double, _DP, POINTER(CSummary)]),
     ("ceres_hip_solve_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, POINTER(CSummary)]),
     ("ceres_hip_load", c_int32, [c_void_p, _DP, _DP, _DP]),
@@ -332,6 +333,12 @@ class HipLinearSolver:
             self.p2p_error = self._lib.ceres_hip_last_error(self._h).decode()
             self.p2p_ok = False
         return rc == 0
+
+    def allreduce_timing(self, n: int, iters: int = 200) -> float:
+        """Collective: average microseconds per all-reduce of n doubles (measurement helper)."""
+        out = np.zeros(1)
+        self._check(self._lib.ceres_hip_debug_allreduce_timing(self._h, int(n), int(iters), _p(out)))
+        return float(out[0])
 
     def p2p_disable(self):
         self._check(self._lib.ceres_hip_comm_p2p_disable(self._h))

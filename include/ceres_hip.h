@@ -208,6 +208,8 @@ int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles /
  * ranks then agree on the verdict out of band and call _disable everywhere if any failed (RCCL takes over).       */
 int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s);
 int ceres_hip_comm_p2p_disable(ceres_hip_solver* s);
+/* Debug / measurement (collective): average microseconds of `iters` back-to-back all-reduces of n doubles. */
+int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t iters, double* avg_us);
 
 /* ---- the boundary call ----------------------------------------------------
  * LinearSolver::Solve (I/linear_solver.h:339-342).  values: num_nonzeros
