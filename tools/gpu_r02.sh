@@ -52,6 +52,31 @@ if vals:
 PY
       done
       cd $REPO ;;
+    pmc)   # HBM traffic counters, one pass per counter set (TCC slots), kernel-trace only: WLS="venice1778 synthetic1M" COUNTERS="FETCH_SIZE WRITE_SIZE"
+      for WL in ${WLS:-venice1778}; do
+        timeout 900 python tools/kernel_times.py $WL > /dev/null 2>&1   # fills the /tmp cache
+        cd /tmp && export TMPDIR=/tmp
+        for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
+          CN=$(echo $C | tr ' ' '+')
+          rm -rf /tmp/pmc_run
+          timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_run -o pmc -- python $REPO/tools/kernel_times.py $WL > /dev/null 2> $OUT/pmc_${CN}_${WL}_$TAG.err
+          F=$(find /tmp/pmc_run -name "*counter_collection.csv" | head -1)
+          [ -n "$F" ] && python3 - "$F" > $OUT/pmc_${CN}_${WL}_$TAG.txt <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    agg[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+for cname, ks in agg.items():
+    print("counter:", cname)
+    for k, v in sorted(ks.items(), key=lambda kv: -sum(kv[1])):
+        v2 = sorted(v)
+        print(f"{k[:110]:110s} n={len(v):5d} mean={sum(v)/len(v):14.1f} median={v2[len(v2)//2]:14.1f} max={v2[-1]:14.1f}")
+PY
+          head -12 $OUT/pmc_${CN}_${WL}_$TAG.txt | cut -c1-200
+        done
+        cd $REPO
+      done ;;
     p2plat) timeout 300 python tools/p2p_latency.py 2>$OUT/p2p_latency_$TAG.err | tail -1 | tee $OUT/p2p_latency_$TAG.json; tail -2 $OUT/p2p_latency_$TAG.err ;;
     bench_n2)  # the N > 1 code path of bench.py and of the library with two ranks on ONE GPU (validation only: timings meaningless)
       for WL in ${WLS:-ladybug1723 synthetic1M}; do for SV in iterative_schur cgnr; do
