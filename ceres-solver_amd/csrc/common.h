@@ -25,8 +25,7 @@ constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic ker
 constexpr int kCamChunk = 512;      // max observations per work item (one wavefront) of the camera-major kernels
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
 constexpr size_t kLdsBytesPerCu = 160 * 1024;  // LDS per CU on gfx950
-constexpr int kZRowAlign = 16;         // camera windows start on a multiple of 16 ring rows (16 x 72 B = nine 128-byte lines)
-constexpr int kMaxWindowCameras = 2048;  // cameras of one window of the camera-major pass: 144 KB of LDS accumulators, 16-bit local index
+constexpr int kZUnit = 64;             // max entries of one work unit of the chunked camera-major pass (cameras not in LDS)
 constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
 
 // ---------------------------------------------------------------------------
@@ -82,15 +81,12 @@ struct BalPlan {
   // Cameras whose 9-double accumulators do not fit in LDS (more than ~2270): the tile pass leaves F^T z per slot and a
   // camera-major pass sums it.  Both can run CHUNK by chunk of tiles through a ring buffer (plan.cc: default one chunk).
   bool cameras_in_lds = true;
-  // Cameras beyond the LDS accumulators: the tile pass leaves F_o^T z_o (one 72-byte row per observation) in a ring that is
-  // ordered by CAMERA WINDOW (contiguous camera ranges with about equal numbers of observations, at most kMaxWindowCameras
-  // cameras each), by slot inside a window; the second pass then streams a window's rows linearly into LDS accumulators.
-  int64_t z_ring_rows = 0;                   // rows of the ring (window starts aligned to kZRowAlign rows; the gaps are never read)
-  int z_max_window_cameras = 0;
-  std::vector<int32_t> z_pos;                // [n_slots] ring row of the slot's observation, -1 for padding slots
-  std::vector<uint16_t> z_cam16;             // [z_ring_rows] camera of the row, relative to its window's first camera
-  std::vector<int32_t> zw_cam_ptr;           // [n_windows + 1] first camera of each window
-  std::vector<int32_t> zw_row_begin, zw_row_end;  // [n_windows] rows of each window
+  int64_t z_ring_slots = 0;                  // slots of the largest chunk = size of the per-slot ring buffer
+  std::vector<int32_t> zc_tile_ptr;          // n_chunks+1 tile boundaries (never inside a long point)
+  std::vector<int32_t> zc_unit_ptr;          // n_chunks+1 into the unit arrays
+  std::vector<int32_t> zu_cam, zu_begin, zu_end;  // unit = <= kZUnit entries of ONE camera inside ONE chunk; [begin, end) into zc_slot
+  std::vector<int32_t> zu_shared;            // 1: the camera has more units in this chunk (combine with atomics), 0: plain read-modify-write
+  std::vector<int32_t> zc_slot;              // per entry: slot index RELATIVE to its chunk's first slot; chunk-major, camera-major inside
   int max_track = 0, max_camera_degree = 0;
 };
 

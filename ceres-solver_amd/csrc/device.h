@@ -37,7 +37,10 @@ struct BalArgs {
   const int32_t* tile_kind = nullptr;
   const int32_t* tile_aux = nullptr;
   int64_t n_tiles = 0, n_slots = 0;
-  const int32_t* z_pos = nullptr;     // cameras not in LDS: ring row of each slot's F^T z (-1: padding slot), see BalPlan::z_pos
+  // tiles this launch walks: [tile_begin, tile_end); tile_end = 0 means all.  Chunked launches (cameras not in LDS) write their
+  // per-slot F^T z into a ring buffer indexed by slot - z_slot0.
+  int64_t tile_begin = 0, tile_end = 0, z_slot0 = 0;
+  int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)
   const int32_t* pt_pos = nullptr;   // nullptr => 3*p
   const int32_t* cam_pos = nullptr;  // nullptr => 9*c   (relative to the F base pointer)
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
@@ -58,7 +61,7 @@ struct BalArgs {
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
-  double* zbuf = nullptr;        // [z_ring_rows][9]   (cameras do not fit in LDS: F^T z per observation, ordered by camera window)
+  double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
@@ -108,15 +111,13 @@ struct CamGather {
   const int32_t* cam_pos = nullptr;
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
 };
-// Second pass when the cameras do not fit in LDS: window w = cameras [cam_ptr[w], cam_ptr[w+1]) owns ring rows
-// [row_begin[w], row_end[w]); `spans` workgroups per window each stream an equal share of the rows into LDS accumulators and leave
-// parts[span][9 c + k] — the layout bal_reduce_partials_kernel sums (every camera is written in every span row, zeros included).
-struct ZWindows {
-  const int32_t *cam_ptr = nullptr, *row_begin = nullptr, *row_end = nullptr;
-  const uint16_t* cam16 = nullptr;  // per ring row: camera relative to the window's first
-  int n_windows = 0, spans = 1, max_window_cameras = 0;
+// Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].
+struct ZUnits {
+  const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr, *shared = nullptr;  // units [first, first + count)
+  const int32_t* slot = nullptr;                                                       // entry -> ring-relative slot
+  int first = 0, count = 0;
 };
-hipError_t LaunchBalCameraWindows(const ZWindows& W, const double* ring, double* parts, int n_f9, const int* status, hipStream_t stream);
+hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             const CamGather& gather, hipStream_t stream);
 

@@ -101,7 +101,7 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
-  int zpos;       // ring row of the slot's F^T z when cameras are not in LDS (BalPlan::z_pos; -1: nothing to store)
+  int64_t zrel;   // slot - A.z_slot0: where the slot's F^T z goes in the (chunk) ring when cameras are not in LDS
   uint32_t seg;
   int cam, pt, first, last;
   bool valid;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
                                           bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
   s.slot = sl;
-  s.zpos = A.z_pos ? A.z_pos[sl] : -1;
+  s.zrel = sl - A.z_slot0;
   s.b0 = 0.0; s.b1 = 0.0;
   if (CAN_GATHER && A.src_values && may_gather) {
     const int ep = A.slot_epos[sl], fp = A.slot_fpos[sl];
@@ -198,17 +198,15 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
 // The software-pipelined streaming kernel splits a slot load in three, each of which only ISSUES
 // loads and consumes nothing: the index words (SlotIdx), the 12 pairs of a packed fp64 tile
 // (issue_pairs), and what is addressed THROUGH the index words (issue_aux, further down).
-struct SlotIdx { int cam; uint32_t seg; int zpos; };
-template <bool LDS>
+struct SlotIdx { int cam; uint32_t seg; };
 __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
   const int64_t sl = tile * kTile + lane;
   i.cam = A.slot_cam[sl];
   i.seg = A.slot_seg[sl];
-  if constexpr (LDS) i.zpos = -1;
-  else i.zpos = A.z_pos[sl];  // unconditional: the pipelined kernel's wait counts are static
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
+  s.zrel = s.slot - A.z_slot0;
   s.b0 = 0.0; s.b1 = 0.0;
   const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
   double2 p[kPairsPerSlot];
@@ -258,28 +256,25 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);  // ds_add_f64
   } else {
-    // cameras do not fit in LDS: leave this observation's contribution F^T z (one 72-byte row) in the ring, at the row the plan
-    // assigned to it (ordered by camera window, by slot inside a window), for bal_camera_windows_kernel.
-    // A lane storing its own row would issue nine 8-byte stores at a 72-byte stride: 576 partial-line write requests per tile,
-    // and it is the L2's request rate, not its bytes, that such stores exhaust.  The wave transposes the tile's 64 x 9 doubles
-    // through a private LDS strip instead: nine consecutive lanes store one row (72 contiguous bytes), seven rows per instruction.
-    // Rows of one window from the tiles a workgroup holds at the same time are neighbours in the ring, so their partial lines
-    // merge in the XCD's L2 before they are written back.
+    // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
+    // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
+    // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
+    // A lane storing its own 72-byte record would issue nine 8-byte stores at a 72-byte stride: 576 partial-line write
+    // requests per tile, and it is the L2's request rate, not its bytes, that such stores exhaust (the per-slot output cost as
+    // much as reading the 200 B / slot tile stream).  The tile's 64 x 9 doubles are one contiguous 4.6 KB range, so the wave
+    // transposes them through a private LDS strip and stores nine fully coalesced 512-byte rows.
     __shared__ double zstage[16][kTile * 9];  // one strip per wave of the (<= 1024-thread) workgroup; only LDS = false kernels carry it
-    if (__ballot(s.valid) == 0ull) return;    // tiles of long points pass through here fully masked
+    // nothing to store for a tile with no valid slot: the pipelined kernel runs the tiles of long points through here with every
+    // lane masked, and their real values are written later by whichever wave owns the point's head tile — zeros from here could land after them
+    if (__ballot(s.valid) == 0ull) return;
     double* st = zstage[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) st[lane * 9 + k] = s.f[k] * z0 + s.f[9 + k] * z1;
+    for (int k = 0; k < 9; ++k) st[lane * 9 + k] = s.valid ? s.f[k] * z0 + s.f[9 + k] * z1 : 0.0;
     __builtin_amdgcn_wave_barrier();
-    const int g = lane / 9, k = lane - 9 * g;
-    const int zp = s.valid ? s.zpos : -1;
+    double* w = acc + 9 * (s.zrel - lane);  // the tile's first slot in the ring (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int r = 7 * j + g;                         // lanes 0..62 cover rows 7j .. 7j+6; lane 63 idles
-      const int p = __shfl(zp, r < kTile ? r : 0);
-      if (g < 7 && r < kTile && p >= 0) acc[9 * int64_t(p) + k] = st[9 * r + k];
-    }
+    for (int j = 0; j < 9; ++j) w[kTile * j + lane] = st[kTile * j + lane];
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -743,8 +738,8 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   }
   const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
-  const int64_t tile_end = A.n_tiles;
-  for (int64_t tile = wave; tile < tile_end; tile += nwaves) {
+  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
+  for (int64_t tile = A.tile_begin + wave; tile < tile_end; tile += nwaves) {
     const int kind = A.tile_kind[tile];
     const int aux = A.tile_aux[tile];
     if constexpr (MODE == kJx) {
@@ -766,6 +761,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     if (threadIdx.x == 0) {
       double t = 0;
       for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      if (MODE == kJtJx && A.pq_accumulate) t += scalar_dst[blockIdx.x];
       scalar_dst[blockIdx.x] = t;
     }
   }
@@ -834,8 +830,8 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
-  const int64_t tile_end = A.n_tiles;
-  const int64_t wave0 = int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
+  const int64_t wave0 = A.tile_begin + int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t last = tile_end - 1;
   if (wave0 < tile_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
@@ -847,13 +843,13 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     int64_t tile = wave0;
     int kind_a = A.tile_kind[tile], aux_a = A.tile_aux[tile], kind_b = 2, aux_b = 0;
     // prologue in the steady-state issue order: index words (1), pairs (0), aux (0)
-    issue_idx<LDS>(A, tile, lane, i2);
+    issue_idx(A, tile, lane, i2);
     __builtin_amdgcn_sched_barrier(0);
-    issue_idx<LDS>(A, min(tile + nwaves, last), lane, i1);
+    issue_idx(A, min(tile + nwaves, last), lane, i1);
     __builtin_amdgcn_sched_barrier(0);
     issue_pairs(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
-    sa.cam = i2.cam; sa.seg = i2.seg; sa.zpos = i2.zpos;
+    sa.cam = i2.cam; sa.seg = i2.seg;
     finish_slot(sa, lane, A.tile_pt0[tile]);
     issue_aux<MODE>(A, sa, lane, kind_a == 0 ? aux_a >> 8 : 0, xa);
     __builtin_amdgcn_sched_barrier(0);
@@ -864,11 +860,11 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       more = tile + nwaves < tile_end;
       nkind = A.tile_kind[next];
       naux = A.tile_aux[next];
-      issue_idx<LDS>(A, min(next + nwaves, last), lane, i2);
+      issue_idx(A, min(next + nwaves, last), lane, i2);
       __builtin_amdgcn_sched_barrier(0);
       issue_pairs(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);
-      n.cam = i1.cam; n.seg = i1.seg; n.zpos = i1.zpos;
+      n.cam = i1.cam; n.seg = i1.seg;
       finish_slot(n, lane, A.tile_pt0[next]);
       issue_aux<MODE>(A, n, lane, nkind == 0 ? naux >> 8 : 0, nx);
       __builtin_amdgcn_sched_barrier(0);
@@ -899,6 +895,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     if (threadIdx.x == 0) {
       double t = 0;
       for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+      if (A.pq_accumulate) t += A.pq_out[blockIdx.x];
       A.pq_out[blockIdx.x] = t;
     }
   }
@@ -1155,49 +1152,41 @@ __global__ __launch_bounds__(64) void bal_camera_finish_kernel(const double* __r
   if (camsq) camsq[9 * int64_t(c) + i] = sqsum;
 }
 
-// Second pass when the camera accumulators of the tile pass do not fit in LDS (device.h: ZWindows).  The tile pass left one
-// 72-byte row F_o^T z_o per observation, ordered by camera window; a workgroup streams its share of ONE window's rows linearly
-// (16 B per lane, four loads in flight) and adds every element into the window's LDS accumulators with ds_add_f64, then writes
-// the window's cameras of parts[span].  Linear reads matter: a camera-by-camera gather of 72-byte rows from a slot-ordered ring
-// fetched 1.6 128-byte lines per row — 2.7x the useful bytes, at the full HBM rate (profiles/r02o_pmc_*synthetic1M*).
-__global__ __launch_bounds__(512) void bal_camera_windows_kernel(ZWindows W, const double* __restrict__ ring, double* __restrict__ parts,
-                                                                 int n_f9, const int* __restrict__ status) {
-  extern __shared__ double wacc[];
+// Camera-major pass of ONE CHUNK of tiles when the camera accumulators do not fit in LDS: the tile pass of the chunk left
+// F_o^T z_o (9 doubles) per slot in a ring buffer that is small enough to still be in the Infinity Cache; a unit = up to kZUnit
+// entries of one camera inside the chunk.  Nine lanes per unit (lane k sums component k: the 72 bytes of an entry are one
+// contiguous access of the group), seven units per wavefront, four entries in flight per lane.  A camera covered by a single
+// unit in this chunk is updated with a plain read-modify-write (chunks run one after the other on the stream); split cameras
+// (more than kZUnit observations inside one chunk: the popular ones) combine with global_atomic_add_f64.
+__global__ __launch_bounds__(256) void bal_camera_chunk_kernel(ZUnits U, const double* __restrict__ ring, double* __restrict__ acc,
+                                                               const int* __restrict__ status) {
   if (status && *status != 0) return;
-  const int w = blockIdx.x / W.spans, span = blockIdx.x - w * W.spans;
-  const int cam0 = W.cam_ptr[w], ncam9 = 9 * (W.cam_ptr[w + 1] - cam0);
-  for (int i = threadIdx.x; i < ncam9; i += 512) wacc[i] = 0.0;
-  __syncthreads();
-  const int64_t rb = W.row_begin[w], re = W.row_end[w];
-  const int64_t per = ((re - rb + W.spans - 1) / W.spans + 63) / 64 * 64;  // rb is a multiple of 16 rows, shares are multiples of 64:
-  const int64_t r0 = min(re, rb + span * per), r1 = min(re, r0 + per);     // a share starts on a 16-byte boundary
-  const int64_t e0 = 9 * r0, e1 = 9 * r1;
-  const double2* ring2 = reinterpret_cast<const double2*>(ring) + (e0 >> 1);
-  const uint16_t* cam16 = W.cam16 + r0;
-  const uint32_t n_pairs = uint32_t((e1 - e0) >> 1);
-  for (uint32_t base = 0; base < n_pairs; base += 4 * 512) {
-    double2 v[4];
+  const int lane = threadIdx.x & 63;
+  const int g = lane / 9, k = lane - 9 * g;
+  const int64_t u = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 7 + g;
+  if (g >= 7 || u >= U.count) return;
+  const int unit = U.first + int(u);
+  const int c = U.cam[unit], beg = U.begin[unit], end = U.end[unit];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int e = beg;
+  for (; e + 7 < end; e += 8) {  // eight index words, then eight entries in flight
+    int a[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t q = base + u * 512 + threadIdx.x;
-      v[u] = q < n_pairs ? ring2[q] : double2{0.0, 0.0};
-    }
+    for (int i = 0; i < 8; ++i) a[i] = U.slot[e + i];
+    double v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t q = base + u * 512 + threadIdx.x;
-      if (q < n_pairs) {
-        const uint32_t e = 2 * q, row = e / 9, k = e - 9 * row;
-        const uint32_t c_a = cam16[row];
-        atomicAdd(&wacc[9 * c_a + k], v[u].x);                          // ds_add_f64
-        if (k == 8) atomicAdd(&wacc[9 * uint32_t(cam16[row + 1])], v[u].y);
-        else atomicAdd(&wacc[9 * c_a + k + 1], v[u].y);
-      }
-    }
+    for (int i = 0; i < 8; ++i) v[i] = ring[9 * int64_t(a[i]) + k];
+    s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
   }
-  if (((e1 - e0) & 1) && threadIdx.x == 0) atomicAdd(&wacc[9 * uint32_t(cam16[r1 - r0 - 1]) + 8], ring[e1 - 1]);
-  __syncthreads();
-  double* out = parts + int64_t(span) * n_f9 + 9 * int64_t(cam0);
-  for (int i = threadIdx.x; i < ncam9; i += 512) out[i] = wacc[i];
+  for (; e + 3 < end; e += 4) {
+    const int a0 = U.slot[e], a1 = U.slot[e + 1], a2 = U.slot[e + 2], a3 = U.slot[e + 3];
+    s0 += ring[9 * int64_t(a0) + k]; s1 += ring[9 * int64_t(a1) + k]; s2 += ring[9 * int64_t(a2) + k]; s3 += ring[9 * int64_t(a3) + k];
+  }
+  for (; e < end; ++e) s0 += ring[9 * int64_t(U.slot[e]) + k];
+  const double v = (s0 + s1) + (s2 + s3);
+  double* dst = acc + 9 * int64_t(c) + k;
+  if (U.shared[unit]) unsafeAtomicAdd(dst, v);
+  else *dst += v;
 }
 
 // In-place inverse of the 9x9 SPD camera blocks from their upper triangle (Cholesky +
@@ -1478,11 +1467,10 @@ hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_pt
   return hipGetLastError();
 }
 
-hipError_t LaunchBalCameraWindows(const ZWindows& W, const double* ring, double* parts, int n_f9, const int* status, hipStream_t stream) {
-  if (W.n_windows == 0) return hipSuccess;
-  const size_t lds = size_t(W.max_window_cameras) * 9 * sizeof(double);
-  if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(bal_camera_windows_kernel)); e != hipSuccess) return e;
-  hipLaunchKernelGGL(bal_camera_windows_kernel, dim3(unsigned(W.n_windows) * W.spans), dim3(512), lds, stream, W, ring, parts, n_f9, status);
+hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream) {
+  if (units.count == 0) return hipSuccess;
+  const int waves = (units.count + 6) / 7;
+  hipLaunchKernelGGL(bal_camera_chunk_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, units, ring, acc, status);
   return hipGetLastError();
 }
 

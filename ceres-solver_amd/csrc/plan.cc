@@ -326,50 +326,48 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
 
-  // Camera windows for camera counts beyond the LDS accumulators (common.h: BalPlan::z_*).
+  // Chunked camera-major pass for camera counts beyond the LDS accumulators.
   P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 512;
   if (!P.cameras_in_lds) {
-    // Number of windows: more windows = smaller accumulators and fewer partial sums in the second pass, but shorter runs of
-    // consecutive ring rows per tile in the first (profiles/r02p_window_sweep_*.txt).  CERES_HIP_Z_WINDOWS overrides.
-    int want = 64;
-    if (const char* e = getenv("CERES_HIP_Z_WINDOWS")) want = std::max(1, atoi(e));
-    want = std::max(want, (P.n_cameras + kMaxWindowCameras - 1) / kMaxWindowCameras);
-    const int64_t target_rows = (P.n_obs + want - 1) / want;
-    const int max_cams = std::min(kMaxWindowCameras, std::max(1, int((int64_t(P.n_cameras) * 3 / 2 + want - 1) / want)));
-    std::vector<int32_t> cam_window(P.n_cameras);
-    P.zw_cam_ptr.assign(1, 0);
-    int64_t rows = 0;
-    for (int c = 0; c < P.n_cameras; ++c) {
-      cam_window[c] = int32_t(P.zw_cam_ptr.size()) - 1;
-      rows += P.cam_ptr[c + 1] - P.cam_ptr[c];
-      if (c + 1 == P.n_cameras || rows >= target_rows || c + 1 - P.zw_cam_ptr.back() == max_cams) {
-        P.zw_cam_ptr.push_back(c + 1);
-        P.z_max_window_cameras = std::max(P.z_max_window_cameras, c + 1 - P.zw_cam_ptr[P.zw_cam_ptr.size() - 2]);
-        rows = 0;
+    // Default: ONE chunk (the whole problem).  Chunks sized for the Infinity Cache (64-128 MiB of per-slot output) were
+    // measured and do not pay on this kernel pair (profiles/r02g_chunk_sweep_synthetic1M.txt: the tile pass is not limited by
+    // the HBM write-back of the ring, and the camera-major pass is latency-bound on its gathers either way), although a
+    // streaming write -> read-back hand-off of that size does stay in the cache (profiles/r02_infinity_cache_handoff_probe.txt).
+    // CERES_HIP_Z_CHUNK_MIB=<n> bounds the ring to n MiB (memory-constrained runs; the chunked path is covered by tests).
+    int64_t chunk_mib = 0;
+    if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
+    const int64_t want_tiles = chunk_mib > 0 ? std::max<int64_t>(1, chunk_mib * (int64_t(1) << 20) / (int64_t(kTile) * 72)) : P.n_tiles;
+    P.zc_tile_ptr.assign(1, 0);
+    for (int64_t t = 0; t < P.n_tiles;) {
+      int64_t e = std::min<int64_t>(P.n_tiles, t + want_tiles);
+      while (e < P.n_tiles && P.tile_kind[e] == 2) ++e;  // keep a long point's tiles together
+      P.zc_tile_ptr.push_back(int32_t(e));
+      P.z_ring_slots = std::max<int64_t>(P.z_ring_slots, (e - t) * kTile);
+      t = e;
+    }
+    const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
+    P.zc_slot.resize(P.n_obs);
+    P.zc_unit_ptr.assign(1, 0);
+    std::vector<int32_t> count(P.n_cameras + 1), cur(P.n_cameras);
+    int64_t base = 0;  // entries emitted so far
+    for (int k = 0; k < n_chunks; ++k) {
+      const int64_t s0 = int64_t(P.zc_tile_ptr[k]) * kTile, s1 = int64_t(P.zc_tile_ptr[k + 1]) * kTile;
+      std::fill(count.begin(), count.end(), 0);
+      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) ++count[P.slot_cam[s] + 1];
+      for (int c = 0; c < P.n_cameras; ++c) {
+        const int n = count[c + 1];
+        count[c + 1] += count[c];
+        cur[c] = count[c];
+        for (int b = 0; b < n; b += kZUnit) {
+          P.zu_cam.push_back(c);
+          P.zu_begin.push_back(int32_t(base + count[c] + b));
+          P.zu_end.push_back(int32_t(base + count[c] + std::min(n, b + kZUnit)));
+          P.zu_shared.push_back(n > kZUnit ? 1 : 0);
+        }
       }
-    }
-    const int n_windows = int(P.zw_cam_ptr.size()) - 1;
-    P.zw_row_begin.resize(n_windows);
-    P.zw_row_end.resize(n_windows);
-    int64_t row = 0;
-    for (int w = 0; w < n_windows; ++w) {
-      P.zw_row_begin[w] = int32_t(row);
-      row += P.cam_ptr[P.zw_cam_ptr[w + 1]] - P.cam_ptr[P.zw_cam_ptr[w]];
-      P.zw_row_end[w] = int32_t(row);
-      row = (row + kZRowAlign - 1) / kZRowAlign * kZRowAlign;
-    }
-    if (row >= (int64_t(1) << 31)) return no("more than 2^31 ring rows");
-    P.z_ring_rows = row;
-    P.z_pos.assign(size_t(P.n_tiles) * kTile, -1);
-    P.z_cam16.assign(size_t(row), 0);
-    std::vector<int32_t> cur(P.zw_row_begin);
-    for (int64_t sl = 0; sl < P.n_tiles * kTile; ++sl) {
-      const int c = P.slot_cam[sl];
-      if (c < 0) continue;
-      const int w = cam_window[c];
-      const int32_t r = cur[w]++;
-      P.z_pos[sl] = r;
-      P.z_cam16[r] = uint16_t(c - P.zw_cam_ptr[w]);
+      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) P.zc_slot[base + cur[P.slot_cam[s]]++] = int32_t(s - s0);
+      base += count[P.n_cameras];
+      P.zc_unit_ptr.push_back(int32_t(P.zu_cam.size()));
     }
   }
   P.eligible = true;

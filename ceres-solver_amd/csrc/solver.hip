@@ -62,9 +62,8 @@ struct ceres_hip_solver {
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
-  ZWindows zwindows;               // camera windows of the second pass (cameras not in LDS)
-  int32_t* d_z_pos = nullptr;      // per slot: ring row of its F^T z
-  int chunk_grid = 0;              // workgroups of the tile pass when cameras are not in LDS
+  ZUnits zunits;                   // chunked camera-major pass (cameras not in LDS): all chunks' units
+  int chunk_grid = 0;              // workgroups of one chunk's tile pass
   // f1: LM step state
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
@@ -215,7 +214,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.pt_pos = s->plan.contiguous_layout ? nullptr : s->d_pt_pos;
   A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
-  A.partials = s->d_partials; A.zbuf = s->d_zbuf; A.z_pos = s->d_z_pos;
+  A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -270,14 +269,26 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
     HIP_TRY(s, LaunchBalFused(mode, A, true, s->fused_grid, s->stream));
   } else {
-    // cameras do not fit in LDS: the tile pass leaves F^T z per observation in a ring ordered by camera window, the second
-    // pass streams each window into LDS accumulators and leaves `spans` partial sums per camera
+    // cameras do not fit in LDS: chunk by chunk, the tile pass leaves F^T z per slot in a ring that is still in the Infinity
+    // Cache when the chunk's camera-major pass adds it into the camera sums
+    const BalPlan& P = s->plan;
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->chunk_grid; }
-    HIP_TRY(s, LaunchBalFused(mode, A, false, s->chunk_grid, s->stream));
-    HIP_TRY(s, LaunchBalCameraWindows(s->zwindows, s->d_zbuf, s->d_partials, n9, status, s->stream));
+    HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
+    const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
+    for (int k = 0; k < n_chunks; ++k) {
+      A.tile_begin = P.zc_tile_ptr[k];
+      A.tile_end = P.zc_tile_ptr[k + 1];
+      A.z_slot0 = int64_t(P.zc_tile_ptr[k]) * kTile;
+      A.pq_accumulate = k > 0 ? 1 : 0;
+      HIP_TRY(s, LaunchBalFused(mode, A, false, s->chunk_grid, s->stream));
+      ZUnits U = s->zunits;
+      U.first = P.zc_unit_ptr[k];
+      U.count = P.zc_unit_ptr[k + 1] - P.zc_unit_ptr[k];
+      HIP_TRY(s, LaunchBalCameraChunk(U, s->d_zbuf, s->d_global_acc, status, s->stream));
+    }
   }
-  const double* parts = s->d_partials;
-  const int nparts = s->lds_mode ? s->fused_grid : s->zwindows.spans;
+  const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
+  const int nparts = s->lds_mode ? s->fused_grid : 1;
   int n_second = 0;
   if (s->world <= 1) {
     HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
@@ -1404,24 +1415,19 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
     const int64_t tiles_per_wg = 512 / kTile;
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
-    if (!s->lds_mode) {
-      ZWindows& Z = s->zwindows;
-      Z.n_windows = int(P.zw_cam_ptr.size()) - 1;
-      Z.max_window_cameras = P.z_max_window_cameras;
-      // workgroups of the second pass: about two per CU (they hold up to 144 KB of LDS each), the same number for every window
-      Z.spans = int(std::max<int64_t>(1, std::min<int64_t>(16, (2 * int64_t(s->num_cus) + Z.n_windows - 1) / Z.n_windows)));
-      if (const char* e = getenv("CERES_HIP_Z_SPANS")) Z.spans = std::max(1, atoi(e));
-      int32_t *cp = nullptr, *rb = nullptr, *re = nullptr;
-      uint16_t* c16 = nullptr;
-      TRY(dev_upload(s, &cp, P.zw_cam_ptr)); TRY(dev_upload(s, &rb, P.zw_row_begin)); TRY(dev_upload(s, &re, P.zw_row_end));
-      TRY(dev_upload(s, &c16, P.z_cam16)); TRY(dev_upload(s, &s->d_z_pos, P.z_pos));
-      Z.cam_ptr = cp; Z.row_begin = rb; Z.row_end = re; Z.cam16 = c16;
-      // the pipelined kernel keeps 8 waves per CU resident: one workgroup per CU, no second round with a ragged tail
-      s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (P.n_tiles + 15) / 16)));
-    }
-    TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : size_t(s->zwindows.spans) * n9));
+    TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
-    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_rows) * 9));  // ring of per-observation F^T z
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_slots) * 9));  // ring of ONE chunk's per-slot F^T z
+    if (!s->lds_mode) {
+      int32_t *uc = nullptr, *ub = nullptr, *ue = nullptr, *us = nullptr, *zs = nullptr;
+      TRY(dev_upload(s, &uc, P.zu_cam)); TRY(dev_upload(s, &ub, P.zu_begin)); TRY(dev_upload(s, &ue, P.zu_end));
+      TRY(dev_upload(s, &us, P.zu_shared)); TRY(dev_upload(s, &zs, P.zc_slot));
+      s->zunits.cam = uc; s->zunits.begin = ub; s->zunits.end = ue; s->zunits.shared = us; s->zunits.slot = zs;
+      // a chunk's tile pass: every wave should see a few tiles (the pipelined kernel has a prologue), at most 4 workgroups per CU
+      const int64_t chunk_tiles = P.z_ring_slots / kTile;
+      // (the pipelined kernel keeps 8 waves per CU resident: one workgroup per CU, no second round with a ragged tail)
+      s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
+    }
     TRY(dev_alloc(s, &s->d_camsq, n9));
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
@@ -2257,28 +2263,6 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
     slot_seg_out[i] = P.slot_seg[i];
   }
   for (int64_t t = 0; t < P.n_tiles; ++t) { tile_kind_out[t] = P.tile_kind[t]; tile_aux_out[t] = P.tile_aux[t]; }
-  return 0;
-}
-
-// Debug: the camera windows of the plan (cameras that do not fit the LDS accumulators).  counts = {n_windows, ring rows,
-// max cameras per window}; with capacity >= the sizes, z_pos[n_tiles * 64], z_cam16[ring rows] (widened to int32),
-// cam_ptr[n_windows + 1], row_begin / row_end[n_windows].  n_windows = 0: the cameras fit in LDS.
-int ceres_hip_debug_plan_windows(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int64_t* counts,
-                                 int32_t* z_pos, int32_t* z_cam, int32_t* cam_ptr, int32_t* row_begin, int32_t* row_end,
-                                 int64_t slot_capacity, int64_t row_capacity, int32_t window_capacity) {
-  HostStructure h;
-  if (!bs || !counts || !AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
-  BalPlan P;
-  BuildBalPlan(h, true, &P);
-  if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
-  const int nw = P.cameras_in_lds ? 0 : int(P.zw_cam_ptr.size()) - 1;
-  counts[0] = nw; counts[1] = P.z_ring_rows; counts[2] = P.z_max_window_cameras;
-  if (nw == 0 || slot_capacity < int64_t(P.z_pos.size()) || row_capacity < P.z_ring_rows || window_capacity < nw) return 0;
-  std::copy(P.z_pos.begin(), P.z_pos.end(), z_pos);
-  for (int64_t r = 0; r < P.z_ring_rows; ++r) z_cam[r] = P.z_cam16[r];
-  std::copy(P.zw_cam_ptr.begin(), P.zw_cam_ptr.end(), cam_ptr);
-  std::copy(P.zw_row_begin.begin(), P.zw_row_begin.end(), row_begin);
-  std::copy(P.zw_row_end.begin(), P.zw_row_end.end(), row_end);
   return 0;
 }
 

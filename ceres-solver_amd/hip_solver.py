@@ -141,8 +141,6 @@ ABI = [
     ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
                                        POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
-    ("ceres_hip_debug_plan_windows", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32),
-                                               POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_int64, c_int64, c_int32]),
 ]
 
 _lib = None
@@ -650,27 +648,6 @@ def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
     return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
             "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tail_a": (seg >> 17) & 63, "has_a": (seg >> 23) & 1,
             "tail_b": (seg >> 24) & 63, "has_b": (seg >> 30) & 1, "tile_kind": kind, "tile_aux": aux}
-
-
-def debug_plan_windows(bs: BlockStructure, num_eliminate_blocks: int, n_tiles: int):
-    """The camera windows of the plan (host only).  None when the cameras fit the LDS accumulators."""
-    lib = load_library()
-    c = bs.as_ctypes()
-    counts = (c_int64 * 3)()
-    null32 = POINTER(c_int32)()
-    rc = lib.ceres_hip_debug_plan_windows(byref(c), num_eliminate_blocks, counts, null32, null32, null32, null32, null32, 0, 0, 0)
-    assert rc == 0, rc
-    nw, rows, max_cams = (int(v) for v in counts)
-    if nw == 0:
-        return None
-    z_pos, z_cam = np.zeros(n_tiles * 64, np.int32), np.zeros(rows, np.int32)
-    cam_ptr, rb, re = np.zeros(nw + 1, np.int32), np.zeros(nw, np.int32), np.zeros(nw, np.int32)
-    ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
-    rc = lib.ceres_hip_debug_plan_windows(byref(c), num_eliminate_blocks, counts, ip(z_pos), ip(z_cam), ip(cam_ptr), ip(rb), ip(re),
-                                          z_pos.size, rows, nw)
-    assert rc == 0, rc
-    return {"n_windows": nw, "ring_rows": rows, "max_window_cameras": max_cams, "z_pos": z_pos, "z_cam": z_cam,
-            "cam_ptr": cam_ptr, "row_begin": rb, "row_end": re}
 
 
 CONVERGENCE, MINIMIZER_NO_CONVERGENCE, MINIMIZER_FAILURE = 0, 1, 2

@@ -465,14 +465,6 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
                          uint32_t* slot_seg, int32_t* tile_kind, int32_t* tile_aux, int64_t slot_capacity,
                          char* why_not, int32_t why_capacity);
 
-/* Debug (host only): the camera windows of the plan when the cameras do not fit the LDS accumulators (the per-observation
- * F^T z ring is ordered by window; see csrc/common.h BalPlan::z_*).  counts = {n_windows, ring rows, max cameras per window};
- * the arrays are filled when the capacities suffice: z_pos[n_tiles * 64] (-1 = padding slot), z_cam[ring rows] (camera relative
- * to its window's first), cam_ptr[n_windows + 1], row_begin / row_end[n_windows].  n_windows = 0: the cameras fit in LDS. */
-int ceres_hip_debug_plan_windows(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int64_t* counts,
-                                 int32_t* z_pos, int32_t* z_cam, int32_t* cam_ptr, int32_t* row_begin, int32_t* row_end,
-                                 int64_t slot_capacity, int64_t row_capacity, int32_t window_capacity);
-
 /* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
  * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */
 int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world);

@@ -177,15 +177,13 @@ def test_bal_without_regulariser_and_global_accumulators(hip, oracle, problems):
     assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL), tol=1e-11)
 
 
-@pytest.mark.parametrize("windows,spans", [("", ""), ("2", "1"), ("500", "3"), ("7", "16")])
-def test_camera_window_pass_window_counts_spans_and_long_points(hip, oracle, problems, monkeypatch, windows, spans):
-    """Cameras not in LDS: the tile pass writes F^T z per observation into a ring ordered by camera window and the second pass
-    streams each window into LDS accumulators (csrc/plan.cc, kernels_bal.hip::bal_camera_windows_kernel).  Defaults, two large
-    windows in one share each, 500 small windows (a popular camera alone in its window), 7 windows in 16 shares (shares shorter
-    than 64 rows, empty shares); points of > 64 observations (whole-tile points) and an odd number of observations per window."""
-    if windows:
-        monkeypatch.setenv("CERES_HIP_Z_WINDOWS", windows)
-        monkeypatch.setenv("CERES_HIP_Z_SPANS", spans)
+@pytest.mark.parametrize("chunk_mib", ["1", "0"])
+def test_chunked_camera_pass_many_chunks_shared_units_and_long_points(hip, oracle, problems, monkeypatch, chunk_mib):
+    """Cameras not in LDS: the tile pass and the camera-major pass run chunk by chunk (csrc/plan.cc, solver.hip::bal_scatter).
+    1 MiB chunks = 227 tiles each: a dozen chunks here, points of > 64 observations (whole-tile points, never split by a chunk
+    boundary), and popular cameras with more than 64 observations inside one chunk (units combined by atomics).  "0" = one
+    chunk for everything (the unchunked reference behaviour of the same kernels)."""
+    monkeypatch.setenv("CERES_HIP_Z_CHUNK_MIB", chunk_mib)
     p = problems.synthetic_bal(None, num_cameras=2600, num_points=3000, num_observations=200000, seed=14, skew=1.2)
     s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
     assert s.info().kernel_path == hip.PATH_BAL and s.info().camera_accum_in_lds == 0
@@ -198,7 +196,7 @@ def test_camera_window_pass_window_counts_spans_and_long_points(hip, oracle, pro
         x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-11))
         xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=300, q_tol=-1.0, r_tol=1e-11)
         assert summ.termination_type == so.termination_type == hip.SUCCESS and rel(x, xo) <= 1e-8
-        # the LM step (fused diagonal, model cost) through the same kernels
+        # the LM step (fused diagonal, model cost) through the same chunked kernels
         step, summ, mcc = s.lm_compute_step(p.values, p.b, 1e4, 0.1)
         m0 = oracle.Matrix(p.bs, 0)
         Dl = np.sqrt(np.clip(m0.squared_column_norm(p.values), 1e-6, 1e32) / 1e4)

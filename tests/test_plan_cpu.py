@@ -199,38 +199,3 @@ def test_point_ids_are_recoverable_from_the_segment_words(problems, seed, nc, np
     assert (np.diff(valid.astype(int), axis=1) <= 0).all()
     if nc >= 100:
         assert (plan["tile_kind"] == 1).any()        # the long-point case is exercised
-
-
-@pytest.mark.parametrize("windows", [None, "3", "400"])
-def test_plan_camera_windows(problems, monkeypatch, windows):
-    """More cameras than the LDS accumulators hold: every observation gets one row of the F^T z ring, rows are grouped by
-    camera window (contiguous camera ranges), ordered by slot inside a window, windows start on 16-row boundaries."""
-    if windows:
-        monkeypatch.setenv("CERES_HIP_Z_WINDOWS", windows)
-    p = problems.synthetic_bal(None, num_cameras=2600, num_points=4000, num_observations=30000, seed=21, skew=0.9)
-    plan = plan_of(p)
-    check_plan_invariants(p, plan)
-    w = pkg.hip_solver.debug_plan_windows(p.bs, p.num_eliminate_blocks, plan["n_tiles"])
-    assert w is not None
-    nw, cam_ptr, rb, re = w["n_windows"], w["cam_ptr"], w["row_begin"], w["row_end"]
-    assert cam_ptr[0] == 0 and cam_ptr[-1] == 2600 and (np.diff(cam_ptr) >= 1).all()
-    assert np.diff(cam_ptr).max() == w["max_window_cameras"] <= 2048
-    if windows:
-        assert int(windows) // 2 <= nw <= 2 * int(windows) + 2  # popular cameras overshoot a window's share of rows
-    assert (rb % 16 == 0).all() and (rb[1:] >= re[:-1]).all() and (rb[1:] - re[:-1] < 16).all() and re[-1] <= w["ring_rows"]
-    valid = plan["valid"].astype(bool)
-    z_pos, cam = w["z_pos"], plan["slot_cam"]
-    assert (z_pos[~valid] == -1).all() and (z_pos[valid] >= 0).all()
-    assert np.unique(z_pos[valid]).size == valid.sum() == 30000
-    window_of_cam = np.searchsorted(cam_ptr, np.arange(2600), side="right") - 1
-    ws = window_of_cam[cam[valid]]
-    zp = z_pos[valid]
-    assert (zp >= rb[ws]).all() and (zp < re[ws]).all()
-    assert ((re - rb) == np.bincount(ws, minlength=nw)).all()
-    assert np.array_equal(w["z_cam"][zp], cam[valid] - cam_ptr[ws])
-    # ordered by slot inside a window
-    for k in range(nw):
-        assert (np.diff(zp[ws == k]) > 0).all()
-    # and nothing of the kind when the cameras fit in LDS
-    q = problems.synthetic_bal(None, num_cameras=40, num_points=500, num_observations=2000, seed=2)
-    assert pkg.hip_solver.debug_plan_windows(q.bs, q.num_eliminate_blocks, plan_of(q)["n_tiles"]) is None

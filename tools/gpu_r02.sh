@@ -83,14 +83,14 @@ PY
         echo "--- $WL $SV"
         CERES_HIP_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload $WL --solver $SV --steps 5 --warmup 2 --no-cpu-baseline 2> $OUT/bench_n2_${WL}_${SV}_$TAG.err | tee $OUT/bench_n2_${WL}_${SV}_$TAG.json | cut -c1-900; tail -2 $OUT/bench_n2_${WL}_${SV}_$TAG.err
       done; done ;;
-    rocprof1m)   # many-camera regime (50 k cameras, 3 M observations): sweep of the camera-window count of the second pass
+    rocprof1m)
       cd /tmp && export TMPDIR=/tmp
-      for WN in ${WINDOWS:-64}; do
+      for MIB in ${CHUNKS:-64}; do
         rm -rf /tmp/prof_1m
-        CERES_HIP_Z_WINDOWS=$WN timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_1m -o s1m -- python $REPO/bench.py --workload synthetic1M --steps 10 --warmup 2 --no-cpu-baseline --both-solvers 1 --minimizer-iterations 0 --host-boundary-steps 0 > $OUT/rocprof_bench_synthetic1M_w${WN}_$TAG.json 2> $OUT/rocprof_synthetic1M_$TAG.err
+        CERES_HIP_Z_CHUNK_MIB=$MIB timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_1m -o s1m -- python $REPO/bench.py --workload synthetic1M --steps 10 --warmup 2 --no-cpu-baseline --both-solvers 0 > $OUT/rocprof_bench_synthetic1M_${MIB}_$TAG.json 2> $OUT/rocprof_synthetic1M_$TAG.err
         F=$(find /tmp/prof_1m -name "*kernel_stats.csv" | head -1)
-        echo "--- windows $WN"; python -c "import json;d=json.loads(open('$OUT/rocprof_bench_synthetic1M_w${WN}_$TAG.json').read());print('sx_ms',d['roofline']['avg_launch_ms'],'frac',d['roofline']['frac'],'jtjx',d.get('roofline_jtjx',{}).get('avg_launch_ms'),'step',d['ms_per_step'])"
-        [ -n "$F" ] && cp $F $OUT/kernel_stats_synthetic1M_w${WN}_$TAG.csv && head -9 $F | cut -c1-200
+        echo "--- chunk MiB $MIB"; python -c "import json;d=json.loads(open('$OUT/rocprof_bench_synthetic1M_${MIB}_$TAG.json').read());print('sx_ms',d['roofline']['avg_launch_ms'],'step',d['ms_per_step'])"
+        [ -n "$F" ] && cp $F $OUT/kernel_stats_synthetic1M_${MIB}_$TAG.csv && head -8 $F | cut -c1-160
       done
       cd $REPO ;;
     rocprof_small)
