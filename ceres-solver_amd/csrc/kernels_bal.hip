@@ -287,6 +287,21 @@ __device__ __forceinline__ void scatter_f_squares(const Slot& s, double* acc) {
   for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * s.f[k] + s.f[9 + k] * s.f[9 + k]);
 }
 
+// A/B builds only (tools/build_variant.sh, loaded through CERES_HIP_LIBRARY): how the cooperative JtJx path stores y_e.
+// 0 = plain stores (the product), 1 = non-temporal stores, 2 = no stores at all (timing ablation: results are wrong).
+#ifndef CERES_HIP_AB_YE_STORE
+#define CERES_HIP_AB_YE_STORE 0
+#endif
+__device__ __forceinline__ void store_ye(double* p, double v) {
+#if CERES_HIP_AB_YE_STORE == 1
+  __builtin_nontemporal_store(v, p);
+#elif CERES_HIP_AB_YE_STORE == 2
+  (void)p; (void)v;
+#else
+  *p = v;
+#endif
+}
+
 enum Mode { kSx = 0, kJtJx = 1, kJtb = 2, kInit = 3, kEte = 4, kBackSub = 5, kCgnrInit = 6, kColNorm = 7, kJx = 8, kSpseZ = 9 };
 
 template <int MODE>
@@ -448,13 +463,13 @@ __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, 
         const double v0 = shfl_idx(w[0], ta), v1 = shfl_idx(w[1], ta), v2 = shfl_idx(w[2], ta);
         const int c = lane % 3;
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 23) & 1) { const double yv = v + x.da * x.da * x.xa; A.y_e[x.base + lane] = yv; dot += x.xa * yv; }
+        if ((s.seg >> 23) & 1) { const double yv = v + x.da * x.da * x.xa; store_ye(A.y_e + x.base + lane, yv); dot += x.xa * yv; }
       }
       if (n3 > 64) {
         const double v0 = shfl_idx(w[0], tb), v1 = shfl_idx(w[1], tb), v2 = shfl_idx(w[2], tb);
         const int c = (lane + 1) % 3;  // (64 + lane) % 3
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 30) & 1) { const double yv = v + x.db * x.db * x.xb; A.y_e[x.base + 64 + lane] = yv; dot += x.xb * yv; }
+        if ((s.seg >> 30) & 1) { const double yv = v + x.db * x.db * x.xb; store_ye(A.y_e + x.base + 64 + lane, yv); dot += x.xb * yv; }
       }
     } else if (s.valid && lane == s.last) {
       const int po = pt_off(A, s.pt);

@@ -40,7 +40,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "csrc", "libceres_hip.so")
+    # CERES_HIP_LIBRARY: an A/B build of the same sources (tools/build_variant.sh); never a different implementation
+    return os.environ.get("CERES_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libceres_hip.so")
 
 
 class COptions(ctypes.Structure):
