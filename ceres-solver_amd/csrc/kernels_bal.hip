@@ -97,6 +97,31 @@ __device__ __forceinline__ void invert_spd3(const double (&a)[6], double (&o)[6]
 }
 
 
+// Streamed-once data is read with non-temporal loads: the L2 then evicts it first, and what is re-used (camera vectors, dirty
+// point-space output lines, the partial sums) stays.  Measured on the pipelined kernels: S.x 0.2115 -> 0.1975 ms, JtJx 0.249 ->
+// 0.231 ms (profiles/r02s_nt_loads_ab_venice.txt).  CERES_HIP_AB_NT_LOADS selects how far this goes in A/B builds
+// (tools/build_variant.sh): 0 = nowhere, 1 = the 12 pairs of a packed tile in the pipelined kernels, 2 = + packed tiles and b in the
+// unpipelined kernels, 3 = + the caller-layout gathers of a step's first pass, 4 = + index words and per-point inverses.
+#ifndef CERES_HIP_AB_NT_LOADS
+#define CERES_HIP_AB_NT_LOADS 1
+#endif
+template <int LEVEL, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr (CERES_HIP_AB_NT_LOADS >= LEVEL) {
+    if constexpr (sizeof(T) == 16) {
+      typedef int v4 __attribute__((ext_vector_type(4)));
+      const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+      T out;
+      __builtin_memcpy(&out, &v, 16);
+      return out;
+    } else {
+      return __builtin_nontemporal_load(p);
+    }
+  } else {
+    return *p;
+  }
+}
+
 struct Slot {
   double e[6], f[18];
   double b0, b1;
@@ -146,10 +171,10 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
       const double* e = A.src_values + ep;
       const double* f = A.src_values + fp;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) v[i] = e[i];
+      for (int i = 0; i < 6; ++i) v[i] = stream_load<3>(e + i);
 #pragma unroll
-      for (int i = 0; i < 18; ++i) v[6 + i] = f[i];
-      if (A.src_b) { const int bp = A.slot_bpos[sl]; s.b0 = A.src_b[bp]; s.b1 = A.src_b[bp + 1]; }
+      for (int i = 0; i < 18; ++i) v[6 + i] = stream_load<3>(f + i);
+      if (A.src_b) { const int bp = A.slot_bpos[sl]; s.b0 = stream_load<3>(A.src_b + bp); s.b1 = stream_load<3>(A.src_b + bp + 1); }
     }
     if constexpr (F32) {
       float4* o = A.Jf_out + tile * (6 * kTile) + lane;
@@ -171,8 +196,8 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
     const float4* J = A.Jf + tile * (6 * kTile) + lane;
     float4 p[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) p[q] = J[q * kTile];
-    if (want_b && A.have_b) { const double2 bb = A.b[sl]; s.b0 = bb.x; s.b1 = bb.y; }
+    for (int q = 0; q < 6; ++q) p[q] = stream_load<2>(J + q * kTile);
+    if (want_b && A.have_b) { const double2 bb = stream_load<2>(A.b + sl); s.b0 = bb.x; s.b1 = bb.y; }
     double v[24];
 #pragma unroll
     for (int q = 0; q < 6; ++q) { v[4 * q] = p[q].x; v[4 * q + 1] = p[q].y; v[4 * q + 2] = p[q].z; v[4 * q + 3] = p[q].w; }
@@ -184,8 +209,8 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
     const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
     double2 p[kPairsPerSlot];
 #pragma unroll
-    for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
-    if (want_b && A.have_b) { const double2 bb = A.b[sl]; s.b0 = bb.x; s.b1 = bb.y; }
+    for (int j = 0; j < kPairsPerSlot; ++j) p[j] = stream_load<2>(J + j * kTile);
+    if (want_b && A.have_b) { const double2 bb = stream_load<2>(A.b + sl); s.b0 = bb.x; s.b1 = bb.y; }
     s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
 #pragma unroll
     for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
@@ -201,8 +226,8 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
 struct SlotIdx { int cam; uint32_t seg; };
 __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int lane, SlotIdx& i) {
   const int64_t sl = tile * kTile + lane;
-  i.cam = A.slot_cam[sl];
-  i.seg = A.slot_seg[sl];
+  i.cam = stream_load<4>(A.slot_cam + sl);
+  i.seg = stream_load<4>(A.slot_seg + sl);
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
@@ -211,7 +236,7 @@ __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int 
   const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
   double2 p[kPairsPerSlot];
 #pragma unroll
-  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = J[j * kTile];
+  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = stream_load<1>(J + j * kTile);
   s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
 #pragma unroll
   for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
@@ -222,7 +247,7 @@ __device__ __forceinline__ int cam_off(const BalArgs& A, int c) { return A.cam_p
 
 __device__ __forceinline__ void load_ete_inverse(const BalArgs& A, int pt, double (&ei)[6]) {
   const double2* q = reinterpret_cast<const double2*>(A.etei + int64_t(pt) * 6);
-  const double2 a = q[0], b = q[1], c = q[2];
+  const double2 a = stream_load<4>(q), b = stream_load<4>(q + 1), c = stream_load<4>(q + 2);
   ei[0] = a.x; ei[1] = a.y; ei[2] = b.x; ei[3] = b.y; ei[4] = c.x; ei[5] = c.y;
 }
 __device__ __forceinline__ void sym3_mul(const double (&m)[6], const double (&u)[3], double (&v)[3]) {
