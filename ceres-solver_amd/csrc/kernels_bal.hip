@@ -98,12 +98,17 @@ __device__ __forceinline__ void invert_spd3(const double (&a)[6], double (&o)[6]
 
 
 // Streamed-once data is read with non-temporal loads: the L2 then evicts it first, and what is re-used (camera vectors, dirty
-// point-space output lines, the partial sums) stays.  Measured on the pipelined kernels: S.x 0.2115 -> 0.1975 ms, JtJx 0.249 ->
-// 0.231 ms (profiles/r02s_nt_loads_ab_venice.txt).  CERES_HIP_AB_NT_LOADS selects how far this goes in A/B builds
+// point-space output lines, the partial sums) stays.  CERES_HIP_AB_NT_LOADS selects how far this goes in A/B builds
 // (tools/build_variant.sh): 0 = nowhere, 1 = the 12 pairs of a packed tile in the pipelined kernels, 2 = + packed tiles and b in the
-// unpipelined kernels, 3 = + the caller-layout gathers of a step's first pass, 4 = + index words and per-point inverses.
+// unpipelined kernels (the product), 3 = + the caller-layout gathers of a step's first pass, 4 = + index words and per-point
+// inverses.  Measured on the Venice shape (profiles/r02t_nt_load_levels_venice.txt): level 1 S.x 0.2138 -> 0.2000 ms and JtJx
+// -7 %, level 2 back-substitution 0.252 -> 0.233 ms; level 3 is a disaster (non-temporal loads bypass the L1 that the per-lane
+// 8-byte gathers of a 192-byte record live on: kInit 0.50 -> 0.75 ms) and level 4 costs S.x 2 %.
+#ifndef CERES_HIP_AB_NT_RING
+#define CERES_HIP_AB_NT_RING 0
+#endif
 #ifndef CERES_HIP_AB_NT_LOADS
-#define CERES_HIP_AB_NT_LOADS 1
+#define CERES_HIP_AB_NT_LOADS 2
 #endif
 template <int LEVEL, typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
@@ -299,7 +304,13 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
     __builtin_amdgcn_wave_barrier();
     double* w = acc + 9 * (s.zrel - lane);  // the tile's first slot in the ring (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) w[kTile * j + lane] = st[kTile * j + lane];
+    for (int j = 0; j < 9; ++j) {
+#if CERES_HIP_AB_NT_RING
+      __builtin_nontemporal_store(st[kTile * j + lane], w + kTile * j + lane);  // A/B: keep the ring out of the way of the camera vector in L2
+#else
+      w[kTile * j + lane] = st[kTile * j + lane];
+#endif
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
