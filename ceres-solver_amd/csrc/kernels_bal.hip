@@ -104,9 +104,25 @@ __device__ __forceinline__ void invert_spd3(const double (&a)[6], double (&o)[6]
 // inverses.  Measured on the Venice shape (profiles/r02t_nt_load_levels_venice.txt): level 1 S.x 0.2138 -> 0.2000 ms and JtJx
 // -7 %, level 2 back-substitution 0.252 -> 0.233 ms; level 3 is a disaster (non-temporal loads bypass the L1 that the per-lane
 // 8-byte gathers of a 192-byte record live on: kInit 0.50 -> 0.75 ms) and level 4 costs S.x 2 %.
-#ifndef CERES_HIP_AB_NT_RING
-#define CERES_HIP_AB_NT_RING 0
+// The tiles a step's first pass writes on the way (fused re-layout) go out with non-temporal stores: 1 GB that the L2 cannot keep
+// until its next reader anyway (kInit 0.484 -> 0.467 ms, CGNR set-up 0.734 -> 0.719 ms, stand-alone pack 0.376 -> 0.360 ms;
+// profiles/r02v_nt_tile_stores_venice.txt).  CERES_HIP_AB_NT_TILE_STORES: 0 = plain stores, 1 = tiles, 2 = + M_o and (E^T E)^-1.
+#ifndef CERES_HIP_AB_NT_TILE_STORES
+#define CERES_HIP_AB_NT_TILE_STORES 1
 #endif
+template <int LEVEL = 1, typename T>
+__device__ __forceinline__ void tile_store(T* p, const T& v) {
+#if CERES_HIP_AB_NT_TILE_STORES
+  if constexpr (CERES_HIP_AB_NT_TILE_STORES < LEVEL) { *p = v; return; }
+  typedef int v4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(T) == 16, "16-byte tile elements");
+  v4 raw;
+  __builtin_memcpy(&raw, &v, 16);
+  __builtin_nontemporal_store(raw, reinterpret_cast<v4*>(p));
+#else
+  *p = v;
+#endif
+}
 #ifndef CERES_HIP_AB_NT_LOADS
 #define CERES_HIP_AB_NT_LOADS 2
 #endif
@@ -184,15 +200,15 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
     if constexpr (F32) {
       float4* o = A.Jf_out + tile * (6 * kTile) + lane;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) o[q * kTile] = make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3]));
+      for (int q = 0; q < 6; ++q) tile_store(o + q * kTile, make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3])));
 #pragma unroll
       for (int i = 0; i < 24; ++i) v[i] = double(float(v[i]));  // this pass computes with what later passes will read
     } else {
       double2* o = A.J_out + tile * (kPairsPerSlot * kTile) + lane;
 #pragma unroll
-      for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+      for (int j = 0; j < kPairsPerSlot; ++j) tile_store(o + j * kTile, make_double2(v[2 * j], v[2 * j + 1]));
     }
-    if (A.src_b) A.b_out[sl] = make_double2(s.b0, s.b1);
+    if (A.src_b) tile_store(A.b_out + sl, make_double2(s.b0, s.b1));
 #pragma unroll
     for (int i = 0; i < 6; ++i) s.e[i] = v[i];
 #pragma unroll
@@ -304,13 +320,7 @@ __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0
     __builtin_amdgcn_wave_barrier();
     double* w = acc + 9 * (s.zrel - lane);  // the tile's first slot in the ring (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-#if CERES_HIP_AB_NT_RING
-      __builtin_nontemporal_store(st[kTile * j + lane], w + kTile * j + lane);  // A/B: keep the ring out of the way of the camera vector in L2
-#else
-      w[kTile * j + lane] = st[kTile * j + lane];
-#endif
-    }
+    for (int j = 0; j < 9; ++j) w[kTile * j + lane] = st[kTile * j + lane];
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -379,7 +389,7 @@ __device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int po, double 
 __device__ __forceinline__ void store_ete_inverse(const BalArgs& A, int pt, const double (&ei)[6]) {
   if (A.etei) {
     double2* q = reinterpret_cast<double2*>(A.etei + int64_t(pt) * 6);
-    q[0] = make_double2(ei[0], ei[1]); q[1] = make_double2(ei[2], ei[3]); q[2] = make_double2(ei[4], ei[5]);
+    tile_store<2>(q, make_double2(ei[0], ei[1])); tile_store<2>(q + 1, make_double2(ei[2], ei[3])); tile_store<2>(q + 2, make_double2(ei[4], ei[5]));
   }
   if (A.point_blocks) {  // dense 3x3 in the all-blocks diagonal store (CGNR JACOBI)
     double* o = A.point_blocks + (A.pt_diag_off ? A.pt_diag_off[pt] : int64_t(9) * pt);
@@ -402,8 +412,8 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
     double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * sl);  // [slot][4]: m00 m01 m11 pad, 32 B per slot
-    mo[0] = make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]));
-    mo[1] = make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0);
+    tile_store<2>(mo, make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2])));
+    tile_store<2>(mo + 1, make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0));
   }
 }
 
@@ -1075,11 +1085,11 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
   if constexpr (F32) {
     float4* o = Jf + tile * (6 * kTile) + lane;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) o[q * kTile] = make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3]));
+    for (int q = 0; q < 6; ++q) tile_store(o + q * kTile, make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3])));
   } else {
     double2* o = J + tile * (kPairsPerSlot * kTile) + lane;
 #pragma unroll
-    for (int j = 0; j < kPairsPerSlot; ++j) o[j * kTile] = make_double2(v[2 * j], v[2 * j + 1]);
+    for (int j = 0; j < kPairsPerSlot; ++j) tile_store(o + j * kTile, make_double2(v[2 * j], v[2 * j + 1]));
   }
   if (b) bt[sl] = make_double2(b0, b1);
 }
