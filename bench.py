@@ -264,7 +264,7 @@ def main():
         body = f"bal_fused_kernel<{mode}, fp32 tiles>" if storage else f"bal_stream_kernel<{mode}>"
         if info.camera_accum_in_lds:
             return body + " + bal_reduce_partials_kernel"
-        return body + " (per-slot F'z, cameras do not fit in LDS) + bal_camera_apply_kernel + bal_reduce_partials_kernel"
+        return body + " (per-slot F'z, cameras do not fit in LDS) + bal_camera_chunk_kernel + bal_reduce_partials_kernel"
 
     def measure_operator(slv, k):
         slv.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())

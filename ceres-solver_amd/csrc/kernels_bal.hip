@@ -292,7 +292,7 @@ __device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], do
 }
 // Camera-space contribution F^T z of one observation.  LDS: nine ds_add_f64 into the
 // workgroup's accumulator.  Otherwise (cameras do not fit in LDS) the nine products are stored per
-// slot and bal_camera_apply_kernel sums them camera by camera in a second pass — global fp64
+// slot and bal_camera_chunk_kernel sums them camera by camera in a second pass — global fp64
 // atomics on a few thousand hot addresses are an order of magnitude slower.
 template <bool LDS>
 __device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
