@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __r
     double m00 = 1.0, m01 = 0.0, m11 = 1.0;
     if constexpr (SCHUR) {
       const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
-      const double2 a = mo[0], b = mo[1];
+      const double2 a = mo[0], b = mo[1];  // plain loads: non-temporal ones (no L1) made this pass 8 % slower (r02y)
       m00 = a.x; m01 = a.y; m11 = b.x;
 #pragma unroll
       for (int k = 0; k < 9; ++k) sq[k] += f0[k] * f0[k] + f1[k] * f1[k];  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
