@@ -9,7 +9,7 @@ import pytest
 
 from conftest import ROOT
 
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")))
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -31,13 +31,36 @@ def test_committed_bench_lines_follow_the_contract(path):
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
     cpu = d.get("cpu_baseline")
-    if "under_rocprof" not in path:            # the profiled runs skip the CPU leg
+    if "under_rocprof" not in path and "fp32" not in path:   # the profiled runs and the fp32-storage run skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
+    if os.path.basename(path).startswith("r02"):   # round 2: what the traffic figure is, and the probe for real Ceres
+        assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+        if cpu:
+            assert "tools/probe.sh" in cpu["sample"]
 
 
-def test_default_line_carries_both_rooflines():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01f_bench_default_iterative_schur.json")).read())
+@pytest.mark.parametrize("tag", ["r01f", "r02x"])
+def test_default_line_carries_both_rooflines(tag):
+    d = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_default_iterative_schur.json")).read())
     assert "kSx" in d["roofline"]["kernel"] and "kJtJx" in d["roofline_jtjx"]["kernel"]
     assert d["config"]["solver"].startswith("ITERATIVE_SCHUR")
     assert d["extra"]["cgnr"]["steps_per_s"] > 0
+
+
+def test_round2_default_line_says_the_whole_truth():
+    """VERDICT r01 "weak" 5 / 7: the host-boundary rate, the scene-valued trust-region rate and the provenance of the
+    traffic figure are first-class fields of the N = 1 line; `value` stays the resident-inputs rate."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02x_bench_default_iterative_schur.json")).read())
+    hb, tr = d["host_boundary"], d["scene_trust_region"]
+    assert hb["steps_per_s"] == pytest.approx(1e3 / hb["ms_per_step"], rel=1e-3) and hb["steps_per_s"] < d["value"] / 5
+    assert hb["upload_ms"] < hb["ms_per_step"] and hb["bytes_h2d"] > 1e9
+    assert tr["lm_iterations"] >= 1 and len(tr["cg_iterations"]) >= tr["lm_iterations"] and tr["ms_per_lm_iteration"] > d["ms_per_step"]
+    assert d["config"]["inputs_resident_in_hbm"] is True
+
+
+def test_synthetic10m_lines_name_the_many_camera_configuration():
+    for storage in ("fp64", "fp32"):
+        d = json.loads(open(os.path.join(ROOT, "profiles", f"r02x_bench_synthetic10M_{storage}.json")).read())
+        assert d["config"]["workload"].startswith("synthetic10M") and d["config"]["jacobian_storage"].startswith(storage)
+        assert d["config"]["camera_accumulators_in_lds"] is False and d["dtype"] == "f64"
