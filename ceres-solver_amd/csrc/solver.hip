@@ -124,6 +124,7 @@ struct ceres_hip_solver {
   unsigned long long p2p_epoch = 0;
   int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived
   double p2p_timeout_s = 10.0;
+  bool p2p_fine_grained = false;   // the receive buffer is a fine-grained allocation (false: the runtime could only export a coarse-grained one)
   ceres_hip_solve_timing timing{};
 };
 
@@ -1505,7 +1506,7 @@ int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world,
   bool ok = false;
   if (!(coarse && atoi(coarse) != 0)) {
     if (hipExtMallocWithFlags(&s->p2p_base, s->p2p_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
-      if (hipIpcGetMemHandle(&h, s->p2p_base) == hipSuccess) ok = true;
+      if (hipIpcGetMemHandle(&h, s->p2p_base) == hipSuccess) { ok = true; s->p2p_fine_grained = true; }
       else { (void)hipFree(s->p2p_base); s->p2p_base = nullptr; }
     }
     (void)hipGetLastError();
@@ -1545,27 +1546,40 @@ int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles) 
   return 0;
 }
 
-// One round trip through the peer-to-peer all-reduce: sum of {rank + 1, 1} over ranks must be {w (w + 1) / 2, w}.
-// A collective: every rank calls it.  Non-zero (with the communicator left disabled) if a peer did not arrive in
-// CERES_HIP_P2P_SELFTEST_TIMEOUT seconds (default 5) or the sums are wrong; callers then agree (e.g. by an RCCL
-// all-reduce of the verdict) and fall back to RCCL with ceres_hip_comm_p2p_disable on every rank.
+// Self-test of the peer-to-peer all-reduce, a collective (every rank calls it): kSelfTestRounds all-reduces of a vector that spans
+// several chunks, with different values every round — round t sums (rank + 1)(t + 1) + i % 7 over ranks.  More than two rounds
+// matter: a slot is re-used every second epoch, so a receive buffer whose lines a cache keeps across epochs (a coarse-grained
+// allocation written by ANOTHER device) passes the first two rounds and fails the third.  Non-zero, with the communicator left
+// disabled, if a peer did not arrive in CERES_HIP_P2P_SELFTEST_TIMEOUT seconds (default 5) or a sum is wrong; callers then
+// agree (e.g. by an all-reduce of the verdict over their bootstrap transport) and fall back to RCCL with
+// ceres_hip_comm_p2p_disable on every rank.
 int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
   if (!s || !s->p2p) return CERES_HIP_E_INVALID;
   HIP_TRY(s, hipSetDevice(s->opt.device));
-  double *d = nullptr, h[2] = {double(s->rank + 1), 1.0};
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), 2 * sizeof(double)));
+  constexpr int kSelfTestRounds = 6;
+  const int n = int(std::min<int64_t>(s->p2p_cap, 2 * kP2pChunk + 3));
+  std::vector<double> h(n);
+  double* d = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(double)));
   const double keep = s->p2p_timeout_s;
   { const char* e = getenv("CERES_HIP_P2P_SELFTEST_TIMEOUT"); s->p2p_timeout_s = (e && atof(e) > 0) ? atof(e) : 5.0; }
   int rc = 0;
-  if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  if (!rc) rc = allreduce(s, d, 2);
-  if (!rc && hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  if (!rc) rc = check_comm_error(s);
+  const double w = double(s->world);
+  for (int t = 0; t < kSelfTestRounds && !rc; ++t) {
+    for (int i = 0; i < n; ++i) h[i] = double(s->rank + 1) * (t + 1) + double(i % 7);
+    if (hipMemcpyAsync(d, h.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+    if (!rc) rc = allreduce(s, d, size_t(n));
+    if (!rc && hipMemcpyAsync(h.data(), d, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+    if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+    if (!rc) rc = check_comm_error(s);
+    for (int i = 0; i < n && !rc; ++i) {
+      const double want = (t + 1) * w * (w + 1.0) / 2.0 + w * double(i % 7);
+      if (h[i] != want) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: round %d element %d is %g, expected %g (world %d, %s receive buffer)",
+                                  t, i, h[i], want, s->world, s->p2p_fine_grained ? "fine-grained" : "coarse-grained");
+    }
+  }
   s->p2p_timeout_s = keep;
   (void)hipFree(d);
-  const double w = double(s->world);
-  if (!rc && (h[0] != w * (w + 1.0) / 2.0 || h[1] != w)) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: got {%g, %g} for world %d", h[0], h[1], s->world);
   if (rc) s->p2p = false;
   return rc;
 }

@@ -204,8 +204,10 @@ int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_I
 int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world_size, int64_t max_elements,
                                uint8_t handle_out[CERES_HIP_IPC_HANDLE_BYTES]);
 int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles /* world_size x 64 bytes */);
-/* Collective self-test (one all-reduce of known values, 5 s timeout): non-zero leaves the path disabled on this rank;
- * ranks then agree on the verdict out of band and call _disable everywhere if any failed (RCCL takes over).       */
+/* Collective self-test (six all-reduces of multi-chunk vectors with values that change every round — a receive slot is
+ * re-used every second epoch, so stale cached lines show from the third round on; 5 s timeout): non-zero leaves the
+ * path disabled on this rank; ranks then agree on the verdict out of band and call _disable everywhere if any failed
+ * (RCCL takes over).                                                                                               */
 int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s);
 int ceres_hip_comm_p2p_disable(ceres_hip_solver* s);
 /* Debug / measurement (collective): average microseconds of `iters` back-to-back all-reduces of n doubles. */
