@@ -76,7 +76,8 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 // pq_out != nullptr: also partial x_f . y_f, one per workgroup (*n_pq of them; needs x_f)
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
-                                   double* pq_out, int* n_pq, hipStream_t stream);
+                                   double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in = nullptr, int n_sum_in = 0,
+                                   double* sum_out = nullptr);  // sum_out: *sum_out = sum(sum_in[0 .. n_sum_in)), see the kernel
 hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
 hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
                                  const int* status, double* pq_out, int* n_pq, hipStream_t stream);
@@ -253,6 +254,9 @@ struct CgBuffers {
   // in registers, otherwise by cg_dot_pq_kernel into slot 1); summed in index order by cg_update_kernel
   const double* pq_parts = nullptr;
   int n_pq = 0;
+  // sharded CGNR, fused iteration: one more term of p.q — the shard's share, already summed over ranks (it travelled with
+  // the camera vector through the operator's all-reduce); nullptr otherwise
+  const double* pq_extra = nullptr;
 };
 constexpr int kMaxPqParts = 2048;
 
@@ -284,6 +288,8 @@ hipError_t LaunchCgFinalize(const CgBuffers& B, hipStream_t stream);
 // pq = sum(pq_parts), alpha; x += alpha p; unless reset: r -= alpha q, partial Q1 / |r|^2 -> slots 2, 3 and, block by block,
 // z = M^-1 r with partial r.z -> slot 0 (the next iteration's rho).  One thread per column block.
 // nine_from: blocks [nine_from, nblocks) of the range are all 9 wide (handled nine lanes per block); nblocks if unknown.
+// Sharded (B.grid_e > 0): the caller guarantees that blocks [0, nine_from) are exactly the shard; workgroups [0, grid_e) then take
+// them and [grid_e, grid) the replicated 9-wide blocks, so that the partial sums split the way total_of() expects.
 hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_block, int col_begin, int nblocks,
                           const int64_t* diag_off, const double* blocks, int reset, int it, int nine_from, hipStream_t stream);
 // Start of a solve with x0 = 0 in two launches: LaunchCgUpdate(..., it = 0) [x = 0, r = rhs, z = M^-1 r, partial |rhs|^2 and r.z] and

@@ -975,10 +975,20 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
 __global__ __launch_bounds__(512) void bal_reduce_partials_kernel(const double* __restrict__ partials, int nparts, int n_f9,
                                            const int32_t* __restrict__ cam_pos, const double* __restrict__ D_f,
                                            const double* __restrict__ x_f, double* __restrict__ y_f,
-                                           const int* __restrict__ status, double* __restrict__ pq_out) {
+                                           const int* __restrict__ status, double* __restrict__ pq_out,
+                                           const double* __restrict__ sum_in, int n_sum_in, double* __restrict__ sum_out) {
   __shared__ double sh[8][64];
   if (status && *status != 0) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // sharded CGNR: this rank's point-space share of p.q (the tile pass's per-workgroup partials) collapsed into ONE double that
+  // travels with the camera vector through the same all-reduce (sum_out = the element after the vector); fixed order
+  if (sum_out && blockIdx.x == gridDim.x - 1 && wv == 7) {
+    double v = 0;
+    for (int k = lane; k < n_sum_in; k += 64) v += sum_in[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) *sum_out = v;
+  }
   const int ngroups = (n_f9 + 63) / 64;
   double dot = 0;
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -1468,12 +1478,13 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
 
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,
-                                   double* pq_out, int* n_pq, hipStream_t stream) {
+                                   double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in, int n_sum_in,
+                                   double* sum_out) {
   const int grid = std::max(1, std::min((n_f9 + 63) / 64, kMaxVecGrid));
   if (!x_f) pq_out = nullptr;
   if (n_pq) *n_pq = pq_out ? grid : 0;
   hipLaunchKernelGGL(bal_reduce_partials_kernel, dim3(grid), dim3(512), 0, stream, partials, nparts,
-                     n_f9, cam_pos, D_f, x_f, y_f, status, pq_out);
+                     n_f9, cam_pos, D_f, x_f, y_f, status, pq_out, sum_in, n_sum_in, sum_out);
   return hipGetLastError();
 }
 

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
     const int staged = S.fail_dir;  // the direction of this iteration failed: forwarded to cg_finalize_direction_kernel
     double v = 0;
     if (!staged) for (int k = threadIdx.x; k < B.n_pq; k += kVecBlock) v += B.pq_parts[k];
-    pq = staged ? 1.0 : block_sum(v, sh);
+    pq = staged ? 1.0 : block_sum(v, sh) + (B.pq_extra ? *B.pq_extra : 0.0);
     rho = S.rho_pp[it & 1];
     fail = staged;
     if (!fail) {
@@ -461,8 +461,9 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
     const int64_t t0 = int64_t(blockIdx.x) * kVecBlock + threadIdx.x, step = int64_t(gridDim.x) * kVecBlock;
     if (reset) {  // x only: r comes from the operator (cg_residual_reset_kernel), then cg_precondition_kernel
       for (int64_t i = t0; i < B.n; i += step) B.x[i] += alpha * B.p[i];
-    } else if (!blocks) {  // IDENTITY: z = r
-      for (int64_t i = t0; i < B.n; i += step) {
+    } else if (!blocks) {  // IDENTITY: z = r   (my_span: a sharded run's partial sums must split at the shard boundary)
+      const Span sp = my_span(B);
+      for (int64_t i = sp.i; i < sp.end; i += sp.step) {
         const double xv = START ? 0.0 : B.x[i] + alpha * B.p[i];
         const double rv = START ? B.rhs[i] : B.r[i] - alpha * B.z[i];
         B.x[i] = xv; B.r[i] = rv; B.z[i] = rv;
@@ -546,8 +547,9 @@ __global__ __launch_bounds__(kVecBlock) void cg_update_kernel(CgBuffers B, GenSt
 __global__ __launch_bounds__(kVecBlock) void cg_begin_kernel(CgBuffers B, double q_tol, double r_tol, int min_it, int max_it) {
   __shared__ double sh[12];
   double nn = 0, rho = 0, unused = 0;
-  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) { nn += B.partials[3 * kMaxVecGrid + k]; rho += B.partials[0 * kMaxVecGrid + k]; }
+  for (int k = B.grid_e + threadIdx.x; k < B.grid; k += kVecBlock) { nn += B.partials[3 * kMaxVecGrid + k]; rho += B.partials[0 * kMaxVecGrid + k]; }
   block_sum3(nn, rho, unused, sh);
+  if (B.grid_e > 0) { nn += B.comm[3]; rho += B.comm[0]; }  // the shard's share, summed over ranks (cg_collapse_kernel + all-reduce)
   const double norm_rhs = sqrt(nn);
   const double tol_r = r_tol * norm_rhs;
   int status = kCgRunning;
@@ -586,12 +588,13 @@ __global__ __launch_bounds__(kVecBlock) void cg_finalize_direction_kernel(CgBuff
     return;
   }
   double Q1 = 0, rr = 0, rho = 0;
-  for (int k = threadIdx.x; k < B.grid; k += kVecBlock) {  // same order in every workgroup: all agree bit for bit
+  for (int k = B.grid_e + threadIdx.x; k < B.grid; k += kVecBlock) {  // same order in every workgroup: all agree bit for bit
     Q1 += B.partials[2 * kMaxVecGrid + k];
     rr += B.partials[3 * kMaxVecGrid + k];
     rho += B.partials[0 * kMaxVecGrid + k];
   }
   block_sum3(Q1, rr, rho, sh);
+  if (B.grid_e > 0) { Q1 += B.comm[2]; rr += B.comm[3]; rho += B.comm[0]; }  // sharded: + the all-reduced shard sums (identical on every rank)
   const double Q0 = S.Q0_pp[it & 1], rho_prev = S.rho_pp[it & 1];
   const double norm_r = sqrt(rr);
   const double zeta = it * (Q1 - Q0) / Q1;
@@ -734,6 +737,7 @@ hipError_t LaunchCgUpdate(const CgBuffers& B, const GenStructure& G, int first_b
   int grid_a = B.grid;  // workgroups of the one-thread-per-block part
   if (n9 > 0) grid_a = nine_from == 0 ? 0 : std::max(1, B.grid - std::max(1, std::min(B.grid / 2, (n9 + 111) / 112)));
   if (n9 > 0 && grid_a >= B.grid) { nine_from = nblocks; grid_a = B.grid; }  // a single workgroup: no room to split
+  if (B.grid_e > 0) grid_a = B.grid_e;  // sharded: the shard's blocks [0, nine_from) are exactly what workgroups [0, grid_e) own
   if (it == 0)  // start of a solve
     hipLaunchKernelGGL((cg_update_kernel<true>), dim3(B.grid), dim3(kVecBlock), 0, s, B, G, first_block, col_begin, nblocks, diag_off, blocks, 0, 0,
                        nine_from, grid_a);

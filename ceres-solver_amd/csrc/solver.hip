@@ -259,8 +259,10 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
 // add_diag: y_f += D_f^2 x_f (after the all-reduce when sharded).
 // pq / n_pq (optional, needs x_f): the kernels that hold x and the finished y in registers also leave the partial sums of
 // x . y (CG's p.q) in pq[0 .. *n_pq) — point part from the JtJx tile pass, camera part from the reduction.
+// Sharded (pq_extra != nullptr on return): the point-space share of x . y has been summed over ranks into *pq_extra — the element
+// right after y_f, which therefore must exist (CG's z vector has the slack) — and pq holds the replicated camera part only.
 int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
-                const int* status, double* pq = nullptr, int* n_pq = nullptr) {
+                const int* status, double* pq = nullptr, int* n_pq = nullptr, const double** pq_extra = nullptr) {
   const int n9 = A.n_f9;
   const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
   const int32_t* cam_pos = A.cam_pos;
@@ -294,10 +296,14 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   if (s->world <= 1) {
     HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   } else {
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream));
+    const bool pack = pq && pq_extra && n_first > 0;  // CGNR's p.q: the shard's share rides along as element n9 of the all-reduce
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream,
+                                       pack ? pq : nullptr, n_first, pack ? y_f + n9 : nullptr));
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
-    TRY(allreduce(s, y_f, size_t(n9)));
-    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
+    TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
+    if (pack) { *pq_extra = y_f + n9; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
+    else if (pq) { pq = nullptr; n_first = 0; }       // sharded without the packing: no p.q from here
+    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq, &n_second, s->stream));
   }
   if (n_pq) *n_pq = n_first + n_second;
   return 0;
@@ -337,15 +343,17 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status, do
 }
 
 // y = (A^T A + D^2) x on full-space vectors.  CgnrLinearOperator (y zeroed by CG first).
-int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status, double* pq = nullptr, int* n_pq = nullptr) {
+int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status, double* pq = nullptr, int* n_pq = nullptr,
+            const double** pq_extra = nullptr) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   if (n_pq) *n_pq = 0;
+  if (pq_extra) *pq_extra = nullptr;
   if (s->path == CERES_HIP_PATH_BAL) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
-    return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status, pq, n_pq);
+    return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status, pq, n_pq, pq_extra);
   }
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
   HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, x, s->tmp_rows, status, st));
@@ -670,7 +678,9 @@ struct CgSpec {
   int64_t n_local = 0;                                  // sharded CGNR: E-space prefix
   std::function<int(const double*, double*)> apply;     // y = A x (assigns)
   // optional: y = A x AND the partial sums of x . y into pq[0 .. *n_pq) (n_pq <= kMaxPqParts); *n_pq = 0 if not produced
-  std::function<int(const double*, double*, double*, int*)> apply_dot;
+  // sharded: *extra = device pointer to the shard's share of x . y, already summed over ranks (nullptr if not produced)
+  std::function<int(const double*, double*, double*, int*, const double**)> apply_dot;
+  bool shard_fused = false;                             // sharded CG vectors, and apply_dot + the block layout support the fused iteration
   std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
   bool x0_nonzero = false;                              // B.x holds an initial guess
   const double* rhs = nullptr;                          // right-hand side (nullptr: s->cg_rhs)
@@ -775,11 +785,12 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   // Fused iteration: operator (+ p.q where its kernels have p and q in registers) -> cg_update (alpha, x, r, M^-1 r)
   // -> cg_finalize_direction (tests, beta, p): 2 launches after the operator instead of 5.  Needs a block-diagonal
   // (or no) preconditioner and unsharded CG vectors (ITERATIVE_SCHUR's camera-space vectors are replicated: fine).
-  const bool fused = s->cg_fused && !spec.precondition && B.grid_e == 0;
+  const bool fused = s->cg_fused && !spec.precondition && (B.grid_e == 0 || spec.shard_fused);
   const bool fused_start = fused && !spec.x0_nonzero;  // x0 = 0: the whole start of the solve is two launches
   if (fused_start) {
     HIP_TRY(s, LaunchCgUpdate(B, s->G, spec.first_block, spec.col_begin, spec.nblocks, spec.diag_off, spec.blocks, 0, 0,
                               s->nine_wide_from - spec.first_block, st));
+    TRY(collapse_and_reduce(s, 0, 4));  // sharded: |rhs|^2 and r.z of the shard, summed over ranks (no-op otherwise)
     HIP_TRY(s, LaunchCgBegin(B, q_tol, r_tol, min_it, max_it, st));
   } else {
   HIP_TRY(s, LaunchCgRhsNorm(B, st));
@@ -810,6 +821,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   };
   if (fused && !fused_start) {  // iteration 1's z = M^-1 r0, rho_1 and p = z; later directions come out of cg_finalize_direction
     TRY(precondition());
+    TRY(collapse_and_reduce(s, 0, 1));
     HIP_TRY(s, LaunchCgDirection(B, st));
   }
   while (s->h_scalars->status == kCgRunning) {
@@ -818,9 +830,12 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
       const int reset = (it % reset_period == 0) ? 1 : 0;
       if (fused) {
         int n_pq = 0;
-        if (spec.apply_dot) TRY(spec.apply_dot(B.p, B.z, s->cg_pq_parts, &n_pq));
+        const double* extra = nullptr;
+        if (spec.apply_dot) TRY(spec.apply_dot(B.p, B.z, s->cg_pq_parts, &n_pq, &extra));
         else TRY(spec.apply(B.p, B.z));
+        B.pq_extra = extra;
         if (n_pq > 0) { B.pq_parts = s->cg_pq_parts; B.n_pq = n_pq; }
+        else if (B.grid_e > 0) return fail(s, CERES_HIP_E_INVALID, "internal: sharded fused CG needs p.q from the operator");
         else {  // the operator did not leave p.q behind: one pass over p and q
           HIP_TRY(s, LaunchCgDotPq(B, st));
           B.pq_parts = B.partials + kMaxVecGrid; B.n_pq = B.grid;
@@ -834,6 +849,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
           TRY(precondition());
           ++s->timing.operator_applications;
         }
+        TRY(collapse_and_reduce(s, 0, 4));  // sharded: the shard's r.z, Q1, |r|^2 in one 4-double all-reduce (no-op otherwise)
         HIP_TRY(s, LaunchCgFinalizeDirection(B, it, st));
         continue;
       }
@@ -1097,7 +1113,10 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
     const int* status = &s->cg.S->status;
     spec.apply = [s, status](const double* in, double* out) { return op_sx(s, in, out, status); };
     if (s->path == CERES_HIP_PATH_BAL)
-      spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq) { return op_sx(s, in, out, status, pq, n_pq); };
+      spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq, const double** extra) {
+        *extra = nullptr;
+        return op_sx(s, in, out, status, pq, n_pq);
+      };
     spec.first_block = h.nelim;
     spec.nblocks = h.ncb - h.nelim;
     spec.col_begin = h.num_cols_e;
@@ -1145,8 +1164,14 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   spec.n_local = h.num_cols_e;  // sharded: first nelim column blocks are this rank's points
   const int* status = &s->cg.S->status;
   spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status); };
-  if (s->path == CERES_HIP_PATH_BAL && s->world <= 1)
-    spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq) { return op_jtjx(s, in, out, status, pq, n_pq); };
+  if (s->path == CERES_HIP_PATH_BAL) {
+    spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq, const double** extra) {
+      return op_jtjx(s, in, out, status, pq, n_pq, extra);
+    };
+    // sharded: the fused iteration needs the shard to be exactly the blocks in front of the 9-wide camera blocks (it is, on this
+    // path: points then cameras) so that cg_update's two workgroup ranges are the shard and the replicated part
+    spec.shard_fused = s->world > 1 && s->nine_wide_from == h.nelim && h.ncb > h.nelim;
+  }
   spec.first_block = 0;
   spec.nblocks = h.ncb;
   spec.n_local_blocks = h.nelim;
@@ -1360,7 +1385,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.r, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.p, size_t(cg_n)));
-  TRY(dev_alloc(s, &s->cg.z, size_t(cg_n)));
+  TRY(dev_alloc(s, &s->cg.z, size_t(cg_n) + 8));  // slack: a sharded operator all-reduces one scalar behind the camera part (bal_scatter)
   TRY(dev_alloc(s, &s->cg_rhs, size_t(cg_n)));
   TRY(dev_alloc(s, &s->cg.partials, size_t(4 * kMaxVecGrid)));
   TRY(dev_alloc(s, &s->cg.comm, 4));

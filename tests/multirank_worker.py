@@ -29,6 +29,7 @@ def run_rank(rank, world, conn, device, scenario):
 
         out = {}
         for name, kw in scenario:
+            os.environ["CERES_HIP_CG_FUSED"] = kw.get("cg_fused", "1")  # read when a solver is created
             kind = kw["kind"]
             if kind == "bal":
                 prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),

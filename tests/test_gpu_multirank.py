@@ -122,3 +122,22 @@ def test_two_ranks_generic_structure(hip, oracle, problems):
         xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=3000, q_tol=-1.0, r_tol=1e-12)
         assert all(rec["converged"][1] == hip.SUCCESS for rec in recs), [rec["converged"][1:] for rec in recs]
         assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-7
+
+
+def test_two_ranks_cgnr_fused_iteration_equals_the_six_kernel_iteration(hip, problems):
+    """Sharded CGNR on the <2,3,9> path: the two-launch iteration (the shard's p.q share travels with the camera vector through
+    the operator's all-reduce, r.z / Q1 / |r|^2 of the shard in one 4-double all-reduce) against the six-kernel sequence with
+    its four scalar all-reduces per iteration: same iteration counts, same termination, solutions equal to rounding — for a
+    converged solve (incl. residual resets every 10th iteration) and for the LM step."""
+    base = dict(kind="bal", seed=77, nc=45, np=5000, no=23000, skew=0.4, solvers=[(hip.CGNR, hip.JACOBI)], max_it=400)
+    res = run_ranks([("fused", dict(base, cg_fused="1")), ("unfused", dict(base, cg_fused="0"))])
+    for r in range(WORLD):
+        a, b = res[r][("fused", hip.CGNR, hip.JACOBI)], res[r][("unfused", hip.CGNR, hip.JACOBI)]
+        for key in ("converged", "lm_style", "lm_step"):
+            assert a[key][1] == b[key][1] == hip.SUCCESS and a[key][2] == b[key][2], (key, a[key][1:3], b[key][1:3])
+            assert rel(a[key][0], b[key][0]) <= 1e-10, key
+        assert a["converged"][2] > 12   # long enough to contain a residual reset
+        assert abs(a["lm_step"][3] - b["lm_step"][3]) <= 1e-10 * abs(b["lm_step"][3])
+    # and the ranks agree with each other on the replicated part, bit for bit, in the fused mode too
+    a0, a1 = res[0][("fused", hip.CGNR, hip.JACOBI)], res[1][("fused", hip.CGNR, hip.JACOBI)]
+    assert np.array_equal(a0["converged"][0][a0["n_e"]:], a1["converged"][0][a1["n_e"]:])
