@@ -22,16 +22,18 @@ def test_committed_bench_lines_follow_the_contract(path):
         assert k in d, k
     assert d["unit"] == "steps/s" and d["higher_is_better"] is True and d["scaling"] == "strong"
     assert d["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
-    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    two_ranks = "two_ranks" in path   # bench.py's N > 1 code path run with two ranks on ONE GPU (validation only, timings meaningless)
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == (2 if two_ranks else 1)
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 * d["n_gpus"]   # whole-job peak
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3)
-    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
+    if not two_ranks:   # N > 1: `achieved` is the sum over ranks, bytes and time on the line are rank 0's shard
+        assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
     cpu = d.get("cpu_baseline")
-    if "under_rocprof" not in path and "fp32" not in path:   # the profiled runs and the fp32-storage run skip the CPU leg
+    if "under_rocprof" not in path and "fp32" not in path and not two_ranks:   # profiled / fp32-storage / validation runs skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
     if os.path.basename(path).startswith("r02"):   # round 2: what the traffic figure is, and the probe for real Ceres
