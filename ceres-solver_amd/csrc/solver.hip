@@ -302,7 +302,8 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
     TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
     if (pack) { *pq_extra = y_f + n9; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
-    else if (pq) { pq = nullptr; n_first = 0; }       // sharded without the packing: no p.q from here
+    else if (n_first > 0) { pq = nullptr; n_first = 0; }  // the shard's point part without the packing: no complete p.q from here
+    // (S.x has no point part: its p.q is the replicated camera part, formed below as on one rank)
     HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq, &n_second, s->stream));
   }
   if (n_pq) *n_pq = n_first + n_second;
