@@ -68,6 +68,10 @@ struct BalArgs {
   const double* copy_src = nullptr;
   double* copy_dst = nullptr;
   int copy_n = 0;
+  // kBackSub as the last kernel of an LM step: store -x (the step) instead of x and raise *nonfinite if an entry is not
+  // finite (LevenbergMarquardtStrategy::ComputeStep's IsArrayValid + negation, I/levenberg_marquardt_strategy.cc:123-153)
+  int negate_out = 0;
+  int* nonfinite = nullptr;
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
@@ -202,8 +206,10 @@ hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partia
 hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t stream);
 // x = -x and *nonfinite += number of non-finite entries (IsArrayValid + negation, :124-132)
 // CGNR: y.g + y.r + |D y|^2 over [begin, end) as per-workgroup partials (nparts <= kMaxVecGrid)
+// neg_out (optional): also neg_out[i] = -y[i] over the range and *nonfinite += (entries that are not finite) — the LM step's
+// finite check + negation, read from the CG solution in the same pass
 hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
-                               double* partials, int* nparts, hipStream_t stream);
+                               double* partials, int* nparts, hipStream_t stream, double* neg_out = nullptr, int* nonfinite = nullptr);
 hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);

@@ -628,7 +628,11 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     seg_scan<3>(u, lane, s.first, span);
     double v[3];
     sym3_mul(ei, u, v);  // the point's solution on the last lane of its segment
-    if (s.valid && lane == s.last) { A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
+    if (s.valid && lane == s.last) {
+      const double sg = A.negate_out ? -1.0 : 1.0;  // the LM step is -x
+      A.y_e[po] = sg * v[0]; A.y_e[po + 1] = sg * v[1]; A.y_e[po + 2] = sg * v[2];
+      if (A.negate_out && !isfinite(v[0] + v[1] + v[2])) atomicAdd(A.nonfinite, 1);
+    }
     if (A.scalar_out) {
       // Model cost change of the trust-region step -x, fused: with m = J x of this observation
       // (F z + E y, y broadcast from the segment's last lane), -(J step)'(f + J step / 2) = m'(f - m / 2).
@@ -679,7 +683,12 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     load_ete_inverse(A, pt, ei);
     sym3_mul(ei, u, v);
     if constexpr (MODE == kBackSub) {
-      if (lane == 0) { const int po = pt_off(A, pt); A.y_e[po] = v[0]; A.y_e[po + 1] = v[1]; A.y_e[po + 2] = v[2]; }
+      if (lane == 0) {
+        const int po = pt_off(A, pt);
+        const double sg = A.negate_out ? -1.0 : 1.0;
+        A.y_e[po] = sg * v[0]; A.y_e[po + 1] = sg * v[1]; A.y_e[po + 2] = sg * v[2];
+        if (A.negate_out && !isfinite(v[0] + v[1] + v[2])) atomicAdd(A.nonfinite, 1);
+      }
       if (A.scalar_out) {  // fused model cost change: second sweep over the point's (L2-warm) tiles
         for (int t = 0; t < nt; ++t) {
           load_slot<false, F32>(A, tile + t, lane, s, true, false);
@@ -795,7 +804,11 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   double lane_acc = 0.0;
   if constexpr (MODE == kBackSub) {  // y_f = z (:238-242), a few KB: no separate copy launch
     if (A.copy_dst)
-      for (int i = blockIdx.x * BLOCK + threadIdx.x; i < A.copy_n; i += gridDim.x * BLOCK) A.copy_dst[i] = A.copy_src[i];
+      for (int i = blockIdx.x * BLOCK + threadIdx.x; i < A.copy_n; i += gridDim.x * BLOCK) {
+        const double z = A.copy_src[i];
+        A.copy_dst[i] = A.negate_out ? -z : z;
+        if (A.negate_out && !isfinite(z)) atomicAdd(A.nonfinite, 1);
+      }
   }
   const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);

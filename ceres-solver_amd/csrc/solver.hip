@@ -70,6 +70,11 @@ struct ceres_hip_solver {
   bool fail_flag_clean = false, nonfinite_clean = false;  // cleared together at the start of a solve: the per-operator memsets are skipped once
   bool have_lm_diag = false;
   bool lm_want_model_cost = false;  // op_back_substitute also accumulates the model cost change (fused <2,3,9> path)
+  // LM step on the fused path: the last kernel that touches the solution writes the negated step and checks it for finiteness
+  // (ITERATIVE_SCHUR: the back-substitution kernel; CGNR: the model-cost kernel, which then also replaces the copy-out of x)
+  bool lm_negate_in_solve = false;
+  bool lm_negated = false;          // set by whoever did it (or, for CGNR, deferred it: lm_cgnr_copy_pending)
+  bool lm_cgnr_copy_pending = false;
   int backsub_cost_parts = 0;       // partials it left in scalar_partials
   bool lm_fuse_active = false;      // this step forms D inside the set-up kernels (no separate column-norm pass)
   ceres_hip_lm_options lm_opts{};
@@ -429,6 +434,12 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
     s->backsub_cost_parts = 0;
     if (s->lm_want_model_cost && z != nullptr) { A.scalar_out = s->scalar_partials; s->backsub_cost_parts = s->fused_grid; }
     if (h.num_cols_f > 0 && z != nullptr) { A.copy_src = z; A.copy_dst = x + h.num_cols_e; A.copy_n = h.num_cols_f; }
+    if (s->lm_negate_in_solve && z != nullptr) {
+      if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
+      s->nonfinite_clean = false;
+      A.negate_out = 1; A.nonfinite = s->d_nonfinite;
+      s->lm_negated = true;
+    }
     HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
     return 0;
   } else {
@@ -1182,7 +1193,9 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   if (defer_check && spec.blocks) spec.setup_fail = s->d_fail_flag;
   TRY(run_cg(s, spec, q_tol, r_tol, summary));
   HIP_TRY(s, hipEventRecord(s->ev[5], st));
-  HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));
+  // LM step: the model-cost kernel reads the solution anyway and writes the negated step (no copy-out, no separate negation pass)
+  if (s->lm_negate_in_solve) s->lm_cgnr_copy_pending = true;
+  else HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));
   HIP_TRY(s, hipEventRecord(s->ev[6], st));
   return 0;
 }
@@ -1746,19 +1759,32 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   s->have_D = true;
   s->lm_want_model_cost = is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->fused_grid <= 2 * kMaxVecGrid;
   s->backsub_cost_parts = 0;
+  // fused <2,3,9> path, implicit solvers: negation + finite check ride in the last kernel that touches the solution
+  s->lm_negate_in_solve = s->path == CERES_HIP_PATH_BAL && !s->opt.use_explicit_schur_complement && !is_dense_schur(s);
+  s->lm_negated = false;
+  s->lm_cgnr_copy_pending = false;
   const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
   s->lm_fuse_active = false;
   s->lm_want_model_cost = false;
+  s->lm_negate_in_solve = false;
+  const bool cgnr_deferred = s->lm_cgnr_copy_pending;
+  s->lm_cgnr_copy_pending = false;
   if (rc) return rc;
   res->step_is_finite = 0;
   const int term = res->linear_solver.termination_type;
-  if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) return 0;
+  if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) {
+    if (cgnr_deferred) HIP_TRY(s, hipMemcpyAsync(dx, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));  // what Solve leaves in x
+    return 0;
+  }
   // Finite check + negation and the model cost change are enqueued together and read back with ONE
   // synchronisation (and, sharded, one all-reduce of {flag, cost}); a non-finite step makes the
   // cost meaningless, it is then ignored.
-  if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
-  s->nonfinite_clean = false;
-  HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
+  if (!s->lm_negated) {
+    if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
+    s->nonfinite_clean = false;
+    if (!cgnr_deferred) HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
+  }
+  double* const neg = cgnr_deferred ? dx : nullptr;  // CGNR: the model-cost kernel writes dx = -y and checks it
   // parts_local: this rank's share (summed over ranks); parts_shared: replicated quantities (counted once)
   const double *parts_local = nullptr, *parts_shared = nullptr;
   int n_local = 0, n_shared = 0;
@@ -1766,14 +1792,14 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     // CGNR: no pass over J is needed.  With y the CG solution (step = -y), g = J^T f and r = g - (J^T J + D^2) y
     // the residual CG carries:  -(J step)'(f + J step / 2) = y.g - |J y|^2 / 2 = (y.g + y.r + |D y|^2) / 2.
     if (s->world > 1) {  // the point part is sharded, the camera part replicated
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols_e, s->scalar_partials, &n_local, st));
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, h.num_cols_e, h.num_cols, s->scalar_partials + kMaxVecGrid, &n_shared, st));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols_e, s->scalar_partials, &n_local, st, neg, s->d_nonfinite));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, h.num_cols_e, h.num_cols, s->scalar_partials + kMaxVecGrid, &n_shared, st, neg, s->d_nonfinite));
       if (h.num_cols_e <= 0) n_local = 0;
       if (h.num_cols <= h.num_cols_e) n_shared = 0;
       parts_local = s->scalar_partials;
       parts_shared = s->scalar_partials + kMaxVecGrid;
     } else {
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st, neg, s->d_nonfinite));
       if (h.num_cols <= 0) n_shared = 0;
       parts_shared = s->scalar_partials;
     }
