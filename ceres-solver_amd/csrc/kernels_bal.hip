@@ -1282,13 +1282,16 @@ __global__ __launch_bounds__(256) void bal_camera_chunk_kernel(ZUnits U, const d
 // order per entry as a scalar column-Cholesky (the reference: Eigen LLT on the upper triangle,
 // I/block_random_access_diagonal_matrix.cc:106-127); one thread per camera, as this kernel first
 // was, ran a ~1000-instruction dependent chain with 648-byte strided accesses: 31 us for 1778 cameras.
-__global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
+constexpr int kInvertGatherWaves = 4;
+__global__ __launch_bounds__(64 * kInvertGatherWaves) void bal_invert9_kernel(double* __restrict__ blocks, const int64_t* __restrict__ cam_diag_off,
                                                          int n_cameras, int* fail_flag, LmFuse lm, CamGather gather) {
-  __shared__ double csum[kCamPart];
-  const int lane = threadIdx.x;
+  __shared__ double csum[kInvertGatherWaves][kCamPart];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
   const int grp = lane / 9, i = lane - 9 * grp;  // lane 63 idles
-  // assembled blocks: seven cameras per wavefront; per-item partial sums (gather.parts): ONE camera per wavefront, whose
-  // 54 lanes first add up the camera's items entry by entry (coalesced 432-byte rows), then lanes 0..8 take the rows
+  // assembled blocks: seven cameras per wavefront (64-thread workgroups); per-item partial sums (gather.parts): ONE camera per
+  // workgroup of kInvertGatherWaves wavefronts, whose 54 lanes each add up every kInvertGatherWaves-th item of the camera entry by
+  // entry (coalesced 432-byte rows) — the kernel lasts as long as its most popular camera, whose item list one wavefront alone
+  // walked for 46 us on the Venice shape —, then wave 0 combines the partial sums in a fixed order and lanes 0..8 take the rows
   const bool gathering = gather.parts != nullptr;
   const int c = gathering ? int(blockIdx.x) : int(blockIdx.x) * 7 + grp;
   const bool active = (gathering ? grp == 0 : grp < 7) && c < n_cameras;
@@ -1300,22 +1303,29 @@ __global__ __launch_bounds__(64) void bal_invert9_kernel(double* __restrict__ bl
     const int item_lo = gather.cam_item_ptr[blockIdx.x], item_hi = gather.cam_item_ptr[blockIdx.x + 1];
     if (lane < kCamPart) {
       double s0 = 0.0, s1 = 0.0;
-      int it = item_lo;
-      for (; it + 1 < item_hi; it += 2) {
+      int it = item_lo + wv;
+      for (; it + nwv < item_hi; it += 2 * nwv) {
         s0 += gather.parts[int64_t(it) * kCamPart + lane];
-        s1 += gather.parts[int64_t(it + 1) * kCamPart + lane];
+        s1 += gather.parts[int64_t(it + nwv) * kCamPart + lane];
       }
       if (it < item_hi) s0 += gather.parts[int64_t(it) * kCamPart + lane];
-      csum[lane] = s0 + s1;
+      csum[wv][lane] = s0 + s1;
     }
     __syncthreads();
+    if (wv != 0) return;
+    if (lane < kCamPart) {
+      double t = csum[0][lane];
+      for (int w = 1; w < nwv; ++w) t += csum[w][lane];
+      csum[0][lane] = t;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (active) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const int ra = k < i ? k : i, rb = k < i ? i : k;
-        row[k] = csum[ra * (19 - ra) / 2 + (rb - ra)];
+        row[k] = csum[0][ra * (19 - ra) / 2 + (rb - ra)];
       }
-      sq_from_items = csum[45 + i];
+      sq_from_items = csum[0][45 + i];
       if (gather.D_f) {
         const double d = gather.D_f[(gather.cam_pos ? gather.cam_pos[c] : 9 * c) + i];
 #pragma unroll
@@ -1532,7 +1542,7 @@ hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* s
 
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             const CamGather& gather, hipStream_t stream) {
-  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3(gather.parts ? n_cameras : (n_cameras + 6) / 7), dim3(64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3(gather.parts ? n_cameras : (n_cameras + 6) / 7), dim3(gather.parts ? 64 * kInvertGatherWaves : 64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
   return hipGetLastError();
 }
 
