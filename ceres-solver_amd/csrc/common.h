@@ -75,8 +75,6 @@ struct BalPlan {
   std::vector<int32_t> cam_ptr;    // n_cameras+1
   std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major
   std::vector<int32_t> cam_slot;   // slot of each observation, camera-major
-  std::vector<int32_t> cam_epos;   // E value offset of each observation, camera-major
-  std::vector<int32_t> cam_pt;     // point of each observation, camera-major
   // work items of the camera-block kernel: (camera, [begin,end) in the camera-major list)
   std::vector<int32_t> item_cam, item_begin, item_end;
   std::vector<int32_t> cam_item_ptr;  // n_cameras+1: items [cam_item_ptr[c], cam_item_ptr[c+1]) belong to camera c

@@ -105,16 +105,8 @@ struct CamItems {
 // column square sums in parts[item][kCamPart]; the items of a camera (cam_item_ptr) are then added in list order either by
 // LaunchBalCameraFinish (raw sums to memory, + D_f^2 if given) or by the load phase of LaunchBalInvert9 (CamGather).
 constexpr int kCamPart = 54;
-// SCHUR items need M_o = I - E_o (E^T E + D^2)^-1 E_o^T of every observation: either read from Mo ([slot][4], written by kInit)
-// through cam_slot, or — recompute != nullptr — formed from the E cell (which shares the F cell's cache lines in the caller's
-// layout) and the point's packed 3x3 inverse.
-struct CamRecompute {
-  const int32_t *cam_epos = nullptr, *cam_pt = nullptr;
-  const double* etei = nullptr;
-};
 hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream,
-                                const CamRecompute* recompute = nullptr);
+                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream);
 hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
                                  const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream);
 struct CamGather {

@@ -1139,12 +1139,11 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // waves stay near 2.2x (1.9 GB for 0.88 GB of F and M_o on the Venice shape).  Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
 // per cell into an LDS strip and each lane picking its observation up from there — one line request per line, but load ->
 // LDS -> compute serialise inside an iteration and the wave count drops with the 36 KB of LDS per workgroup.
-template <bool SCHUR, bool RECOMPUTE = false>
+template <bool SCHUR>
 __global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __restrict__ values, CamItems items,
                                                                const int32_t* __restrict__ cam_fpos,
                                                                const int32_t* __restrict__ cam_slot,
-                                                               const double* __restrict__ Mo, double* __restrict__ parts,
-                                                               CamRecompute R) {
+                                                               const double* __restrict__ Mo, double* __restrict__ parts) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= items.count) return;
@@ -1160,26 +1159,10 @@ __global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __r
 #pragma unroll
     for (int k = 0; k < 9; ++k) { f0[k] = f[k]; f1[k] = f[9 + k]; }
     double m00 = 1.0, m01 = 0.0, m11 = 1.0;
-    if constexpr (SCHUR && RECOMPUTE) {
-      // M = I - E Ei E^T from the E cell (same 192-byte record as F in Ceres' layouts: no extra cache line) and the point's
-      // packed inverse (48 bytes out of a 48 MB array instead of 32 bytes out of a 169 MB one); same arithmetic as kInit's
-      const double* e = values + R.cam_epos[q];
-      const double2* qi = reinterpret_cast<const double2*>(R.etei + int64_t(R.cam_pt[q]) * 6);
-      const double2 ia = qi[0], ib = qi[1], ic = qi[2];
-      const double ei[6] = {ia.x, ia.y, ib.x, ib.y, ic.x, ic.y};
-      const double r0[3] = {e[0], e[1], e[2]}, r1[3] = {e[3], e[4], e[5]};
-      double q0[3], q1[3];
-      sym3_mul(ei, r0, q0);
-      sym3_mul(ei, r1, q1);
-      m00 = 1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]);
-      m01 = -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]);
-      m11 = 1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]);
-    } else if constexpr (SCHUR) {
+    if constexpr (SCHUR) {
       const double2* mo = reinterpret_cast<const double2*>(Mo + 4 * int64_t(cam_slot[q]));
       const double2 a = mo[0], b = mo[1];  // plain loads: non-temporal ones (no L1) made this pass 8 % slower (r02y)
       m00 = a.x; m01 = a.y; m11 = b.x;
-    }
-    if constexpr (SCHUR) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) sq[k] += f0[k] * f0[k] + f1[k] * f1[k];  // column norms of the camera columns (the blocks hold F^T M F, not F^T F)
     }
@@ -1564,14 +1547,11 @@ hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_c
 }
 
 hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream,
-                                const CamRecompute* recompute) {
+                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
   const dim3 grid((items.count + 3) / 4);
-  const CamRecompute none;
-  if (schur && recompute) hipLaunchKernelGGL((bal_camera_items_kernel<true, true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts, *recompute);
-  else if (schur) hipLaunchKernelGGL((bal_camera_items_kernel<true, false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts, none);
-  else hipLaunchKernelGGL((bal_camera_items_kernel<false, false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts, none);
+  if (schur) hipLaunchKernelGGL((bal_camera_items_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  else hipLaunchKernelGGL((bal_camera_items_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
   return hipGetLastError();
 }
 

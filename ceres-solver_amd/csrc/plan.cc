@@ -301,8 +301,6 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   }
   P.cam_fpos.resize(P.n_obs);
   P.cam_slot.resize(P.n_obs);
-  P.cam_epos.resize(P.n_obs);
-  P.cam_pt.resize(P.n_obs);
   {
     std::vector<int32_t> cur(P.cam_ptr.begin(), P.cam_ptr.end() - 1);
     for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
@@ -310,8 +308,6 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
       const int q = cur[P.slot_cam[s]]++;
       P.cam_fpos[q] = P.slot_fpos[s];
       P.cam_slot[q] = int32_t(s);
-      P.cam_epos[q] = P.slot_epos[s];
-      P.cam_pt[q] = P.slot_pt[s];
     }
   }
   // Item size: kCamChunk at scale; smaller problems get shorter items so that they too spread over the chip, but never

@@ -59,8 +59,6 @@ struct ceres_hip_solver {
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
-  bool mo_recompute = false;       // SCHUR_JACOBI items form M_o from the E cell and the point inverse instead of reading kInit's M_o array
-  CamRecompute cam_recompute;
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
@@ -396,7 +394,7 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
   if (s->path == CERES_HIP_PATH_BAL) {
     BalArgs A = bal_args(s);
     A.D_e = s->D;
-    A.Mo = (want_Mo && !s->mo_recompute) ? s->d_Mo : nullptr;
+    A.Mo = want_Mo ? s->d_Mo : nullptr;
     use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
     if (s->have_b) return bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr);
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
@@ -473,8 +471,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     if (s->path == CERES_HIP_PATH_BAL) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
       const bool fuse = s->lm_fuse_active && invert;
-      HIP_TRY(s, LaunchBalCameraItems(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st,
-                                      (schur && s->mo_recompute) ? &s->cam_recompute : nullptr));
+      HIP_TRY(s, LaunchBalCameraItems(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
       if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
         CamGather g;
@@ -1433,16 +1430,6 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_cam_fpos, P.cam_fpos));
     TRY(dev_upload(s, &s->d_cam_slot, P.cam_slot));
     {
-      // fp64 tiles only: with fp32 tiles kInit's M_o is formed from the ROUNDED E, which the caller's layout does not hold
-      const char* e = getenv("CERES_HIP_MO_RECOMPUTE");
-      s->mo_recompute = s->opt.jacobian_storage == 0 && (e ? atoi(e) != 0 : false);
-      if (s->mo_recompute) {
-        int32_t *ce = nullptr, *cp = nullptr;
-        TRY(dev_upload(s, &ce, P.cam_epos)); TRY(dev_upload(s, &cp, P.cam_pt));
-        s->cam_recompute.cam_epos = ce; s->cam_recompute.cam_pt = cp;
-      }
-    }
-    {
       int32_t *ic = nullptr, *ib = nullptr, *ie = nullptr;
       TRY(dev_upload(s, &ic, P.item_cam));
       TRY(dev_upload(s, &ib, P.item_begin));
@@ -1461,9 +1448,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));
     else TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
-    TRY(dev_alloc(s, &s->d_Mo, s->mo_recompute ? size_t(1) : 4 * n_slots));
+    TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
-    s->cam_recompute.etei = s->etei;
     const size_t n9 = size_t(9) * P.n_cameras;
     s->lds_mode = P.cameras_in_lds;
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
