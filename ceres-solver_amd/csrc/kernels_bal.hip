@@ -1136,7 +1136,10 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 // Loads: every lane reads "its" 144-byte cell (18 loads of 8 bytes, all issued before the first use).  A naive lane-per-cell
 // gather LOOP with half a million lanes in flight (tools/probes/gather_probe.hip) fetches 3-5x its useful bytes by FETCH_SIZE,
 // whatever the order of the cells (profiles/r02l_gather_probe_fetch_size_calibration.txt); this kernel's few, register-heavy
-// waves stay near 2.2x (1.9 GB for 0.88 GB of F and M_o on the Venice shape).  Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
+// waves stay near 2.2x (1.9 GB for 0.88 GB of F and M_o on the Venice shape).  Measured, no effect (r02af): nine 16-byte loads per
+// cell instead of eighteen 8-byte ones.  Measured SLOWER (r02ae, 0.46 vs 0.33 ms): forming M_o here from the E cell and the point's
+// packed inverse instead of reading the M_o record (it saves kInit 0.034 ms of writes and costs this pass 0.13 ms).
+// Tried and measured SLOWER (r02m, 0.65 vs 0.37 ms on the Venice shape): cooperative loading, nine lanes x 16 bytes
 // per cell into an LDS strip and each lane picking its observation up from there — one line request per line, but load ->
 // LDS -> compute serialise inside an iteration and the wave count drops with the 36 KB of LDS per workgroup.
 template <bool SCHUR>
