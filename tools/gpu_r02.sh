@@ -77,6 +77,8 @@ PY
         done
         cd $REPO
       done ;;
+    boxinfo)   # what kind of box is this (write-carrying kernels vary by box)
+      { rocm-smi --showcomputepartition --showmemorypartition --showclocks --showperflevel --showpower --showtemp --showuse 2>&1 | grep -v "^$" | head -60; } | tee $OUT/boxinfo_$TAG.txt ;;
     p2plat) timeout 300 python tools/p2p_latency.py 2>$OUT/p2p_latency_$TAG.err | tail -1 | tee $OUT/p2p_latency_$TAG.json; tail -2 $OUT/p2p_latency_$TAG.err ;;
     bench_n2)  # the N > 1 code path of bench.py and of the library with two ranks on ONE GPU (validation only: timings meaningless)
       for WL in ${WLS:-ladybug1723 synthetic1M}; do for SV in iterative_schur cgnr; do
