@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU-box session (run through gpurun).  usage: tools/gpu_r02.sh TAG stage [stage ...]
-# stages: probe pytest smoke bench bench_cgnr bench10m bench10m_fp32 longcg small rocprof rocprof10m
+# stages: probe boxinfo pytest pytest_all smoke bench bench_cgnr bench10m bench10m_fp32 bench1m bench_n2 longcg small ktimes ktimes1m pmc p2plat gather ab_mo ab_z rocprof rocprof10m rocprof1m rocprof_small
 TAG=$1; shift
 REPO=$(cd $(dirname $0)/.. && pwd)
 OUT=$REPO/gpurun_out
