@@ -23,6 +23,26 @@ namespace {
 
 int g_threads = 1;
 
+// ParallelSetZero / ParallelAssign (I/parallel_vector_ops.h: the reference splits vectors above a minimum block size
+// over its thread pool; used by ImplicitSchurComplement for every temporary, I/implicit_schur_complement.cc:109-158, :212-241)
+constexpr long kMinParallelVectorSize = 1 << 16;
+void parallel_set_zero(double* x, long n) {
+  if (g_threads == 1 || n < kMinParallelVectorSize) { std::fill(x, x + n, 0.0); return; }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < n; ++i) x[i] = 0.0;
+}
+void parallel_negate(double* x, long n) {
+  if (g_threads == 1 || n < kMinParallelVectorSize) { for (long i = 0; i < n; ++i) x[i] = -x[i]; return; }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < n; ++i) x[i] = -x[i];
+}
+// y = a - y
+void parallel_subtract_from(const double* a, double* y, long n) {
+  if (g_threads == 1 || n < kMinParallelVectorSize) { for (long i = 0; i < n; ++i) y[i] = a[i] - y[i]; return; }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < n; ++i) y[i] = a[i] - y[i];
+}
+
 using Vec = std::vector<double>;
 
 // --------------------------------------------------------------------------
@@ -526,13 +546,13 @@ void add_diagonal_and_invert(const oracle_matrix* m, int first_block, int num_bl
 void isc_update_rhs(oracle_isc* s) {
   // I/implicit_schur_complement.cc:251-276
   const oracle_matrix* m = s->m;
-  std::fill(s->tmp_e.begin(), s->tmp_e.end(), 0.0);
+  parallel_set_zero(s->tmp_e.data(), long(s->tmp_e.size()));
   oracle_left_multiply_e(m, s->values, s->b, s->tmp_e.data());
-  std::fill(s->tmp_e2.begin(), s->tmp_e2.end(), 0.0);
+  parallel_set_zero(s->tmp_e2.data(), long(s->tmp_e2.size()));
   oracle_block_diagonal_apply(m->nelim, s->e_sizes.data(), s->ete_inv.data(), s->tmp_e.data(), s->tmp_e2.data());
-  std::fill(s->tmp_rows.begin(), s->tmp_rows.end(), 0.0);
+  parallel_set_zero(s->tmp_rows.data(), long(s->tmp_rows.size()));
   oracle_right_multiply_e(m, s->values, s->tmp_e2.data(), s->tmp_rows.data());
-  for (int i = 0; i < m->num_rows; ++i) s->tmp_rows[i] = s->b[i] - s->tmp_rows[i];
+  parallel_subtract_from(s->b, s->tmp_rows.data(), m->num_rows);
   std::fill(s->rhs.begin(), s->rhs.end(), 0.0);
   oracle_left_multiply_f(m, s->values, s->tmp_rows.data(), s->rhs.data());
 }
@@ -567,13 +587,13 @@ void oracle_isc_init(oracle_isc* s, const double* values, const double* D, const
 // RightMultiplyAndAccumulate, :106-144.  Note: ASSIGNS y.
 void oracle_isc_sx(oracle_isc* s, const double* x, double* y) {
   const oracle_matrix* m = s->m;
-  std::fill(s->tmp_rows.begin(), s->tmp_rows.end(), 0.0);
+  parallel_set_zero(s->tmp_rows.data(), long(s->tmp_rows.size()));
   oracle_right_multiply_f(m, s->values, x, s->tmp_rows.data());
-  std::fill(s->tmp_e.begin(), s->tmp_e.end(), 0.0);
+  parallel_set_zero(s->tmp_e.data(), long(s->tmp_e.size()));
   oracle_left_multiply_e(m, s->values, s->tmp_rows.data(), s->tmp_e.data());
-  std::fill(s->tmp_e2.begin(), s->tmp_e2.end(), 0.0);
+  parallel_set_zero(s->tmp_e2.data(), long(s->tmp_e2.size()));
   oracle_block_diagonal_apply(m->nelim, s->e_sizes.data(), s->ete_inv.data(), s->tmp_e.data(), s->tmp_e2.data());
-  for (double& t : s->tmp_e2) t = -t;
+  parallel_negate(s->tmp_e2.data(), long(s->tmp_e2.size()));
   oracle_right_multiply_e(m, s->values, s->tmp_e2.data(), s->tmp_rows.data());
   if (s->D && s->f_diagonal_in_sx) {
     const double* Df = s->D + m->num_cols_e;
@@ -636,12 +656,12 @@ void oracle_isc_ete_inverse(const oracle_isc* s, double* blocks) { std::copy(s->
 // BackSubstitute, :208-243.  z may be NULL when there are no F blocks.
 void oracle_isc_back_substitute(oracle_isc* s, const double* z, double* x) {
   const oracle_matrix* m = s->m;
-  std::fill(s->tmp_rows.begin(), s->tmp_rows.end(), 0.0);
+  parallel_set_zero(s->tmp_rows.data(), long(s->tmp_rows.size()));
   if (m->num_cols_f > 0) oracle_right_multiply_f(m, s->values, z, s->tmp_rows.data());
-  for (int i = 0; i < m->num_rows; ++i) s->tmp_rows[i] = s->b[i] - s->tmp_rows[i];
-  std::fill(s->tmp_e.begin(), s->tmp_e.end(), 0.0);
+  parallel_subtract_from(s->b, s->tmp_rows.data(), m->num_rows);
+  parallel_set_zero(s->tmp_e.data(), long(s->tmp_e.size()));
   oracle_left_multiply_e(m, s->values, s->tmp_rows.data(), s->tmp_e.data());
-  std::fill(x, x + m->num_cols, 0.0);
+  parallel_set_zero(x, m->num_cols);
   oracle_block_diagonal_apply(m->nelim, s->e_sizes.data(), s->ete_inv.data(), s->tmp_e.data(), x);
   for (int i = 0; i < m->num_cols_f; ++i) x[m->num_cols_e + i] = z[i];
 }
