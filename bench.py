@@ -35,6 +35,13 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # cpu_baseline leg (N = 1 only): keep the oracle's OpenMP threads next to each other and on the socket that holds the
+    # data — 8 % on the two-socket host of the GPU boxes (tools/cpu_oracle_probe.py); must be set before any OpenMP
+    # runtime starts.  Not for N > 1: every rank's main thread would be pinned to the same core.
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

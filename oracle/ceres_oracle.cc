@@ -224,6 +224,8 @@ struct oracle_matrix {
   // (camera degrees are heavily skewed; the reference balances its ParallelFor the same way, by cumulative nnz,
   // I/partitioned_matrix_view_impl.h:89-103)
   std::vector<int> f_ranges;
+  std::vector<int> col_ranges;  // all column blocks cut into runs of about equal numbers of non-zeros (as the reference's
+                                // ParallelFor over the transpose structure partitions by cumulative_nnz, I/block_sparse_matrix.cc:293-325)
 };
 
 extern "C" {
@@ -297,6 +299,23 @@ oracle_matrix* oracle_matrix_create(const oracle_block_structure* bs, int num_el
       if (j > m->f_ranges.back() && j < m->ncb) m->f_ranges.push_back(j);
     }
     m->f_ranges.push_back(m->ncb);
+  }
+  {
+    std::vector<int64_t> nnz(m->ncb + 1, 0);
+    for (int j = 0; j < m->ncb; ++j) {
+      int64_t n = 0;
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) n += int64_t(m->rsz[m->trow[t]]) * m->csz[j];
+      nnz[j + 1] = nnz[j] + n;
+    }
+    const int want = std::max(1, std::min(m->ncb, 4096));
+    m->col_ranges.assign(1, 0);
+    for (int k = 1; k < want; ++k) {
+      const int64_t target = nnz[m->ncb] * k / want;
+      int j = int(std::lower_bound(nnz.begin(), nnz.end(), target) - nnz.begin());
+      j = std::max(j, m->col_ranges.back());
+      if (j > m->col_ranges.back() && j < m->ncb) m->col_ranges.push_back(j);
+    }
+    m->col_ranges.push_back(m->ncb);
   }
   // Chunks: maximal runs of rows sharing their first (E) block.
   if (m->nelim > 0) {
@@ -374,25 +393,29 @@ void oracle_left_multiply(const oracle_matrix* m, const double* v, const double*
       }
     return;
   }
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
-  for (int j = 0; j < m->ncb; ++j)
-    for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
-      const int i = m->trow[t], k = m->tcell[t];
-      mat_t_vec(v + m->cval[k], m->rsz[i], m->csz[j], x + m->rpos[i], y + m->cpos[j], 1);
-    }
+  const int n_ranges = int(m->col_ranges.size()) - 1;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+  for (int rg = 0; rg < n_ranges; ++rg)
+    for (int j = m->col_ranges[rg]; j < m->col_ranges[rg + 1]; ++j)
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
+        const int i = m->trow[t], k = m->tcell[t];
+        mat_t_vec(v + m->cval[k], m->rsz[i], m->csz[j], x + m->rpos[i], y + m->cpos[j], 1);
+      }
 }
 
 // I/block_sparse_matrix.cc:351-401.
 void oracle_squared_column_norm(const oracle_matrix* m, const double* v, double* x) {
-  std::fill(x, x + m->num_cols, 0.0);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
-  for (int j = 0; j < m->ncb; ++j)
-    for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
-      const int i = m->trow[t], k = m->tcell[t];
-      const double* a = v + m->cval[k];
-      for (int r = 0; r < m->rsz[i]; ++r)
-        for (int c = 0; c < m->csz[j]; ++c) x[m->cpos[j] + c] += a[r * m->csz[j] + c] * a[r * m->csz[j] + c];
-    }
+  parallel_set_zero(x, m->num_cols);
+  const int n_ranges = int(m->col_ranges.size()) - 1;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+  for (int rg = 0; rg < n_ranges; ++rg)
+    for (int j = m->col_ranges[rg]; j < m->col_ranges[rg + 1]; ++j)
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
+        const int i = m->trow[t], k = m->tcell[t];
+        const double* a = v + m->cval[k];
+        for (int r = 0; r < m->rsz[i]; ++r)
+          for (int c = 0; c < m->csz[j]; ++c) x[m->cpos[j] + c] += a[r * m->csz[j] + c] * a[r * m->csz[j] + c];
+      }
 }
 
 // I/block_sparse_matrix.cc:403-450.
@@ -901,18 +924,20 @@ void block_jacobi(const oracle_matrix* m, const double* v, const double* D, doub
                   oracle_allreduce_fn ar, void* ctx) {
   const int64_t len = m->diag_offset_all.back();
   std::fill(inv, inv + len, 0.0);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
-  for (int j = 0; j < m->ncb; ++j)
-    for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
-      const int i = m->trow[t], k = m->tcell[t];
-      mat_t_mat(v + m->cval[k], m->rsz[i], m->csz[j], v + m->cval[k], m->csz[j], inv + m->diag_offset_all[j], 0, 0, m->csz[j], 1);
-    }
+  const int n_ranges = int(m->col_ranges.size()) - 1;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+  for (int rg = 0; rg < n_ranges; ++rg)
+    for (int j = m->col_ranges[rg]; j < m->col_ranges[rg + 1]; ++j)
+      for (int t = m->tptr[j]; t < m->tptr[j + 1]; ++t) {
+        const int i = m->trow[t], k = m->tcell[t];
+        mat_t_mat(v + m->cval[k], m->rsz[i], m->csz[j], v + m->cval[k], m->csz[j], inv + m->diag_offset_all[j], 0, 0, m->csz[j], 1);
+      }
   if (ar) ar(ctx, inv + m->diag_offset_all[m->nelim], len - m->diag_offset_all[m->nelim]);
   if (D)
     for (int j = 0; j < m->ncb; ++j)
       for (int i = 0; i < m->csz[j]; ++i) inv[m->diag_offset_all[j] + i * m->csz[j] + i] += D[m->cpos[j] + i] * D[m->cpos[j] + i];
   if (raw) std::copy(inv, inv + len, raw);
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 256)
   for (int j = 0; j < m->ncb; ++j) invert_spd_upper(m->csz[j], inv + m->diag_offset_all[j]);
 }
 
