@@ -72,6 +72,9 @@ struct BalArgs {
   // finite (LevenbergMarquardtStrategy::ComputeStep's IsArrayValid + negation, I/levenberg_marquardt_strategy.cc:123-153)
   int negate_out = 0;
   int* nonfinite = nullptr;
+  // Speculative tail of an LM step: the kernel is enqueued BEFORE the host knows whether CG has ended, and does nothing
+  // unless *run_after_cg is a terminal status that lets the solution be used (CgStatusAllowsSolution)
+  const int* run_after_cg = nullptr;
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
 };
@@ -208,8 +211,10 @@ hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, d
 // CGNR: y.g + y.r + |D y|^2 over [begin, end) as per-workgroup partials (nparts <= kMaxVecGrid)
 // neg_out (optional): also neg_out[i] = -y[i] over the range and *nonfinite += (entries that are not finite) — the LM step's
 // finite check + negation, read from the CG solution in the same pass
+// gate (optional): a CG status word; the kernel does nothing unless CgStatusAllowsSolution(*gate) (speculative LM tail)
 hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
-                               double* partials, int* nparts, hipStream_t stream, double* neg_out = nullptr, int* nonfinite = nullptr);
+                               double* partials, int* nparts, hipStream_t stream, double* neg_out = nullptr, int* nonfinite = nullptr,
+                               const int* gate = nullptr);
 hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);
@@ -229,6 +234,11 @@ enum CgStatus {
   kCgInitialResidual = 9,  // min_num_iterations == 0 and |r0| <= tol
   kCgSetupFailed = 10,     // the preconditioner blocks could not be factorized (flag checked by the init kernels, no host round trip)
 };
+// Terminal CG states whose solution the caller uses: SUCCESS and NO_CONVERGENCE (solve_loaded back-substitutes for these and
+// for no others; fill_summary maps the rest to FAILURE).
+__host__ __device__ inline bool CgStatusAllowsSolution(int st) {
+  return st != kCgRunning && st != kCgFailRho && st != kCgFailBeta && st != kCgFailAlpha && st != kCgSetupFailed;
+}
 
 struct CgScalars {
   double norm_rhs, tol_r, q_tol;

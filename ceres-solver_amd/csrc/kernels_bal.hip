@@ -789,6 +789,7 @@ template <int MODE, bool LDS, int BLOCK, bool F32>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;  // CG already terminated: nothing to do
+  if (A.run_after_cg && !CgStatusAllowsSolution(*A.run_after_cg)) return;  // speculative tail: CG has not ended (or failed)
   constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm || MODE == kSpseZ);
   double* acc = nullptr;
   if constexpr (kScatters) {

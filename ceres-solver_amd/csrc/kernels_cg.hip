@@ -142,8 +142,9 @@ __global__ __launch_bounds__(kVecBlock) void negate_and_check_kernel(double* x, 
 // Partial sums of  y.g + y.r + |D y|^2  over [begin, end) (one partial per workgroup).
 __global__ __launch_bounds__(kVecBlock) void cgnr_model_cost_kernel(const double* y, const double* g, const double* r, const double* D,
                                                                      int64_t begin, int64_t end, double* partials,
-                                                                     double* neg_out, int* nonfinite) {
+                                                                     double* neg_out, int* nonfinite, const int* gate) {
   __shared__ double sh[4];
+  if (gate && !CgStatusAllowsSolution(*gate)) return;
   double v = 0;
   int bad = 0;
   for (int64_t i = begin + int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < end; i += int64_t(gridDim.x) * kVecBlock) {
@@ -671,11 +672,11 @@ hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partia
   return hipGetLastError();
 }
 hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
-                               double* partials, int* nparts, hipStream_t s, double* neg_out, int* nonfinite) {
+                               double* partials, int* nparts, hipStream_t s, double* neg_out, int* nonfinite, const int* gate) {
   const int grid = vec_grid(end - begin);
   *nparts = grid;
   if (end > begin) hipLaunchKernelGGL(cgnr_model_cost_kernel, dim3(grid), dim3(kVecBlock), 0, s, y, g, r, D, begin, end, partials,
-                                      nonfinite ? neg_out : nullptr, nonfinite);
+                                      nonfinite ? neg_out : nullptr, nonfinite, gate);
   return hipGetLastError();
 }
 hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t s) {

@@ -75,6 +75,15 @@ struct ceres_hip_solver {
   bool lm_negate_in_solve = false;
   bool lm_negated = false;          // set by whoever did it (or, for CGNR, deferred it: lm_cgnr_copy_pending)
   bool lm_cgnr_copy_pending = false;
+  // Speculative tail (one host synchronisation per LM step instead of two): before each poll of the CG status word the solvers
+  // enqueue the rest of the step — back-substitution (ITERATIVE_SCHUR) or the model-cost kernel (CGNR), negation and finite
+  // check folded in, and the read-back copy of {cost partials, flags} — gated ON THE DEVICE by the status word, so that the
+  // poll that sees CG end has the step's results behind it already.  CERES_HIP_SPECULATE=0 switches it off.
+  bool speculate = true;            // CERES_HIP_SPECULATE
+  bool lm_speculate = false;        // asked for by lm_step_loaded (fused path, one rank)
+  bool gate_on_cg_status = false;   // op_back_substitute: launch gated
+  bool spec_tail_done = false;      // the gated tail and the copy sit in front of the last poll
+  int spec_cgnr_parts = 0;
   int backsub_cost_parts = 0;       // partials it left in scalar_partials
   bool lm_fuse_active = false;      // this step forms D inside the set-up kernels (no separate column-norm pass)
   ceres_hip_lm_options lm_opts{};
@@ -434,6 +443,7 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
     s->backsub_cost_parts = 0;
     if (s->lm_want_model_cost && z != nullptr) { A.scalar_out = s->scalar_partials; s->backsub_cost_parts = s->fused_grid; }
     if (h.num_cols_f > 0 && z != nullptr) { A.copy_src = z; A.copy_dst = x + h.num_cols_e; A.copy_n = h.num_cols_f; }
+    if (s->gate_on_cg_status) A.run_after_cg = &s->cg.S->status;
     if (s->lm_negate_in_solve && z != nullptr) {
       if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
       s->nonfinite_clean = false;
@@ -692,6 +702,7 @@ struct CgSpec {
   // optional: y = A x AND the partial sums of x . y into pq[0 .. *n_pq) (n_pq <= kMaxPqParts); *n_pq = 0 if not produced
   // sharded: *extra = device pointer to the shard's share of x . y, already summed over ranks (nullptr if not produced)
   std::function<int(const double*, double*, double*, int*, const double**)> apply_dot;
+  std::function<int()> before_poll;                     // enqueued before every poll of the status word (speculative LM tail)
   bool shard_fused = false;                             // sharded CG vectors, and apply_dot + the block layout support the fused iteration
   std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
   bool x0_nonzero = false;                              // B.x holds an initial guess
@@ -881,6 +892,7 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
       TRY(collapse_and_reduce(s, 2, 2));
       HIP_TRY(s, LaunchCgFinalize(B, st));
     }
+    if (spec.before_poll) TRY(spec.before_poll());
     TRY(poll_scalars(s));
     if (adaptive) interval = std::min(16, interval * 2);
     if (it > max_it && s->h_scalars->status == kCgRunning)
@@ -1141,9 +1153,21 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
       TRY(op_spse_apply(s, s->rhs_f, s->cg.x, spse_iters, s->opt.spse_tolerance, nullptr));
       spec.x0_nonzero = true;
     }
+    s->spec_tail_done = false;
+    if (s->lm_speculate && s->path == CERES_HIP_PATH_BAL && h.num_cols_f > 0) {
+      spec.before_poll = [s, x]() {
+        s->gate_on_cg_status = true;
+        const int rc = op_back_substitute(s, s->cg.x, x);
+        s->gate_on_cg_status = false;
+        if (rc) return rc;
+        HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, s->stream));
+        s->spec_tail_done = true;
+        return 0;
+      };
+    }
     TRY(run_cg(s, spec, q_tol, r_tol, summary));
     HIP_TRY(s, hipEventRecord(s->ev[5], st));
-    if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR)
+    if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR && !s->spec_tail_done)
       TRY(op_back_substitute(s, s->cg.x, x));
     HIP_TRY(s, hipEventRecord(s->ev[6], st));
     return 0;
@@ -1191,6 +1215,19 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   spec.diag_off = s->G.diag_off_all;
   spec.blocks = pre == CERES_HIP_JACOBI ? s->precond : nullptr;
   if (defer_check && spec.blocks) spec.setup_fail = s->d_fail_flag;
+  s->spec_tail_done = false;
+  if (s->lm_speculate && s->lm_negate_in_solve && s->path == CERES_HIP_PATH_BAL) {
+    spec.before_poll = [s, x]() {
+      const HostStructure& hh = s->hs;
+      if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), s->stream));
+      s->nonfinite_clean = false;
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, hh.num_cols, s->scalar_partials, &s->spec_cgnr_parts, s->stream,
+                                     x, s->d_nonfinite, &s->cg.S->status));
+      HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, s->stream));
+      s->spec_tail_done = true;
+      return 0;
+    };
+  }
   TRY(run_cg(s, spec, q_tol, r_tol, summary));
   HIP_TRY(s, hipEventRecord(s->ev[5], st));
   // LM step: the model-cost kernel reads the solution anyway and writes the negated step (no copy-out, no separate negation pass)
@@ -1405,6 +1442,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->cg.comm, 4));
   TRY(dev_alloc(s, &s->cg_pq_parts, size_t(kMaxPqParts)));
   { const char* e = getenv("CERES_HIP_CG_FUSED"); s->cg_fused = !(e && atoi(e) == 0); }
+  { const char* e = getenv("CERES_HIP_SPECULATE"); s->speculate = !(e && atoi(e) == 0); }
   TRY(dev_alloc(s, &s->cg.S, 1));
   HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
   TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back())));
@@ -1763,7 +1801,12 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   s->lm_negate_in_solve = s->path == CERES_HIP_PATH_BAL && !s->opt.use_explicit_schur_complement && !is_dense_schur(s);
   s->lm_negated = false;
   s->lm_cgnr_copy_pending = false;
+  s->lm_speculate = s->speculate && s->lm_negate_in_solve && s->world <= 1 && (!is_schur(s) || s->lm_want_model_cost);
+  s->spec_tail_done = false;
   const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
+  const bool spec_done = s->spec_tail_done;
+  s->spec_tail_done = false;
+  s->lm_speculate = false;
   s->lm_fuse_active = false;
   s->lm_want_model_cost = false;
   s->lm_negate_in_solve = false;
@@ -1779,7 +1822,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   // Finite check + negation and the model cost change are enqueued together and read back with ONE
   // synchronisation (and, sharded, one all-reduce of {flag, cost}); a non-finite step makes the
   // cost meaningless, it is then ignored.
-  if (!s->lm_negated) {
+  if (!s->lm_negated && !spec_done) {
     if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), st));
     s->nonfinite_clean = false;
     if (!cgnr_deferred) HIP_TRY(s, LaunchNegateAndCheck(dx, h.num_cols, s->d_nonfinite, st));
@@ -1799,7 +1842,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
       parts_local = s->scalar_partials;
       parts_shared = s->scalar_partials + kMaxVecGrid;
     } else {
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st, neg, s->d_nonfinite));
+      if (spec_done) n_shared = s->spec_cgnr_parts;  // the gated kernel in front of the last poll already did all of it
+      else HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st, neg, s->d_nonfinite));
       if (h.num_cols <= 0) n_shared = 0;
       parts_shared = s->scalar_partials;
     }
@@ -1825,7 +1869,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   double* hl = hp;                  // host images of the two partial lists
   double* hsh = hp + kMaxVecGrid;
   if (one_copy) {
-    HIP_TRY(s, hipMemcpyAsync(hp, sp, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, st));
+    // speculative tail: this copy was enqueued in front of the poll that saw CG end, and that poll synchronised
+    if (!spec_done) HIP_TRY(s, hipMemcpyAsync(hp, sp, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, st));
     h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
     if (n_local > 0) hl = hp + (parts_local - sp);
     if (n_shared > 0) hsh = hp + (parts_shared - sp);
@@ -1836,8 +1881,10 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     }
     if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(s, hipStreamSynchronize(st));
-  TRY(check_comm_error(s));
+  if (!(spec_done && one_copy)) {
+    HIP_TRY(s, hipStreamSynchronize(st));
+    TRY(check_comm_error(s));
+  }
   if (s->world > 1) { v[0] = hp[0]; v[1] = hp[1]; }
   else {
     v[0] = double(*h_flag != 0);
