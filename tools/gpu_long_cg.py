@@ -13,7 +13,7 @@ prob = pkg.problems.synthetic_bal("venice1778", layout="schur", seed=38401, skew
 dev = torch.device("cuda", 0)
 tv, tb, tD = (torch.from_numpy(a).to(dev) for a in (prob.values, prob.b, prob.D))
 tx = torch.empty(prob.num_cols, dtype=torch.float64, device=dev)
-out = {"K": K, "fuse": os.environ.get("CERES_HIP_CG_FUSE", "1")}
+out = {"K": K, "cg_fused": os.environ.get("CERES_HIP_CG_FUSED", "1")}
 for name, typ, pre in (("cgnr", hs.CGNR, hs.JACOBI), ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)):
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=K, max_num_iterations=K,
                                                   elimination_groups=[prob.num_eliminate_blocks]))
