@@ -128,3 +128,44 @@ def test_lm_step_sharded_code_paths_in_loopback(hip, problems, solver_type, pre)
         assert rel(b[0], a[0]) <= 1e-10 and abs(a[2] - b[2]) <= 1e-10 * abs(a[2])
     ref.close()
     loop.close()
+
+
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
+def test_speculative_tail_equals_the_two_synchronisation_sequence(hip, oracle, problems, monkeypatch, solver_type, pre):
+    """The LM step's tail (back-substitution / model cost, negation, finite check, read-back) is enqueued in front of every poll
+    of the CG status word and gated by it on the device.  Every class of CG ending must give what the plain
+    sequence (CERES_HIP_SPECULATE=0) gives: convergence inside the first batch of iterations, convergence after several polls
+    (the gated kernels ran as no-ops first), NO_CONVERGENCE at the iteration cap (the step is still produced), a non-finite
+    Jacobian (FAILURE: nothing is produced)."""
+    layout = "schur" if solver_type == hip.ITERATIVE_SCHUR else "cgnr"
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=35, num_points=2500, num_observations=12000, seed=61, skew=0.6)
+    if solver_type == hip.CGNR:
+        p.num_eliminate_blocks = 0
+    # badly scaled camera columns: CG needs a few dozen iterations at a small eta
+    cams = np.flatnonzero(np.asarray(p.bs.col_block_size) == 9)
+    scale = np.ones(p.bs.num_cols)
+    for j in cams[::3]:
+        scale[p.bs.col_block_pos[j]:p.bs.col_block_pos[j] + 9] = 30.0
+    hard = type(p)(p.bs, oracle.Matrix(p.bs, 0).scale_columns(p.values, scale), p.b, None, p.num_eliminate_blocks)
+    bad = type(p)(p.bs, p.values.copy(), p.b, None, p.num_eliminate_blocks)
+    bad.values[::997] = np.nan
+    runs = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("CERES_HIP_SPECULATE", spec)
+        out = []
+        for prob, eta, max_it in ((p, 0.1, 500), (hard, 1e-8, 500), (hard, 1e-8, 3), (bad, 0.1, 500)):
+            s = make_solver(hip, prob, solver_type, pre, max_it=max_it)
+            step, summ, mcc = s.lm_compute_step(prob.values, prob.b, 1e4, eta)
+            out.append((step, summ.termination_type, summ.num_iterations, mcc))
+            s.close()
+        runs[spec] = out
+    a, b = runs["1"], runs["0"]
+    assert [r[1] for r in a] == [r[1] for r in b] == [hip.SUCCESS, hip.SUCCESS, hip.NO_CONVERGENCE, hip.FAILURE]
+    assert [r[2] for r in a][:3] == [r[2] for r in b][:3]
+    assert a[0][2] <= 2 and a[1][2] > 4 and a[2][2] == 3   # inside the first batch / after several polls / at the cap
+    for k in range(3):
+        assert rel(a[k][0], b[k][0]) <= 1e-12 and abs(a[k][3] - b[k][3]) <= 1e-12 * abs(b[k][3]), k
+    # the converged cases also against the oracle
+    ref_step, ref_summ, ref_mcc, _, _ = reference_step(oracle, hip, hard, solver_type, pre, 1e4, 1e-8)
+    if ref_summ.num_iterations == a[1][2]:
+        assert rel(a[1][0], ref_step) <= 1e-8
