@@ -1,14 +1,16 @@
 // kernels_bal.hip — fused single-pass kernels for the static <2,3,9> (BAL) structure.
 //
-// Data layout in HBM (built once per LM step by bal_pack_kernel from the caller's
-// values, whatever their layout):
+// Data layout in HBM (built once per LM step from the caller's values, whatever their layout — by the step's first pass over
+// J, which gathers through cell.position and writes the tiles on the way; bal_pack_kernel is the stand-alone form):
 //   tiles of 64 observation slots, one wavefront per tile;
 //   J   [tile][12][64] double2   pair j of slot l holds Jacobian doubles (2j, 2j+1) of the
 //                                24 = 6 (E, 2x3 row-major) + 18 (F, 2x9 row-major)
 //   b   [tile][64]     double2   the two residuals of the slot
-//   cam [tile][64] int32, pt [tile][64] int32, seg [tile][64] uint32 (first|last<<8|valid<<16)
+//   cam [tile][64] int32, seg [tile][64] uint32 (first | last<<8 | valid<<16 | store lanes of the tile's dense point range),
+//   pt0 [tile] int32             points of a tile are consecutive ids: a slot's point = pt0 + (segment heads at or below it) - 1
 // so that every global load of the hot kernels is a 16-byte-per-lane, 1 KiB-per-wave
-// contiguous access and the algorithmic traffic is 192 + 8 (+4) bytes per observation.
+// contiguous access and the algorithmic traffic is 192 + 8 bytes per observation.  Streamed-once data is read with
+// non-temporal loads (stream_load<>), the tiles are written with non-temporal stores (tile_store<>).
 //
 // All per-point reductions (E^T·, (E^T E)^-1) are segmented wavefront scans over
 // __shfl_up — observations of a point are adjacent lanes by construction of the
@@ -16,17 +18,24 @@
 // handled by the same wave in two sweeps.  Per-camera sums (F^T·) go to a
 // workgroup-private accumulator in LDS (9 doubles per camera: 128 KB for Venice's
 // 1778 cameras, LDS is 160 KB) with ds_add_f64, flushed once per workgroup and
-// combined by bal_reduce_partials_kernel; when the cameras do not fit in LDS the
-// same code accumulates into a zeroed global array with global_atomic_add_f64.
+// combined by bal_reduce_partials_kernel; when the cameras do not fit in LDS the tile pass leaves F_o^T z_o per slot
+// (72-byte rows, transposed through LDS into coalesced stores) and bal_camera_chunk_kernel sums them camera by camera.
+// Camera-major work on the Jacobian itself (the 9x9 preconditioner blocks) is bal_camera_items_kernel (per-item partial sums)
+// + bal_invert9_kernel (sums a camera's items, adds D^2 or the fused LM diagonal, inverts).
 //
 // Reference operators restated by each MODE (file:line in include/ceres_hip.h):
 //   kSx        ImplicitSchurComplement::RightMultiplyAndAccumulate (4 passes there, 1 here)
-//   kJtJx      CgnrLinearOperator::RightMultiplyAndAccumulate      (2 passes there, 1 here)
+//   kJtJx      CgnrLinearOperator::RightMultiplyAndAccumulate      (2 passes there, 1 here); also leaves partial sums of x . y
 //   kJtb       A^T b
 //   kInit      ImplicitSchurComplement::Init: (E^T E + D^2)^-1, rhs; also the 2x2 blocks
-//              M_o = I - E_o (E^T E)^-1 E_o^T that SCHUR_JACOBI needs
+//              M_o = I - E_o (E^T E)^-1 E_o^T that SCHUR_JACOBI needs, and the fused LM diagonal of the point columns
+//   kCgnrInit  J^T b, the point blocks of JACOBI and the fused LM diagonal, in one pass
 //   kEte       block diagonal (E^T E + D^2)^-1 only (CGNR JACOBI point blocks)
-//   kBackSub   ImplicitSchurComplement::BackSubstitute
+//   kColNorm   BlockSparseMatrix::SquaredColumnNorm
+//   kBackSub   ImplicitSchurComplement::BackSubstitute; as the last kernel of an LM step also the negation, the finite check
+//              and the model-cost partial sums (gated on the CG status word when enqueued speculatively)
+//   kSpseZ     the inverse power-series operator of SCHUR_POWER_SERIES_EXPANSION (S.x without the F^T F term)
+//   kJx        J x (model cost where nothing else has it in hand)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
