@@ -1,10 +1,12 @@
-// solver.hip — the C ABI of include/ceres_hip.h: solver objects, the two LinearSolver
-// implementations (CGNR, ITERATIVE_SCHUR), operator-level entry points and timing.
+// solver.hip — the C ABI of include/ceres_hip.h: solver objects, the LinearSolver implementations (CGNR, ITERATIVE_SCHUR implicit
+// and explicit, DENSE_SCHUR), the Levenberg-Marquardt step around them, operator-level entry points, communicators and timing.
 //
 // A solver instance is device resident: the structure (and, for <2,3,9> problems, the
 // tile packing plan) is uploaded once; per solve only values/b/D go up and x comes down
 // (SURVEY.md §7 "design stance").  Everything runs on one HIP stream owned by the
-// instance; the host blocks only to poll the CG status word and to hand back x.
+// instance; the host blocks only to poll the CG status word — with the rest of an LM step already enqueued behind the
+// iterations, gated on that word (speculative tail) — and to hand back x.  Sharded instances (one process per GPU) sum their
+// camera-space vectors with the one-shot peer-to-peer all-reduce of kernels_cg.hip, RCCL as fallback.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
