@@ -133,6 +133,7 @@ def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve"):
             return s
         return solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
     iters = []
+    sync()  # N > 1: ranks leave set_structure (host-side planning) at different times; the in-kernel all-reduce has a timeout
     for _ in range(warmup):
         s = one()
         assert s.termination_type in (0, 1), s
