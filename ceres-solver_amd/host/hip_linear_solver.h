@@ -135,8 +135,51 @@ class HipLinearSolver final : public LinearSolver {
   HipLinearSolver(const HipLinearSolver&) = delete;
   HipLinearSolver& operator=(const HipLinearSolver&) = delete;
 
+  // LevenbergMarquardtStrategy::ComputeStep (internal/ceres/levenberg_marquardt_strategy.cc:69-157) and the model cost change of
+  // TrustRegionMinimizer::ComputeTrustRegionStep (internal/ceres/trust_region_minimizer.cc:425-437) in one call:
+  // diag = clamp(SquaredColumnNorm(J)) unless reuse_diagonal, D = sqrt(diag / radius), Solve at q_tolerance = eta,
+  // finite check, step = -x, model_cost_change = -(J step)'(f + J step / 2).
+  struct LmStep {
+    Summary summary;                 // FAILURE also when the step is not finite
+    double model_cost_change = 0.0;
+    bool step_is_finite = false;
+  };
+  LmStep ComputeLmStep(BlockSparseMatrix* jacobian, const double* residuals, double radius, double eta, double* step,
+                       bool reuse_diagonal = false, double min_diagonal = 1e-6, double max_diagonal = 1e32) {
+    LmStep out;
+    if (!EnsureStructure(jacobian, &out.summary)) return out;
+    ceres_hip_lm_options o{radius, min_diagonal, max_diagonal, eta, reuse_diagonal ? 1 : 0, 0};
+    ceres_hip_lm_result r{};
+    const int rc = ceres_hip_lm_compute_step(handle_, jacobian->values(), residuals, &o, step, &r);
+    out.summary.residual_norm = r.linear_solver.residual_norm;
+    out.summary.num_iterations = r.linear_solver.num_iterations;
+    out.summary.termination_type = rc == CERES_HIP_OK ? static_cast<LinearSolverTerminationType>(r.linear_solver.termination_type)
+                                                      : LinearSolverTerminationType::FATAL_ERROR;
+    out.summary.message = rc == CERES_HIP_OK ? r.linear_solver.message : ceres_hip_last_error(handle_);
+    out.model_cost_change = r.model_cost_change;
+    out.step_is_finite = r.step_is_finite != 0;
+    return out;
+  }
+
   Summary Solve(BlockSparseMatrix* A, const double* b, const PerSolveOptions& per_solve_options, double* x) override {
     Summary summary;
+    if (!EnsureStructure(A, &summary)) return summary;
+    ceres_hip_summary s{};
+    const int rc = ceres_hip_solve(handle_, A->values(), b, per_solve_options.D, per_solve_options.q_tolerance,
+                                   per_solve_options.r_tolerance, x, &s);
+    summary.residual_norm = s.residual_norm;
+    summary.num_iterations = s.num_iterations;
+    summary.termination_type = rc == CERES_HIP_OK ? static_cast<LinearSolverTerminationType>(s.termination_type)
+                                                  : LinearSolverTerminationType::FATAL_ERROR;
+    summary.message = rc == CERES_HIP_OK ? s.message : ceres_hip_last_error(handle_);
+    return summary;
+  }
+  ceres_hip_info info() const { ceres_hip_info i{}; ceres_hip_get_info(handle_, &i); return i; }
+  ceres_hip_solver* handle() const { return handle_; }
+
+ private:
+  // Flattens the structure on first use: one instance sees one sparsity (internal/ceres/linear_solver.h:137-142).
+  bool EnsureStructure(BlockSparseMatrix* A, Summary* summary) {
     if (!structure_set_) {
       const CompressedRowBlockStructure* bs = A->block_structure();
       std::vector<int32_t> rsz, rpos, csz, cpos, ptr{0}, ccol, cval;
@@ -150,25 +193,14 @@ class HipLinearSolver final : public LinearSolver {
       ceres_hip_block_structure flat{int32_t(rsz.size()), int32_t(csz.size()), rsz.data(), rpos.data(), csz.data(),
                                      cpos.data(), ptr.data(), ccol.data(), cval.data()};
       if (ceres_hip_set_structure(handle_, &flat) != CERES_HIP_OK) {
-        summary.termination_type = LinearSolverTerminationType::FATAL_ERROR;
-        summary.message = ceres_hip_last_error(handle_);
-        return summary;
+        summary->termination_type = LinearSolverTerminationType::FATAL_ERROR;
+        summary->message = ceres_hip_last_error(handle_);
+        return false;
       }
       structure_set_ = true;
     }
-    ceres_hip_summary s{};
-    const int rc = ceres_hip_solve(handle_, A->values(), b, per_solve_options.D, per_solve_options.q_tolerance,
-                                   per_solve_options.r_tolerance, x, &s);
-    summary.residual_norm = s.residual_norm;
-    summary.num_iterations = s.num_iterations;
-    summary.termination_type = rc == CERES_HIP_OK ? static_cast<LinearSolverTerminationType>(s.termination_type)
-                                                  : LinearSolverTerminationType::FATAL_ERROR;
-    summary.message = rc == CERES_HIP_OK ? s.message : ceres_hip_last_error(handle_);
-    return summary;
+    return true;
   }
-  ceres_hip_info info() const { ceres_hip_info i{}; ceres_hip_get_info(handle_, &i); return i; }
-
- private:
   Options options_;
   ceres_hip_solver* handle_ = nullptr;
   bool structure_set_ = false;

@@ -3,7 +3,8 @@
 // and a small BAL-shaped <2,3,9> problem, both solved with ITERATIVE_SCHUR and CGNR and
 // checked against a dense solve of the regularised normal equations (the pattern of
 // internal/ceres/iterative_schur_complement_solver_test.cc:75-117).  Prints one line per
-// case and exits non-zero on any mismatch.  Built by build.py with g++ against the C ABI.
+// case and exits non-zero on any mismatch; then the whole Levenberg-Marquardt step (ComputeLmStep) on the BAL-shaped problem
+// against dense algebra.  Built by build.py with g++ against the C ABI.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,8 +18,8 @@ using namespace ceres_hip;
 
 namespace {
 
-// Dense reference: solve (A^T A + D^2) x = A^T b by Gaussian elimination with pivoting.
-std::vector<double> DenseSolve(const BlockSparseMatrix& A, const std::vector<double>& b, const std::vector<double>& D) {
+// Row-major dense image of A.
+std::vector<double> Dense(const BlockSparseMatrix& A) {
   const int m = A.num_rows(), n = A.num_cols();
   std::vector<double> dense(size_t(m) * n, 0.0);
   const auto* bs = A.block_structure();
@@ -29,6 +30,13 @@ std::vector<double> DenseSolve(const BlockSparseMatrix& A, const std::vector<dou
         for (int j = 0; j < cb.size; ++j)
           dense[size_t(r.block.position + i) * n + cb.position + j] = A.values()[c.position + i * cb.size + j];
     }
+  return dense;
+}
+
+// Dense reference: solve (A^T A + D^2) x = A^T b by Gaussian elimination with pivoting.
+std::vector<double> DenseSolve(const BlockSparseMatrix& A, const std::vector<double>& b, const std::vector<double>& D) {
+  const int m = A.num_rows(), n = A.num_cols();
+  const std::vector<double> dense = Dense(A);
   std::vector<double> H(size_t(n) * n, 0.0), g(n, 0.0);
   for (int i = 0; i < n; ++i) {
     for (int j = 0; j < n; ++j) {
@@ -130,6 +138,45 @@ int RunCase(const char* name, BlockSparseMatrix* A, const std::vector<double>& b
   return ok ? 0 : 1;
 }
 
+// LevenbergMarquardtStrategy::ComputeStep + the model cost change through the C++ mirror, against dense algebra:
+// D = sqrt(clamp(diag(J'J)) / radius), step = -(J'J + D^2)^-1 J'f, model cost change = -(J step)'(f + J step / 2).
+int RunLmStep(const char* name, BlockSparseMatrix* A, const std::vector<double>& f, int nelim, LinearSolverType type,
+              PreconditionerType pre, double tol) {
+  LinearSolver::Options o;
+  o.type = type;
+  o.preconditioner_type = pre;
+  o.min_num_iterations = 0;
+  o.max_num_iterations = 4 * A->num_cols();
+  o.elimination_groups = {type == CGNR ? 0 : nelim};
+  HipLinearSolver solver(o);
+  const double radius = 1e4;
+  const int n = A->num_cols(), m = A->num_rows();
+  const std::vector<double> dense = Dense(*A);
+  std::vector<double> D(n);
+  for (int j = 0; j < n; ++j) {
+    double d = 0;
+    for (int i = 0; i < m; ++i) d += dense[size_t(i) * n + j] * dense[size_t(i) * n + j];
+    D[j] = std::sqrt(std::min(std::max(d, 1e-6), 1e32) / radius);
+  }
+  std::vector<double> ref = DenseSolve(*A, f, D);
+  for (auto& v : ref) v = -v;
+  double ref_cost = 0;
+  for (int i = 0; i < m; ++i) {
+    double mi = 0;
+    for (int j = 0; j < n; ++j) mi += dense[size_t(i) * n + j] * ref[j];
+    ref_cost -= mi * (f[i] + mi / 2);
+  }
+  std::vector<double> step(n, std::nan(""));
+  const auto r = solver.ComputeLmStep(A, f.data(), radius, /*eta=*/1e-13, step.data());
+  double num = 0, den = 0;
+  for (int j = 0; j < n; ++j) { num += (step[j] - ref[j]) * (step[j] - ref[j]); den += ref[j] * ref[j]; }
+  const double err = std::sqrt(num / den), cost_err = std::fabs(r.model_cost_change - ref_cost) / std::fabs(ref_cost);
+  const bool ok = r.summary.termination_type == LinearSolverTerminationType::SUCCESS && r.step_is_finite && err <= tol && cost_err <= tol;
+  std::printf("%s %-28s type=%d pre=%d iterations=%d step_rel_err=%.2e model_cost_rel_err=%.2e (%s)\n", ok ? "PASS" : "FAIL", name,
+              int(type), int(pre), r.summary.num_iterations, err, cost_err, r.summary.message.c_str());
+  return ok ? 0 : 1;
+}
+
 }  // namespace
 
 // host_driver <problem.txt> [max_num_iterations]: BALProblem + Evaluator + TrustRegionMinimizer through the C++ mirror
@@ -172,6 +219,8 @@ int main(int argc, char** argv) {
   auto bal = SmallBal(7, 60, &b, &D, &nelim);
   bad += RunCase("bal<2,3,9>", bal.get(), b, D, nelim, ITERATIVE_SCHUR, SCHUR_JACOBI, 1e-9);
   bad += RunCase("bal<2,3,9>", bal.get(), b, D, nelim, CGNR, JACOBI, 1e-7);
+  bad += RunLmStep("lm step bal<2,3,9>", bal.get(), b, nelim, ITERATIVE_SCHUR, SCHUR_JACOBI, 1e-8);
+  bad += RunLmStep("lm step bal<2,3,9>", bal.get(), b, nelim, CGNR, JACOBI, 1e-6);
   std::printf(bad ? "host_driver: %d case(s) FAILED\n" : "host_driver: all cases passed\n", bad);
   return bad ? 1 : 0;
 }
