@@ -88,6 +88,14 @@ def parse():
     ap.add_argument("--minimizer-iterations", type=int, default=8,
                     help="also run the device-resident trust-region loop (f4) for this many iterations and report it in `extra` (0: skip)")
     ap.add_argument("--both-solvers", type=int, default=1, help="also report the other solver in `extra` (N=1 only)")
+    ap.add_argument("--eta", type=float, default=0.1, help="q_tolerance of the timed steps (Solver::Options::eta; bundle_adjuster runs 0.01)")
+    ap.add_argument("--scene-step-steps", type=int, default=10,
+                    help="also time this many LM steps at eta = 0.1 and 0.01 on the Jacobi-scaled Jacobian of the synthetic SCENE the device "
+                         "evaluator produces (scene_step; N=1, needs --minimizer-iterations > 0; 0: skip)")
+    ap.add_argument("--extra-synthetic10m", type=int, default=1,
+                    help="default venice1778 run at N=1: also run `--workload synthetic10M` (BASELINE.json configs[4]) in a child process and put a "
+                         "condensed result under extra.synthetic10M (0: skip)")
+    ap.add_argument("--also-fp32", type=int, default=0, help="many-camera workloads: also time the fp32-tile storage mode (extra.fp32_tiles)")
     return ap.parse_args()
 
 
@@ -123,15 +131,35 @@ def make_solver(hs, bs, nelim, solver, device, comm=None, storage=0):
 RADIUS = 1e4  # Solver::Options::initial_trust_region_radius; D = sqrt(clamp(diag(J'J)) / RADIUS)
 
 
-def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve"):
+def step_min_bytes(solver_kind, n_obs, n_points, n_cameras, cg_iterations, s=8):
+    """Minimum HBM bytes of one whole LM step with `cg_iterations` CG iterations IF the Jacobian already sat in the layout each
+    pass wants (DESIGN.md §7 "step roofline"): what the step's passes must move at the very least, tile re-layout NOT counted.
+      ITERATIVE_SCHUR + SCHUR_JACOBI: Init (J + ids + b in, M_o + (E'E)^-1 + D_e out) + SCHUR_JACOBI blocks (F cell + M_o + index per
+      observation) + k S.x + back-substitution (J + ids + b in, point inverses in, step out);
+      CGNR + JACOBI: set-up (J + ids + b in; rhs, point blocks, D out) + camera blocks (F cell + index) + k (JtJx + the CG vector passes:
+      cg_update reads x p r q rhs M and writes x r z, the direction update reads z p and writes p)."""
+    n_cols = 3 * n_points + 9 * n_cameras
+    j_once = n_obs * (24 * s + 8)
+    if solver_kind == "iterative_schur":
+        init = j_once + n_obs * 2 * s + n_obs * 3 * s + n_points * (6 * s + 6 * s) + n_cameras * 9 * s
+        precond = n_obs * (18 * s + 3 * s + 4) + n_cameras * 81 * s
+        backsub = j_once + n_obs * 2 * s + n_points * (6 * s + 3 * s) + n_cameras * 9 * s
+        return init + precond + cg_iterations * algorithmic_bytes("sx", n_obs, n_points, n_cameras, s) + backsub
+    setup = j_once + n_obs * 2 * s + n_points * (3 * s + 9 * s + 6 * s) + n_cameras * 9 * s
+    precond = n_obs * (18 * s + 4) + n_cameras * 81 * s
+    cg_vectors = n_cols * s * (8 + 3) + n_points * 9 * s + n_cameras * 81 * s
+    return setup + precond + cg_iterations * (algorithmic_bytes("jtjx", n_obs, n_points, n_cameras, s) + cg_vectors)
+
+
+def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta=0.1):
     tv, tb, tD, tx = ptrs
 
     def one():
         if step_kind == "lm_step":  # the diagonal is recomputed every step, as after an accepted step
-            s, mcc, finite = solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS, 0.1)
+            s, mcc, finite = solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS, eta)
             assert finite and mcc > 0, (s, mcc)
             return s
-        return solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), 0.1, -1.0)
+        return solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), eta, -1.0)
     iters = []
     sync()  # N > 1: ranks leave set_structure (host-side planning) at different times; the in-kernel all-reduce has a timeout
     for _ in range(warmup):
@@ -253,7 +281,7 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: K LM linear solves, inputs resident in HBM -------------------
-    elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync, args.step)
+    elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync, args.step, args.eta)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -315,7 +343,7 @@ def main():
         s2 = make_solver(hs, bs, nelim_local, other, local_rank, None, storage)
         tx2 = torch.empty_like(tx)  # keep the primary solver's step in tx for the parity check below
         n2 = max(3, args.steps // 4)
-        e2, it2, _ = timed_steps(s2, (tv, tb, tD, tx2), n2, 1, sync, args.step)
+        e2, it2, _ = timed_steps(s2, (tv, tb, tD, tx2), n2, 1, sync, args.step, args.eta)
         k2 = "sx" if other == "iterative_schur" else "jtjx"
         ms2, nb2, gb2 = measure_operator(s2, k2)
         tr2, src2 = pmc_traffic(k2)
@@ -362,6 +390,7 @@ def main():
 
     # ---- the whole trust-region loop on the device, for the record (N = 1) ----------
     scene_tr = None
+    scene_step = None
     if world == 1 and args.minimizer_iterations > 0 and not many_cameras and not storage:
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40 * n_obs * 24:  # its own Jacobian, tiles and vectors next to the bench's
@@ -386,11 +415,89 @@ def main():
                 "initial_cost": Sm.initial_cost, "final_cost": Sm.final_cost, "successful_steps": Sm.num_successful_steps,
                 "cg_iterations": [Sm.iterations[i].linear_solver_iterations for i in range(1, Sm.num_iterations_logged)],
                 "termination": Sm.message.decode(errors="replace")}
+            # scene_step: the LM step of `value` (same entry point, same solver instance) on the Jacobian the device evaluator
+            # produces for this scene at its start point, Jacobi-scaled like TrustRegionMinimizer (trust_region_minimizer.cc:263-279),
+            # at eta = 0.1 (Solver::Options default) and 0.01 (bundle_adjuster's): a step whose time is mostly CG, i.e. the hot kernel
+            if args.scene_step_steps > 0 and np.array_equal(bp.row_order(), np.arange(n_obs, dtype=np.int32)):
+                _, res_s, _, vals_s = bp.evaluate(x0, residuals=True, jacobian=True)
+                tvs, tbs = torch.from_numpy(vals_s).to(dev), torch.from_numpy(res_s).to(dev)
+                del vals_s, res_s
+                pt_cols = torch.from_numpy(bs.col_block_pos[prob.point_of_row].astype(np.int64)).to(dev)
+                cam_cols = torch.from_numpy(bs.col_block_pos[prob.camera_of_row].astype(np.int64)).to(dev)
+                E, F = tvs[: 6 * n_obs].view(n_obs, 2, 3), tvs[6 * n_obs:].view(n_obs, 2, 9)
+                cn = torch.zeros(bs.num_cols, dtype=torch.float64, device=dev)
+                for c in range(3):
+                    cn.index_add_(0, pt_cols + c, (E[:, :, c] ** 2).sum(1))
+                for c in range(9):
+                    cn.index_add_(0, cam_cols + c, (F[:, :, c] ** 2).sum(1))
+                scale = 1.0 / (1.0 + torch.sqrt(cn))
+                for c in range(3):
+                    E[:, :, c] *= scale[pt_cols + c][:, None]
+                for c in range(9):
+                    F[:, :, c] *= scale[cam_cols + c][:, None]
+                del pt_cols, cam_cols, cn, scale
+                txs = torch.empty_like(tx)
+                scene_step = {"what": f"ceres_hip_lm_compute_step_device on the Jacobi-scaled Snavely Jacobian of the {args.workload}-shaped synthetic scene "
+                                      "(values and residuals from the device evaluator at the start point), inputs resident in HBM"}
+                for eta_s in (0.1, 0.01):
+                    es, its, _ = timed_steps(solver, (tvs, tbs, None, txs), args.scene_step_steps, 2, sync, "lm_step", eta_s)
+                    tms = solver.last_timing()
+                    k_it = int(its[-1])
+                    mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
+                    scene_step[f"eta_{eta_s}"] = {
+                        "ms_per_step": round(1e3 * es / args.scene_step_steps, 4), "steps_per_s": round(args.scene_step_steps / es, 3),
+                        "cg_iterations": k_it, "cg_ms": round(tms.cg_ms, 4), "cg_share_of_step": round(tms.cg_ms / max(tms.total_ms, 1e-9), 3),
+                        "step_roofline_frac": round(mb / (es / args.scene_step_steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                del tvs, tbs, txs
             bp.close()
     extra["solve_phases_ms"] = {k: round(getattr(timing, k), 4) for k in
                                 ("pack_ms", "setup_ms", "preconditioner_ms", "cg_ms", "back_substitute_ms", "total_ms")}
     extra["operator_launches_enqueued_last_step"] = int(timing.operator_applications)
     extra["device_bytes"] = int(info.device_bytes)
+
+    # ---- many-camera workloads: the fp32-tile storage mode next to fp64 (BASELINE.json configs[4]: "fp32 and fp64") ----
+    if world == 1 and many_cameras and args.also_fp32 and not storage:
+        s32 = make_solver(hs, bs, nelim_local, args.solver, local_rank, None, 1)
+        tx32 = torch.empty_like(tx)
+        n32 = max(3, args.steps // 2)
+        e32, it32, _ = timed_steps(s32, (tv, tb, tD, tx32), n32, 1, sync, args.step, args.eta)
+        s32.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())
+        ms32 = s32.time_op(hs.TIMED_JTJX if kind == "jtjx" else hs.TIMED_SX, args.kernel_iters)
+        nb32 = algorithmic_bytes(kind, my_obs, my_points, n_cams, 4)
+        extra["fp32_tiles"] = {"what": "Jacobian tiles rounded to fp32, fp64 arithmetic: an accuracy mode, never parity",
+                               "steps_per_s": round(n32 / e32, 3), "ms_per_step": round(1e3 * e32 / n32, 4), "cg_iterations": it32[-1],
+                               f"{kind}_ms": round(ms32, 5), f"{kind}_frac_hbm_of_fp32_bytes": round(nb32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "step_rel_diff_vs_fp64": float((torch.linalg.norm(tx32 - tx) / torch.linalg.norm(tx)).item())}
+        s32.close()
+        del tx32
+
+    # ---- BASELINE.json configs[4] on the DEFAULT line: synthetic10M in a child process (its own 20 GB of HBM), condensed ----
+    if world == 1 and args.extra_synthetic10m and args.workload == "venice1778" and not storage:
+        import subprocess
+        t10 = time.perf_counter()
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b < 60e9:
+            extra["synthetic10M"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the child wants 60"}
+        else:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "synthetic10M", "--steps", "5", "--warmup", "1", "--kernel-iters", "20",
+                   "--no-cpu-baseline", "--host-boundary-steps", "0", "--minimizer-iterations", "0", "--extra-synthetic10m", "0", "--also-fp32", "1",
+                   "--solver", args.solver, "--eta", str(args.eta)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                other = "cgnr" if args.solver == "iterative_schur" else "iterative_schur"
+                ro, rj = d["roofline"], d.get("roofline_jtjx") or d.get("roofline_sx") or {}
+                extra["synthetic10M"] = {
+                    "what": "bench.py --workload synthetic10M in a child process: 10 M points x 3 observations, 50 000 cameras (camera accumulators do "
+                            "not fit in LDS), fp64, values generated in HBM; same step, same entry point",
+                    "workload": d["config"]["workload"], "steps_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                    "cg_iterations_per_step": d["config"]["cg_iterations_per_step"], "solver": d["config"]["solver"],
+                    ("sx" if kind == "sx" else "jtjx"): {"frac": ro["frac"], "GBs": ro["achieved"], "ms": ro["avg_launch_ms"], "kernel": ro["kernel"]},
+                    ("jtjx" if kind == "sx" else "sx"): {"frac": rj.get("frac"), "GBs": rj.get("achieved"), "ms": rj.get("avg_launch_ms")},
+                    other: d["extra"].get(other), "fp32_tiles": d["extra"].get("fp32_tiles"),
+                    "child_wall_s": round(time.perf_counter() - t10, 1)}
+            except Exception as ex:  # the default line must not depend on the child
+                extra["synthetic10M"] = {"error": repr(ex)[:300]}
 
     # ---- CPU baseline: the oracle (a restatement of Ceres' algorithm, "port") on this box's cores ----
     cpu = None
@@ -416,7 +523,7 @@ def main():
                 Dc = np.sqrt(diag / RADIUS)
             else:
                 Dc = h_D
-            xo_, so_ = fn(h_values, h_b, Dc, preconditioner=pre, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
+            xo_, so_ = fn(h_values, h_b, Dc, preconditioner=pre, min_it=0, max_it=500, q_tol=args.eta, r_tol=-1.0)
             if args.step == "lm_step":
                 xo_ = -xo_
                 model = m_all.right_multiply(h_values, xo_)
@@ -451,7 +558,7 @@ def main():
         except Exception:
             pass
         cpu = {"value": round(n_done / cpu_t, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_done} full {args.workload}-shaped {args.solver} " + ("LM steps (diag, solve, model cost)" if args.step == "lm_step" else "solves") + " (same inputs, eta=0.1), "
+               "sample": f"{n_done} full {args.workload}-shaped {args.solver} " + ("LM steps (diag, solve, model cost)" if args.step == "lm_step" else "solves") + " (same inputs, eta={args.eta}), "
                          f"oracle/libceres_oracle.so with OpenMP over {cores} threads, {cpu_t:.1f} s; "
                          f"one-step probe seconds by thread count: { {k: round(v, 2) for k, v in probe.items()} } on {ncpu} host cpus" + probe_txt,
                "cg_iterations": cpu_iters, "step_rel_diff_vs_gpu": parity}
@@ -471,7 +578,7 @@ def main():
                        "solver": "CGNR + JACOBI" if args.solver == "cgnr" else "ITERATIVE_SCHUR + SCHUR_JACOBI",
                        "step": ("LevenbergMarquardtStrategy::ComputeStep (diag(J'J), D = sqrt(diag/1e4), Solve, finite check, negate) + "
                                 "model cost change, all on the device" if args.step == "lm_step" else "LinearSolver::Solve"),
-                       "eta": 0.1, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
+                       "eta": args.eta, "max_num_iterations": 500, "cg_iterations_per_step": iters[-1],
                        "termination": hs.TERMINATION_NAMES[last.termination_type],
                        "parallelism": (f"points sharded over {world} rank(s), camera-space sums by " +
                                        ("the one-shot peer-to-peer all-reduce (hipIpc / xGMI)" if solver.p2p_ok else "RCCL all-reduce") +
@@ -480,12 +587,19 @@ def main():
                        "jacobian_storage": "fp32 tiles, fp64 arithmetic (accuracy mode, not parity)" if storage else "fp64",
                        "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",
                        "camera_accumulators_in_lds": bool(info.camera_accum_in_lds)},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host_boundary, "scene_trust_region": scene_tr, "extra": extra,
+            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host_boundary, "scene_trust_region": scene_tr, "scene_step": scene_step,
+            "extra": extra,
         }
+        if args.step == "lm_step":  # the whole step against ITS roofline: minimum bytes of all its passes / measured time / peak
+            tot_obs, tot_pts = (n_obs, n_points)
+            mb = step_min_bytes(args.solver, tot_obs, tot_pts, n_cams, int(iters[-1]), scalar_bytes)
+            line["step_roofline"] = {"bound": "hbm", "min_bytes_per_step": int(mb), "achieved": round(mb / (elapsed / args.steps) / 1e9, 1),
+                                     "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(mb / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                     "what": "minimum HBM bytes of every pass of the step (J in the layout each pass wants; re-layout not counted) / ms_per_step"}
         if roofline_other is not None:
             line["roofline_jtjx" if args.solver == "iterative_schur" else "roofline_sx"] = roofline_other
-        if cpu:
-            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 2)
+        if cpu:  # a reported ratio, not a quality measure (the baseline is a port on 16 threads): kept inside cpu_baseline
+            cpu["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
     solver.close()
     if dist is not None:

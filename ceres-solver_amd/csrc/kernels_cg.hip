@@ -803,6 +803,8 @@ namespace {
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n,
                                                             P2pPeers P, int rank, int world, unsigned long long epoch,
                                                             int64_t cap, int chunks_cap, int* error_flag, long long timeout_ticks) {
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
   const int parity = int(epoch & 1ull);
   const int c = blockIdx.x;
   const int64_t lo = int64_t(c) * kP2pChunk;
@@ -829,7 +831,11 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
     const unsigned long long* f = P.flags[rank] + (int64_t(parity) * world + q) * chunks_cap + c;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if (wall_clock64() - t0 > timeout_ticks) { atomicExch(error_flag, 1); break; }  // a peer never arrived: do not hang the GPU
+      if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: do not hang the GPU
+        __hip_atomic_store(error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // mapped host memory: the host reads it after its next synchronisation
+        timed_out = 1;
+        break;
+      }
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -842,7 +848,9 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
     if (i < n) {
       double s = 0.0;
       for (int q = 0; q < world; ++q) s += mine[q * cap + i];
-      out[i] = s;
+      // an incomplete sum must not be consumed: NaN flows into the CG scalars, whose tests then end the solve (rho / alpha not finite), and
+      // the host reports CERES_HIP_E_COMM at its next poll
+      out[i] = timed_out ? __builtin_nan("") : s;
     }
   }
 }

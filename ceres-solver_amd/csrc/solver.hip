@@ -138,7 +138,8 @@ struct ceres_hip_solver {
   P2pPeers p2p_peers{};
   void* p2p_opened[kP2pMaxWorld] = {};
   unsigned long long p2p_epoch = 0;
-  int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived
+  int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived: device view of h_comm_error
+  int* h_comm_error = nullptr;      // mapped pinned host memory
   double p2p_timeout_s = 10.0;
   bool p2p_fine_grained = false;   // the receive buffer is a fine-grained allocation (false: the runtime could only export a coarse-grained one)
   ceres_hip_solve_timing timing{};
@@ -244,13 +245,27 @@ BalArgs bal_args(ceres_hip_solver* s) {
 
 // First pass over a step's Jacobian: let the kernel gather from the caller's layout and write
 // the tiles on the way (fused re-layout).  Call right before launching; marks the tiles valid.
-void use_gather_if_unpacked(ceres_hip_solver* s, BalArgs& A) {
-  if (s->packed) return;
+// The tiles count as valid only once the gathering kernel has been enqueued successfully: the guard takes `packed` back on every
+// error path (a failed launch would otherwise leave later operators reading stale tiles, with no error on a retry).
+struct PackGuard {
+  ceres_hip_solver* s = nullptr;
+  bool armed = false;
+  PackGuard() = default;
+  PackGuard(ceres_hip_solver* s_, bool a) : s(s_), armed(a) {}
+  PackGuard(PackGuard&& o) noexcept : s(o.s), armed(o.armed) { o.armed = false; }
+  PackGuard(const PackGuard&) = delete;
+  PackGuard& operator=(const PackGuard&) = delete;
+  ~PackGuard() { if (armed) s->packed = false; }
+  int commit(int rc) { if (rc == 0) armed = false; return rc; }
+};
+[[nodiscard]] PackGuard use_gather_if_unpacked(ceres_hip_solver* s, BalArgs& A) {
+  if (s->packed) return PackGuard();
   A.src_values = s->values;
   A.src_b = s->b;
   A.slot_epos = s->d_slot_epos; A.slot_fpos = s->d_slot_fpos; A.slot_bpos = s->d_slot_bpos;
   A.J_out = s->d_J; A.Jf_out = s->d_Jf; A.b_out = s->d_bt;
   s->packed = true;
+  return PackGuard(s, true);
 }
 
 int ensure_packed(ceres_hip_solver* s) {
@@ -284,6 +299,9 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   const int32_t* cam_pos = A.cam_pos;
   A.status = status;
   int n_first = 0;
+  // cg_pq_parts holds kMaxPqParts partial sums: the tile pass's (one per workgroup) + the reduction's (<= kMaxVecGrid).  A grid that
+  // would not fit leaves p.q to the caller (run_cg then takes one pass over p and q) instead of writing past the buffer.
+  if (pq && (s->lds_mode ? s->fused_grid : s->chunk_grid) + kMaxVecGrid > kMaxPqParts) { pq = nullptr; if (n_pq) *n_pq = 0; }
   if (s->lds_mode) {
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
     HIP_TRY(s, LaunchBalFused(mode, A, true, s->fused_grid, s->stream));
@@ -389,8 +407,8 @@ int op_jtb(ceres_hip_solver* s, double* y) {
   if (s->path == CERES_HIP_PATH_BAL) {
     BalArgs A = bal_args(s);
     A.y_e = y;
-    use_gather_if_unpacked(s, A);  // first pass over freshly loaded values (the evaluator's gradient): fused with the re-layout
-    return bal_scatter(s, kBalJtb, A, nullptr, y + h.num_cols_e, false, nullptr);
+    PackGuard g = use_gather_if_unpacked(s, A);  // first pass over freshly loaded values (the evaluator's gradient): fused with the re-layout
+    return g.commit(bal_scatter(s, kBalJtb, A, nullptr, y + h.num_cols_e, false, nullptr));
   }
   HIP_TRY(s, hipMemsetAsync(y, 0, sizeof(double) * h.num_cols, st));
   HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, s->b, y, nullptr, st));
@@ -406,11 +424,11 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
     BalArgs A = bal_args(s);
     A.D_e = s->D;
     A.Mo = want_Mo ? s->d_Mo : nullptr;
-    use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
-    if (s->have_b) return bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr);
+    PackGuard g = use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
+    if (s->have_b) return g.commit(bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr));
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
     HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->fused_grid, st));
-    return 0;
+    return g.commit(0);
   }
   // block diagonal of E^T E + D_e^2, inverted in place
   HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kE, s->D, s->etei, h.diag_off_e.back(), st));
@@ -561,8 +579,10 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   A.y_e = rhs;
   A.point_blocks = jacobi ? blocks : nullptr;
   A.pt_diag_off = s->d_pt_diag_off;
-  use_gather_if_unpacked(s, A);
-  TRY(bal_scatter(s, kBalCgnrInit, A, nullptr, rhs + h.num_cols_e, false, nullptr));
+  {
+    PackGuard g = use_gather_if_unpacked(s, A);
+    TRY(g.commit(bal_scatter(s, kBalCgnrInit, A, nullptr, rhs + h.num_cols_e, false, nullptr)));
+  }
   if (!jacobi) return 0;
   const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
@@ -660,8 +680,8 @@ int op_squared_column_norm(ceres_hip_solver* s, double* out) {
   if (s->path == CERES_HIP_PATH_BAL && s->lds_mode) {  // sharded: bal_scatter all-reduces the camera part
     BalArgs A = bal_args(s);
     A.y_e = out;
-    use_gather_if_unpacked(s, A);
-    return bal_scatter(s, kBalColNorm, A, nullptr, out + h.num_cols_e, false, nullptr);
+    PackGuard g = use_gather_if_unpacked(s, A);
+    return g.commit(bal_scatter(s, kBalColNorm, A, nullptr, out + h.num_cols_e, false, nullptr));
   }
   HIP_TRY(s, LaunchGenSquaredColumnNorm(s->G, s->values, out, s->stream));
   if (s->world > 1) TRY(allreduce(s, out + h.num_cols_e, size_t(h.num_cols_f)));
@@ -758,10 +778,10 @@ void fill_summary(const CgScalars& S, int device_status, ceres_hip_summary* out)
 }
 
 int check_comm_error(ceres_hip_solver* s) {  // after a stream synchronisation
-  if (!s->p2p) return 0;
-  int flag = 0;
-  HIP_TRY(s, hipMemcpy(&flag, s->d_comm_error, sizeof(int), hipMemcpyDeviceToHost));
-  if (flag) return fail(s, CERES_HIP_E_COMM, "peer-to-peer all-reduce timed out after %.1f s: a rank did not arrive", s->p2p_timeout_s);
+  // the flag lives in mapped pinned host memory (a timed-out kernel stores into it with system scope): no copy, no extra synchronisation
+  if (!s->p2p || !s->h_comm_error) return 0;
+  if (*static_cast<volatile int*>(s->h_comm_error))
+    return fail(s, CERES_HIP_E_COMM, "peer-to-peer all-reduce timed out after %.1f s: a rank did not arrive (its output was poisoned with NaN)", s->p2p_timeout_s);
   return 0;
 }
 
@@ -954,7 +974,16 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 // The two LinearSolver::SolveImpl bodies.  x is a device pointer (num_cols).
+int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary);
 int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
+  const int rc = solve_loaded_impl(s, q_tol, r_tol, x, summary);
+  // "the flags were cleared together at the start" holds INSIDE one solve only: paths that never consume the promise (DENSE_SCHUR,
+  // explicit S, IDENTITY, early returns) clear and raise d_fail_flag themselves, and a later op-level call must not skip its memset
+  s->fail_flag_clean = false;
+  s->nonfinite_clean = false;
+  return rc;
+}
+int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   memset(summary, 0, sizeof(*summary));
@@ -1345,7 +1374,7 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   if (s->comm) (void)ncclCommDestroy(s->comm);
   for (int q = 0; q < kP2pMaxWorld; ++q) if (s->p2p_opened[q]) (void)hipIpcCloseMemHandle(s->p2p_opened[q]);
   if (s->p2p_base) (void)hipFree(s->p2p_base);
-  if (s->d_comm_error) (void)hipFree(s->d_comm_error);
+  if (s->h_comm_error) (void)hipHostFree(s->h_comm_error);
   free_all(s);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -1495,6 +1524,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
     const int64_t tiles_per_wg = 512 / kTile;
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
+    s->fused_grid = std::min(s->fused_grid, kMaxPqParts - kMaxVecGrid);  // one p.q partial per workgroup must fit cg_pq_parts (bal_scatter)
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
     TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_slots) * 9));  // ring of ONE chunk's per-slot F^T z
@@ -1540,6 +1570,8 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
   info->device_bytes = s->device_bytes;
   info->camera_accum_in_lds = s->lds_mode ? 1 : 0;
   info->world_size = s->world; info->rank = s->rank;
+  info->p2p_enabled = s->p2p ? 1 : 0;
+  info->p2p_fine_grained = s->p2p_fine_grained ? 1 : 0;
   return 0;
 }
 
@@ -1595,8 +1627,9 @@ int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world,
     HIP_TRY(s, hipIpcGetMemHandle(&h, s->p2p_base));
   }
   HIP_TRY(s, hipMemset(s->p2p_base, 0, s->p2p_bytes));
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error), sizeof(int)));
-  HIP_TRY(s, hipMemset(s->d_comm_error, 0, sizeof(int)));
+  HIP_TRY(s, hipHostMalloc(reinterpret_cast<void**>(&s->h_comm_error), sizeof(int), hipHostMallocMapped));
+  *s->h_comm_error = 0;
+  HIP_TRY(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_comm_error), s->h_comm_error, 0));
   HIP_TRY(s, hipDeviceSynchronize());
   { const char* e = getenv("CERES_HIP_P2P_TIMEOUT"); if (e && atof(e) > 0) s->p2p_timeout_s = atof(e); }
   memcpy(handle_out, &h, sizeof(h));
@@ -1622,7 +1655,11 @@ int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles) 
     s->p2p_peers.slots[q] = reinterpret_cast<double*>(static_cast<char*>(base) + flag_bytes);
   }
   s->p2p = true;
-  return 0;
+  // The path is enabled only after it has carried known values: a coarse-grained receive buffer (the fallback of _prepare) written by
+  // ANOTHER device may keep stale lines in this device's L2 across slot re-use, which only shows in the data.  Every rank is inside
+  // _connect at this point (it is collective), so the self-test can run here; on failure the path stays disabled on this rank and
+  // the callers agree on the verdict out of band (ceres_hip_comm_p2p_disable everywhere, RCCL takes over).
+  return ceres_hip_comm_p2p_selftest(s);
 }
 
 // Self-test of the peer-to-peer all-reduce, a collective (every rank calls it): kSelfTestRounds all-reduces of a vector that spans
@@ -1687,7 +1724,7 @@ int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t ite
 int ceres_hip_comm_p2p_disable(ceres_hip_solver* s) {
   if (!s) return CERES_HIP_E_INVALID;
   s->p2p = false;
-  if (s->d_comm_error) { HIP_TRY(s, hipSetDevice(s->opt.device)); HIP_TRY(s, hipMemset(s->d_comm_error, 0, sizeof(int))); }
+  if (s->h_comm_error) { HIP_TRY(s, hipSetDevice(s->opt.device)); HIP_TRY(s, hipStreamSynchronize(s->stream)); *s->h_comm_error = 0; }
   return 0;
 }
 

@@ -63,7 +63,7 @@ class CInfo(ctypes.Structure):
                 ("num_f_blocks", c_int32), ("row_block_size", c_int32), ("e_block_size", c_int32),
                 ("f_block_size", c_int32), ("num_nonzeros", c_int64), ("num_observations", c_int64),
                 ("num_tiles", c_int64), ("device_bytes", c_int64), ("camera_accum_in_lds", c_int32),
-                ("world_size", c_int32), ("rank", c_int32)]
+                ("world_size", c_int32), ("rank", c_int32), ("p2p_enabled", c_int32), ("p2p_fine_grained", c_int32)]
 
 
 class CTiming(ctypes.Structure):
@@ -326,7 +326,8 @@ class HipLinearSolver:
             self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
 
     def p2p_selftest(self) -> bool:
-        """Collective: one all-reduce of known values through the peer-to-peer path."""
+        """Collective: all-reduces of known values through the peer-to-peer path.  ceres_hip_comm_p2p_connect has already run it once
+        (the path is never enabled untested); this repeats it on request."""
         if not self.p2p_ok:
             return False
         rc = self._lib.ceres_hip_comm_p2p_selftest(self._h)

@@ -160,6 +160,9 @@ typedef struct ceres_hip_info {
   int64_t device_bytes;     /* HBM held by this handle                                 */
   int32_t camera_accum_in_lds; /* BAL path: 1 if the F-space accumulators fit in LDS   */
   int32_t world_size, rank;
+  int32_t p2p_enabled;      /* the one-shot peer-to-peer all-reduce is connected AND passed its self-test */
+  int32_t p2p_fine_grained; /* its receive buffer is a fine-grained allocation (0: the runtime could only export a
+                               coarse-grained one — fine between ranks that share a device, self-tested otherwise)  */
 } ceres_hip_info;
 
 typedef struct ceres_hip_solver ceres_hip_solver; /* opaque */
@@ -203,6 +206,8 @@ int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_I
 #define CERES_HIP_IPC_HANDLE_BYTES 64
 int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world_size, int64_t max_elements,
                                uint8_t handle_out[CERES_HIP_IPC_HANDLE_BYTES]);
+/* _connect is collective and ENDS WITH THE SELF-TEST below: it returns non-zero, with the path disabled on this rank, unless known
+ * values made it through every peer's buffer.  Callers never get an untested peer-to-peer path.                         */
 int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles /* world_size x 64 bytes */);
 /* Collective self-test (six all-reduces of multi-chunk vectors with values that change every round — a receive slot is
  * re-used every second epoch, so stale cached lines show from the third round on; 5 s timeout): non-zero leaves the

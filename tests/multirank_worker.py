@@ -53,13 +53,13 @@ def run_rank(rank, world, conn, device, scenario):
                        "col_index": sh.col_index, "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum())}
                 # (1) converged solve
                 x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=-1.0, r_tolerance=1e-12))
-                rec["converged"] = (x, summ.termination_type, summ.num_iterations)
+                rec["converged"] = (x, summ.termination_type, summ.num_iterations, None, summ.message)
                 # (2) the call LM makes
                 x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=0.1, r_tolerance=-1.0))
-                rec["lm_style"] = (x, summ.termination_type, summ.num_iterations)
+                rec["lm_style"] = (x, summ.termination_type, summ.num_iterations, None, summ.message)
                 # (3) the whole LM step on the device (f1), incl. the all-reduced {finite flag, model cost}
                 step, summ, mcc = s.lm_compute_step(v, b, 1e4, 0.1)
-                rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc)
+                rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
                 # (4) operators that sum over ranks
                 if solver_type == hs.ITERATIVE_SCHUR:
                     s.load(v, b, D)

@@ -2,7 +2,7 @@
 Venice-shaped step takes it about a second), plus size-independent properties.
 
   dubrovnik16  (16 / 22 106 / 83 718)        both solvers: every operator 1e-12, the LM-style eta = 0.1 solve
-  ladybug1723  (1723 / 156 502 / 678 718)    (iteration count +-1, step 1e-9 when the counts coincide), converged solve 1e-8
+  ladybug1723  (1723 / 156 502 / 678 718)    (eta = 0.1 and bundle_adjuster's 0.01: tests/step_check.py, no escape hatch), converged solve 1e-8
   venice1778   (1778 / 993 923 / 5 001 946)  operators of BOTH solvers: S x, rhs, (E^T E)^-1, back-substitution,
                                              SCHUR_JACOBI blocks, JtJx, J^T b, JACOBI blocks; eta = 0.1 solves
   many cameras (50 000 cameras)              the regime of BASELINE.json configs[4] (camera accumulators do not fit
@@ -11,11 +11,13 @@ Venice-shaped step takes it about a second), plus size-independent properties.
 import numpy as np
 import pytest
 
+from step_check import assert_lm_style_step
 from test_gpu_operators import make_solver, rel
 
 pytestmark = pytest.mark.gpu
 
 OP_TOL = 1e-12
+ETAS = (0.1, 0.01)   # Solver::Options::eta default / bundle_adjuster's --eta
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -54,13 +56,12 @@ def check_schur_side(hip, oracle, p, expect_lds, solve=True):
     for k, v in errs.items():  # inverted blocks carry their condition number: 1e-11
         assert v <= (1e-11 if k.endswith("_inv") else OP_TOL), (k, v)
     if solve:
-        # the call LevenbergMarquardtStrategy makes: eta = 0.1, r_tolerance = -1
-        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
-        xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
-        assert summ.termination_type == so.termination_type == hip.SUCCESS
-        assert abs(summ.num_iterations - so.num_iterations) <= 1, (summ, so)
-        if summ.num_iterations == so.num_iterations:
-            assert rel(x, xo) <= 1e-9, rel(x, xo)
+        # the call LevenbergMarquardtStrategy makes, r_tolerance = -1: eta = 0.1 (Solver::Options default, solver.h:628) and
+        # eta = 0.01 (what bundle_adjuster runs, examples/bundle_adjuster.cc:116) — checked unconditionally (tests/step_check.py)
+        for eta in ETAS:
+            x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=eta, r_tolerance=-1.0))
+            assert_lm_style_step(x, summ, lambda lo, hi, q, r: m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, min_it=lo, max_it=hi,
+                                                                                        q_tol=q, r_tol=r), eta, hip.SUCCESS)
     s.close()
     return m
 
@@ -82,12 +83,10 @@ def check_cgnr_side(hip, oracle, p, expect_lds, solve=True):
     for k, v in errs.items():  # inverted blocks carry their condition number: 1e-11, like the reference's inverse checks
         assert v <= (1e-11 if k.endswith("_inv") else OP_TOL), (k, v)
     if solve:
-        xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
-        xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=500, q_tol=0.1, r_tol=-1.0)
-        assert summ.termination_type == so.termination_type == hip.SUCCESS
-        assert abs(summ.num_iterations - so.num_iterations) <= 1, (summ, so)
-        if summ.num_iterations == so.num_iterations:
-            assert rel(xs, xo) <= 1e-9, rel(xs, xo)
+        for eta in ETAS:
+            xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=eta, r_tolerance=-1.0))
+            assert_lm_style_step(xs, summ, lambda lo, hi, q, r: m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=lo, max_it=hi,
+                                                                              q_tol=q, r_tol=r), eta, hip.SUCCESS)
     s.close()
 
 

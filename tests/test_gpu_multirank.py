@@ -1,6 +1,6 @@
-"""SURVEY.md §8(e) with PRODUCT code on real ranks: two processes, one rank each, sharded by point
+"""SURVEY.md §8(e) with PRODUCT code on real ranks: 2, 3, 4 and 8 processes, one rank each, sharded by point
 (ceres-solver_amd/partition.py), camera-space sums combined by the library's one-shot peer-to-peer all-reduce over
-hipIpc-mapped buffers.  The GPU box has one MI355X, so both ranks run on device 0 — the same code path (hipIpc
+hipIpc-mapped buffers.  The GPU box has one MI355X, so all ranks run on device 0 — the same code path (hipIpc
 mapping, system-scope flags, rank-ordered sums) that runs over xGMI between the GPUs of a node.  Rung (5) of the
 parity ladder: multi-GPU vs 1-GPU / oracle, same tolerances (sums are re-associated again)."""
 import multiprocessing as mp
@@ -8,14 +8,15 @@ import multiprocessing as mp
 import numpy as np
 import pytest
 
+from step_check import assert_lm_style_step
 from test_gpu_operators import rel
 
 pytestmark = pytest.mark.gpu
 
-WORLD = 2
+WORLDS = (2, 3, 4, 8)   # the peer-to-peer all-reduce indexes [parity][source rank][cap] slots for world <= 8 (kernels_cg.hip)
 
 
-def run_ranks(scenario, timeout=420):
+def run_ranks(scenario, WORLD=2, timeout=420):
     from multirank_worker import run_rank
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(WORLD)]
@@ -60,58 +61,71 @@ def assemble(partition_mod, recs, num_cols, key):
     return x
 
 
-def test_two_ranks_bal_both_solvers_against_the_oracle(hip, oracle, problems):
+@pytest.fixture(scope="module")
+def bal_case(hip, oracle, problems):
+    """The problem of the sharded BAL test and everything the oracle says about it (computed once for all world sizes)."""
     kw = dict(kind="bal", seed=31, nc=37, np=6000, no=26000, skew=0.5,
               solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)])
-    res = run_ranks([("bal", kw)])
     p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=37, num_points=6000, num_observations=26000)
     m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
     m0 = oracle.Matrix(p.bs, 0)
-    nce = m.num_cols_e
+    ref = {}
     for solver_type, pre in kw["solvers"]:
-        recs = [res[r][("bal", solver_type, pre)] for r in range(WORLD)]
-        assert all(rec["path"] == hip.PATH_BAL and rec["world"] == WORLD for rec in recs) and [rec["rank"] for rec in recs] == [0, 1]
         fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m0.cgnr_solve
+        ref[(solver_type, "solve")] = lambda lo, hi, q, r, fn=fn, pre=pre: fn(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r)
+        ref[(solver_type, "converged")] = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=400, q_tol=-1.0, r_tol=1e-12)
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    xf = np.random.default_rng(5).standard_normal(m.num_cols_f)
+    ref["rhs"], ref["sx"], ref["precond"] = isc.rhs().copy(), isc.sx(xf).copy(), m.schur_jacobi(p.values, p.D)[0]
+    xx = np.random.default_rng(6).standard_normal(p.bs.num_cols)
+    ref["jtjx"] = m0.left_multiply(p.values, m0.right_multiply(p.values, xx)) + p.D ** 2 * xx
+    ref["jtb"] = m0.left_multiply(p.values, p.b)
+    return kw, p, m0, ref
+
+
+@pytest.mark.parametrize("world", WORLDS)
+def test_sharded_bal_both_solvers_against_the_oracle(hip, bal_case, world):
+    kw, p, m0, ref = bal_case
+    res = run_ranks([("bal", kw)], world)
+    for solver_type, pre in kw["solvers"]:
+        recs = [res[r][("bal", solver_type, pre)] for r in range(world)]
+        assert all(rec["path"] == hip.PATH_BAL and rec["world"] == world for rec in recs) and [rec["rank"] for rec in recs] == list(range(world))
         # converged solve
-        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=400, q_tol=-1.0, r_tol=1e-12)
+        xo, so = ref[(solver_type, "converged")]
         assert all(rec["converged"][1] == hip.SUCCESS for rec in recs)
         assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-8
-        # the camera part is REPLICATED: identical bits on both ranks (the all-reduce sums in rank order everywhere)
-        for key in ("converged", "lm_style"):
-            a, b = recs[0][key][0][recs[0]["n_e"]:], recs[1][key][0][recs[1]["n_e"]:]
-            assert np.array_equal(a, b), key
-            assert recs[0][key][2] == recs[1][key][2]   # same iteration count on every rank
-        # LM-style call: iteration count within 1 of the oracle, step 1e-9 when the counts coincide
-        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=400, q_tol=0.1, r_tol=-1.0)
-        assert abs(recs[0]["lm_style"][2] - so.num_iterations) <= 1
-        if recs[0]["lm_style"][2] == so.num_iterations:
-            assert rel(assemble(None, recs, p.bs.num_cols, "lm_style"), xo) <= 1e-9
-        # the LM step on the device: step = -(solve), model cost change summed over ranks and equal on both
+        # the camera part is REPLICATED: identical bits on every rank (the all-reduce sums in rank order everywhere)
+        for key in ("converged", "lm_style", "lm_step"):
+            a = recs[0][key][0][recs[0]["n_e"]:]
+            for rec in recs[1:]:
+                assert np.array_equal(a, rec[key][0][rec["n_e"]:]), key
+                assert recs[0][key][2] == rec[key][2]   # same iteration count on every rank
+                assert recs[0][key][4] == rec[key][4]   # and the same message (zeta, |r|): the replicated CG state is bit-identical
+        # LM-style call (eta = 0.1): unconditional comparison with the oracle's CG sequence (tests/step_check.py)
+        class S:  # the summary every rank reported
+            termination_type, num_iterations, message = recs[0]["lm_style"][1], recs[0]["lm_style"][2], recs[0]["lm_style"][4]
+        xo, so = assert_lm_style_step(assemble(None, recs, p.bs.num_cols, "lm_style"), S, ref[(solver_type, "solve")], 0.1, hip.SUCCESS)
+        # the LM step on the device: step = -(solve), model cost change summed over ranks and equal on all of them
         step = assemble(None, recs, p.bs.num_cols, "lm_step")
-        assert recs[0]["lm_step"][3] == recs[1]["lm_step"][3] > 0
-        if recs[0]["lm_step"][2] == so.num_iterations:
-            assert rel(step, -xo) <= 1e-9
-            Jx = m0.right_multiply(p.values, step)
-            assert abs(recs[0]["lm_step"][3] - (-(Jx @ (p.b + Jx / 2)))) <= 1e-9 * abs(recs[0]["lm_step"][3])
+        assert all(rec["lm_step"][3] == recs[0]["lm_step"][3] for rec in recs) and recs[0]["lm_step"][3] > 0
+        S.termination_type, S.num_iterations, S.message = recs[0]["lm_step"][1], recs[0]["lm_step"][2], recs[0]["lm_step"][4]
+        assert_lm_style_step(-step, S, ref[(solver_type, "solve")], 0.1, hip.SUCCESS)
+        Jx = m0.right_multiply(p.values, step)   # the model cost change belongs to the step the ranks produced, whatever its index
+        assert abs(recs[0]["lm_step"][3] - (-(Jx @ (p.b + Jx / 2)))) <= 1e-9 * abs(recs[0]["lm_step"][3])
         if solver_type == hip.ITERATIVE_SCHUR:
-            isc = oracle.ImplicitSchurComplement(m)
-            isc.init(p.values, p.D, p.b)
-            xf = np.random.default_rng(5).standard_normal(m.num_cols_f)
-            inv, _ = m.schur_jacobi(p.values, p.D)
             for rec in recs:
-                assert rel(rec["rhs"], isc.rhs()) <= 1e-12 and rel(rec["sx"], isc.sx(xf)) <= 1e-12 and rel(rec["precond"], inv) <= 1e-11
+                assert rel(rec["rhs"], ref["rhs"]) <= 1e-12 and rel(rec["sx"], ref["sx"]) <= 1e-12 and rel(rec["precond"], ref["precond"]) <= 1e-11
         else:
-            xx = np.random.default_rng(6).standard_normal(p.bs.num_cols)
-            want = m0.left_multiply(p.values, m0.right_multiply(p.values, xx)) + p.D ** 2 * xx
-            g = m0.left_multiply(p.values, p.b)
             for rec in recs:
                 ci = rec["col_index"]
-                assert rel(rec["jtjx"], want[ci]) <= 1e-12 and rel(rec["jtb"], g[ci]) <= 1e-12
+                assert rel(rec["jtjx"], ref["jtjx"][ci]) <= 1e-12 and rel(rec["jtb"], ref["jtb"][ci]) <= 1e-12
 
 
-def test_two_ranks_generic_structure(hip, oracle, problems):
+@pytest.mark.parametrize("WORLD", (2, 3))
+def test_sharded_generic_structure(hip, oracle, problems, WORLD):
     kw = dict(kind="general", seed=6, ne=40, nf=7, solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)], max_it=3000)
-    res = run_ranks([("general", kw)])
+    res = run_ranks([("general", kw)], WORLD)
     p = problems.random_schur_problem(num_e_blocks=40, num_f_blocks=7, num_no_e_rows=2, seed=6)
     m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
     m0 = oracle.Matrix(p.bs, 0)
@@ -124,13 +138,14 @@ def test_two_ranks_generic_structure(hip, oracle, problems):
         assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-7
 
 
-def test_two_ranks_cgnr_fused_iteration_equals_the_six_kernel_iteration(hip, problems):
+@pytest.mark.parametrize("WORLD", (2, 4))
+def test_sharded_cgnr_fused_iteration_equals_the_six_kernel_iteration(hip, problems, WORLD):
     """Sharded CGNR on the <2,3,9> path: the two-launch iteration (the shard's p.q share travels with the camera vector through
     the operator's all-reduce, r.z / Q1 / |r|^2 of the shard in one 4-double all-reduce) against the six-kernel sequence with
     its four scalar all-reduces per iteration: same iteration counts, same termination, solutions equal to rounding — for a
     converged solve (incl. residual resets every 10th iteration) and for the LM step."""
     base = dict(kind="bal", seed=77, nc=45, np=5000, no=23000, skew=0.4, solvers=[(hip.CGNR, hip.JACOBI)], max_it=400)
-    res = run_ranks([("fused", dict(base, cg_fused="1")), ("unfused", dict(base, cg_fused="0"))])
+    res = run_ranks([("fused", dict(base, cg_fused="1")), ("unfused", dict(base, cg_fused="0"))], WORLD)
     for r in range(WORLD):
         a, b = res[r][("fused", hip.CGNR, hip.JACOBI)], res[r][("unfused", hip.CGNR, hip.JACOBI)]
         for key in ("converged", "lm_style", "lm_step"):
@@ -139,5 +154,7 @@ def test_two_ranks_cgnr_fused_iteration_equals_the_six_kernel_iteration(hip, pro
         assert a["converged"][2] > 12   # long enough to contain a residual reset
         assert abs(a["lm_step"][3] - b["lm_step"][3]) <= 1e-10 * abs(b["lm_step"][3])
     # and the ranks agree with each other on the replicated part, bit for bit, in the fused mode too
-    a0, a1 = res[0][("fused", hip.CGNR, hip.JACOBI)], res[1][("fused", hip.CGNR, hip.JACOBI)]
-    assert np.array_equal(a0["converged"][0][a0["n_e"]:], a1["converged"][0][a1["n_e"]:])
+    a0 = res[0][("fused", hip.CGNR, hip.JACOBI)]
+    for r in range(1, WORLD):
+        a1 = res[r][("fused", hip.CGNR, hip.JACOBI)]
+        assert np.array_equal(a0["converged"][0][a0["n_e"]:], a1["converged"][0][a1["n_e"]:])
