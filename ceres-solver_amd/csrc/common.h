@@ -24,6 +24,12 @@ constexpr int kTile = 64;           // observation slots per tile = one wavefron
 constexpr int kMaxGenericBlock = 16;  // largest block dimension the generic kernels take
 constexpr int kCamChunk = 512;      // max observations per work item (one wavefront) of the camera-major kernels
 constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12 double2
+// double2 elements from one tile to the next.  A/B builds only (tools/build_variant.sh): 13 rows leave a 1 KiB gap behind each
+// tile (an experiment on where JtJx's point-space output should live); the product packs the tiles back to back.
+#ifndef CERES_HIP_AB_TILE_ROWS
+#define CERES_HIP_AB_TILE_ROWS 12
+#endif
+constexpr int kTilePitch = CERES_HIP_AB_TILE_ROWS * 64;
 constexpr size_t kLdsBytesPerCu = 160 * 1024;  // LDS per CU on gfx950
 constexpr int kZUnit = 64;             // max entries of one work unit of the chunked camera-major pass (cameras not in LDS)
 constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
@@ -88,6 +94,11 @@ struct BalPlan {
   std::vector<int32_t> zu_shared;            // 1: the camera has more units in this chunk (combine with atomics), 0: plain read-modify-write
   std::vector<int32_t> zc_slot;              // per entry: slot index RELATIVE to its chunk's first slot; chunk-major, camera-major inside
   int max_track = 0, max_camera_degree = 0;
+  // REMAINDER: trailing row blocks [rem_row0, nrb) that are not "one point cell + one camera cell" but touch camera blocks only
+  // (rows without an E block: priors / regularisers on cameras, the rows SchurEliminator::NoEBlockRowsUpdate handles,
+  // I/schur_eliminator_impl.h:574-666, and PartitionedMatrixView's second loops, I/partitioned_matrix_view_impl.h:171-190).  The fused
+  // tiles cover rows [0, rem_row0); the remainder's contributions are sums over its rows and are added by small generic kernels.
+  int rem_row0 = 0, n_rem_rows = 0;
 };
 
 // Storage of an EXPLICIT Schur complement: what SparseSchurComplementSolver::InitStorage builds

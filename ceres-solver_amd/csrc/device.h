@@ -111,13 +111,15 @@ constexpr int kCamPart = 54;
 hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
                                 const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream);
 hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
-                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream);
+                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream,
+                                 const double* extra = nullptr);  // extra: as CamGather::extra
 struct CamGather {
   const double* parts = nullptr;          // nullptr: the blocks are already assembled in memory
   const int32_t* cam_item_ptr = nullptr;
   const double* D_f = nullptr;            // added squared to the diagonal (indexed through cam_pos)
   const int32_t* cam_pos = nullptr;
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
+  const double* extra = nullptr;          // [81 c + 9 a + b] raw sums added to the camera's block (rows outside the tiles: LaunchRemCameraBlocks)
 };
 // Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].
 struct ZUnits {
@@ -175,6 +177,11 @@ hipError_t LaunchGenExtractDiagBlocks(const GenStructure& G, const double* S, co
                                       hipStream_t stream);
 hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                double* lhs, hipStream_t stream);
+
+// ---- remainder rows of the fused <2,3,9> path: rows without a point cell, R = their own GenStructure (kernels_generic.hip) ----
+hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, double* out, hipStream_t stream);
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, double* y, hipStream_t stream);
+hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t stream);
 
 // ---- explicit Schur complement solvers (kernels_schur.hip) ------------------
 struct SchurPairs {  // device image of SchurStorage (common.h)

@@ -213,7 +213,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
 #pragma unroll
       for (int i = 0; i < 24; ++i) v[i] = double(float(v[i]));  // this pass computes with what later passes will read
     } else {
-      double2* o = A.J_out + tile * (kPairsPerSlot * kTile) + lane;
+      double2* o = A.J_out + tile * kTilePitch + lane;
 #pragma unroll
       for (int j = 0; j < kPairsPerSlot; ++j) tile_store(o + j * kTile, make_double2(v[2 * j], v[2 * j + 1]));
     }
@@ -236,7 +236,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
 #pragma unroll
     for (int i = 0; i < 18; ++i) s.f[i] = v[6 + i];
   } else {
-    const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
+    const double2* J = A.J + tile * kTilePitch + lane;
     double2 p[kPairsPerSlot];
 #pragma unroll
     for (int j = 0; j < kPairsPerSlot; ++j) p[j] = stream_load<2>(J + j * kTile);
@@ -263,7 +263,7 @@ __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int 
   s.slot = tile * kTile + lane;
   s.zrel = s.slot - A.z_slot0;
   s.b0 = 0.0; s.b1 = 0.0;
-  const double2* J = A.J + tile * (kPairsPerSlot * kTile) + lane;
+  const double2* J = A.J + tile * kTilePitch + lane;
   double2 p[kPairsPerSlot];
 #pragma unroll
   for (int j = 0; j < kPairsPerSlot; ++j) p[j] = stream_load<1>(J + j * kTile);
@@ -347,13 +347,61 @@ __device__ __forceinline__ void scatter_f_squares(const Slot& s, double* acc) {
 #ifndef CERES_HIP_AB_YE_STORE
 #define CERES_HIP_AB_YE_STORE 0
 #endif
-__device__ __forceinline__ void store_ye(double* p, double v) {
+// 3 (timing ablation, needs CERES_HIP_AB_TILE_ROWS=13): the output goes into the 1 KiB gap right behind the tile it was computed from
+// (`alt`), i.e. into the DRAM neighbourhood the wave is reading anyway, instead of the point-space vector.
+__device__ __forceinline__ void store_ye(double* p, double v, double* alt = nullptr) {
 #if CERES_HIP_AB_YE_STORE == 1
   __builtin_nontemporal_store(v, p);
 #elif CERES_HIP_AB_YE_STORE == 2
   (void)p; (void)v;
+#elif CERES_HIP_AB_YE_STORE == 3
+  (void)p; *alt = v;
+#elif CERES_HIP_AB_YE_STORE == 4   // sc1: system-scope (write-through) store
+  (void)alt; asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif CERES_HIP_AB_YE_STORE == 5   // sc0 sc1
+  (void)alt; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#elif CERES_HIP_AB_YE_STORE == 6   // sc0 sc1 nt
+  (void)alt; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
 #else
+  (void)alt;
   *p = v;
+#endif
+}
+// A/B builds only: non-temporal loads for the point-space x / D of the pipelined JtJx (each scalar is read by exactly one tile)
+#ifndef CERES_HIP_AB_XE_NT
+#define CERES_HIP_AB_XE_NT 0
+#endif
+__device__ __forceinline__ double load_xe(const double* p) {
+#if CERES_HIP_AB_XE_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+// XCD-aware tile walk: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and neighbouring tiles share lines of
+// everything indexed by point (x_e, D_e, y_e, (E^T E)^-1: a tile's point range starts wherever the previous one ended).  Workgroup b
+// therefore walks the tile groups of "logical workgroup" (b % 8) * (grid / 8) + b / 8: XCD x gets the logical workgroups
+// [x grid / 8, (x + 1) grid / 8), whose tiles are neighbours at every step of the grid-strided loop, so a shared line is fetched
+// into ONE L2 instead of two.  Measured on the Venice shape (profiles/r03a_ab_*): S.x 0.2010 -> 0.1933 ms, JtJx 0.2374 -> 0.2334 ms.
+// CERES_HIP_AB_XCD_GROUP=0 in an A/B build restores the identity mapping.
+#ifndef CERES_HIP_AB_XCD_GROUP
+#define CERES_HIP_AB_XCD_GROUP 1
+#endif
+__device__ __forceinline__ int64_t logical_workgroup() {
+#if CERES_HIP_AB_XCD_GROUP
+  return (gridDim.x % 8 == 0) ? int64_t(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : int64_t(blockIdx.x);
+#else
+  return blockIdx.x;
+#endif
+}
+
+__device__ __forceinline__ double* ye_alt(const BalArgs& A, const Slot& s) {
+#if CERES_HIP_AB_YE_STORE == 3
+  static_assert(CERES_HIP_AB_TILE_ROWS == 13, "the gap behind the tile");
+  return reinterpret_cast<double*>(const_cast<double2*>(A.J) + (s.slot / kTile) * kTilePitch + kPairsPerSlot * kTile);
+#else
+  (void)A; (void)s;
+  return nullptr;
 #endif
 }
 
@@ -518,13 +566,13 @@ __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, 
         const double v0 = shfl_idx(w[0], ta), v1 = shfl_idx(w[1], ta), v2 = shfl_idx(w[2], ta);
         const int c = lane % 3;
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 23) & 1) { const double yv = v + x.da * x.da * x.xa; store_ye(A.y_e + x.base + lane, yv); dot += x.xa * yv; }
+        if ((s.seg >> 23) & 1) { const double yv = v + x.da * x.da * x.xa; store_ye(A.y_e + x.base + lane, yv, ye_alt(A, s) + lane); dot += x.xa * yv; }
       }
       if (n3 > 64) {
         const double v0 = shfl_idx(w[0], tb), v1 = shfl_idx(w[1], tb), v2 = shfl_idx(w[2], tb);
         const int c = (lane + 1) % 3;  // (64 + lane) % 3
         const double v = c == 0 ? v0 : (c == 1 ? v1 : v2);
-        if ((s.seg >> 30) & 1) { const double yv = v + x.db * x.db * x.xb; store_ye(A.y_e + x.base + 64 + lane, yv); dot += x.xb * yv; }
+        if ((s.seg >> 30) & 1) { const double yv = v + x.db * x.db * x.xb; store_ye(A.y_e + x.base + 64 + lane, yv, ye_alt(A, s) + 64 + lane); dot += x.xb * yv; }
       }
     } else if (s.valid && lane == s.last) {
       const int po = pt_off(A, s.pt);
@@ -820,7 +868,7 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
         if (A.negate_out && !isfinite(z)) atomicAdd(A.nonfinite, 1);
       }
   }
-  const int64_t wave = int64_t(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t wave = logical_workgroup() * (BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
   const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
   for (int64_t tile = A.tile_begin + wave; tile < tile_end; tile += nwaves) {
@@ -892,7 +940,7 @@ __device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int l
     // selecting zeros here would consume the loads — a wait — in the issue phase)
     const bool a = lane < n3, b = lane + 64 < n3;
     const int64_t ia = x.base + (a ? lane : 0), ib = x.base + (b ? 64 + lane : 0);
-    x.xa = A.x_e[ia]; x.da = A.D_e[ia]; x.xb = A.x_e[ib]; x.db = A.D_e[ib];
+    x.xa = load_xe(A.x_e + ia); x.da = load_xe(A.D_e + ia); x.xb = load_xe(A.x_e + ib); x.db = load_xe(A.D_e + ib);
   }
 }
 
@@ -915,7 +963,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
   const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
-  const int64_t wave0 = A.tile_begin + int64_t(blockIdx.x) * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t wave0 = A.tile_begin + logical_workgroup() * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t last = tile_end - 1;
   if (wave0 < tile_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
@@ -1052,7 +1100,7 @@ __global__ __launch_bounds__(1024) void bal_stream_probe_kernel(const double2* _
   const int64_t wave = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 6), nwaves = int64_t(gridDim.x) * 16;
   double acc = 0;
   for (int64_t tile = wave; tile < n_tiles; tile += nwaves) {
-    const double2* p = J + tile * (kPairsPerSlot * kTile) + lane;
+    const double2* p = J + tile * kTilePitch + lane;
     double2 v[kPairsPerSlot];
 #pragma unroll
     for (int j = 0; j < kPairsPerSlot; ++j) v[j] = p[j * kTile];
@@ -1120,7 +1168,7 @@ __global__ __launch_bounds__(256) void bal_pack_kernel(const double* __restrict_
 #pragma unroll
     for (int q = 0; q < 6; ++q) tile_store(o + q * kTile, make_float4(float(v[4 * q]), float(v[4 * q + 1]), float(v[4 * q + 2]), float(v[4 * q + 3])));
   } else {
-    double2* o = J + tile * (kPairsPerSlot * kTile) + lane;
+    double2* o = J + tile * kTilePitch + lane;
 #pragma unroll
     for (int j = 0; j < kPairsPerSlot; ++j) tile_store(o + j * kTile, make_double2(v[2 * j], v[2 * j + 1]));
   }
@@ -1231,13 +1279,18 @@ __device__ __forceinline__ void gather_camera_row(const double* __restrict__ par
 __global__ __launch_bounds__(64) void bal_camera_finish_kernel(const double* __restrict__ parts, const int32_t* __restrict__ cam_item_ptr,
                                                                const double* __restrict__ D_f, const int32_t* __restrict__ cam_pos,
                                                                const int64_t* __restrict__ cam_diag_off, double* __restrict__ blocks,
-                                                               double* __restrict__ camsq, int n_cameras) {
+                                                               double* __restrict__ camsq, int n_cameras, const double* __restrict__ extra) {
   const int lane = threadIdx.x;
   const int grp = lane / 9, i = lane - 9 * grp;
   const int c = blockIdx.x * 7 + grp;
   if (grp >= 7 || c >= n_cameras) return;
   double row[9], sqsum;
   gather_camera_row(parts, cam_item_ptr[c], cam_item_ptr[c + 1], i, row, sqsum, camsq != nullptr);
+  if (extra) {  // rows outside the tiles (no point cell): their F^T F, whose diagonal is their share of the column square sums
+    const double* x = extra + 81 * int64_t(c) + 9 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { row[k] += x[k]; if (k == i) sqsum += x[k]; }
+  }
   if (D_f) {
     const double d = D_f[(cam_pos ? cam_pos[c] : 9 * c) + i];
 #pragma unroll
@@ -1339,6 +1392,11 @@ __global__ __launch_bounds__(64 * kInvertGatherWaves) void bal_invert9_kernel(do
         row[k] = csum[0][ra * (19 - ra) / 2 + (rb - ra)];
       }
       sq_from_items = csum[0][45 + i];
+      if (gather.extra) {  // rows outside the tiles (no point cell): their F^T F, whose diagonal is their share of the column square sums
+        const double* x = gather.extra + 81 * int64_t(c) + 9 * i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { row[k] += x[k]; if (k == i) sq_from_items += x[k]; }
+      }
       if (gather.D_f) {
         const double d = gather.D_f[(gather.cam_pos ? gather.cam_pos[c] : 9 * c) + i];
 #pragma unroll
@@ -1569,9 +1627,9 @@ hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems
 }
 
 hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
-                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream) {
+                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream, const double* extra) {
   if (n_cameras > 0) hipLaunchKernelGGL(bal_camera_finish_kernel, dim3((n_cameras + 6) / 7), dim3(64), 0, stream, parts, cam_item_ptr, D_f, cam_pos,
-                                        cam_diag_off, blocks, camsq, n_cameras);
+                                        cam_diag_off, blocks, camsq, n_cameras, extra);
   return hipGetLastError();
 }
 

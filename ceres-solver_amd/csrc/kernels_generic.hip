@@ -365,7 +365,62 @@ __global__ __launch_bounds__(kB) void gen_extract_diag_blocks_kernel(GenStructur
 
 inline unsigned blocks_for(int64_t n) { return unsigned((n + kB - 1) / kB); }
 
+// ---- remainder rows of the fused <2,3,9> path (rows without a point cell; R = their own GenStructure, compact row space) ----
+// out[81 c + 9 a + b] = sum over the remainder cells of camera c of (F^T F)(a, b): what SchurEliminator::NoEBlockRowsUpdate adds to
+// the diagonal cell of S (I/schur_eliminator_impl.h:574-666) and UpdateBlockDiagonalFtF's second loop to blockdiag(F^T F)
+// (I/partitioned_matrix_view_impl.h:617-658).  One thread per entry through the transpose list of the camera's column block.
+__global__ __launch_bounds__(kB) void rem_camera_blocks_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
+                                                               int n_cameras, double* __restrict__ out) {
+  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
+  if (e >= int64_t(81) * n_cameras) return;
+  const int c = int(e / 81), a = int(e % 81) / 9, b = int(e % 9);
+  const int j = cam_block[c];
+  double s = 0;
+  for (int t = R.tptr[j]; t < R.tptr[j + 1]; ++t) {
+    const int i = R.trow[t], k = R.tcell[t];
+    const double* m = v + R.cval[k];
+    const int rs = R.rsz[i];
+    for (int r = 0; r < rs; ++r) s += m[r * 9 + a] * m[r * 9 + b];
+  }
+  out[e] = s;
+}
+// y[pos(c) + k] += blocks[81 c + 10 k]: the remainder's share of the camera columns' squared norms
+__global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int n_cameras,
+                                                          double* __restrict__ y) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= 9 * n_cameras) return;
+  const int c = i / 9, k = i % 9;
+  y[(cam_pos ? cam_pos[c] : 9 * c) + k] += blocks[81 * int64_t(c) + 10 * k];
+}
+// One workgroup: *out = sum_r m_r (f_r - m_r / 2)   (mode 0: m = J x of the un-negated solution, the back-substitution kernel's
+// convention) or  -sum_r m_r (f_r + m_r / 2)  (mode 1: m = J step) — the remainder rows' share of the model cost change,
+// I/trust_region_minimizer.cc:420-438.  gate: optional CG status word, as in the fused kernels.
+__global__ __launch_bounds__(kB) void rem_model_cost_kernel(const double* __restrict__ m, const double* __restrict__ f, int n, int mode,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[kB / 64];
+  double acc = 0;
+  for (int r = threadIdx.x; r < n; r += kB) acc += mode == 0 ? m[r] * (f[r] - 0.5 * m[r]) : -m[r] * (f[r] + 0.5 * m[r]);
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) acc += __shfl_xor(acc, w, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kB / 64; ++i) t += sh[i]; *out = t; }
+}
+
 }  // namespace
+
+hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, double* out, hipStream_t s) {
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_camera_blocks_kernel, dim3(blocks_for(int64_t(81) * n_cameras)), dim3(kB), 0, s, R, values, cam_block, n_cameras, out);
+  return hipGetLastError();
+}
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, double* y, hipStream_t s) {
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_add_diag_kernel, dim3(blocks_for(9 * n_cameras)), dim3(kB), 0, s, blocks, cam_pos, n_cameras, y);
+  return hipGetLastError();
+}
+hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(rem_model_cost_kernel, dim3(1), dim3(kB), 0, s, m, f, n, mode, out);
+  return hipGetLastError();
+}
 
 hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
                                   const int* status, hipStream_t s) {

@@ -155,9 +155,23 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   if (P.n_points == 0 || P.n_cameras == 0) return no("no point or no camera blocks");
   auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
 
-  // Every row: 2 scalar rows, exactly one point cell and one camera cell.
-  std::vector<int32_t> row_pt(h.nrb), row_cam(h.nrb), row_epos(h.nrb), row_fpos(h.nrb);
-  for (int i = 0; i < h.nrb; ++i) {
+  // Remainder: the longest run of TRAILING rows that touch camera blocks only (no point cell; possibly no cell at all).  A conforming
+  // row has a point cell, so the split is unambiguous.  Everything in front of it must conform.
+  int n_conf = h.nrb;
+  while (n_conf > 0) {
+    const int i = n_conf - 1;
+    bool camera_only = true;
+    for (int k = h.rptr[i]; k < h.rptr[i + 1] && camera_only; ++k) camera_only = !is_point(h.ccol[k]);
+    if (!camera_only) break;
+    if (h.rsz[i] > kMaxGenericBlock) return no("a row without a point cell is higher than the generic kernels take");
+    --n_conf;
+  }
+  if (n_conf == 0) return no("no row with a point cell");
+  P.rem_row0 = n_conf;
+  P.n_rem_rows = h.nrb - n_conf;
+  // Every other row: 2 scalar rows, exactly one point cell and one camera cell.
+  std::vector<int32_t> row_pt(n_conf), row_cam(n_conf), row_epos(n_conf), row_fpos(n_conf);
+  for (int i = 0; i < n_conf; ++i) {
     if (h.rsz[i] != 2) return no("row block that is not 2 high");
     if (h.rptr[i + 1] - h.rptr[i] != 2) return no("row without exactly two cells");
     const int k0 = h.rptr[i], k1 = k0 + 1;
@@ -175,13 +189,13 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   if (h.nelim > 0 && !h.chunks_contiguous) return no("rows of one E block are not contiguous");
 
   // Observations grouped by point (stable: keeps the caller's order inside a point).
-  std::vector<int32_t> order(h.nrb);
+  std::vector<int32_t> order(n_conf);
   std::iota(order.begin(), order.end(), 0);
   bool sorted = true;
-  for (int i = 1; i < h.nrb && sorted; ++i) sorted = row_pt[i - 1] <= row_pt[i];
+  for (int i = 1; i < n_conf && sorted; ++i) sorted = row_pt[i - 1] <= row_pt[i];
   if (!sorted) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return row_pt[a] < row_pt[b]; });
   std::vector<int32_t> track(P.n_points, 0);
-  for (int i = 0; i < h.nrb; ++i) ++track[row_pt[i]];
+  for (int i = 0; i < n_conf; ++i) ++track[row_pt[i]];
   for (int p = 0; p < P.n_points; ++p) {
     if (track[p] == 0) return no("point without observations");
     P.max_track = std::max(P.max_track, track[p]);
@@ -190,13 +204,13 @@ void BuildBalPlan(const HostStructure& h, bool /*allow_e_free_layout*/, BalPlan*
   // always satisfies it).
   {
     std::vector<int32_t> last_point_of_cam(P.n_cameras, -1);
-    for (int idx = 0; idx < h.nrb; ++idx) {
+    for (int idx = 0; idx < n_conf; ++idx) {
       const int i = order[idx];
       if (last_point_of_cam[row_cam[i]] == row_pt[i]) return no("a point observes one camera twice");
       last_point_of_cam[row_cam[i]] = row_pt[i];
     }
   }
-  P.n_obs = h.nrb;
+  P.n_obs = n_conf;
 
   // Vector offsets.
   P.pt_pos.resize(P.n_points);

@@ -95,6 +95,13 @@ struct ceres_hip_solver {
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
   double* d_zbuf = nullptr;
+  // Remainder rows of the fused path (BalPlan::rem_row0: trailing rows without a point cell): their own structure for the generic
+  // kernels (compact row space), the residual offset of the first of them, a row-space temporary and their F^T F per camera
+  GenStructure GR;
+  int rem_rows = 0, rem_b0 = 0;
+  double *rem_tmp = nullptr, *rem_blocks = nullptr;
+  int32_t* d_cam_block = nullptr;
+  bool rem_blocks_valid = false;
   int bal_flags = 0;
   bool lds_mode = false;
   int fused_grid = 0;
@@ -286,6 +293,46 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
   return f;
 }
 
+// ---- remainder rows (no point cell) next to the tiles: every contribution is a sum over those rows, added by generic kernels ----
+bool has_remainder(const ceres_hip_solver* s) { return s->path == CERES_HIP_PATH_BAL && s->rem_rows > 0; }
+// raw F^T F of the remainder rows, per camera (cached until the next load)
+int ensure_rem_blocks(ceres_hip_solver* s) {
+  if (!has_remainder(s) || s->rem_blocks_valid) return 0;
+  HIP_TRY(s, LaunchRemCameraBlocks(s->GR, s->values, s->d_cam_block, s->plan.n_cameras, s->rem_blocks, s->stream));
+  s->rem_blocks_valid = true;
+  return 0;
+}
+const double* rem_extra_blocks(ceres_hip_solver* s) { return has_remainder(s) ? s->rem_blocks : nullptr; }
+// y_f += what the remainder rows add to the camera part of a fused operator's output (before any all-reduce: the rows live on one rank)
+int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f, const int* status) {
+  if (!has_remainder(s)) return 0;
+  hipStream_t st = s->stream;
+  const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  switch (mode) {
+    case kBalSx: case kBalJtJx:   // F_R^T (F_R x)
+      HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
+      HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, status, st));
+      HIP_TRY(s, LaunchGenLeftMultiply(s->GR, s->values, kF, s->rem_tmp, y_f, status, st));
+      return 0;
+    case kBalInit: case kBalJtb: case kBalCgnrInit:   // F_R^T b_R
+      if (s->have_b) HIP_TRY(s, LaunchGenLeftMultiply(s->GR, s->values, kF, s->b + s->rem_b0, y_f, status, st));
+      return 0;
+    case kBalColNorm:   // diag(F_R^T F_R)
+      TRY(ensure_rem_blocks(s));
+      HIP_TRY(s, LaunchRemAddDiag(s->rem_blocks, cam_pos, s->plan.n_cameras, y_f, st));
+      return 0;
+    default: return 0;  // kSpseZ: F^T E (E^T E)^-1 E^T F has no share from rows without an E block
+  }
+}
+// the remainder rows' share of the model cost change into *out (one double); x_f: camera part of the solution (mode 0) / the step (mode 1)
+int rem_model_cost(ceres_hip_solver* s, const double* x_f, int mode, double* out) {
+  hipStream_t st = s->stream;
+  HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
+  HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, nullptr, st));
+  HIP_TRY(s, LaunchRemModelCost(s->rem_tmp, s->b + s->rem_b0, s->rem_rows, mode, out, st));
+  return 0;
+}
+
 // Run one fused kernel that scatters into camera space and produce y_f.
 // add_diag: y_f += D_f^2 x_f (after the all-reduce when sharded).
 // pq / n_pq (optional, needs x_f): the kernels that hold x and the finished y in registers also leave the partial sums of
@@ -327,12 +374,18 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
   const int nparts = s->lds_mode ? s->fused_grid : 1;
   int n_second = 0;
-  if (s->world <= 1) {
+  if (s->world <= 1 && has_remainder(s)) {
+    // rows outside the tiles join the raw sums first; D_f^2 x_f and the camera part of x . y follow on the COMPLETE output
+    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream));
+    TRY(add_remainder(s, mode, x_f, y_f, status));
+    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
+  } else if (s->world <= 1) {
     HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   } else {
     const bool pack = pq && pq_extra && n_first > 0;  // CGNR's p.q: the shard's share rides along as element n9 of the all-reduce
     HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream,
                                        pack ? pq : nullptr, n_first, pack ? y_f + n9 : nullptr));
+    TRY(add_remainder(s, mode, x_f, y_f, status));  // this rank's rows without a point cell (partition.py hands them to one rank)
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
     TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
     if (pack) { *pq_extra = y_f + n9; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
@@ -471,6 +524,10 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
       s->lm_negated = true;
     }
     HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
+    if (s->backsub_cost_parts > 0 && has_remainder(s)) {  // the rows outside the tiles: one more partial sum behind the workgroups'
+      TRY(rem_model_cost(s, z, 0, s->scalar_partials + s->backsub_cost_parts));
+      ++s->backsub_cost_parts;
+    }
     return 0;
   } else {
     HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
@@ -502,16 +559,18 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
       const bool fuse = s->lm_fuse_active && invert;
       HIP_TRY(s, LaunchBalCameraItems(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
+      TRY(ensure_rem_blocks(s));  // rows without a point cell add their F^T F to the diagonal cells (NoEBlockRowsUpdate) and to the column norms
       if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
         CamGather g;
         g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.want_sq = (fuse && schur) ? 1 : 0;
+        g.extra = rem_extra_blocks(s);
         g.D_f = fuse ? nullptr : D_f;
         HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
       } else {
         // raw sums in memory first (no diagonal when sharded: the ranks' sums are added up, then D_f^2 joins once)
         HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
-                                         (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st));
+                                         (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
         if (s->world > 1) {
           TRY(allreduce(s, out, size_t(len)));
           if (fuse && schur) TRY(allreduce(s, s->d_camsq, size_t(9) * s->plan.n_cameras));  // column norms of the camera columns
@@ -545,8 +604,10 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     A.pt_diag_off = s->d_pt_diag_off;
     HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
     HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
+    TRY(ensure_rem_blocks(s));
     CamGather g;
     g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.D_f = D_f;
+    g.extra = rem_extra_blocks(s);
     g.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
     HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
     return 0;
@@ -586,16 +647,19 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   if (!jacobi) return 0;
   const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
   HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
+  TRY(ensure_rem_blocks(s));
   if (s->world <= 1) {
     CamGather g;
     g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.cam_pos = cam_pos;
+    g.extra = rem_extra_blocks(s);
     g.D_f = s->lm_fuse_active ? nullptr : D_f;  // fused LM diagonal: bal_invert9_kernel forms D_f from the block's own diagonal and adds it
     HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
     return 0;
   }
   // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
   // behind the point blocks in the Schur-ordered layout a sharded run requires)
-  HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, s->plan.n_cameras, st));
+  HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, s->plan.n_cameras, st,
+                                   rem_extra_blocks(s)));
   const int64_t first = h.diag_off_all[h.nelim];
   TRY(allreduce(s, blocks + first, size_t(len - first)));
   if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
@@ -699,9 +763,10 @@ int enqueue_model_cost_change(ceres_hip_solver* s, const double* x, const double
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e;
     A.scalar_out = s->scalar_partials;
-    *nparts = std::min(s->fused_grid, kMaxVecGrid);
+    *nparts = std::min(s->fused_grid, kMaxVecGrid - 1);
     *dev_parts = s->scalar_partials;
     HIP_TRY(s, LaunchBalFused(kBalJx, A, false, *nparts, st));
+    if (has_remainder(s)) { TRY(rem_model_cost(s, x + h.num_cols_e, 1, s->scalar_partials + *nparts)); ++*nparts; }
     return 0;
   }
   // model = J x ; partial sums of -model .* (b + model / 2)
@@ -951,6 +1016,7 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->precond_valid = false;
   s->ftf_inv_valid = false;
   s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
+  s->rem_blocks_valid = false;
   s->loaded = true;
   return 0;
 }
@@ -1515,7 +1581,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_cam_diag_off, cdo));
     const size_t n_slots = size_t(P.n_tiles) * kTile;
     if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));
-    else TRY(dev_alloc(s, &s->d_J, n_slots * kPairsPerSlot));
+    else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * kTilePitch));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
     TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
@@ -1539,6 +1605,40 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
     }
     TRY(dev_alloc(s, &s->d_camsq, n9));
+    if (P.n_rem_rows > 0) {
+      // the remainder rows as a structure of their own: compact row space, cells and transpose lists rebased, columns shared with G
+      const int r0 = P.rem_row0, nr = P.n_rem_rows, k0 = h.rptr[r0];
+      GenStructure& R = s->GR;
+      R = s->G;
+      R.nrb = nr; R.nrbe = 0;
+      s->rem_b0 = h.rpos[r0];
+      s->rem_rows = h.num_rows - h.rpos[r0];
+      R.num_rows = s->rem_rows;
+      std::vector<int32_t> rsz(h.rsz.begin() + r0, h.rsz.end()), rpos(nr), rptr(nr + 1), ccol(h.ccol.begin() + k0, h.ccol.end()),
+          cval(h.cval.begin() + k0, h.cval.end()), rbo(s->rem_rows), tptr(h.ncb + 1, 0), trow, tcell;
+      for (int i = 0; i < nr; ++i) { rpos[i] = h.rpos[r0 + i] - s->rem_b0; std::fill_n(rbo.begin() + rpos[i], rsz[i], i); }
+      for (int i = 0; i <= nr; ++i) rptr[i] = h.rptr[r0 + i] - k0;
+      for (int j = 0; j < h.ncb; ++j) {  // the transpose lists are in row order: the remainder's entries are their tails
+        tptr[j] = int32_t(trow.size());
+        for (int t = h.tptr[j]; t < h.tptr[j + 1]; ++t)
+          if (h.trow[t] >= r0) { trow.push_back(h.trow[t] - r0); tcell.push_back(h.tcell[t] - k0); }
+      }
+      tptr[h.ncb] = int32_t(trow.size());
+      int32_t* q = nullptr;
+      TRY(dev_upload(s, &q, rsz)); R.rsz = q;
+      TRY(dev_upload(s, &q, rpos)); R.rpos = q;
+      TRY(dev_upload(s, &q, rptr)); R.rptr = q;
+      TRY(dev_upload(s, &q, ccol)); R.ccol = q;
+      TRY(dev_upload(s, &q, cval)); R.cval = q;
+      TRY(dev_upload(s, &q, rbo)); R.row_block_of = q;
+      TRY(dev_upload(s, &q, tptr)); R.tptr = q;
+      TRY(dev_upload(s, &q, trow)); R.trow = q;
+      TRY(dev_upload(s, &q, tcell)); R.tcell = q;
+      R.row_e_block = nullptr;
+      TRY(dev_upload(s, &s->d_cam_block, P.cam_block));
+      TRY(dev_alloc(s, &s->rem_tmp, size_t(s->rem_rows)));
+      TRY(dev_alloc(s, &s->rem_blocks, size_t(81) * P.n_cameras));
+    }
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
       s->bal_flags = (e && atoi(e) == 0) ? 1 : 0;
@@ -1834,13 +1934,14 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   s->have_lm_diag = true;
   s->D = s->lm_D;
   s->have_D = true;
-  s->lm_want_model_cost = is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->fused_grid <= 2 * kMaxVecGrid;
+  s->lm_want_model_cost = is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->fused_grid < 2 * kMaxVecGrid;  // (< : room for the remainder rows' partial)
   s->backsub_cost_parts = 0;
   // fused <2,3,9> path, implicit solvers: negation + finite check ride in the last kernel that touches the solution
   s->lm_negate_in_solve = s->path == CERES_HIP_PATH_BAL && !s->opt.use_explicit_schur_complement && !is_dense_schur(s);
   s->lm_negated = false;
   s->lm_cgnr_copy_pending = false;
-  s->lm_speculate = s->speculate && s->lm_negate_in_solve && s->world <= 1 && (!is_schur(s) || s->lm_want_model_cost);
+  // (rows outside the tiles add ungated generic launches to the ITERATIVE_SCHUR tail: no speculation then)
+  s->lm_speculate = s->speculate && s->lm_negate_in_solve && s->world <= 1 && (!is_schur(s) || (s->lm_want_model_cost && !has_remainder(s)));
   s->spec_tail_done = false;
   const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
   const bool spec_done = s->spec_tail_done;
@@ -1988,6 +2089,7 @@ int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, do
   HIP_TRY(s, hipMemcpyAsync(s->scratch_vec, host_scale, sizeof(double) * s->hs.num_cols, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(s, LaunchGenScaleColumns(s->G, s->own_values, s->scratch_vec, s->stream));
   s->packed = false;
+  s->rem_blocks_valid = false;
   s->precond_valid = false;
   s->ftf_inv_valid = false;
   if (host_values_out)
@@ -2367,7 +2469,7 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       if (s->d_Jf) return fail(s, CERES_HIP_E_UNSUPPORTED, "copy probe needs the fp64 tile buffer");
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "copy probe uses the packed buffer of the <2,3,9> path");
       body = [&] {
-        HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTile * 24), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTilePitch * 2), hipMemcpyDeviceToDevice, st));
         return 0;
       };
       break;

@@ -367,6 +367,52 @@ def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_
     return LinearProblem(bs, values, b, D, nelim, {}, cam_block, point_block)
 
 
+def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair_fraction=0.0) -> LinearProblem:
+    """Appends `num_rows` row blocks WITHOUT a point cell to a BAL-shaped problem (either layout): priors / regularisers on
+    cameras — one `row_size` x 9 cell on camera i mod n_cameras, or (a `pair_fraction` of the rows) two cells coupling two
+    cameras.  In the Schur ordering these are the rows behind num_row_blocks_e that SchurEliminator::NoEBlockRowsUpdate
+    (internal/ceres/schur_eliminator_impl.h:574-666) and PartitionedMatrixView's second loops
+    (internal/ceres/partitioned_matrix_view_impl.h:171-190) handle.  Values are appended behind the existing ones."""
+    rng = np.random.default_rng(seed + 991)
+    bs = prob.bs
+    cam_blocks = np.flatnonzero(bs.col_block_size == 9)
+    n_cams = cam_blocks.shape[0]
+    two = rng.random(num_rows) < pair_fraction
+    c0 = cam_blocks[np.arange(num_rows) % n_cams]
+    c1 = cam_blocks[(np.arange(num_rows) * 7 + 3) % n_cams]
+    two &= c0 != c1
+    ncell = np.where(two, 2, 1)
+    row_sizes = np.full(num_rows, row_size, np.int32)
+    row_pos = bs.num_rows + row_size * np.arange(num_rows, dtype=np.int64)
+    extent0 = bs.values_extent() if bs.num_cells else 0
+    cell_cols, cell_pos, pos = [], [], extent0
+    for i in range(num_rows):
+        cols = sorted({int(c0[i]), int(c1[i])}) if two[i] else [int(c0[i])]
+        for c in cols:
+            cell_cols.append(c)
+            cell_pos.append(pos)
+            pos += row_size * 9
+    new_bs = BlockStructure(np.concatenate([bs.row_block_size, row_sizes]), np.concatenate([bs.row_block_pos, row_pos]),
+                            bs.col_block_size, bs.col_block_pos,
+                            np.concatenate([bs.row_cell_ptr.astype(np.int64), bs.row_cell_ptr[-1] + np.cumsum(ncell)]),
+                            np.concatenate([bs.cell_col_block, np.asarray(cell_cols, np.int32)]),
+                            np.concatenate([bs.cell_value_pos, np.asarray(cell_pos, np.int64)]))
+    if prob.values is None or prob.values.shape[0] == 0:
+        return LinearProblem(new_bs, np.zeros(0), np.zeros(0), None, prob.num_eliminate_blocks, {}, prob.camera_of_row, prob.point_of_row)
+    extra = rng.standard_normal(pos - extent0)
+    values = np.concatenate([prob.values[:extent0], extra])
+    b = np.concatenate([prob.b, rng.standard_normal(row_size * num_rows)])
+    D = prob.D
+    if D is not None:
+        diag = (D * D) * 1e4
+        cp = bs.col_block_pos.astype(np.int64)
+        for k, c in enumerate(cell_cols):
+            blk = extra[cell_pos[k] - extent0: cell_pos[k] - extent0 + row_size * 9].reshape(row_size, 9)
+            diag[cp[c]: cp[c] + 9] += (blk * blk).sum(0)
+        D = np.sqrt(np.clip(diag, 1e-6, 1e32) / 1e4)
+    return LinearProblem(new_bs, values, b, D, prob.num_eliminate_blocks, {}, prob.camera_of_row, prob.point_of_row)
+
+
 # --------------------------------------------------------------------------
 # Scene-based values: the first LM linear system of a synthetic bundle-adjustment problem
 # --------------------------------------------------------------------------

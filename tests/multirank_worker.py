@@ -34,6 +34,8 @@ def run_rank(rank, world, conn, device, scenario):
             if kind == "bal":
                 prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),
                                                   num_cameras=kw["nc"], num_points=kw["np"], num_observations=kw["no"])
+                if kw.get("camera_rows", 0):  # rows without a point cell: partition.py hands them to the last rank
+                    prob = pkg.problems.add_camera_rows(prob, kw["camera_rows"], seed=kw["seed"], pair_fraction=0.3)
             else:
                 prob = pkg.problems.random_schur_problem(num_e_blocks=kw["ne"], num_f_blocks=kw["nf"], num_no_e_rows=2, seed=kw["seed"])
             sh = partition.shard_by_point(prob.bs, prob.num_eliminate_blocks, world, rank)

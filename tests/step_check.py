@@ -23,7 +23,8 @@ def rel(a, b):
 
 
 def reported_zeta(message):
-    m = re.search(r"zeta = ([-+0-9.eE]+|nan|inf) < ([-+0-9.eE]+)", message)
+    num = r"([-+]?(?:[0-9]*\.?[0-9]+(?:[eE][-+]?[0-9]+)?|nan|inf))"
+    m = re.search(rf"zeta = {num} < {num}", message)
     assert m, f"not a zeta termination: {message!r}"
     return float(m.group(1)), float(m.group(2))
 

@@ -158,3 +158,44 @@ def test_sharded_cgnr_fused_iteration_equals_the_six_kernel_iteration(hip, probl
     for r in range(1, WORLD):
         a1 = res[r][("fused", hip.CGNR, hip.JACOBI)]
         assert np.array_equal(a0["converged"][0][a0["n_e"]:], a1["converged"][0][a1["n_e"]:])
+
+
+@pytest.mark.parametrize("WORLD", (2, 3))
+def test_sharded_bal_with_leftover_rows(hip, oracle, problems, WORLD):
+    """Rows without a point cell (camera priors) in a sharded run of the fused path: partition.py gives them to the last rank, whose
+    generic kernels add their sums BEFORE the camera-space all-reduce (csrc/solver.hip: add_remainder)."""
+    kw = dict(kind="bal", seed=41, nc=29, np=3000, no=14000, skew=0.5, camera_rows=40,
+              solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)])
+    res = run_ranks([("bal", kw)], WORLD)
+    p = problems.add_camera_rows(problems.synthetic_bal(None, layout="schur", seed=41, skew=0.5, num_cameras=29, num_points=3000, num_observations=14000),
+                                 40, seed=41, pair_fraction=0.3)
+    m, m0 = oracle.Matrix(p.bs, p.num_eliminate_blocks), oracle.Matrix(p.bs, 0)
+    for solver_type, pre in kw["solvers"]:
+        recs = [res[r][("bal", solver_type, pre)] for r in range(WORLD)]
+        assert all(rec["path"] == hip.PATH_BAL for rec in recs)
+        fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m0.cgnr_solve
+        solve = lambda lo, hi, q, r: fn(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r)
+        xo, so = solve(0, 400, -1.0, 1e-12)
+        assert all(rec["converged"][1] == hip.SUCCESS for rec in recs)
+        assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-8
+
+        class S:
+            termination_type, num_iterations, message = recs[0]["lm_style"][1], recs[0]["lm_style"][2], recs[0]["lm_style"][4]
+        assert_lm_style_step(assemble(None, recs, p.bs.num_cols, "lm_style"), S, solve, 0.1, hip.SUCCESS)
+        step = assemble(None, recs, p.bs.num_cols, "lm_step")
+        Jx = m0.right_multiply(p.values, step)
+        assert abs(recs[0]["lm_step"][3] - (-(Jx @ (p.b + Jx / 2)))) <= 1e-9 * abs(recs[0]["lm_step"][3])
+        if solver_type == hip.ITERATIVE_SCHUR:
+            isc = oracle.ImplicitSchurComplement(m)
+            isc.init(p.values, p.D, p.b)
+            xf = np.random.default_rng(5).standard_normal(m.num_cols_f)
+            inv, _ = m.schur_jacobi(p.values, p.D)
+            for rec in recs:
+                assert rel(rec["rhs"], isc.rhs()) <= 1e-12 and rel(rec["sx"], isc.sx(xf)) <= 1e-12 and rel(rec["precond"], inv) <= 1e-10
+        else:
+            xx = np.random.default_rng(6).standard_normal(p.bs.num_cols)
+            want = m0.left_multiply(p.values, m0.right_multiply(p.values, xx)) + p.D ** 2 * xx
+            g = m0.left_multiply(p.values, p.b)
+            for rec in recs:
+                ci = rec["col_index"]
+                assert rel(rec["jtjx"], want[ci]) <= 1e-12 and rel(rec["jtb"], g[ci]) <= 1e-12

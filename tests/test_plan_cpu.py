@@ -199,3 +199,34 @@ def test_point_ids_are_recoverable_from_the_segment_words(problems, seed, nc, np
     assert (np.diff(valid.astype(int), axis=1) <= 0).all()
     if nc >= 100:
         assert (plan["tile_kind"] == 1).any()        # the long-point case is exercised
+
+
+@pytest.mark.parametrize("layout", ["schur", "cgnr"])
+def test_trailing_rows_without_a_point_cell_are_a_remainder_not_a_rejection(problems, layout):
+    """Rows behind the BAL rows that touch camera blocks only (priors, regularisers: the rows of
+    SchurEliminator::NoEBlockRowsUpdate, internal/ceres/schur_eliminator_impl.h:574-666) leave the tile plan of the BAL rows
+    untouched; the same rows in FRONT of BAL rows, or a trailing row with a point cell, still send the problem to the generic path."""
+    p = problems.synthetic_bal(None, layout=layout, num_cameras=15, num_points=700, num_observations=3300, seed=4, skew=0.3)
+    nelim = p.num_eliminate_blocks
+    base = plan_of(p)
+    q = problems.add_camera_rows(p, 25, seed=2, row_size=5, pair_fraction=0.5)
+    with_rows = pkg.hip_solver.debug_plan(q.bs, nelim)
+    assert with_rows["eligible"] and with_rows["n_tiles"] == base["n_tiles"]
+    for k in ("slot_row", "slot_cam", "slot_pt", "tile_kind", "tile_aux"):
+        assert np.array_equal(with_rows[k], base[k]), k
+    # a row higher than the generic kernels take
+    tall = problems.add_camera_rows(p, 3, seed=2, row_size=17)
+    assert not pkg.hip_solver.debug_plan(tall.bs, nelim)["eligible"]
+    # camera-only rows that are NOT trailing: put one BAL row behind them
+    from ceres_solver_amd.block_structure import BlockStructure
+    b = q.bs
+    nrb = b.num_row_blocks
+    ptr = b.row_cell_ptr.astype(np.int64)
+    rs = np.concatenate([b.row_block_size, [2]])
+    rp = np.concatenate([b.row_block_pos, [b.num_rows]])
+    cells0 = b.cell_col_block[ptr[0]:ptr[1]]
+    bad = BlockStructure(rs, rp, b.col_block_size, b.col_block_pos, np.concatenate([ptr, [ptr[-1] + 2]]),
+                         np.concatenate([b.cell_col_block, cells0]), np.concatenate([b.cell_value_pos, b.cell_value_pos[ptr[0]:ptr[1]]]))
+    assert bad.num_row_blocks == nrb + 1
+    if layout == "cgnr":   # (in the Schur ordering an E row behind E-free rows is not a valid structure for a Schur solver at all)
+        assert not pkg.hip_solver.debug_plan(bad, nelim)["eligible"]
