@@ -111,7 +111,7 @@ def make_solver(hs, bs, nelim, solver, device, comm=None, storage=0):
         kw = dict(comm_id=comm[0], rank=comm[1], world_size=comm[2])
         if comm[3] is not None:
             f = bs.col_block_size[nelim:].astype(np.int64)
-            kw.update(p2p_exchange=comm[3], p2p_max_elements=int(max((f * f).sum(), f.sum(), 2)))
+            kw.update(p2p_exchange=comm[3], p2p_max_elements=int((f * f).sum() + 2 * f.sum() + 2))  # blocks + rhs + column norms: ONE all-reduce per step
         s = hs.HipLinearSolver(o, **kw)
         if comm[3] is not None:  # agree on the verdict of the self-test: all ranks use the peer-to-peer path, or none does
             import torch

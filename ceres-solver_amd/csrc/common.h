@@ -67,6 +67,7 @@ struct BalPlan {
   int n_points = 0, n_cameras = 0;
   int64_t n_obs = 0, n_tiles = 0;
   bool contiguous_layout = false;  // pt_pos = 3p, cam_pos(F-relative) = 9c
+  bool points_contiguous = false, cameras_contiguous = false;  // each half of it (points are renumbered for the Schur solvers: plan.cc)
   std::vector<int32_t> pt_block, cam_block;   // column block of each point / camera
   std::vector<int32_t> pt_pos, cam_pos;       // scalar offset in x (camera: minus num_cols_e)
   // per slot (n_tiles * 64)
@@ -122,7 +123,8 @@ void BuildSchurStorage(const HostStructure& hs, SchurStorage* out);
 // Fills hs from the ABI structure; returns "" or an error message.
 std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs);
 // Decides whether the fused <2,3,9> path applies and, if so, builds the packing plan.
-void BuildBalPlan(const HostStructure& hs, bool allow_e_free_layout, BalPlan* plan);
+// reorder_points: renumber the points so that the tiles fill up (plan.cc; only where no caller-visible vector is walked in tile order)
+void BuildBalPlan(const HostStructure& hs, bool reorder_points, BalPlan* plan);
 
 }  // namespace chip
 #endif

@@ -336,8 +336,8 @@ struct P2pPeers {
 };
 // out = sum over ranks of in (n <= cap; in may alias out).  `epoch` counts this communicator's all-reduces from 1.
 hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
-                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, double timeout_seconds,
-                              hipStream_t stream);
+                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag /* mapped host memory */,
+                              int* error_seen /* device memory */, double timeout_seconds, hipStream_t stream);
 
 // ---- f4: BAL evaluator (kernels_evaluator.hip) ----
 struct BalEvalArgs {

@@ -1550,9 +1550,10 @@ static bool UsePipeline() {
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   const bool big = BalBlockFor(mode) == 1024;
-  if (UsePipeline() && !A.Jf && !A.src_values && !A.pt_pos && !A.cam_pos && !(A.flags & 1)) {
+  if (UsePipeline() && !A.Jf && !A.src_values && !A.cam_pos && !(A.flags & 1)) {
+    // (S.x and the power-series operator index nothing of the caller's by point: pt_pos may be set — renumbered points, plan.cc)
     if (mode == kSx) return launch_stream<kSx>(A, lds, grid, stream);
-    if (mode == kJtJx && A.D_e) return launch_stream<kJtJx>(A, lds, grid, stream);
+    if (mode == kJtJx && A.D_e && !A.pt_pos) return launch_stream<kJtJx>(A, lds, grid, stream);
     if (mode == kSpseZ) return launch_stream<kSpseZ>(A, lds, grid, stream);
   }
   switch (mode) {

@@ -802,9 +802,19 @@ namespace chip {
 namespace {
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n,
                                                             P2pPeers P, int rank, int world, unsigned long long epoch,
-                                                            int64_t cap, int chunks_cap, int* error_flag, long long timeout_ticks) {
+                                                            int64_t cap, int chunks_cap, int* error_flag, int* error_seen, long long timeout_ticks) {
   __shared__ int timed_out;
-  if (threadIdx.x == 0) timed_out = 0;
+  // a communicator that has timed out once stays broken: later all-reduces poison their output at once instead of waiting the
+  // timeout again (error_seen: device memory, a cheap load; error_flag: mapped host memory for the host)
+  if (threadIdx.x == 0) timed_out = __hip_atomic_load(error_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (timed_out) {
+    for (int k = 0; k < kP2pChunk / 256; ++k) {
+      const int64_t i = int64_t(blockIdx.x) * kP2pChunk + threadIdx.x + 256 * k;
+      if (i < n) out[i] = __builtin_nan("");
+    }
+    return;
+  }
   const int parity = int(epoch & 1ull);
   const int c = blockIdx.x;
   const int64_t lo = int64_t(c) * kP2pChunk;
@@ -833,6 +843,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: do not hang the GPU
         __hip_atomic_store(error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // mapped host memory: the host reads it after its next synchronisation
+        __hip_atomic_store(error_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         timed_out = 1;
         break;
       }
@@ -857,13 +868,13 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
 }  // namespace
 
 hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
-                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, double timeout_seconds,
+                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, int* error_seen, double timeout_seconds,
                               hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   const int grid = int((n + kP2pChunk - 1) / kP2pChunk);
   const long long ticks = (long long)(timeout_seconds * 1e8);  // wall_clock64 counts at 100 MHz
   hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(grid), dim3(256), 0, stream, in, out, n, peers, rank, world, epoch, cap, chunks_cap,
-                     error_flag, ticks);
+                     error_flag, error_seen, ticks);
   return hipGetLastError();
 }
 }  // namespace chip

@@ -91,12 +91,20 @@ struct ceres_hip_solver {
   ceres_hip_lm_options lm_opts{};
   double* d_camsq = nullptr;
   int64_t *d_pt_diag_off = nullptr, *d_cam_diag_off = nullptr;  // into the all-blocks store (CGNR JACOBI)
+  int64_t* d_pt_eoff = nullptr;                                 // into the E-block store (ceres_hip_get_ete_inverse)
   double2 *d_J = nullptr, *d_bt = nullptr;
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
   double* d_zbuf = nullptr;
   // Remainder rows of the fused path (BalPlan::rem_row0: trailing rows without a point cell): their own structure for the generic
   // kernels (compact row space), the residual offset of the first of them, a row-space temporary and their F^T F per camera
+  // Sharded <2,3,9> steps sum their per-step camera-space quantities in ONE all-reduce: the buffers sit back to back
+  // (ITERATIVE_SCHUR: [preconditioner blocks 81 n_c | rhs 9 n_c | camera column norms 9 n_c]; CGNR: [camera blocks 81 n_c | J^T f,
+  // camera part 9 n_c]) and the first producer defers its collective to the last one (solve_loaded sets merge_step_reduce).
+  bool merged_layout = false;       // the buffers were allocated back to back (set_structure)
+  bool merge_step_reduce = false;   // this solve may defer
+  bool rhs_reduce_pending = false;  // rhs holds this rank's raw sums; the all-reduce is still owed
+  double* cgnr_rhs_tail = nullptr;  // CGNR: 9 n_c doubles behind the camera blocks of `precond`
   GenStructure GR;
   int rem_rows = 0, rem_b0 = 0;
   double *rem_tmp = nullptr, *rem_blocks = nullptr;
@@ -147,6 +155,7 @@ struct ceres_hip_solver {
   unsigned long long p2p_epoch = 0;
   int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived: device view of h_comm_error
   int* h_comm_error = nullptr;      // mapped pinned host memory
+  int* d_comm_error_seen = nullptr; // device memory: set with it, so that later all-reduces do not wait the timeout again
   double p2p_timeout_s = 10.0;
   bool p2p_fine_grained = false;   // the receive buffer is a fine-grained allocation (false: the runtime could only export a coarse-grained one)
   ceres_hip_solve_timing timing{};
@@ -214,7 +223,7 @@ int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
     for (size_t off = 0; off < n; off += size_t(s->p2p_cap)) {
       const int64_t len = int64_t(std::min<size_t>(size_t(s->p2p_cap), n - off));
       HIP_TRY(s, LaunchP2pAllReduce(dev + off, dev + off, len, s->p2p_peers, s->rank, s->world, ++s->p2p_epoch, s->p2p_cap,
-                                    s->p2p_chunks_cap, s->d_comm_error, s->p2p_timeout_s, s->stream));
+                                    s->p2p_chunks_cap, s->d_comm_error, s->d_comm_error_seen, s->p2p_timeout_s, s->stream));
     }
     return 0;
   }
@@ -236,8 +245,8 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.slot_cam = s->d_slot_cam; A.tile_pt0 = s->d_tile_pt0; A.slot_seg = s->d_slot_seg;
   A.tile_kind = s->d_tile_kind; A.tile_aux = s->d_tile_aux;
   A.n_tiles = s->plan.n_tiles; A.n_slots = s->plan.n_tiles * kTile;
-  A.pt_pos = s->plan.contiguous_layout ? nullptr : s->d_pt_pos;
-  A.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  A.pt_pos = s->plan.points_contiguous ? nullptr : s->d_pt_pos;
+  A.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.n_f9 = 9 * s->plan.n_cameras;
@@ -287,7 +296,7 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
   if (!s->lm_fuse_active) return f;
   f.radius = s->lm_opts.radius; f.min_d = s->lm_opts.min_diagonal; f.max_d = s->lm_opts.max_diagonal;
   f.camsq = schur_blocks ? s->d_camsq : nullptr;
-  f.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  f.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
   f.diag_f = s->lm_diag + s->hs.num_cols_e;
   f.D_f = s->lm_D + s->hs.num_cols_e;
   return f;
@@ -307,7 +316,7 @@ const double* rem_extra_blocks(ceres_hip_solver* s) { return has_remainder(s) ? 
 int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f, const int* status) {
   if (!has_remainder(s)) return 0;
   hipStream_t st = s->stream;
-  const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  const int32_t* cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
   switch (mode) {
     case kBalSx: case kBalJtJx:   // F_R^T (F_R x)
       HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
@@ -340,7 +349,8 @@ int rem_model_cost(ceres_hip_solver* s, const double* x_f, int mode, double* out
 // Sharded (pq_extra != nullptr on return): the point-space share of x . y has been summed over ranks into *pq_extra — the element
 // right after y_f, which therefore must exist (CG's z vector has the slack) — and pq holds the replicated camera part only.
 int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
-                const int* status, double* pq = nullptr, int* n_pq = nullptr, const double** pq_extra = nullptr) {
+                const int* status, double* pq = nullptr, int* n_pq = nullptr, const double** pq_extra = nullptr,
+                bool defer_allreduce = false) {  // sharded: leave this rank's raw sums in y_f, the caller owes the all-reduce
   const int n9 = A.n_f9;
   const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
   const int32_t* cam_pos = A.cam_pos;
@@ -387,7 +397,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
                                        pack ? pq : nullptr, n_first, pack ? y_f + n9 : nullptr));
     TRY(add_remainder(s, mode, x_f, y_f, status));  // this rank's rows without a point cell (partition.py hands them to one rank)
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
-    TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
+    if (!defer_allreduce) TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
     if (pack) { *pq_extra = y_f + n9; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
     else if (n_first > 0) { pq = nullptr; n_first = 0; }  // the shard's point part without the packing: no complete p.q from here
     // (S.x has no point part: its p.q is the replicated camera part, formed below as on one rank)
@@ -478,7 +488,12 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
     A.D_e = s->D;
     A.Mo = want_Mo ? s->d_Mo : nullptr;
     PackGuard g = use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
-    if (s->have_b) return g.commit(bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr));
+    if (s->have_b) {
+      const bool defer = s->world > 1 && s->merge_step_reduce && s->merged_layout;
+      TRY(g.commit(bal_scatter(s, kBalInit, A, nullptr, s->rhs_f, false, nullptr, nullptr, nullptr, nullptr, defer)));
+      s->rhs_reduce_pending = defer;
+      return 0;
+    }
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
     HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->fused_grid, st));
     return g.commit(0);
@@ -572,8 +587,15 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
         HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
                                          (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
         if (s->world > 1) {
-          TRY(allreduce(s, out, size_t(len)));
-          if (fuse && schur) TRY(allreduce(s, s->d_camsq, size_t(9) * s->plan.n_cameras));  // column norms of the camera columns
+          const size_t n9c = size_t(9) * s->plan.n_cameras;
+          if (s->rhs_reduce_pending && out == s->precond && s->merged_layout) {
+            // ONE collective for the step's camera-space sums: [blocks | rhs | column norms] are contiguous (set_structure)
+            TRY(allreduce(s, out, size_t(len) + n9c + ((fuse && schur) ? n9c : 0)));
+            s->rhs_reduce_pending = false;
+          } else {
+            TRY(allreduce(s, out, size_t(len)));
+            if (fuse && schur) TRY(allreduce(s, s->d_camsq, n9c));  // column norms of the camera columns
+          }
           // fused LM diagonal: D_f does not exist yet, bal_invert9_kernel forms it from the reduced sums and adds it
           if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
         }
@@ -608,7 +630,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     CamGather g;
     g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.D_f = D_f;
     g.extra = rem_extra_blocks(s);
-    g.cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+    g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
     HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
     return 0;
   }
@@ -640,12 +662,14 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   A.y_e = rhs;
   A.point_blocks = jacobi ? blocks : nullptr;
   A.pt_diag_off = s->d_pt_diag_off;
+  // sharded with JACOBI: the camera part of J^T f is left raw behind the camera blocks and rides in their all-reduce
+  const bool merge = s->world > 1 && jacobi && s->merge_step_reduce && s->merged_layout && blocks == s->precond && s->cgnr_rhs_tail;
   {
     PackGuard g = use_gather_if_unpacked(s, A);
-    TRY(g.commit(bal_scatter(s, kBalCgnrInit, A, nullptr, rhs + h.num_cols_e, false, nullptr)));
+    TRY(g.commit(bal_scatter(s, kBalCgnrInit, A, nullptr, merge ? s->cgnr_rhs_tail : rhs + h.num_cols_e, false, nullptr, nullptr, nullptr, nullptr, merge)));
   }
   if (!jacobi) return 0;
-  const int32_t* cam_pos = s->plan.contiguous_layout ? nullptr : s->d_cam_pos;
+  const int32_t* cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
   HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
   TRY(ensure_rem_blocks(s));
   if (s->world <= 1) {
@@ -661,7 +685,12 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, s->plan.n_cameras, st,
                                    rem_extra_blocks(s)));
   const int64_t first = h.diag_off_all[h.nelim];
-  TRY(allreduce(s, blocks + first, size_t(len - first)));
+  if (merge) {
+    TRY(allreduce(s, blocks + first, size_t(len - first) + size_t(h.num_cols_f)));
+    HIP_TRY(s, hipMemcpyAsync(rhs + h.num_cols_e, s->cgnr_rhs_tail, sizeof(double) * h.num_cols_f, hipMemcpyDeviceToDevice, st));
+  } else {
+    TRY(allreduce(s, blocks + first, size_t(len - first)));
+  }
   if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
     HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
   HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), CamGather(), st));
@@ -1067,7 +1096,13 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   if (is_schur(s)) {
     // IterativeSchurComplementSolver::SolveImpl, I/iterative_schur_complement_solver.cc:64-157
     const int pre = s->opt.preconditioner_type;
-    TRY(op_schur_init(s, pre == CERES_HIP_SCHUR_JACOBI));
+    // sharded fused path, block-diagonal preconditioner from the camera-major pass: rhs, the blocks and the camera column norms go
+    // through ONE all-reduce, issued by op_preconditioner
+    s->merge_step_reduce = s->world > 1 && s->path == CERES_HIP_PATH_BAL && (pre == CERES_HIP_SCHUR_JACOBI || pre == CERES_HIP_JACOBI) &&
+                           !s->opt.use_spse_initialization;
+    const int rc_init = op_schur_init(s, pre == CERES_HIP_SCHUR_JACOBI);
+    s->merge_step_reduce = false;
+    TRY(rc_init);
     bool bad = false;
     if (s->path != CERES_HIP_PATH_BAL) TRY(check_factorization(s, &bad));
     if (bad) {
@@ -1226,6 +1261,10 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       }
       s->precond_valid = true;
     }
+    if (s->rhs_reduce_pending) {  // nobody took the deferred all-reduce along (cannot happen on the paths that set the flag; kept as a guard)
+      TRY(allreduce(s, s->rhs_f, size_t(h.num_cols_f)));
+      s->rhs_reduce_pending = false;
+    }
     HIP_TRY(s, hipEventRecord(s->ev[4], st));
     CgSpec spec;
     spec.rhs = s->rhs_f;  // CG only reads it: no copy into cg_rhs
@@ -1273,7 +1312,10 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   const int pre = s->opt.preconditioner_type;
   HIP_TRY(s, hipEventRecord(s->ev[3], st));
   if (s->path == CERES_HIP_PATH_BAL) {
-    TRY(op_cgnr_setup_bal(s, pre == CERES_HIP_JACOBI, s->cg_rhs, s->precond));
+    s->merge_step_reduce = s->world > 1;
+    const int rc_setup = op_cgnr_setup_bal(s, pre == CERES_HIP_JACOBI, s->cg_rhs, s->precond);
+    s->merge_step_reduce = false;
+    TRY(rc_setup);
   } else {
     if (pre == CERES_HIP_JACOBI) TRY(op_preconditioner(s, pre, s->precond, true));
     TRY(op_jtb(s, s->cg_rhs));
@@ -1441,6 +1483,7 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   for (int q = 0; q < kP2pMaxWorld; ++q) if (s->p2p_opened[q]) (void)hipIpcCloseMemHandle(s->p2p_opened[q]);
   if (s->p2p_base) (void)hipFree(s->p2p_base);
   if (s->h_comm_error) (void)hipHostFree(s->h_comm_error);
+  if (s->d_comm_error_seen) (void)hipFree(s->d_comm_error_seen);
   free_all(s);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -1464,11 +1507,13 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   if (s->world > 1 && !h.chunks_contiguous) return fail(s, CERES_HIP_E_INVALID, "sharded runs need the Schur ordering");
   s->nine_wide_from = h.ncb;
   while (s->nine_wide_from > 0 && h.csz[s->nine_wide_from - 1] == 9) --s->nine_wide_from;
-  BuildBalPlan(h, true, &s->plan);
+  // Schur solvers: no CG vector lives in point space, so the points may be renumbered to fill the tiles (plan.cc); CGNR walks x, r, p,
+  // q in tile order and keeps the caller's numbering.  CERES_HIP_REORDER_POINTS=0 switches the renumbering off (A/B measurements).
+  { const char* e = getenv("CERES_HIP_REORDER_POINTS"); BuildBalPlan(h, is_schur(s) && !(e && atoi(e) == 0), &s->plan); }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !is_dense_schur(s)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
-  if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !s->plan.contiguous_layout)
+  if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !(is_schur(s) ? s->plan.cameras_contiguous : s->plan.contiguous_layout))
     return fail(s, CERES_HIP_E_UNSUPPORTED, "sharded <2,3,9> runs need points-then-cameras column order");
 
   // explicit S: block-sparse (BlockRandomAccessSparseMatrix) on one rank; dense for DENSE_SCHUR and for sharded runs (one all-reduce of S)
@@ -1542,7 +1587,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   { const char* e = getenv("CERES_HIP_SPECULATE"); s->speculate = !(e && atoi(e) == 0); }
   TRY(dev_alloc(s, &s->cg.S, 1));
   HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
-  TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back())));
+  // (+ 18 doubles per F block: room for the step's other camera-space sums right behind the blocks, see merged_layout)
+  TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back()) + 2 * size_t(h.num_cols_f)));
   if (is_schur(s)) {
     TRY(dev_alloc(s, &s->ftf_inv, size_t(h.diag_off_f.back())));
     TRY(dev_alloc(s, &s->spse_a, size_t(h.num_cols_f)));
@@ -1579,6 +1625,11 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     for (int c = 0; c < P.n_cameras; ++c) cdo[c] = h.diag_off_all[P.cam_block[c]];
     TRY(dev_upload(s, &s->d_pt_diag_off, pdo));
     TRY(dev_upload(s, &s->d_cam_diag_off, cdo));
+    if (h.nelim > 0) {  // where each (internally numbered) point's dense 3x3 block sits in the E-block store
+      std::vector<int64_t> peo(P.n_points);
+      for (int p = 0; p < P.n_points; ++p) peo[p] = h.diag_off_e[P.pt_block[p]];
+      TRY(dev_upload(s, &s->d_pt_eoff, peo));
+    }
     const size_t n_slots = size_t(P.n_tiles) * kTile;
     if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));
     else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * kTilePitch));
@@ -1605,6 +1656,16 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
     }
     TRY(dev_alloc(s, &s->d_camsq, n9));
+    if (s->world > 1 && (is_schur(s) ? P.cameras_contiguous : P.contiguous_layout) && int64_t(n9) == int64_t(h.num_cols_f)) {
+      // one all-reduce per step for the camera-space sums: rhs and the column norms live right behind the preconditioner blocks
+      s->merged_layout = true;
+      if (is_schur(s)) {
+        s->rhs_f = s->precond + h.diag_off_f.back();
+        s->d_camsq = s->rhs_f + n9;
+      } else {
+        s->cgnr_rhs_tail = s->precond + h.diag_off_all.back();
+      }
+    }
     if (P.n_rem_rows > 0) {
       // the remainder rows as a structure of their own: compact row space, cells and transpose lists rebased, columns shared with G
       const int r0 = P.rem_row0, nr = P.n_rem_rows, k0 = h.rptr[r0];
@@ -1730,6 +1791,8 @@ int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world,
   HIP_TRY(s, hipHostMalloc(reinterpret_cast<void**>(&s->h_comm_error), sizeof(int), hipHostMallocMapped));
   *s->h_comm_error = 0;
   HIP_TRY(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_comm_error), s->h_comm_error, 0));
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error_seen), sizeof(int)));
+  HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
   HIP_TRY(s, hipDeviceSynchronize());
   { const char* e = getenv("CERES_HIP_P2P_TIMEOUT"); if (e && atof(e) > 0) s->p2p_timeout_s = atof(e); }
   memcpy(handle_out, &h, sizeof(h));
@@ -1824,7 +1887,12 @@ int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t ite
 int ceres_hip_comm_p2p_disable(ceres_hip_solver* s) {
   if (!s) return CERES_HIP_E_INVALID;
   s->p2p = false;
-  if (s->h_comm_error) { HIP_TRY(s, hipSetDevice(s->opt.device)); HIP_TRY(s, hipStreamSynchronize(s->stream)); *s->h_comm_error = 0; }
+  if (s->h_comm_error) {
+    HIP_TRY(s, hipSetDevice(s->opt.device));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    *s->h_comm_error = 0;
+    HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
+  }
   return 0;
 }
 
@@ -2228,7 +2296,7 @@ int ceres_hip_get_ete_inverse(ceres_hip_solver* s, double* blocks, int64_t capac
   if (s->path == CERES_HIP_PATH_BAL) {
     double* tmp = nullptr;
     HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * len));
-    hipError_t e = LaunchExpandSym3(s->etei, tmp, nullptr, s->plan.n_points, s->stream);
+    hipError_t e = LaunchExpandSym3(s->etei, tmp, s->d_pt_eoff, s->plan.n_points, s->stream);  // internal point order -> the caller's E blocks
     int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "expand failed");
     (void)hipFree(tmp);
     return rc;
@@ -2503,7 +2571,8 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
   std::string e = AnalyzeStructure(*bs, num_eliminate_blocks, &h);
   if (!e.empty()) { if (why_not) snprintf(why_not, why_capacity, "%s", e.c_str()); *eligible = 0; return CERES_HIP_E_INVALID; }
   BalPlan P;
-  BuildBalPlan(h, true, &P);
+  // CERES_HIP_DEBUG_PLAN_REORDER=1: the plan a Schur solver builds (points renumbered so that the tiles fill up)
+  { const char* e = getenv("CERES_HIP_DEBUG_PLAN_REORDER"); BuildBalPlan(h, e && atoi(e) != 0 && num_eliminate_blocks > 0, &P); }
   *eligible = P.eligible ? 1 : 0;
   if (why_not) snprintf(why_not, why_capacity, "%s", P.why_not.c_str());
   *n_tiles = P.n_tiles;

@@ -29,6 +29,7 @@ DENSE_SCHUR, ITERATIVE_SCHUR, CGNR = 3, 5, 6
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 PATH_GENERIC, PATH_BAL = 0, 1
+E_INVALID, E_UNSUPPORTED, E_HIP, E_COMM, E_NODEVICE = -1, -2, -3, -4, -5   # CERES_HIP_E_* (include/ceres_hip.h)
 TERMINATION_NAMES = {0: "SUCCESS", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "FATAL_ERROR"}
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
@@ -286,7 +287,7 @@ class HipLinearSolver:
                  world_size: int = 1, loopback_world: int = 0, p2p_exchange=None, p2p_max_elements: int = 0):
         """comm_id: RCCL unique id (ceres_hip_comm_init).  p2p_exchange: callable(bytes) -> list of every rank's bytes in
         rank order (e.g. a torch.distributed all_gather); connects the one-shot peer-to-peer all-reduce for vectors of
-        up to p2p_max_elements doubles (81 * number of F blocks covers a solve)."""
+        up to p2p_max_elements doubles (99 * number of F blocks covers a step: blocks, rhs and column norms go through ONE all-reduce)."""
         self._lib = load_library()
         self.options = options
         nelim = options.elimination_groups[0] if options.elimination_groups else 0

@@ -59,7 +59,7 @@ extern "C" {
 #define CERES_HIP_E_INVALID (-1)     /* bad argument / call order               */
 #define CERES_HIP_E_UNSUPPORTED (-2) /* structure or option not implemented     */
 #define CERES_HIP_E_HIP (-3)         /* a HIP runtime call failed               */
-#define CERES_HIP_E_COMM (-4)        /* an RCCL call failed                     */
+#define CERES_HIP_E_COMM (-4)        /* an RCCL call failed, or a peer never arrived (p2p timeout) */
 #define CERES_HIP_E_NODEVICE (-5)    /* no usable gfx950 device                 */
 
 /* ---- enums: numeric values equal the reference's -------------------------
@@ -200,7 +200,7 @@ int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_I
  * sharded solve exchanges are 9 or 81 doubles per camera: latency-bound, several per step, so the collective is a
  * single kernel (push to every peer, flag, wait, sum in rank order = identical bits on every rank) instead of an
  * RCCL call.  Step 1: every rank calls _prepare (before set_structure) with the largest vector it will sum
- * (81 * num_f_blocks covers a solve) and receives a 64-byte hipIpc handle; the host gathers the handles of all
+ * (99 * num_f_blocks covers a step: blocks, rhs and column norms are summed in ONE all-reduce) and receives a 64-byte hipIpc handle; the host gathers the handles of all
  * ranks in rank order by any means; step 2: every rank calls _connect.  With both communicators present, messages
  * longer than max_elements go to RCCL; with only this one they are cut into pieces.  world_size <= 8.       */
 #define CERES_HIP_IPC_HANDLE_BYTES 64

@@ -30,6 +30,7 @@ def run_rank(rank, world, conn, device, scenario):
         out = {}
         for name, kw in scenario:
             os.environ["CERES_HIP_CG_FUSED"] = kw.get("cg_fused", "1")  # read when a solver is created
+            os.environ["CERES_HIP_P2P_TIMEOUT"] = str(kw.get("p2p_timeout", 20))
             kind = kw["kind"]
             if kind == "bal":
                 prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),
@@ -42,7 +43,7 @@ def run_rank(rank, world, conn, device, scenario):
             v, b, D = sh.local_values(prob.values), sh.local_rows(prob.b), sh.local_cols(prob.D)
             n_f_blocks = sh.bs.num_col_blocks - sh.num_eliminate_blocks
             fsz = sh.bs.col_block_size[sh.num_eliminate_blocks:].astype(np.int64)
-            max_elems = int(max((fsz ** 2).sum(), fsz.sum(), 2))
+            max_elems = int((fsz ** 2).sum() + 2 * fsz.sum() + 2)   # a step sums [blocks | rhs | column norms] in one all-reduce
             for solver_type, pre in kw["solvers"]:
                 o = hs.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=kw.get("max_it", 400),
                                            elimination_groups=[sh.num_eliminate_blocks], device=device,
@@ -51,6 +52,23 @@ def run_rank(rank, world, conn, device, scenario):
                 assert s.p2p_selftest(), s.p2p_error
                 s.set_structure(sh.bs)
                 info = s.info()
+                if "drop_rank" in kw:  # no-hang scenario: one rank leaves after the communicator is up, the others must not hang
+                    import time
+                    if rank == kw["drop_rank"]:
+                        out[(name, solver_type, pre)] = {"dropped": True}
+                        time.sleep(1.0)
+                        s.close()
+                        continue
+                    t0 = time.perf_counter()
+                    try:
+                        s.lm_compute_step(v, b, 1e4, 0.1)
+                        err = None
+                    except hs.HipError as ex:
+                        err = str(ex)
+                    out[(name, solver_type, pre)] = {"dropped": False, "error": err, "seconds": time.perf_counter() - t0,
+                                                     "p2p_enabled": int(info.p2p_enabled), "fine_grained": int(info.p2p_fine_grained)}
+                    s.close()
+                    continue
                 rec = {"path": int(info.kernel_path), "world": int(info.world_size), "rank": int(info.rank),
                        "col_index": sh.col_index, "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum())}
                 # (1) converged solve

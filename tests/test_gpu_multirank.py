@@ -199,3 +199,19 @@ def test_sharded_bal_with_leftover_rows(hip, oracle, problems, WORLD):
             for rec in recs:
                 ci = rec["col_index"]
                 assert rel(rec["jtjx"], want[ci]) <= 1e-12 and rel(rec["jtb"], g[ci]) <= 1e-12
+
+
+def test_a_rank_that_leaves_mid_run_is_an_error_not_a_hang(hip):
+    """One of three ranks goes away after the communicator is connected; the other two enter an LM step.  Their all-reduces wait
+    CERES_HIP_P2P_TIMEOUT seconds for the missing rank ONCE, poison their output with NaN, and the step returns CERES_HIP_E_COMM
+    at its next poll — within a few timeouts, never a hung GPU (the collective is a spin-waiting kernel)."""
+    kw = dict(kind="bal", seed=31, nc=20, np=1500, no=7000, skew=0.5, solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)],
+              drop_rank=2, p2p_timeout=2)
+    res = run_ranks([("drop", kw)], 3, timeout=180)
+    for solver in kw["solvers"]:
+        assert res[2][("drop",) + solver]["dropped"]
+        for r in (0, 1):
+            rec = res[r][("drop",) + solver]
+            assert rec["p2p_enabled"] == 1
+            assert rec["error"] is not None and "timed out" in rec["error"] and f"error {hip.E_COMM}" in rec["error"], rec
+            assert rec["seconds"] < 30.0, rec

@@ -230,3 +230,40 @@ def test_trailing_rows_without_a_point_cell_are_a_remainder_not_a_rejection(prob
     assert bad.num_row_blocks == nrb + 1
     if layout == "cgnr":   # (in the Schur ordering an E row behind E-free rows is not a valid structure for a Schur solver at all)
         assert not pkg.hip_solver.debug_plan(bad, nelim)["eligible"]
+
+
+@pytest.mark.parametrize("shape,kw", [("ladybug1723", {}), (None, dict(num_cameras=300, num_points=250, num_observations=9000)),
+                                      (None, dict(num_cameras=40, num_points=30000, num_observations=70000))])
+def test_renumbered_points_fill_the_tiles(problems, shape, kw, monkeypatch):
+    """The plan of the Schur solvers renumbers the points (windowed best fit, csrc/plan.cc): same rows, each exactly once, whole
+    points per tile with consecutive INTERNAL ids, a point's rows still in the caller's order — and far fewer padding slots."""
+    p = problems.synthetic_bal(shape, layout="schur", seed=5, skew=0.6, **kw)
+    plain = plan_of(p)
+    monkeypatch.setenv("CERES_HIP_DEBUG_PLAN_REORDER", "1")
+    plan = plan_of(p)
+    assert plan["eligible"]
+    valid = plan["valid"].astype(bool)
+    rows = plan["slot_row"][valid]
+    assert np.array_equal(np.sort(rows), np.arange(p.bs.num_row_blocks))           # every row, once
+    ipt = plan["slot_pt"][valid]                                                      # internal point ids
+    caller_pt = p.point_of_row[rows]
+    # internal ids are a renumbering of the caller's points: one-to-one
+    pairs = np.unique(np.stack([ipt, caller_pt], 1), axis=0)
+    assert len(pairs) == len(np.unique(ipt)) == len(np.unique(caller_pt))
+    # slots in tile order: internal ids never decrease, a point's rows are consecutive slots in the caller's row order
+    assert (np.diff(ipt) >= 0).all()
+    same = np.diff(ipt) == 0
+    assert (np.diff(rows)[same] > 0).all()
+    nt = plan["n_tiles"]
+    # no normal tile splits a point; tiles hold at most 42 points
+    tile_of = (np.flatnonzero(valid) // 64)
+    normal = plan["tile_kind"][tile_of] == 0
+    first_tile = {}
+    for t, q in zip(tile_of[normal].tolist(), ipt[normal].tolist()):
+        assert first_tile.setdefault(q, t) == t
+    assert plan["n_tiles"] <= plain["n_tiles"]
+    waste = 1.0 - valid.sum() / (64.0 * nt)
+    waste_plain = 1.0 - plain["valid"].sum() / (64.0 * plain["n_tiles"])
+    print(f"padding {waste_plain:.4f} -> {waste:.4f} ({plain['n_tiles']} -> {nt} tiles)")
+    if shape == "ladybug1723":
+        assert waste < 0.012 and waste < 0.4 * waste_plain
