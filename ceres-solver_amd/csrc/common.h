@@ -33,6 +33,9 @@ constexpr int kTilePitch = CERES_HIP_AB_TILE_ROWS * 64;
 constexpr size_t kLdsBytesPerCu = 160 * 1024;  // LDS per CU on gfx950
 constexpr int kZUnit = 64;             // max entries of one work unit of the chunked camera-major pass (cameras not in LDS)
 constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
+// The per-slot index word of the tiles: camera id in the low kSlotCamBits bits, LDS accumulator row above them (kSlotSpill = none)
+constexpr int kSlotCamBits = 20;
+constexpr int kSlotSpill = 0xFFF;
 
 // ---------------------------------------------------------------------------
 // Host-side analysis (plan.cc).  Pure C++, unit-testable without a GPU through
@@ -67,7 +70,9 @@ struct BalPlan {
   int n_points = 0, n_cameras = 0;
   int64_t n_obs = 0, n_tiles = 0;
   bool contiguous_layout = false;  // pt_pos = 3p, cam_pos(F-relative) = 9c
-  bool points_contiguous = false, cameras_contiguous = false;  // each half of it (points are renumbered for the Schur solvers: plan.cc)
+  bool points_contiguous = false, cameras_contiguous = false;  // each half of it (points may be renumbered: plan.cc)
+  bool caller_contiguous = false;  // the CALLER's column layout is points-then-cameras back to back (before any renumbering)
+  bool renumbered = false;         // internal point p is the caller's point of column block pt_block[p], at pt_pos[p]
   std::vector<int32_t> pt_block, cam_block;   // column block of each point / camera
   std::vector<int32_t> pt_pos, cam_pos;       // scalar offset in x (camera: minus num_cols_e)
   // per slot (n_tiles * 64)
@@ -88,12 +93,21 @@ struct BalPlan {
   // Cameras whose 9-double accumulators do not fit in LDS (more than ~2270): the tile pass leaves F^T z per slot and a
   // camera-major pass sums it.  Both can run CHUNK by chunk of tiles through a ring buffer (plan.cc: default one chunk).
   bool cameras_in_lds = true;
-  int64_t z_ring_slots = 0;                  // slots of the largest chunk = size of the per-slot ring buffer
+  std::vector<int32_t> slot_word;            // per slot, what the kernels read: camera | accumulator row << kSlotCamBits (plan.cc)
+  int64_t z_ring_rows = 0;                   // 72-byte rows of the largest chunk's ring (spilled slots + the hybrid flush rows)
+  std::vector<int32_t> tile_zbase;           // per tile: ring row of its first spilled slot (chunk-relative)
   std::vector<int32_t> zc_tile_ptr;          // n_chunks+1 tile boundaries (never inside a long point)
   std::vector<int32_t> zc_unit_ptr;          // n_chunks+1 into the unit arrays
   std::vector<int32_t> zu_cam, zu_begin, zu_end;  // unit = <= kZUnit entries of ONE camera inside ONE chunk; [begin, end) into zc_slot
   std::vector<int32_t> zu_shared;            // 1: the camera has more units in this chunk (combine with atomics), 0: plain read-modify-write
-  std::vector<int32_t> zc_slot;              // per entry: slot index RELATIVE to its chunk's first slot; chunk-major, camera-major inside
+  std::vector<int32_t> zc_slot;              // per entry: ring row (chunk-relative); chunk-major, camera-major inside
+  // Hybrid accumulation (plan.cc): hyb_groups workgroups with hyb_rows LDS accumulator rows each (the first hyb_hot of them the
+  // same popular cameras everywhere, the rest the workgroup's own window); group g walks tiles [grp_tile_ptr[g], grp_tile_ptr[g+1])
+  // and flushes its rows to ring rows [z_flush_row0 + g hyb_rows, + hyb_rows)
+  bool hybrid = false;
+  int hyb_groups = 0, hyb_rows = 0, hyb_hot = 0;
+  int64_t z_flush_row0 = 0, n_local_obs = 0;  // n_local_obs: observations summed in LDS (the others are spilled)
+  std::vector<int32_t> grp_tile_ptr;
   int max_track = 0, max_camera_degree = 0;
   // REMAINDER: trailing row blocks [rem_row0, nrb) that are not "one point cell + one camera cell" but touch camera blocks only
   // (rows without an E block: priors / regularisers on cameras, the rows SchurEliminator::NoEBlockRowsUpdate handles,
@@ -123,8 +137,13 @@ void BuildSchurStorage(const HostStructure& hs, SchurStorage* out);
 // Fills hs from the ABI structure; returns "" or an error message.
 std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs);
 // Decides whether the fused <2,3,9> path applies and, if so, builds the packing plan.
-// reorder_points: renumber the points so that the tiles fill up (plan.cc; only where no caller-visible vector is walked in tile order)
-void BuildBalPlan(const HostStructure& hs, bool reorder_points, BalPlan* plan);
+// hyb: the workgroups and LDS accumulator rows of the tile pass (hybrid camera accumulation when the cameras do not fit in LDS;
+// needs reorder_points; groups = 0: never)
+struct HybridRequest { int groups = 0, rows = 0; };
+// reorder_mode: renumber the points (fuller tiles; hybrid groups) never / always (Schur solvers: no CG vector lives in point space) /
+// only if the caller's layout is points-then-cameras back to back (CGNR: its CG vectors then ARE the caller's with the points renumbered)
+constexpr int kReorderNever = 0, kReorderAlways = 1, kReorderIfContiguous = 2;
+void BuildBalPlan(const HostStructure& hs, int reorder_mode, const HybridRequest& hyb, BalPlan* plan);
 
 }  // namespace chip
 #endif

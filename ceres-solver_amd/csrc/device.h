@@ -39,10 +39,20 @@ struct BalArgs {
   int64_t n_tiles = 0, n_slots = 0;
   // tiles this launch walks: [tile_begin, tile_end); tile_end = 0 means all.  Chunked launches (cameras not in LDS) write their
   // per-slot F^T z into a ring buffer indexed by slot - z_slot0.
-  int64_t tile_begin = 0, tile_end = 0, z_slot0 = 0;
+  int64_t tile_begin = 0, tile_end = 0;
+  // cameras not in LDS (plan.cc): tile_zbase = ring row of each tile's first spilled slot; hybrid accumulation: workgroup g walks the
+  // tiles [grp_tile_ptr[g], grp_tile_ptr[g + 1]) with hyb_rows accumulator rows in LDS, flushed to ring rows z_flush_row0 + g hyb_rows ..
+  const int32_t* tile_zbase = nullptr;
+  const int32_t* grp_tile_ptr = nullptr;
+  int hyb_rows = 0;
+  int64_t z_flush_row0 = 0;
   int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)
   const int32_t* pt_pos = nullptr;   // nullptr => 3*p
   const int32_t* cam_pos = nullptr;  // nullptr => 9*c   (relative to the F base pointer)
+  // CGNR on internally numbered points: x_e / y_e / point_blocks are internal (pt_pos == nullptr) while D_e, lm_diag_e, lm_D_e are the
+  // caller's: d_pos[p] = the caller's offset of internal point p (nullptr: the same offsets as x_e); D_int_out: D_e in the internal order
+  const int32_t* d_pos = nullptr;
+  double* D_int_out = nullptr;
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
   const double* x_e = nullptr;
   const double* x_f = nullptr;
@@ -61,7 +71,7 @@ struct BalArgs {
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
-  double* zbuf = nullptr;        // [n_slots][9]   (cameras do not fit in LDS: F^T z per slot, second pass by camera)
+  double* zbuf = nullptr;        // [rows][9]      (cameras do not fit in LDS: the ring of spilled / flushed F^T z rows, second pass by camera)
   int n_f9 = 0;                  // 9 * n_cameras
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
@@ -219,9 +229,18 @@ hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, d
 // neg_out (optional): also neg_out[i] = -y[i] over the range and *nonfinite += (entries that are not finite) — the LM step's
 // finite check + negation, read from the CG solution in the same pass
 // gate (optional): a CG status word; the kernel does nothing unless CgStatusAllowsSolution(*gate) (speculative LM tail)
+// CGNR on internally numbered points (solver.hip): the CG vectors hold internal point p at [3 p, 3 p + 3), the caller's vectors at
+// pt_pos[p]; D_e = the point part of D in the internal order
+struct PointPerm {
+  const int32_t* pt_pos = nullptr;
+  const double* D_e = nullptr;
+  int64_t n_e = 0;
+};
 hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
                                double* partials, int* nparts, hipStream_t stream, double* neg_out = nullptr, int* nonfinite = nullptr,
-                               const int* gate = nullptr);
+                               const int* gate = nullptr, const PointPerm& perm = PointPerm());
+// the 3-wide point blocks [0, n_e) between the caller's order and the internal one (to_internal: out[i] = in[pos(i)]); [n_e, n) copied
+hipError_t LaunchPermutePoints(const double* in, double* out, const int32_t* pt_pos, int64_t n_e, int64_t n, bool to_internal, hipStream_t stream);
 hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);

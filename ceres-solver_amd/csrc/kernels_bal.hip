@@ -156,9 +156,10 @@ struct Slot {
   double e[6], f[18];
   double b0, b1;
   int64_t slot;
-  int64_t zrel;   // slot - A.z_slot0: where the slot's F^T z goes in the (chunk) ring when cameras are not in LDS
+  int64_t zbase;  // cameras not in LDS: ring row of the tile's first spilled slot (wave-uniform)
   uint32_t seg;
   int cam, pt, first, last;
+  int acc;        // LDS accumulator row of the slot's camera (kSlotSpill: none, the slot's F^T z is spilled); plan.cc, slot_word
   bool valid;
 };
 
@@ -174,7 +175,9 @@ __device__ __forceinline__ void finish_slot(Slot& s, int lane, int pt0) {
   const unsigned long long heads = __ballot(s.valid && lane == s.first);
   const int rank = __popcll(heads & ((2ull << lane) - 1ull)) - 1;
   s.pt = pt0 + rank;
-  if (!s.valid) { s.cam = 0; s.pt = 0; }
+  s.acc = int(uint32_t(s.cam) >> kSlotCamBits);   // the index word: camera | accumulator row << kSlotCamBits (0 above the camera when every camera has its LDS row)
+  s.cam &= (1 << kSlotCamBits) - 1;
+  if (!s.valid) { s.cam = 0; s.pt = 0; s.acc = kSlotSpill; }
 }
 
 // Loads one slot.  Normally from the packed tiles; on the FIRST pass over a step's Jacobian
@@ -190,7 +193,7 @@ __device__ __forceinline__ void load_slot(const BalArgs& A, int64_t tile, int la
                                           bool may_gather = true) {
   const int64_t sl = tile * kTile + lane;
   s.slot = sl;
-  s.zrel = sl - A.z_slot0;
+  s.zbase = A.tile_zbase ? A.tile_zbase[tile] : 0;
   s.b0 = 0.0; s.b1 = 0.0;
   if (CAN_GATHER && A.src_values && may_gather) {
     const int ep = A.slot_epos[sl], fp = A.slot_fpos[sl];
@@ -261,7 +264,7 @@ __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int la
 }
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
-  s.zrel = s.slot - A.z_slot0;
+  s.zbase = A.tile_zbase ? A.tile_zbase[tile] : 0;
   s.b0 = 0.0; s.b1 = 0.0;
   const double2* J = A.J + tile * kTilePitch + lane;
   double2 p[kPairsPerSlot];
@@ -299,37 +302,45 @@ __device__ __forceinline__ void f_times(const Slot& s, const double (&xc)[9], do
 #pragma unroll
   for (int k = 0; k < 9; ++k) { t0 += s.f[k] * xc[k]; t1 += s.f[9 + k] * xc[k]; }
 }
-// Camera-space contribution F^T z of one observation.  LDS: nine ds_add_f64 into the
-// workgroup's accumulator.  Otherwise (cameras do not fit in LDS) the nine products are stored per
-// slot and bal_camera_chunk_kernel sums them camera by camera in a second pass — global fp64
-// atomics on a few thousand hot addresses are an order of magnitude slower.
+// Camera-space contribution F^T z of one observation.  LDS: nine ds_add_f64 into the workgroup's accumulator, one row per camera.
+// Otherwise (more cameras than LDS rows) the HYBRID form: a slot whose camera has a row in THIS workgroup's accumulator (one of
+// the popular cameras every workgroup holds, or a camera of the workgroup's own window: Slot::acc, plan.cc) adds into it the same
+// way; the others are SPILLED — the nine products are stored in a ring, the spilled slots of a tile back to back from the tile's
+// ring row s.zbase on, and bal_camera_chunk_kernel sums them camera by camera in a second pass (global fp64 atomics on a few
+// thousand hot addresses are an order of magnitude slower).  A lane storing its own 72-byte row would issue nine 8-byte stores
+// at a 72-byte stride, and it is the L2's request rate, not its bytes, that such stores exhaust (the per-slot output cost as much
+// as reading the 200 B / slot tile stream): the wave packs the rows through a private LDS strip (behind the accumulator rows) and
+// stores one contiguous range.  Without a hybrid plan (CGNR on caller-ordered vectors, chunked rings) every slot spills.
 template <bool LDS>
-__device__ __forceinline__ void scatter_ft(const Slot& s, double* acc, double z0, double z1) {
+__device__ __forceinline__ void scatter_ft(const BalArgs& A, const Slot& s, double* acc, double z0, double z1) {
   if constexpr (LDS) {
     if (!s.valid) return;
     const int base = 9 * s.cam;
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);  // ds_add_f64
   } else {
-    // cameras do not fit in LDS: leave this observation's contribution F^T z (72 B) for the camera-major
-    // pass, which then gathers 72 contiguous bytes per observation — and neither the 144-byte F cell
-    // (1.8x over-fetched from the caller's layout) nor a 16-byte z out of a 128-byte line, as it first did.
-    // A lane storing its own 72-byte record would issue nine 8-byte stores at a 72-byte stride: 576 partial-line write
-    // requests per tile, and it is the L2's request rate, not its bytes, that such stores exhaust (the per-slot output cost as
-    // much as reading the 200 B / slot tile stream).  The tile's 64 x 9 doubles are one contiguous 4.6 KB range, so the wave
-    // transposes them through a private LDS strip and stores nine fully coalesced 512-byte rows.
-    __shared__ double zstage[16][kTile * 9];  // one strip per wave of the (<= 1024-thread) workgroup; only LDS = false kernels carry it
-    // nothing to store for a tile with no valid slot: the pipelined kernel runs the tiles of long points through here with every
-    // lane masked, and their real values are written later by whichever wave owns the point's head tile — zeros from here could land after them
-    if (__ballot(s.valid) == 0ull) return;
-    double* st = zstage[threadIdx.x >> 6];
+    const bool local = s.valid && s.acc != kSlotSpill;
+    if (local) {
+      const int base = 9 * s.acc;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) atomicAdd(&acc[base + k], s.f[k] * z0 + s.f[9 + k] * z1);
+    }
+    const bool spill = s.valid && !local;
+    // (nothing to store for a tile without spilled slots: that includes the tiles of long points the pipelined kernel runs through
+    // here with every lane masked — their real values are written by whichever wave owns the point's head tile)
+    const unsigned long long mask = __ballot(spill);
+    if (mask == 0ull) return;
     const int lane = threadIdx.x & 63;
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull)), n9 = 9 * __popcll(mask);
+    double* st = acc + 9 * A.hyb_rows + (threadIdx.x >> 6) * (kTile * 9);  // this wave's strip
+    if (spill) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) st[lane * 9 + k] = s.valid ? s.f[k] * z0 + s.f[9 + k] * z1 : 0.0;
+      for (int k = 0; k < 9; ++k) st[rank * 9 + k] = s.f[k] * z0 + s.f[9 + k] * z1;
+    }
     __builtin_amdgcn_wave_barrier();
-    double* w = acc + 9 * (s.zrel - lane);  // the tile's first slot in the ring (wave-uniform)
+    double* w = A.zbuf + 9 * s.zbase;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) w[kTile * j + lane] = st[kTile * j + lane];
+    for (int j = 0; j < 9; ++j) if (kTile * j + lane < n9) w[kTile * j + lane] = st[kTile * j + lane];
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -427,18 +438,24 @@ __device__ __forceinline__ void ete_of(const Slot& s, double (&a)[6]) {
 // diag(J^T J) over the point's columns: d = clamp(a_jj, min, max), D^2 = d / radius
 // (LevenbergMarquardtStrategy::ComputeStep, I/levenberg_marquardt_strategy.cc:84-96); `writer`
 // lanes record d (for a later reuse_diagonal step) and D.
-__device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int po, double (&a)[6], bool writer) {
+// pt / po: the point and its offset in x_e / y_e; the caller's D (and the LM diagonal) may live at another offset (A.d_pos: CGNR on
+// internally numbered points), and then the writer also leaves D in the internal order (A.D_int_out) for the operator.
+__device__ __forceinline__ void add_e_diagonal(const BalArgs& A, int pt, int po, double (&a)[6], bool writer) {
+  const int pd = A.d_pos ? A.d_pos[pt] : po;
   if (A.lm_radius > 0.0) {
     const double d0 = fmin(fmax(a[0], A.lm_min), A.lm_max), d1 = fmin(fmax(a[3], A.lm_min), A.lm_max),
                  d2 = fmin(fmax(a[5], A.lm_min), A.lm_max);
     const double q0 = d0 / A.lm_radius, q1 = d1 / A.lm_radius, q2 = d2 / A.lm_radius;
     if (writer) {
-      A.lm_diag_e[po] = d0; A.lm_diag_e[po + 1] = d1; A.lm_diag_e[po + 2] = d2;
-      A.lm_D_e[po] = sqrt(q0); A.lm_D_e[po + 1] = sqrt(q1); A.lm_D_e[po + 2] = sqrt(q2);
+      const double s0 = sqrt(q0), s1 = sqrt(q1), s2 = sqrt(q2);
+      A.lm_diag_e[pd] = d0; A.lm_diag_e[pd + 1] = d1; A.lm_diag_e[pd + 2] = d2;
+      A.lm_D_e[pd] = s0; A.lm_D_e[pd + 1] = s1; A.lm_D_e[pd + 2] = s2;
+      if (A.D_int_out) { A.D_int_out[po] = s0; A.D_int_out[po + 1] = s1; A.D_int_out[po + 2] = s2; }
     }
     a[0] += q0; a[3] += q1; a[5] += q2;
   } else if (A.D_e) {
-    const double d0 = A.D_e[po], d1 = A.D_e[po + 1], d2 = A.D_e[po + 2];
+    const double d0 = A.D_e[pd], d1 = A.D_e[pd + 1], d2 = A.D_e[pd + 2];
+    if (writer && A.D_int_out) { A.D_int_out[po] = d0; A.D_int_out[po + 1] = d1; A.D_int_out[po + 2] = d2; }
     a[0] += d0 * d0; a[3] += d1 * d1; a[5] += d2 * d2;
   }
 }
@@ -462,7 +479,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
   sym3_mul(ei, g, h);
   const double w0 = b0 - (s.e[0] * h[0] + s.e[1] * h[1] + s.e[2] * h[2]);
   const double w1 = b1 - (s.e[3] * h[0] + s.e[4] * h[1] + s.e[5] * h[2]);
-  if (A.have_b) scatter_ft<LDS>(s, acc, w0, w1);
+  if (A.have_b) scatter_ft<LDS>(A, s, acc, w0, w1);
   if (A.Mo && s.valid) {  // M = I - E Ei E^T, symmetric 2x2
     const double r0[3] = {s.e[0], s.e[1], s.e[2]}, r1[3] = {s.e[3], s.e[4], s.e[5]};
     double q0[3], q1[3];
@@ -533,7 +550,7 @@ __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, 
     const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
     const double z0 = MODE == kSx ? t0 - ev0 : ev0;
     const double z1 = MODE == kSx ? t1 - ev1 : ev1;
-    scatter_ft<LDS>(s, acc, z0, z1);
+    scatter_ft<LDS>(A, s, acc, z0, z1);
   } else {
     static_assert(MODE == kJtJx, "streaming modes");
     const int n3 = 3 * npts;
@@ -555,7 +572,7 @@ __device__ __forceinline__ void compute_stream(const BalArgs& A, const Slot& s, 
     f_times(s, x.xc, z0, z1);
     z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
     z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
-    scatter_ft<LDS>(s, acc, z0, z1);
+    scatter_ft<LDS>(A, s, acc, z0, z1);
     double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
     if (!s.valid) { w[0] = w[1] = w[2] = 0; }
     seg_scan<3>(w, lane, s.first, span);
@@ -594,7 +611,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     load_aux<MODE>(A, s, lane, npts, x);
     compute_stream<MODE, LDS>(A, s, lane, span, npts, x, acc, lane_acc);
   } else if constexpr (MODE == kJtb) {
-    scatter_ft<LDS>(s, acc, s.b0, s.b1);
+    scatter_ft<LDS>(A, s, acc, s.b0, s.b1);
     double w[3] = {s.e[0] * s.b0 + s.e[3] * s.b1, s.e[1] * s.b0 + s.e[4] * s.b1, s.e[2] * s.b0 + s.e[5] * s.b1};
     if (!s.valid) { w[0] = w[1] = w[2] = 0; }
     seg_scan<3>(w, lane, s.first, span);
@@ -623,7 +640,7 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
       for (int i = 0; i < 6; ++i) r[i] = a6[i];
     }
     double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-    add_e_diagonal(A, po, a, s.valid && lane == s.last);
+    add_e_diagonal(A, s.pt, po, a, s.valid && lane == s.last);
     if (!s.valid) { a[0] = a[3] = a[5] = 1.0; a[1] = a[2] = a[4] = 0.0; }
     invert_spd3(a, ei);
     if (s.valid && lane == s.last) store_ete_inverse(A, s.pt, ei);
@@ -662,13 +679,13 @@ __device__ __forceinline__ void process_tile(const BalArgs& A, int64_t tile, int
     r[6] = s.valid ? s.e[0] * s.b0 + s.e[3] * s.b1 : 0.0;
     r[7] = s.valid ? s.e[1] * s.b0 + s.e[4] * s.b1 : 0.0;
     r[8] = s.valid ? s.e[2] * s.b0 + s.e[5] * s.b1 : 0.0;
-    scatter_ft<LDS>(s, acc, s.b0, s.b1);
+    scatter_ft<LDS>(A, s, acc, s.b0, s.b1);
     seg_scan<9>(r, lane, s.first, span);
     if (s.valid && lane == s.last) {
       A.y_e[po] = r[6]; A.y_e[po + 1] = r[7]; A.y_e[po + 2] = r[8];
       if (A.point_blocks) {
         double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-        add_e_diagonal(A, po, a, true);
+        add_e_diagonal(A, s.pt, po, a, true);
         invert_spd3(a, ei);
         store_ete_inverse(A, s.pt, ei);
       }
@@ -767,7 +784,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
         f_times(s, xc, t0, t1);
         const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
         const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
-        scatter_ft<LDS>(s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
+        scatter_ft<LDS>(A, s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
       }
     }
   } else if constexpr (MODE == kJtJx || MODE == kJtb) {
@@ -790,7 +807,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
       } else {
         z0 = s.b0; z1 = s.b1;
       }
-      scatter_ft<LDS>(s, acc, z0, z1);
+      scatter_ft<LDS>(A, s, acc, z0, z1);
       if (s.valid) { w[0] += s.e[0] * z0 + s.e[3] * z1; w[1] += s.e[1] * z0 + s.e[4] * z1; w[2] += s.e[2] * z0 + s.e[5] * z1; }
     }
     wave_allreduce<3>(w);
@@ -809,7 +826,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     for (int t = 0; t < nt; ++t) {
       load_slot<kCanGather<MODE>, F32>(A, tile + t, lane, s, kWantsB<MODE>);
       if (t == 0) pt = __shfl(s.pt, 0, 64);
-      if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(s, acc, s.b0, s.b1);
+      if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(A, s, acc, s.b0, s.b1);
       if (s.valid) {
         double a[6];
         ete_of(s, a);
@@ -821,7 +838,7 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
     wave_allreduce<9>(r);
     const int po = pt_off(A, pt);
     double a[6] = {r[0], r[1], r[2], r[3], r[4], r[5]}, ei[6];
-    add_e_diagonal(A, po, a, lane == 0);
+    add_e_diagonal(A, pt, po, a, lane == 0);
     invert_spd3(a, ei);
     if constexpr (MODE == kCgnrInit) {
       if (lane == 0) {
@@ -850,13 +867,11 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm || MODE == kSpseZ);
   double* acc = nullptr;
   if constexpr (kScatters) {
-    if constexpr (LDS) {
-      acc = lds_acc;
-      for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) acc[i] = 0.0;
-      __syncthreads();
-    } else {
-      acc = reinterpret_cast<double*>(A.zbuf);
-    }
+    // every camera's accumulator row (LDS), or the hybrid rows of this workgroup — hyb_rows of them, then one strip per wave (scatter_ft)
+    acc = lds_acc;
+    const int n_acc = LDS ? A.n_f9 : 9 * A.hyb_rows;
+    for (int i = threadIdx.x; i < n_acc; i += BLOCK) acc[i] = 0.0;
+    __syncthreads();
   }
   const int lane = threadIdx.x & 63;
   double lane_acc = 0.0;
@@ -868,10 +883,12 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
         if (A.negate_out && !isfinite(z)) atomicAdd(A.nonfinite, 1);
       }
   }
-  const int64_t wave = logical_workgroup() * (BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
-  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
-  for (int64_t tile = A.tile_begin + wave; tile < tile_end; tile += nwaves) {
+  // grid-strided over [tile_begin, tile_end); hybrid accumulation: workgroup g owns the tiles of group g (plan.cc)
+  const bool grouped = kScatters && !LDS && A.grp_tile_ptr != nullptr;
+  const int64_t tile0 = grouped ? A.grp_tile_ptr[blockIdx.x] + (threadIdx.x >> 6) : A.tile_begin + logical_workgroup() * (BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = grouped ? BLOCK / 64 : int64_t(gridDim.x) * (BLOCK / 64);
+  const int64_t tile_end = grouped ? A.grp_tile_ptr[blockIdx.x + 1] : (A.tile_end > 0 ? A.tile_end : A.n_tiles);
+  for (int64_t tile = tile0; tile < tile_end; tile += nwaves) {
     const int kind = A.tile_kind[tile];
     const int aux = A.tile_aux[tile];
     if constexpr (MODE == kJx) {
@@ -901,6 +918,12 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     __syncthreads();
     double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
     for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
+  } else if constexpr (kScatters) {
+    if (A.hyb_rows > 0) {  // this workgroup's accumulator rows join the spilled rows in the ring: the second pass sums both
+      __syncthreads();
+      double* out = A.zbuf + 9 * (A.z_flush_row0 + int64_t(blockIdx.x) * A.hyb_rows);
+      for (int i = threadIdx.x; i < 9 * A.hyb_rows; i += BLOCK) out[i] = acc[i];
+    }
   }
 }
 
@@ -949,21 +972,22 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   constexpr int BLOCK = 512;
   extern __shared__ double lds_acc[];
   if (A.status && *A.status != 0) return;
-  double* acc = nullptr;
-  if constexpr (LDS) {
-    acc = lds_acc;
-    for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) acc[i] = 0.0;
+  double* acc = lds_acc;  // every camera's accumulator row (LDS), or the hybrid rows of this workgroup + one strip per wave (scatter_ft)
+  {
+    const int n_acc = LDS ? A.n_f9 : 9 * A.hyb_rows;
+    for (int i = threadIdx.x; i < n_acc; i += BLOCK) acc[i] = 0.0;
     __syncthreads();
-  } else {
-    acc = reinterpret_cast<double*>(A.zbuf);
   }
   const int lane = threadIdx.x & 63;
   double dot = 0.0;  // kJtJx: this lane's share of x_e . y_e
-  const int64_t nwaves = int64_t(gridDim.x) * (BLOCK / 64);
+  // grid-strided over [tile_begin, tile_end); hybrid accumulation: workgroup g owns the tiles of group g (plan.cc)
+  const bool grouped = !LDS && A.grp_tile_ptr != nullptr;
+  const int64_t nwaves = grouped ? BLOCK / 64 : int64_t(gridDim.x) * (BLOCK / 64);
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
-  const int64_t tile_end = A.tile_end > 0 ? A.tile_end : A.n_tiles;
-  const int64_t wave0 = A.tile_begin + logical_workgroup() * (BLOCK / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t tile_end = grouped ? A.grp_tile_ptr[blockIdx.x + 1] : (A.tile_end > 0 ? A.tile_end : A.n_tiles);
+  const int64_t wave0 = (grouped ? int64_t(A.grp_tile_ptr[blockIdx.x]) : A.tile_begin + logical_workgroup() * (BLOCK / 64)) +
+                        __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t last = tile_end - 1;
   if (wave0 < tile_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
@@ -1035,6 +1059,12 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     __syncthreads();
     double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
     for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
+  } else {
+    if (A.hyb_rows > 0) {  // this workgroup's accumulator rows join the spilled rows in the ring: the second pass sums both
+      __syncthreads();
+      double* out = A.zbuf + 9 * (A.z_flush_row0 + int64_t(blockIdx.x) * A.hyb_rows);
+      for (int i = threadIdx.x; i < 9 * A.hyb_rows; i += BLOCK) out[i] = acc[i];
+    }
   }
 }
 
@@ -1512,7 +1542,13 @@ static hipError_t launch_fused2(const BalArgs& A, bool lds, int grid, hipStream_
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   } else {
-    hipLaunchKernelGGL((bal_fused_kernel<MODE, false, BLOCK, F32>), dim3(grid), dim3(BLOCK), 0, stream, A);
+    // scattering modes: the hybrid accumulator rows (none without a hybrid plan) + one 64 x 9 strip per wave for the spilled rows
+    constexpr bool kScatters = (MODE == kSx || MODE == kJtJx || MODE == kJtb || MODE == kInit || MODE == kCgnrInit || MODE == kColNorm || MODE == kSpseZ);
+    const size_t bytes = kScatters ? (size_t(A.hyb_rows) * 9 + size_t(BLOCK / 64) * kTile * 9) * sizeof(double) : 0;
+    auto k = bal_fused_kernel<MODE, false, BLOCK, F32>;
+    if (bytes > 0)
+      if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), bytes, stream, A);
   }
   return hipGetLastError();
 }
@@ -1537,7 +1573,9 @@ static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
   } else {
-    hipLaunchKernelGGL((bal_stream_kernel<MODE, false>), dim3(grid), dim3(512), 0, stream, A);
+    auto k = bal_stream_kernel<MODE, false>;
+    if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), (size_t(A.hyb_rows) * 9 + size_t(512 / 64) * kTile * 9) * sizeof(double), stream, A);
   }
   return hipGetLastError();
 }
@@ -1550,6 +1588,7 @@ static bool UsePipeline() {
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   const bool big = BalBlockFor(mode) == 1024;
+  const bool big_s = big && (lds || A.hyb_rows == 0);  // scattering modes with hybrid rows: the rows are sized for 8 waves' strips
   if (UsePipeline() && !A.Jf && !A.src_values && !A.cam_pos && !(A.flags & 1)) {
     // (S.x and the power-series operator index nothing of the caller's by point: pt_pos may be set — renumbered points, plan.cc)
     if (mode == kSx) return launch_stream<kSx>(A, lds, grid, stream);
@@ -1557,16 +1596,16 @@ hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStr
     if (mode == kSpseZ) return launch_stream<kSpseZ>(A, lds, grid, stream);
   }
   switch (mode) {
-    case kSx: return big ? launch_fused<kSx, 1024>(A, lds, grid, stream) : launch_fused<kSx, 512>(A, lds, grid, stream);
-    case kJtJx: return big ? launch_fused<kJtJx, 1024>(A, lds, grid, stream) : launch_fused<kJtJx, 512>(A, lds, grid, stream);
-    case kJtb: return (big && !A.src_values) ? launch_fused<kJtb, 1024>(A, lds, grid, stream) : launch_fused<kJtb, 512>(A, lds, grid, stream);
+    case kSx: return big_s ? launch_fused<kSx, 1024>(A, lds, grid, stream) : launch_fused<kSx, 512>(A, lds, grid, stream);
+    case kJtJx: return big_s ? launch_fused<kJtJx, 1024>(A, lds, grid, stream) : launch_fused<kJtJx, 512>(A, lds, grid, stream);
+    case kJtb: return (big_s && !A.src_values) ? launch_fused<kJtb, 1024>(A, lds, grid, stream) : launch_fused<kJtb, 512>(A, lds, grid, stream);
     case kInit: return launch_fused<kInit, 512>(A, lds, grid, stream);
     case kEte: return big ? launch_fused<kEte, 1024>(A, false, grid, stream) : launch_fused<kEte, 512>(A, false, grid, stream);
     case kBackSub: return big ? launch_fused<kBackSub, 1024>(A, false, grid, stream) : launch_fused<kBackSub, 512>(A, false, grid, stream);
     case kCgnrInit: return launch_fused<kCgnrInit, 512>(A, lds, grid, stream);
     case kColNorm: return launch_fused<kColNorm, 512>(A, true, grid, stream);
     case kJx: return launch_fused<kJx, 1024>(A, false, grid, stream);
-    case kSpseZ: return big ? launch_fused<kSpseZ, 1024>(A, lds, grid, stream) : launch_fused<kSpseZ, 512>(A, lds, grid, stream);
+    case kSpseZ: return big_s ? launch_fused<kSpseZ, 1024>(A, lds, grid, stream) : launch_fused<kSpseZ, 512>(A, lds, grid, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -139,18 +139,20 @@ __global__ __launch_bounds__(kVecBlock) void negate_and_check_kernel(double* x, 
   if (bad) atomicAdd(nonfinite, bad);
 }
 
-// Partial sums of  y.g + y.r + |D y|^2  over [begin, end) (one partial per workgroup).
+// Partial sums of  y.g + y.r + |D y|^2  over [begin, end) (one partial per workgroup).  perm (CGNR on internally numbered points,
+// solver.hip): y, g, r are in the internal order, D's point part comes from perm.D_e (internal) and -y goes out in the caller's order.
 __global__ __launch_bounds__(kVecBlock) void cgnr_model_cost_kernel(const double* y, const double* g, const double* r, const double* D,
                                                                      int64_t begin, int64_t end, double* partials,
-                                                                     double* neg_out, int* nonfinite, const int* gate) {
+                                                                     double* neg_out, int* nonfinite, const int* gate, PointPerm perm) {
   __shared__ double sh[4];
   if (gate && !CgStatusAllowsSolution(*gate)) return;
   double v = 0;
   int bad = 0;
   for (int64_t i = begin + int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < end; i += int64_t(gridDim.x) * kVecBlock) {
-    const double yi = y[i], d = D ? D[i] * yi : 0.0;
+    const bool pt = perm.pt_pos && i < perm.n_e;
+    const double yi = y[i], d = D ? (pt ? perm.D_e[i] : D[i]) * yi : 0.0;
     v += yi * (g[i] + r[i]) + d * d;
-    if (neg_out) { neg_out[i] = -yi; if (!isfinite(yi)) ++bad; }
+    if (neg_out) { neg_out[pt ? perm.pt_pos[i / 3] + int(i % 3) : i] = -yi; if (!isfinite(yi)) ++bad; }
   }
   if (bad) atomicAdd(nonfinite, bad);
   v = block_sum(v, sh);
@@ -672,11 +674,24 @@ hipError_t LaunchDot(const double* x, const double* y, int64_t n, double* partia
   return hipGetLastError();
 }
 hipError_t LaunchCgnrModelCost(const double* y, const double* g, const double* r, const double* D, int64_t begin, int64_t end,
-                               double* partials, int* nparts, hipStream_t s, double* neg_out, int* nonfinite, const int* gate) {
+                               double* partials, int* nparts, hipStream_t s, double* neg_out, int* nonfinite, const int* gate,
+                               const PointPerm& perm) {
   const int grid = vec_grid(end - begin);
   *nparts = grid;
   if (end > begin) hipLaunchKernelGGL(cgnr_model_cost_kernel, dim3(grid), dim3(kVecBlock), 0, s, y, g, r, D, begin, end, partials,
-                                      nonfinite ? neg_out : nullptr, nonfinite, gate);
+                                      nonfinite ? neg_out : nullptr, nonfinite, gate, perm);
+  return hipGetLastError();
+}
+// out (caller's point order) <- in (internal order), or the other way round, over the 3-wide point blocks [0, n_e); [n_e, n) is copied
+__global__ __launch_bounds__(kVecBlock) void permute_points_kernel(const double* in, double* out, const int32_t* pt_pos, int64_t n_e, int64_t n, int to_internal) {
+  for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) {
+    const int64_t o = i < n_e ? pt_pos[i / 3] + int(i % 3) : i;
+    if (to_internal) out[i] = in[o];
+    else out[o] = in[i];
+  }
+}
+hipError_t LaunchPermutePoints(const double* in, double* out, const int32_t* pt_pos, int64_t n_e, int64_t n, bool to_internal, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(permute_points_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, in, out, pt_pos, n_e, n, to_internal ? 1 : 0);
   return hipGetLastError();
 }
 hipError_t LaunchLmDiagonal(double* diag, double lo, double hi, double radius, double* D, int64_t n, hipStream_t s) {

@@ -129,7 +129,7 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
   return "";
 }
 
-void BuildBalPlan(const HostStructure& h, bool reorder_points, BalPlan* plan) {
+void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest& hyb, BalPlan* plan) {
   BalPlan& P = *plan;
   P = BalPlan();
   auto no = [&](const char* why) { P.eligible = false; P.why_not = why; };
@@ -216,38 +216,140 @@ void BuildBalPlan(const HostStructure& h, bool reorder_points, BalPlan* plan) {
   std::vector<int32_t> row_start(P.n_points + 1, 0);
   for (int p = 0; p < P.n_points; ++p) row_start[p + 1] = row_start[p] + track[p];
 
+  // the caller's column layout: points-then-cameras, back to back?
+  P.caller_contiguous = true;
+  for (int p = 0; p < P.n_points && P.caller_contiguous; ++p) P.caller_contiguous = h.cpos[P.pt_block[p]] == 3 * p;
+  for (int c = 0; c < P.n_cameras && P.caller_contiguous; ++c) P.caller_contiguous = h.cpos[P.cam_block[c]] - h.num_cols_e == 9 * c;
+  const bool reorder_points = reorder_mode == kReorderAlways || (reorder_mode == kReorderIfContiguous && P.caller_contiguous);
+  P.renumbered = reorder_points;
+
+  // Cameras whose 9-double accumulators do not fit in LDS (decided here: the point order below depends on it).
+  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 512;
+  int64_t chunk_mib = 0;  // CERES_HIP_Z_CHUNK_MIB=<n>: bound the F^T z ring to n MiB (memory-constrained runs)
+  if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
+  if (!P.cameras_in_lds && P.n_cameras >= (1 << kSlotCamBits)) return no("more cameras than the slot word holds");
+
+  // HYBRID camera accumulation (more cameras than LDS holds; needs the freedom to renumber the points).  The tile pass runs
+  // hyb.groups workgroups, each with hyb.rows accumulator rows (9 doubles) in LDS:
+  //   rows [0, K_h)        the K_h most popular cameras — the same in every workgroup;
+  //   rows [K_h, K_h+K_w)  the workgroup's WINDOW: K_w cameras that no other workgroup holds.
+  // Every point is handed to a workgroup whose window holds one of its (cold) cameras, so of a point's k observations the hot ones
+  // and at least one cold one are summed in LDS; the others are SPILLED (a 72-byte row F_o^T z_o into a ring, summed by the
+  // camera-major second pass, which also collects the rows every workgroup flushes at its end).  A spill-everything pass moves
+  // 72 + ~200 bytes per observation on top of the 204 it reads (the second pass fetches whole lines around its 72-byte rows); with
+  // three observations per point and 50 000 cameras 58 % of the observations stay in LDS.  Windows are built from runs of
+  // kHybBlock consecutive camera ids (cameras of neighbouring ids see the same points in real scenes) dealt to the least loaded
+  // window, heaviest run first; a point goes to the least loaded of its candidate workgroups, or — above a load cap — to the
+  // least loaded workgroup overall (all its cold observations then spill: balance before locality).
+  bool hybrid = reorder_points && !P.cameras_in_lds && hyb.groups >= 2 && hyb.rows >= 64 && chunk_mib <= 0 && hyb.rows < kSlotSpill;
+  if (const char* e = getenv("CERES_HIP_HYBRID")) hybrid = hybrid && atoi(e) != 0;
+  std::vector<int32_t> cam_row;                 // camera -> accumulator row (hot: < K_h; windowed: >= K_h)
+  std::vector<int32_t> cam_group;               // camera -> the workgroup whose window holds it (-1: hot, or in no window)
+  std::vector<std::vector<int32_t>> grp_points; // caller-order points of each group
+  int K_h = 0, K_w = 0;
+  if (hybrid) {
+    const int G = hyb.groups, K = hyb.rows;
+    K_w = std::min(K, std::max(1, (P.n_cameras - K + (G - 2)) / (G - 1)));   // (G - 1) K_w >= n_c - K  <=>  G K_w >= n_c - K_h
+    K_h = K - K_w;
+    std::vector<int64_t> deg(P.n_cameras, 0);
+    for (int i = 0; i < n_conf; ++i) ++deg[row_cam[i]];
+    cam_row.assign(P.n_cameras, -1);
+    cam_group.assign(P.n_cameras, -1);
+    {
+      std::vector<int32_t> by_deg(P.n_cameras);
+      std::iota(by_deg.begin(), by_deg.end(), 0);
+      std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+      for (int r = 0; r < K_h; ++r) cam_row[by_deg[r]] = r;
+    }
+    // cold cameras in id order, cut into runs of kHybBlock; runs sorted by weight, each to the least loaded window with room
+    constexpr int kHybBlock = 8;
+    std::vector<int32_t> cold;
+    for (int c = 0; c < P.n_cameras; ++c) if (cam_row[c] < 0) cold.push_back(c);
+    const int n_runs = (int(cold.size()) + kHybBlock - 1) / kHybBlock;
+    std::vector<int64_t> run_w(n_runs, 0);
+    for (size_t i = 0; i < cold.size(); ++i) run_w[i / kHybBlock] += deg[cold[i]];
+    std::vector<int32_t> run_order(n_runs);
+    std::iota(run_order.begin(), run_order.end(), 0);
+    std::stable_sort(run_order.begin(), run_order.end(), [&](int a, int b) { return run_w[a] > run_w[b]; });
+    std::vector<int64_t> win_w(G, 0);
+    std::vector<int32_t> win_n(G, 0);
+    for (int r : run_order) {
+      const int lo = r * kHybBlock, hi = std::min<int>(int(cold.size()), lo + kHybBlock);
+      int best = -1;
+      for (int g = 0; g < G; ++g)
+        if (win_n[g] + (hi - lo) <= K_w && (best < 0 || win_w[g] < win_w[best])) best = g;
+      if (best < 0) continue;   // more cameras than G windows hold: this run always spills
+      for (int i = lo; i < hi; ++i) { cam_group[cold[i]] = best; cam_row[cold[i]] = K_h + win_n[best]++; }
+      win_w[best] += run_w[r];
+    }
+    // points -> groups
+    grp_points.assign(G, {});
+    std::vector<int64_t> load(G, 0);
+    const int64_t cap = (int64_t(n_conf) * 103 / 100 + G - 1) / G + kTile;
+    int least = 0, since_scan = 0;
+    for (int p = 0; p < P.n_points; ++p) {
+      if ((since_scan++ & 1023) == 0) least = int(std::min_element(load.begin(), load.end()) - load.begin());
+      int best = -1;
+      for (int q = row_start[p]; q < row_start[p + 1]; ++q) {
+        const int g = cam_group[row_cam[order[q]]];
+        if (g >= 0 && (best < 0 || load[g] < load[best])) best = g;
+      }
+      if (best < 0 || load[best] >= cap) {
+        if (load[least] >= cap) least = int(std::min_element(load.begin(), load.end()) - load.begin());
+        best = least;
+      }
+      grp_points[best].push_back(p);
+      load[best] += track[p];
+    }
+  }
+
   // INTERNAL point order.  A tile holds whole points, so the greedy packing in the caller's order wastes the slots behind the last
   // point that fits: about half a track per tile, 5 % of the slots on the Venice shape — 5 % of the bytes of EVERY pass over the
-  // tiles.  With reorder_points (the Schur solvers: no CG vector lives in point space, the kernels reach point-indexed data of the
-  // caller — D, the step — through pt_pos) the points are renumbered: when the next point does not fit, the largest point among
-  // the next kReorderWindow ones that does fit is pulled forward (best fit in a window: the gathers from the caller's layout stay
-  // local).  seq[i] = caller-order point of internal point i.
+  // tiles.  With reorder_points (no CG vector walks the caller's point order in tile order: the Schur solvers, and CGNR on internal
+  // vectors; the kernels reach point-indexed data of the caller — D, the step — through pt_pos) the points are renumbered: when the
+  // next point does not fit, the largest point among the next kReorderWindow ones that does fit is pulled forward (best fit in a
+  // window: the gathers from the caller's layout stay local).  seq[i] = caller-order point of internal point i.  Hybrid: group by
+  // group, every group starting a tile of its own (grp_pt_ptr = first internal point of each group).
   constexpr int kReorderWindow = 96;
-  std::vector<int32_t> seq(P.n_points);
-  if (!reorder_points) {
-    std::iota(seq.begin(), seq.end(), 0);
-  } else {
-    std::vector<uint8_t> taken(P.n_points, 0);
+  std::vector<int32_t> seq;
+  seq.reserve(P.n_points);
+  std::vector<int32_t> grp_pt_ptr;
+  auto pack_order = [&](const int32_t* pts, int n) {   // appends pts[0 .. n) in packing order; starts on a fresh tile
+    std::vector<uint8_t> taken(n, 0);
     int next = 0, placed = 0, used = kTile, npts = 0;
-    while (placed < P.n_points) {
+    auto put = [&](int i) { taken[i] = 1; seq.push_back(pts[i]); ++placed; };
+    while (placed < n) {
       while (taken[next]) ++next;
-      const int k = track[next];
-      auto put = [&](int p) { taken[p] = 1; seq[placed++] = p; };
+      const int k = track[pts[next]];
       if (k > kTile) { put(next); used = kTile; npts = 0; continue; }   // a long point owns its tiles
       if (used + k <= kTile && npts < kMaxPointsPerTile) { put(next); used += k; ++npts; continue; }
       int best = -1;
       const int room = kTile - used;
       if (room > 0 && npts < kMaxPointsPerTile) {
         int seen = 0;
-        for (int q = next + 1; q < P.n_points && seen < kReorderWindow; ++q) {
+        for (int q = next + 1; q < n && seen < kReorderWindow; ++q) {
           if (taken[q]) continue;
           ++seen;
-          if (track[q] <= room && (best < 0 || track[q] > track[best])) { best = q; if (track[q] == room) break; }
+          const int kq = track[pts[q]];
+          if (kq <= room && (best < 0 || kq > track[pts[best]])) { best = q; if (kq == room) break; }
         }
       }
-      if (best >= 0) { put(best); used += track[best]; ++npts; continue; }
+      if (best >= 0) { put(best); used += track[pts[best]]; ++npts; continue; }
       put(next); used = k; npts = 1;   // new tile
     }
+  };
+  if (!reorder_points) {
+    seq.resize(P.n_points);
+    std::iota(seq.begin(), seq.end(), 0);
+  } else if (hybrid) {
+    for (const auto& g : grp_points) { grp_pt_ptr.push_back(int32_t(seq.size())); pack_order(g.data(), int(g.size())); }
+    grp_pt_ptr.push_back(int32_t(seq.size()));
+  } else {
+    std::vector<int32_t> all(P.n_points);
+    std::iota(all.begin(), all.end(), 0);
+    pack_order(all.data(), P.n_points);
+  }
+  if (reorder_points) {
     std::vector<int32_t> blk(P.n_points), trk(P.n_points);
     for (int i = 0; i < P.n_points; ++i) { blk[i] = P.pt_block[seq[i]]; trk[i] = track[seq[i]]; }
     P.pt_block.swap(blk);
@@ -283,7 +385,10 @@ void BuildBalPlan(const HostStructure& h, bool reorder_points, BalPlan* plan) {
   int64_t tile = -1;
   int used = kTile;  // slots used in the current tile (kTile forces a new one)
   int npts_in_tile = 0;
+  size_t next_group = 0;
   for (int p = 0; p < P.n_points; ++p) {
+    // hybrid: a group's tiles are its own (empty groups own none)
+    while (next_group < grp_pt_ptr.size() && grp_pt_ptr[next_group] == p) { P.grp_tile_ptr.push_back(int32_t(P.tile_kind.size())); used = kTile; ++next_group; }
     const int k = track[p];
     int idx = row_start[seq[p]];   // the point's rows, in the caller's order
     if (k > kTile) {
@@ -318,6 +423,7 @@ void BuildBalPlan(const HostStructure& h, bool reorder_points, BalPlan* plan) {
     used += k;
   }
   P.n_tiles = int64_t(P.tile_kind.size());
+  while (next_group < grp_pt_ptr.size()) { P.grp_tile_ptr.push_back(int32_t(P.n_tiles)); ++next_group; }  // trailing empty groups + the end
   P.tile_pt0.resize(P.n_tiles);
   for (int64_t t = 0; t < P.n_tiles; ++t) P.tile_pt0[t] = P.slot_pt[t * kTile];
   // Normal tiles: tile_aux = longest track in the tile (bounds the segmented-scan steps).
@@ -383,47 +489,92 @@ void BuildBalPlan(const HostStructure& h, bool reorder_points, BalPlan* plan) {
   }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
 
-  // Chunked camera-major pass for camera counts beyond the LDS accumulators.
-  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 512;
+  // The word the kernels read per slot: camera id | accumulator row << kSlotCamBits (kSlotSpill: no LDS row, the slot's F^T z is
+  // spilled).  With the accumulators of ALL cameras in LDS the row is the camera id itself and the upper bits stay 0.
+  P.slot_word.assign(P.slot_cam.begin(), P.slot_cam.end());
   if (!P.cameras_in_lds) {
-    // Default: ONE chunk (the whole problem).  Chunks sized for the Infinity Cache (64-128 MiB of per-slot output) were
-    // measured and do not pay on this kernel pair (profiles/r02g_chunk_sweep_synthetic1M.txt: the tile pass is not limited by
-    // the HBM write-back of the ring, and the camera-major pass is latency-bound on its gathers either way), although a
-    // streaming write -> read-back hand-off of that size does stay in the cache (profiles/r02_infinity_cache_handoff_probe.txt).
-    // CERES_HIP_Z_CHUNK_MIB=<n> bounds the ring to n MiB (memory-constrained runs; the chunked path is covered by tests).
-    int64_t chunk_mib = 0;
-    if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
+    // Camera-major second pass.  The tile pass leaves the spilled rows of a tile back to back in a ring (tile_zbase = the tile's
+    // first row; a slot's row = tile_zbase + its rank among the tile's spilled slots), the hybrid workgroups append their accumulator
+    // rows behind them (z_flush_row0 + group * hyb_rows + row), and every camera has the list of ring rows that are its own, cut into
+    // units of <= kZUnit entries.  Default: ONE chunk (the whole problem).  Chunks sized for the Infinity Cache (64-128 MiB of ring)
+    // were measured and do not pay on this kernel pair (profiles/r02g_chunk_sweep_synthetic1M.txt), although a streaming write ->
+    // read-back hand-off of that size does stay in the cache (profiles/r02_infinity_cache_handoff_probe.txt); CERES_HIP_Z_CHUNK_MIB
+    // bounds the ring (no hybrid then: a chunk is a launch of its own; the chunked path is covered by tests).
+    const int G = hybrid ? hyb.groups : 0, K = hybrid ? hyb.rows : 0;
+    P.hybrid = hybrid;
+    P.hyb_groups = G; P.hyb_rows = K; P.hyb_hot = K_h;
+    std::vector<int32_t> tile_group(P.n_tiles, 0);
+    if (hybrid)
+      for (int g = 0; g < G; ++g)
+        for (int t = P.grp_tile_ptr[g]; t < P.grp_tile_ptr[g + 1]; ++t) tile_group[t] = g;
+    int64_t n_local = 0;
+    for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
+      const int c = P.slot_cam[s];
+      if (c < 0) continue;
+      int row = kSlotSpill;
+      if (hybrid && cam_row[c] >= 0 && (cam_group[c] < 0 || cam_group[c] == tile_group[s / kTile])) { row = cam_row[c]; ++n_local; }
+      P.slot_word[s] = int32_t(uint32_t(c) | (uint32_t(row) << kSlotCamBits));
+    }
+    P.n_local_obs = n_local;
     const int64_t want_tiles = chunk_mib > 0 ? std::max<int64_t>(1, chunk_mib * (int64_t(1) << 20) / (int64_t(kTile) * 72)) : P.n_tiles;
     P.zc_tile_ptr.assign(1, 0);
     for (int64_t t = 0; t < P.n_tiles;) {
       int64_t e = std::min<int64_t>(P.n_tiles, t + want_tiles);
       while (e < P.n_tiles && P.tile_kind[e] == 2) ++e;  // keep a long point's tiles together
       P.zc_tile_ptr.push_back(int32_t(e));
-      P.z_ring_slots = std::max<int64_t>(P.z_ring_slots, (e - t) * kTile);
       t = e;
     }
     const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
-    P.zc_slot.resize(P.n_obs);
+    P.tile_zbase.assign(P.n_tiles, 0);
+    std::vector<int32_t> slot_zrow(size_t(P.n_tiles) * kTile, -1);
     P.zc_unit_ptr.assign(1, 0);
     std::vector<int32_t> count(P.n_cameras + 1), cur(P.n_cameras);
     int64_t base = 0;  // entries emitted so far
     for (int k = 0; k < n_chunks; ++k) {
-      const int64_t s0 = int64_t(P.zc_tile_ptr[k]) * kTile, s1 = int64_t(P.zc_tile_ptr[k + 1]) * kTile;
+      const int64_t t0 = P.zc_tile_ptr[k], t1 = P.zc_tile_ptr[k + 1];
+      int64_t row = 0;
       std::fill(count.begin(), count.end(), 0);
-      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) ++count[P.slot_cam[s] + 1];
+      for (int64_t t = t0; t < t1; ++t) {
+        P.tile_zbase[t] = int32_t(row);
+        for (int l = 0; l < kTile; ++l) {
+          const int64_t s = t * kTile + l;
+          if (P.slot_cam[s] < 0 || (uint32_t(P.slot_word[s]) >> kSlotCamBits) != uint32_t(kSlotSpill)) continue;
+          slot_zrow[s] = int32_t(row++);
+          ++count[P.slot_cam[s] + 1];
+        }
+      }
+      const int64_t flush_row0 = row;
+      if (hybrid) {
+        P.z_flush_row0 = flush_row0;
+        row += int64_t(G) * K;
+        for (int c = 0; c < P.n_cameras; ++c)
+          if (cam_row[c] >= 0) count[c + 1] += cam_group[c] < 0 ? G : 1;   // hot: a row in every workgroup; windowed: in one
+      }
+      if (row >= (int64_t(1) << 31)) return no("F^T z ring beyond 2^31 rows");
+      P.z_ring_rows = std::max<int64_t>(P.z_ring_rows, row);
+      if (base + count[P.n_cameras] >= (int64_t(1) << 31)) return no("more than 2^31 ring entries");
+      std::vector<int32_t> start(P.n_cameras + 1, 0);
       for (int c = 0; c < P.n_cameras; ++c) {
         const int n = count[c + 1];
-        count[c + 1] += count[c];
-        cur[c] = count[c];
+        start[c + 1] = start[c] + n;
+        cur[c] = start[c];
         for (int b = 0; b < n; b += kZUnit) {
           P.zu_cam.push_back(c);
-          P.zu_begin.push_back(int32_t(base + count[c] + b));
-          P.zu_end.push_back(int32_t(base + count[c] + std::min(n, b + kZUnit)));
+          P.zu_begin.push_back(int32_t(base + start[c] + b));
+          P.zu_end.push_back(int32_t(base + start[c] + std::min(n, b + kZUnit)));
           P.zu_shared.push_back(n > kZUnit ? 1 : 0);
         }
       }
-      for (int64_t s = s0; s < s1; ++s) if (P.slot_cam[s] >= 0) P.zc_slot[base + cur[P.slot_cam[s]]++] = int32_t(s - s0);
-      base += count[P.n_cameras];
+      P.zc_slot.resize(size_t(base + start[P.n_cameras]));
+      for (int64_t s = t0 * kTile; s < t1 * kTile; ++s)
+        if (slot_zrow[s] >= 0) P.zc_slot[base + cur[P.slot_cam[s]]++] = slot_zrow[s];
+      if (hybrid)
+        for (int c = 0; c < P.n_cameras; ++c) {
+          if (cam_row[c] < 0) continue;
+          if (cam_group[c] >= 0) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(cam_group[c]) * K + cam_row[c]);
+          else for (int g = 0; g < G; ++g) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(g) * K + cam_row[c]);
+        }
+      base += start[P.n_cameras];
       P.zc_unit_ptr.push_back(int32_t(P.zu_cam.size()));
     }
   }

@@ -61,6 +61,7 @@ struct ceres_hip_solver {
   uint32_t* d_slot_seg = nullptr;
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
+  int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
@@ -113,6 +114,14 @@ struct ceres_hip_solver {
   int bal_flags = 0;
   bool lds_mode = false;
   int fused_grid = 0;
+  // CGNR on INTERNALLY numbered points (the plan renumbered them: fuller tiles, hybrid groups; only where the caller's columns are
+  // points-then-cameras back to back, so that block sizes, offsets and the block-diagonal store read the same under the renumbering):
+  // the CG vectors, J^T f and the JACOBI point blocks of a solve hold internal point p at [3 p, 3 p + 3); the caller's D is read, and the
+  // solution written, through pt_pos.  Operator-level entry points keep the caller's order (BalArgs::pt_pos).
+  bool cgnr_internal = false;
+  double* D_int = nullptr;        // D's point part in the internal order (written by the set-up kernel, or gathered)
+  bool D_int_valid = false;
+  bool precond_internal = false;  // s->precond holds the point blocks of a solve (internal order): operator-level readers rebuild it
 
   // per-solve inputs: either owned copies (host entry points) or caller's device memory
   double *own_values = nullptr, *own_b = nullptr, *own_D = nullptr, *own_x = nullptr;
@@ -249,6 +258,8 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
+  A.tile_zbase = s->d_tile_zbase; A.grp_tile_ptr = s->d_grp_tile_ptr;
+  A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -300,6 +311,32 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
   f.diag_f = s->lm_diag + s->hs.num_cols_e;
   f.D_f = s->lm_D + s->hs.num_cols_e;
   return f;
+}
+
+// CGNR on internally numbered points: turn the caller's view of the point space (bal_args) into the solve's
+void use_internal_points(const ceres_hip_solver* s, BalArgs& A) {
+  if (!s->cgnr_internal) return;
+  A.d_pos = A.pt_pos;   // D and the LM diagonal stay the caller's
+  A.pt_pos = nullptr;
+  A.pt_diag_off = nullptr;
+}
+PointPerm point_perm(const ceres_hip_solver* s) {
+  PointPerm p;
+  if (s->cgnr_internal) { p.pt_pos = s->d_pt_pos; p.D_e = s->D_int; p.n_e = s->hs.num_cols_e; }
+  return p;
+}
+int ensure_D_int(ceres_hip_solver* s) {
+  if (!s->cgnr_internal || !s->D || s->D_int_valid) return 0;
+  HIP_TRY(s, LaunchPermutePoints(s->D, s->D_int, s->d_pt_pos, s->hs.num_cols_e, s->hs.num_cols_e, true, s->stream));
+  s->D_int_valid = true;
+  return 0;
+}
+// the solution of a CGNR solve (CG's order) -> the caller's
+int copy_out_cgnr_solution(ceres_hip_solver* s, double* x) {
+  const HostStructure& h = s->hs;
+  if (s->cgnr_internal) HIP_TRY(s, LaunchPermutePoints(s->cg.x, x, s->d_pt_pos, h.num_cols_e, h.num_cols, false, s->stream));
+  else HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, s->stream));
+  return 0;
 }
 
 // ---- remainder rows (no point cell) next to the tiles: every contribution is a sum over those rows, added by generic kernels ----
@@ -363,8 +400,9 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
     HIP_TRY(s, LaunchBalFused(mode, A, true, s->fused_grid, s->stream));
   } else {
-    // cameras do not fit in LDS: chunk by chunk, the tile pass leaves F^T z per slot in a ring that is still in the Infinity
-    // Cache when the chunk's camera-major pass adds it into the camera sums
+    // cameras do not fit in LDS: the tile pass sums what it can in LDS (hybrid plan) and leaves the other slots' F^T z, and at its
+    // end its accumulator rows, in a ring; the camera-major pass adds the ring rows into the camera sums.  (Chunk by chunk when the
+    // ring is bounded, CERES_HIP_Z_CHUNK_MIB.)
     const BalPlan& P = s->plan;
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->chunk_grid; }
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
@@ -372,7 +410,6 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     for (int k = 0; k < n_chunks; ++k) {
       A.tile_begin = P.zc_tile_ptr[k];
       A.tile_end = P.zc_tile_ptr[k + 1];
-      A.z_slot0 = int64_t(P.zc_tile_ptr[k]) * kTile;
       A.pq_accumulate = k > 0 ? 1 : 0;
       HIP_TRY(s, LaunchBalFused(mode, A, false, s->chunk_grid, s->stream));
       ZUnits U = s->zunits;
@@ -441,8 +478,9 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status, do
 }
 
 // y = (A^T A + D^2) x on full-space vectors.  CgnrLinearOperator (y zeroed by CG first).
+// internal: x and y are a solve's CG vectors (internally numbered points where the plan renumbered them, D_int must be valid)
 int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status, double* pq = nullptr, int* n_pq = nullptr,
-            const double** pq_extra = nullptr) {
+            const double** pq_extra = nullptr, bool internal = false) {
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   if (n_pq) *n_pq = 0;
@@ -451,6 +489,7 @@ int op_jtjx(ceres_hip_solver* s, const double* x, double* y, const int* status, 
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
     A.x_e = x; A.x_f = x + h.num_cols_e; A.y_e = y; A.D_e = s->D;
+    if (internal && s->cgnr_internal) { use_internal_points(s, A); A.d_pos = nullptr; if (s->D) A.D_e = s->D_int; }
     return bal_scatter(s, kBalJtJx, A, x + h.num_cols_e, y + h.num_cols_e, true, status, pq, n_pq, pq_extra);
   }
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
@@ -615,8 +654,9 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     }
     return 0;
   }
-  // CGNR JACOBI
+  // CGNR JACOBI (the caller's block order)
   const int64_t len = h.diag_off_all.back();
+  if (out == s->precond) s->precond_internal = false;
   if (s->path == CERES_HIP_PATH_BAL && s->world <= 1 && invert) {
     TRY(ensure_packed(s));
     BalArgs A = bal_args(s);
@@ -662,6 +702,12 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   A.y_e = rhs;
   A.point_blocks = jacobi ? blocks : nullptr;
   A.pt_diag_off = s->d_pt_diag_off;
+  if (s->cgnr_internal) {  // rhs and the point blocks in CG's order; D read at the caller's offsets and left in CG's order on the way
+    use_internal_points(s, A);
+    A.D_int_out = s->D_int;
+    s->D_int_valid = jacobi && (s->D != nullptr || s->lm_fuse_active);
+    if (jacobi && blocks == s->precond) s->precond_internal = true;
+  }
   // sharded with JACOBI: the camera part of J^T f is left raw behind the camera blocks and rides in their all-reduce
   const bool merge = s->world > 1 && jacobi && s->merge_step_reduce && s->merged_layout && blocks == s->precond && s->cgnr_rhs_tail;
   {
@@ -1046,6 +1092,7 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->ftf_inv_valid = false;
   s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
   s->rem_blocks_valid = false;
+  s->D_int_valid = false;
   s->loaded = true;
   return 0;
 }
@@ -1313,9 +1360,11 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   HIP_TRY(s, hipEventRecord(s->ev[3], st));
   if (s->path == CERES_HIP_PATH_BAL) {
     s->merge_step_reduce = s->world > 1;
+    s->D_int_valid = false;
     const int rc_setup = op_cgnr_setup_bal(s, pre == CERES_HIP_JACOBI, s->cg_rhs, s->precond);
     s->merge_step_reduce = false;
     TRY(rc_setup);
+    TRY(ensure_D_int(s));  // (IDENTITY: the set-up kernel forms no point blocks and leaves D where it is)
   } else {
     if (pre == CERES_HIP_JACOBI) TRY(op_preconditioner(s, pre, s->precond, true));
     TRY(op_jtb(s, s->cg_rhs));
@@ -1338,10 +1387,10 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   spec.n = h.num_cols;
   spec.n_local = h.num_cols_e;  // sharded: first nelim column blocks are this rank's points
   const int* status = &s->cg.S->status;
-  spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status); };
+  spec.apply = [s, status](const double* in, double* out) { return op_jtjx(s, in, out, status, nullptr, nullptr, nullptr, true); };
   if (s->path == CERES_HIP_PATH_BAL) {
     spec.apply_dot = [s, status](const double* in, double* out, double* pq, int* n_pq, const double** extra) {
-      return op_jtjx(s, in, out, status, pq, n_pq, extra);
+      return op_jtjx(s, in, out, status, pq, n_pq, extra, true);
     };
     // sharded: the fused iteration needs the shard to be exactly the blocks in front of the 9-wide camera blocks (it is, on this
     // path: points then cameras) so that cg_update's two workgroup ranges are the shard and the replicated part
@@ -1361,7 +1410,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       if (!s->nonfinite_clean) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, sizeof(int), s->stream));
       s->nonfinite_clean = false;
       HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, hh.num_cols, s->scalar_partials, &s->spec_cgnr_parts, s->stream,
-                                     x, s->d_nonfinite, &s->cg.S->status));
+                                     x, s->d_nonfinite, &s->cg.S->status, point_perm(s)));
       HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, s->stream));
       s->spec_tail_done = true;
       return 0;
@@ -1371,7 +1420,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   HIP_TRY(s, hipEventRecord(s->ev[5], st));
   // LM step: the model-cost kernel reads the solution anyway and writes the negated step (no copy-out, no separate negation pass)
   if (s->lm_negate_in_solve) s->lm_cgnr_copy_pending = true;
-  else HIP_TRY(s, hipMemcpyAsync(x, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));
+  else TRY(copy_out_cgnr_solution(s, x));
   HIP_TRY(s, hipEventRecord(s->ev[6], st));
   return 0;
 }
@@ -1509,11 +1558,20 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   while (s->nine_wide_from > 0 && h.csz[s->nine_wide_from - 1] == 9) --s->nine_wide_from;
   // Schur solvers: no CG vector lives in point space, so the points may be renumbered to fill the tiles (plan.cc); CGNR walks x, r, p,
   // q in tile order and keeps the caller's numbering.  CERES_HIP_REORDER_POINTS=0 switches the renumbering off (A/B measurements).
-  { const char* e = getenv("CERES_HIP_REORDER_POINTS"); BuildBalPlan(h, is_schur(s) && !(e && atoi(e) == 0), &s->plan); }
+  {
+    const char* e = getenv("CERES_HIP_REORDER_POINTS");
+    // more cameras than LDS rows: one workgroup per CU, each with the accumulator rows that fit next to its eight waves' spill strips
+    HybridRequest hyb;
+    hyb.groups = s->num_cus;
+    hyb.rows = int((kMaxLdsBytes - 512 - size_t(512 / kTile) * kTile * 9 * sizeof(double)) / (9 * sizeof(double))) / kTile * kTile;
+    // Schur solvers: no CG vector lives in point space; CGNR: only where its CG vectors can be the caller's with the points renumbered
+    BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
+  }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !is_dense_schur(s)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
-  if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !(is_schur(s) ? s->plan.cameras_contiguous : s->plan.contiguous_layout))
+  s->cgnr_internal = !is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->plan.renumbered;
+  if (s->world > 1 && s->path == CERES_HIP_PATH_BAL && !(is_schur(s) ? s->plan.cameras_contiguous : s->plan.caller_contiguous))
     return fail(s, CERES_HIP_E_UNSUPPORTED, "sharded <2,3,9> runs need points-then-cameras column order");
 
   // explicit S: block-sparse (BlockRandomAccessSparseMatrix) on one rank; dense for DENSE_SCHUR and for sharded runs (one all-reduce of S)
@@ -1600,7 +1658,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_slot_epos, P.slot_epos));
     TRY(dev_upload(s, &s->d_slot_fpos, P.slot_fpos));
     TRY(dev_upload(s, &s->d_slot_bpos, P.slot_bpos));
-    TRY(dev_upload(s, &s->d_slot_cam, P.slot_cam));
+    TRY(dev_upload(s, &s->d_slot_cam, P.slot_word));  // camera | accumulator row << kSlotCamBits
     TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
     TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));
@@ -1644,19 +1702,23 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = std::min(s->fused_grid, kMaxPqParts - kMaxVecGrid);  // one p.q partial per workgroup must fit cg_pq_parts (bal_scatter)
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
-    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_slots) * 9));  // ring of ONE chunk's per-slot F^T z
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_rows) * 9));  // ring of ONE chunk's F^T z rows
     if (!s->lds_mode) {
+      TRY(dev_upload(s, &s->d_tile_zbase, P.tile_zbase));
+      if (P.hybrid) TRY(dev_upload(s, &s->d_grp_tile_ptr, P.grp_tile_ptr));
       int32_t *uc = nullptr, *ub = nullptr, *ue = nullptr, *us = nullptr, *zs = nullptr;
       TRY(dev_upload(s, &uc, P.zu_cam)); TRY(dev_upload(s, &ub, P.zu_begin)); TRY(dev_upload(s, &ue, P.zu_end));
       TRY(dev_upload(s, &us, P.zu_shared)); TRY(dev_upload(s, &zs, P.zc_slot));
       s->zunits.cam = uc; s->zunits.begin = ub; s->zunits.end = ue; s->zunits.shared = us; s->zunits.slot = zs;
       // a chunk's tile pass: every wave should see a few tiles (the pipelined kernel has a prologue), at most 4 workgroups per CU
-      const int64_t chunk_tiles = P.z_ring_slots / kTile;
+      int64_t chunk_tiles = 0;
+      for (size_t k = 0; k + 1 < P.zc_tile_ptr.size(); ++k) chunk_tiles = std::max<int64_t>(chunk_tiles, P.zc_tile_ptr[k + 1] - P.zc_tile_ptr[k]);
       // (the pipelined kernel keeps 8 waves per CU resident: one workgroup per CU, no second round with a ragged tail)
-      s->chunk_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
+      s->chunk_grid = P.hybrid ? P.hyb_groups : int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
     }
     TRY(dev_alloc(s, &s->d_camsq, n9));
-    if (s->world > 1 && (is_schur(s) ? P.cameras_contiguous : P.contiguous_layout) && int64_t(n9) == int64_t(h.num_cols_f)) {
+    if (s->cgnr_internal) TRY(dev_alloc(s, &s->D_int, size_t(h.num_cols_e)));
+    if (s->world > 1 && (is_schur(s) ? P.cameras_contiguous : P.caller_contiguous) && int64_t(n9) == int64_t(h.num_cols_f)) {
       // one all-reduce per step for the camera-space sums: rhs and the column norms live right behind the preconditioner blocks
       s->merged_layout = true;
       if (is_schur(s)) {
@@ -2024,7 +2086,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   res->step_is_finite = 0;
   const int term = res->linear_solver.termination_type;
   if (term == CERES_HIP_FAILURE || term == CERES_HIP_FATAL_ERROR) {
-    if (cgnr_deferred) HIP_TRY(s, hipMemcpyAsync(dx, s->cg.x, sizeof(double) * h.num_cols, hipMemcpyDeviceToDevice, st));  // what Solve leaves in x
+    if (cgnr_deferred) TRY(copy_out_cgnr_solution(s, dx));  // what Solve leaves in x
     return 0;
   }
   // Finite check + negation and the model cost change are enqueued together and read back with ONE
@@ -2043,15 +2105,15 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     // CGNR: no pass over J is needed.  With y the CG solution (step = -y), g = J^T f and r = g - (J^T J + D^2) y
     // the residual CG carries:  -(J step)'(f + J step / 2) = y.g - |J y|^2 / 2 = (y.g + y.r + |D y|^2) / 2.
     if (s->world > 1) {  // the point part is sharded, the camera part replicated
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols_e, s->scalar_partials, &n_local, st, neg, s->d_nonfinite));
-      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, h.num_cols_e, h.num_cols, s->scalar_partials + kMaxVecGrid, &n_shared, st, neg, s->d_nonfinite));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols_e, s->scalar_partials, &n_local, st, neg, s->d_nonfinite, nullptr, point_perm(s)));
+      HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, h.num_cols_e, h.num_cols, s->scalar_partials + kMaxVecGrid, &n_shared, st, neg, s->d_nonfinite, nullptr, point_perm(s)));
       if (h.num_cols_e <= 0) n_local = 0;
       if (h.num_cols <= h.num_cols_e) n_shared = 0;
       parts_local = s->scalar_partials;
       parts_shared = s->scalar_partials + kMaxVecGrid;
     } else {
       if (spec_done) n_shared = s->spec_cgnr_parts;  // the gated kernel in front of the last poll already did all of it
-      else HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st, neg, s->d_nonfinite));
+      else HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, h.num_cols, s->scalar_partials, &n_shared, st, neg, s->d_nonfinite, nullptr, point_perm(s)));
       if (h.num_cols <= 0) n_shared = 0;
       parts_shared = s->scalar_partials;
     }
@@ -2377,6 +2439,7 @@ int ceres_hip_get_preconditioner_blocks(ceres_hip_solver* s, int32_t not_inverte
   if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
   if (!not_inverted) {
     if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
+    if (s->precond_internal) TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));  // a CGNR solve left its point blocks in CG's order
     return down(s, blocks, s->precond, size_t(len));
   }
   // re-assemble without inverting, into a temporary
@@ -2395,6 +2458,7 @@ int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y) 
   TRY(require_loaded(s));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
+  if (s->precond_internal) TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));  // a CGNR solve left its point blocks in CG's order
   const HostStructure& h = s->hs;
   const int n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(up(s, s->cg.p, x, n));
@@ -2500,7 +2564,8 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
   switch (op) {
     case CERES_HIP_TIMED_JTJX:
       if (is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "jtjx needs a CGNR instance");
-      body = [&] { return op_jtjx(s, s->cg.p, s->cg.z, nullptr); };
+      TRY(ensure_D_int(s));
+      body = [&] { return op_jtjx(s, s->cg.p, s->cg.z, nullptr, nullptr, nullptr, nullptr, true); };  // as CG applies it
       break;
     case CERES_HIP_TIMED_SX:
       if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "Sx needs an ITERATIVE_SCHUR instance");
@@ -2572,7 +2637,7 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
   if (!e.empty()) { if (why_not) snprintf(why_not, why_capacity, "%s", e.c_str()); *eligible = 0; return CERES_HIP_E_INVALID; }
   BalPlan P;
   // CERES_HIP_DEBUG_PLAN_REORDER=1: the plan a Schur solver builds (points renumbered so that the tiles fill up)
-  { const char* e = getenv("CERES_HIP_DEBUG_PLAN_REORDER"); BuildBalPlan(h, e && atoi(e) != 0 && num_eliminate_blocks > 0, &P); }
+  { const char* e = getenv("CERES_HIP_DEBUG_PLAN_REORDER"); BuildBalPlan(h, (e && atoi(e) != 0 && num_eliminate_blocks > 0) ? kReorderAlways : kReorderNever, HybridRequest(), &P); }
   *eligible = P.eligible ? 1 : 0;
   if (why_not) snprintf(why_not, why_capacity, "%s", P.why_not.c_str());
   *n_tiles = P.n_tiles;
@@ -2586,6 +2651,35 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
     slot_seg_out[i] = P.slot_seg[i];
   }
   for (int64_t t = 0; t < P.n_tiles; ++t) { tile_kind_out[t] = P.tile_kind[t]; tile_aux_out[t] = P.tile_aux[t]; }
+  return 0;
+}
+
+int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t groups, int32_t rows,
+                                int64_t counts[8], int32_t* slot_word, int32_t* slot_row, int32_t* tile_zbase, int32_t* grp_tile_ptr,
+                                int32_t* entry_row, int32_t* unit_cam, int32_t* unit_begin, int32_t* unit_end,
+                                int64_t slot_capacity, int64_t entry_capacity, int64_t unit_capacity) {
+  if (!bs || !counts) return CERES_HIP_E_INVALID;
+  HostStructure h;
+  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
+  BalPlan P;
+  HybridRequest hyb;
+  hyb.groups = groups; hyb.rows = rows;
+  BuildBalPlan(h, num_eliminate_blocks > 0 ? kReorderAlways : kReorderNever, hyb, &P);
+  if (!P.eligible || P.cameras_in_lds) return CERES_HIP_E_UNSUPPORTED;
+  const int64_t n_slots = P.n_tiles * kTile, n_entries = int64_t(P.zc_slot.size()), n_units = int64_t(P.zu_cam.size());
+  counts[0] = P.n_tiles; counts[1] = P.hybrid ? 1 : 0; counts[2] = P.hyb_rows; counts[3] = P.hyb_hot;
+  counts[4] = P.z_flush_row0; counts[5] = P.z_ring_rows; counts[6] = n_entries; counts[7] = n_units;
+  if (slot_capacity < n_slots || entry_capacity < n_entries || unit_capacity < n_units) return 0;  // the caller only wanted the counts
+  for (int64_t i = 0; i < n_slots; ++i) {
+    slot_word[i] = P.slot_cam[i] < 0 ? -1 : P.slot_word[i];
+    slot_row[i] = P.slot_bpos[i] < 0 ? -1 : P.slot_bpos[i] / 2;
+  }
+  std::copy(P.tile_zbase.begin(), P.tile_zbase.end(), tile_zbase);
+  if (P.hybrid) std::copy(P.grp_tile_ptr.begin(), P.grp_tile_ptr.end(), grp_tile_ptr);
+  std::copy(P.zc_slot.begin(), P.zc_slot.end(), entry_row);
+  std::copy(P.zu_cam.begin(), P.zu_cam.end(), unit_cam);
+  std::copy(P.zu_begin.begin(), P.zu_begin.end(), unit_begin);
+  std::copy(P.zu_end.begin(), P.zu_end.end(), unit_end);
   return 0;
 }
 

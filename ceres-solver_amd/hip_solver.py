@@ -143,6 +143,8 @@ ABI = [
     ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
                                        POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
+    ("ceres_hip_debug_hybrid_plan", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, POINTER(c_int64)] + [POINTER(c_int32)] * 8 +
+     [c_int64, c_int64, c_int64]),
 ]
 
 _lib = None
@@ -651,6 +653,35 @@ def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
     return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
             "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tail_a": (seg >> 17) & 63, "has_a": (seg >> 23) & 1,
             "tail_b": (seg >> 24) & 63, "has_b": (seg >> 30) & 1, "tile_kind": kind, "tile_aux": aux}
+
+
+def debug_hybrid_plan(bs: BlockStructure, num_eliminate_blocks: int, groups: int, rows: int):
+    """The camera-accumulation plan for more cameras than LDS rows (csrc/plan.cc; no device needed): hybrid for groups >= 2,
+    spill-everything for groups = 0.  Returns None when the structure is not <2,3,9>-shaped or its cameras fit in LDS."""
+    lib = load_library()
+    c = bs.as_ctypes()
+    counts = (c_int64 * 8)()
+    n32 = POINTER(c_int32)()
+    fn = lib.ceres_hip_debug_hybrid_plan
+    rc = fn(byref(c), c_int32(num_eliminate_blocks), c_int32(groups), c_int32(rows), counts, n32, n32, n32, n32, n32, n32, n32, n32,
+            c_int64(0), c_int64(0), c_int64(0))
+    if rc != 0:
+        return None
+    nt, hyb, k, kh, flush0, ring_rows, ne, nu = (int(v) for v in counts)
+    word, row = np.zeros(nt * 64, np.int32), np.zeros(nt * 64, np.int32)
+    zbase, grp = np.zeros(nt, np.int32), np.zeros(max(groups, 0) + 1, np.int32)
+    ent, ucam, ub, ue = np.zeros(ne, np.int32), np.zeros(nu, np.int32), np.zeros(nu, np.int32), np.zeros(nu, np.int32)
+    ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
+    rc = fn(byref(c), c_int32(num_eliminate_blocks), c_int32(groups), c_int32(rows), counts, ip(word), ip(row), ip(zbase), ip(grp), ip(ent),
+            ip(ucam), ip(ub), ip(ue), c_int64(nt * 64), c_int64(ne), c_int64(nu))
+    assert rc == 0
+    valid = word != -1   # (a spilled slot's word has its top bits set: negative as int32, but never -1)
+    uw = word.view(np.uint32)
+    return {"n_tiles": nt, "hybrid": bool(hyb), "rows": k, "hot_rows": kh, "flush_row0": flush0, "ring_rows": ring_rows,
+            "valid": valid, "slot_cam": np.where(valid, (uw & 0xFFFFF).astype(np.int64), -1),
+            "slot_acc": np.where(valid, (uw >> 20).astype(np.int64), 0xFFF),
+            "slot_row": row, "tile_zbase": zbase, "grp_tile_ptr": grp if hyb else None, "entry_row": ent, "unit_cam": ucam,
+            "unit_begin": ub, "unit_end": ue}
 
 
 CONVERGENCE, MINIMIZER_NO_CONVERGENCE, MINIMIZER_FAILURE = 0, 1, 2

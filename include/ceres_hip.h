@@ -472,6 +472,19 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
                          uint32_t* slot_seg, int32_t* tile_kind, int32_t* tile_aux, int64_t slot_capacity,
                          char* why_not, int32_t why_capacity);
 
+/* Debug: the camera-accumulation plan for more cameras than LDS rows (csrc/plan.cc; pure host code).  With groups >= 2 and
+ * num_eliminate_blocks > 0 this is the HYBRID plan a Schur solver builds for `groups` workgroups of `rows` LDS accumulator rows;
+ * with groups = 0 the spill-everything plan.  counts[8] = {n_tiles, hybrid (0/1), rows per workgroup, rows shared by every
+ * workgroup (the popular cameras), first flush row of the ring, ring rows, entries of the second pass, units of the second pass}.
+ * slot_word = camera | accumulator row << 20 (row 0xFFF: the slot is spilled), -1 = padding slot; tile_zbase = ring row of a tile's
+ * first spilled slot; group g walks the tiles [grp_tile_ptr[g], grp_tile_ptr[g+1]) and flushes accumulator row r to ring row
+ * counts[4] + g rows + r; unit u sums the ring rows entry_row[unit_begin[u] .. unit_end[u]) into camera unit_cam[u].  Call once with
+ * capacities 0 for the counts.  Returns CERES_HIP_E_UNSUPPORTED if the structure is not <2,3,9>-shaped or its cameras fit in LDS. */
+int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t groups, int32_t rows,
+                                int64_t counts[8], int32_t* slot_word, int32_t* slot_row, int32_t* tile_zbase, int32_t* grp_tile_ptr,
+                                int32_t* entry_row, int32_t* unit_cam, int32_t* unit_begin, int32_t* unit_end,
+                                int64_t slot_capacity, int64_t entry_capacity, int64_t unit_capacity);
+
 /* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
  * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */
 int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world);

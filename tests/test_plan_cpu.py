@@ -267,3 +267,76 @@ def test_renumbered_points_fill_the_tiles(problems, shape, kw, monkeypatch):
     print(f"padding {waste_plain:.4f} -> {waste:.4f} ({plain['n_tiles']} -> {nt} tiles)")
     if shape == "ladybug1723":
         assert waste < 0.012 and waste < 0.4 * waste_plain
+
+
+def simulate_camera_accumulation(pl, n_cameras, groups, rng):
+    """The two passes of the many-camera regime on the host, with one scalar per observation in place of the 72-byte row:
+    tile pass (LDS rows per group, spilled rows into the ring, flush) and camera-major pass (units over ring rows)."""
+    valid, acc, cam = pl["valid"], pl["slot_acc"], pl["slot_cam"]
+    nt = pl["n_tiles"]
+    v = rng.standard_normal(valid.shape[0])
+    v[~valid] = 0.0
+    want = np.bincount(cam[valid], weights=v[valid], minlength=n_cameras)
+    ring = np.full(pl["ring_rows"], np.nan)
+    spill = valid & (acc == 0xFFF)
+    sp2 = spill.reshape(nt, 64)
+    rows_of = (pl["tile_zbase"][:, None] + np.cumsum(sp2, axis=1) - sp2).reshape(-1)   # a slot's row = tile base + rank among the tile's spilled slots
+    assert len(np.unique(rows_of[spill])) == spill.sum()
+    ring[rows_of[spill]] = v[spill]
+    if pl["hybrid"]:
+        K = pl["rows"]
+        sizes = np.diff(pl["grp_tile_ptr"])
+        assert pl["grp_tile_ptr"][0] == 0 and pl["grp_tile_ptr"][-1] == nt and (sizes >= 0).all()
+        slot_group = np.repeat(np.repeat(np.arange(groups), sizes), 64)
+        loc = valid & ~spill
+        assert (acc[loc] < K).all()
+        accs = np.zeros(groups * K)
+        np.add.at(accs, slot_group[loc] * K + acc[loc], v[loc])
+        ring[pl["flush_row0"]: pl["flush_row0"] + groups * K] = accs
+        # a row of the shared (popular) part means the same camera in every group; a window row belongs to ONE group
+        hot = loc & (acc < pl["hot_rows"])
+        pairs = np.unique(np.stack([acc[hot], cam[hot]], 1), axis=0)
+        assert len(np.unique(pairs[:, 0])) == len(pairs)
+        win = loc & (acc >= pl["hot_rows"])
+        trip = np.unique(np.stack([cam[win], slot_group[win], acc[win]], 1), axis=0)
+        assert len(np.unique(trip[:, 0])) == len(trip)
+    else:
+        assert not (valid & ~spill).any()
+    assert not np.isnan(ring).any()
+    ub, ue, uc, ent = pl["unit_begin"], pl["unit_end"], pl["unit_cam"], pl["entry_row"]
+    assert ((ue - ub) <= 64).all() and (ue > ub).all() and ub[0] == 0 and ue[-1] == len(ent) and (ub[1:] == ue[:-1]).all()
+    assert len(np.unique(ent)) == len(ent)          # every ring row is summed at most once
+    got = np.bincount(np.repeat(uc, ue - ub), weights=ring[ent], minlength=n_cameras)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    return float((valid & ~spill).sum()) / float(valid.sum())
+
+
+@pytest.mark.parametrize("kw,groups,rows,min_local", [
+    (dict(num_cameras=5000, num_points=40000, num_observations=120000), 64, 256, 0.45),     # 3 observations per point: one stays, + the popular ones
+    (dict(num_cameras=3000, num_points=3000, num_observations=30000), 16, 512, 0.3),       # 10 per point
+    (dict(num_cameras=2400, num_points=900, num_observations=90000), 8, 320, 0.1),          # long points (100 per point) own their tiles
+    (dict(num_cameras=40000, num_points=30000, num_observations=60000), 4, 64, 0.0),        # more cameras than groups x rows: some are in no window
+])
+def test_hybrid_camera_accumulation_plan(problems, kw, groups, rows, min_local):
+    """More cameras than LDS rows (csrc/plan.cc): popular cameras in every workgroup's LDS, the others in ONE workgroup's window, each
+    point with a workgroup that holds one of its cameras, everything else spilled — replayed on the host, pass by pass, against plain
+    per-camera sums; and the spill-everything plan (CGNR on caller-ordered vectors, chunked rings) the same way."""
+    p = problems.synthetic_bal(None, layout="schur", seed=11, skew=0.6, with_values=False, **kw)
+    rng = np.random.default_rng(5)
+    pl = pkg.hip_solver.debug_hybrid_plan(p.bs, p.num_eliminate_blocks, groups, rows)
+    assert pl is not None and pl["hybrid"] and pl["rows"] == rows
+    rows_seen = pl["slot_row"][pl["valid"]]
+    assert np.array_equal(np.sort(rows_seen), np.arange(p.bs.num_row_blocks))
+    local = simulate_camera_accumulation(pl, kw["num_cameras"], groups, rng)
+    sizes = np.diff(pl["grp_tile_ptr"])
+    print(f"summed in LDS: {local:.3f} of the observations; tiles per group {sizes.min()}..{sizes.max()}")
+    assert local >= min_local
+    assert sizes.max() <= 1.06 * sizes.mean() + 2      # balance before locality
+    plain = pkg.hip_solver.debug_hybrid_plan(p.bs, p.num_eliminate_blocks, 0, 0)
+    assert plain is not None and not plain["hybrid"]
+    assert simulate_camera_accumulation(plain, kw["num_cameras"], 0, rng) == 0.0
+
+
+def test_cameras_that_fit_in_lds_have_no_ring(problems):
+    p = problems.synthetic_bal("ladybug1723", layout="schur", seed=5, with_values=False)
+    assert pkg.hip_solver.debug_hybrid_plan(p.bs, p.num_eliminate_blocks, 256, 1728) is None
