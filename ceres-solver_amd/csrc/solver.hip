@@ -2654,6 +2654,54 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
   return 0;
 }
 
+int ceres_hip_op_dense_cholesky_solve(ceres_hip_solver* s, int32_t n, const double* A, const double* b, double* x, int32_t repeats,
+                                      double* factor_ms, int32_t* failed) {
+  if (!s || !A || !b || !x || n < 1 || repeats < 1) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  hipStream_t st = s->stream;
+  const size_t nn = size_t(n) * size_t(n);
+  double *dA0 = nullptr, *dA = nullptr, *dx = nullptr;
+  int* dflag = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&] {
+    if (dA0) (void)hipFree(dA0); if (dA) (void)hipFree(dA); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dA0), nn * sizeof(double)));
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dA), nn * sizeof(double)));
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dx), size_t(n) * sizeof(double)));
+    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dflag), sizeof(int)));
+    HIP_TRY(s, hipEventCreate(&e0)); HIP_TRY(s, hipEventCreate(&e1));
+    HIP_TRY(s, hipMemcpyAsync(dA0, A, nn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(dx, b, size_t(n) * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemsetAsync(dflag, 0, sizeof(int), st));
+    double total = 0.0;
+    for (int r = 0; r < repeats; ++r) {   // the factorisation is in place: every repeat starts from a fresh copy, only the factorisation is timed
+      HIP_TRY(s, hipMemcpyAsync(dA, dA0, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+      HIP_TRY(s, hipEventRecord(e0, st));
+      HIP_TRY(s, LaunchDenseCholesky(dA, n, dflag, st));
+      HIP_TRY(s, hipEventRecord(e1, st));
+      HIP_TRY(s, hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_TRY(s, hipEventElapsedTime(&ms, e0, e1));
+      total += ms;
+    }
+    if (factor_ms) *factor_ms = total / repeats;
+    int flag = 0;
+    HIP_TRY(s, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    if (failed) *failed = flag;
+    if (!flag) HIP_TRY(s, LaunchDenseCholeskySolve(dA, n, dx, st));
+    HIP_TRY(s, hipMemcpyAsync(x, dx, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    return 0;
+  };
+  const int rc = run();
+  cleanup();
+  return rc;
+}
+
 int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t groups, int32_t rows,
                                 int64_t counts[8], int32_t* slot_word, int32_t* slot_row, int32_t* tile_zbase, int32_t* grp_tile_ptr,
                                 int32_t* entry_row, int32_t* unit_cam, int32_t* unit_begin, int32_t* unit_end,

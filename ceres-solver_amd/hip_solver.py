@@ -143,6 +143,7 @@ ABI = [
     ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
                                        POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
+    ("ceres_hip_op_dense_cholesky_solve", c_int32, [c_void_p, c_int32, _DP, _DP, _DP, c_int32, POINTER(c_double), POINTER(c_int32)]),
     ("ceres_hip_debug_hybrid_plan", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, POINTER(c_int64)] + [POINTER(c_int32)] * 8 +
      [c_int64, c_int64, c_int64]),
 ]
@@ -598,6 +599,18 @@ class HipLinearSolver:
         z = np.zeros_like(x)
         self._check(self._lib.ceres_hip_op_axpby(self._h, a, _p(x), b, _p(y), x.shape[0], _p(z)))
         return z
+
+    def dense_cholesky_solve(self, A: np.ndarray, b: np.ndarray, repeats: int = 1):
+        """DenseCholesky::FactorAndSolve (internal/ceres/dense_cholesky.cc) on a caller-supplied SPD matrix (upper triangle
+        authoritative): returns (x, average factorisation ms, failed).  What DENSE_SCHUR runs on its reduced system."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        n = A.shape[0]
+        assert A.shape == (n, n) and b.shape == (n,)
+        x = np.zeros(n)
+        ms, failed = c_double(0.0), c_int32(0)
+        self._check(self._lib.ceres_hip_op_dense_cholesky_solve(self._h, n, _p(A), _p(b), _p(x), repeats, byref(ms), byref(failed)))
+        return x, float(ms.value), bool(failed.value)
 
     def time_op(self, op: int, iters: int = 20) -> float:
         """Average milliseconds per application (HIP events on the solver's stream)."""

@@ -472,6 +472,13 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
                          uint32_t* slot_seg, int32_t* tile_kind, int32_t* tile_aux, int64_t slot_capacity,
                          char* why_not, int32_t why_capacity);
 
+/* DenseCholesky::FactorAndSolve on a caller-supplied matrix (I/dense_cholesky.cc: what DENSE_SCHUR runs on its reduced system,
+ * I/schur_complement_solver.cc:163-222): A is n x n row-major with its UPPER triangle authoritative, x = A^-1 b.  The blocked
+ * factorisation (128-wide panels, trailing update on v_mfma_f64_16x16x4_f64) runs `repeats` times from fresh copies; *factor_ms =
+ * its average duration (HIP events), *failed = 1 if a pivot was not positive (x is then b).  Needs only a created handle.          */
+int ceres_hip_op_dense_cholesky_solve(ceres_hip_solver* s, int32_t n, const double* A, const double* b, double* x, int32_t repeats,
+                                      double* factor_ms, int32_t* failed);
+
 /* Debug: the camera-accumulation plan for more cameras than LDS rows (csrc/plan.cc; pure host code).  With groups >= 2 and
  * num_eliminate_blocks > 0 this is the HYBRID plan a Schur solver builds for `groups` workgroups of `rows` LDS accumulator rows;
  * with groups = 0 the spill-everything plan.  counts[8] = {n_tiles, hybrid (0/1), rows per workgroup, rows shared by every

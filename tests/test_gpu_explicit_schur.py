@@ -246,3 +246,24 @@ def test_explicit_sparse_on_a_wide_problem_matches_implicit(hip, oracle, problem
                                 min_num_iterations=0, max_num_iterations=2000)
     xi, si = solve(hip, p, o, -1.0, 1e-12)
     assert rel(x, xi) <= 1e-8 and abs(si.num_iterations - s.num_iterations) <= 2
+
+
+@pytest.mark.parametrize("n", [1, 17, 128, 129, 300, 1000])
+def test_dense_cholesky_on_the_matrix_pipe(hip, n):
+    """The blocked factorisation behind DENSE_SCHUR (128-wide panels: diagonal block in LDS, substitution below it, trailing update on
+    v_mfma_f64_16x16x4_f64) against numpy on random SPD matrices whose LOWER triangle is garbage (the upper one is authoritative, as
+    DenseCholesky's callers leave it): sizes around the panel and tile edges."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 3))
+    A = M @ M.T + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    Au = np.triu(A) + np.tril(rng.standard_normal((n, n)), -1)
+    s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.DENSE_SCHUR, elimination_groups=[1], max_num_iterations=1))
+    x, ms, failed = s.dense_cholesky_solve(Au, b, repeats=1)
+    assert not failed
+    ref = np.linalg.solve(A, b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref), np.linalg.norm(x - ref) / np.linalg.norm(ref)
+    Au[n // 2, n // 2] = -1.0   # not positive definite
+    _, _, failed = s.dense_cholesky_solve(Au, b, repeats=1)
+    assert failed
+    s.close()
