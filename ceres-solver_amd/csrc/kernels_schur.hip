@@ -12,6 +12,8 @@
 //     32-wide panels (diagonal block in LDS, panel solve one thread per row, LDS-tiled symmetric rank-32 update).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "device.h"
 
 namespace chip {
@@ -154,9 +156,11 @@ __global__ __launch_bounds__(kB) void dense_mirror_upper_kernel(double* __restri
 
 // Right-looking blocked Cholesky with kPanel-wide panels (DenseCholesky::FactorAndSolve for DENSE_SCHUR's reduced system,
 // I/schur_complement_solver.cc:163-222, I/dense_cholesky.cc).  Per panel three kernels:
-//   dense_potrf_panel_kernel   the kw x kw diagonal block, in LDS, one workgroup: 16-wide steps — a 16 x 16 factorisation by ONE
-//                              wavefront on registers and shuffles, the rows below by substitution, the block's own trailing update;
-//   dense_trsm_panel_kernel    rows below the block: X L_kk^T = A_panel by substitution, one thread per row, L_kk in LDS;
+//   dense_potrf_panel_kernel   the kw x kw diagonal block, in LDS, one workgroup: 16-wide steps — a 16 x 16 factorisation AND inversion
+//                              by one wavefront on registers and shuffles, the rows below as X^T = L_ss^-1 A^T and the block's own
+//                              trailing update as 16 x 16 MFMA tiles on LDS operands;
+//   dense_trsm_mfma_kernel     rows below the block: X^T = L_kk^-1 A^T, one wavefront per 16 rows, a chain of MFMAs whose accumulators
+//                              are the next products' operands (blocked substitution; only the 16 x 16 diagonal sub-blocks are inverted);
 //   dense_syrk_mfma_kernel     the trailing update C -= X X^T, the n^3 / 3 of the factorisation: v_mfma_f64_16x16x4_f64, one wavefront
 //                              per 64 x 64 output tile (16 accumulator tiles), K = the panel width.
 // A rank-32 update (the first version) moves 16 B per 64 flops of every trailing entry: HBM-bound at a quarter of the fp64 rate; at
@@ -167,29 +171,58 @@ constexpr int kPanelPitch = kPanel + 1;   // LDS row pitch (doubles): column acc
 constexpr int kSub = 16;                  // step width inside the diagonal block
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Where the inverse of the 16 x 16 diagonal sub-block s of a panel's diagonal block is parked for the kernels that multiply by it:
+// a 16 x 16 sub-block strictly ABOVE the diagonal of the same kPanel x kPanel block (free: the factorisation lives in the lower triangle).
+__device__ __forceinline__ int linv_block_row(int s) { return s < kPanel / kSub - 1 ? s : kPanel / kSub - 3; }
+__device__ __forceinline__ int linv_block_col(int s) { return s < kPanel / kSub - 1 ? s + 1 : kPanel / kSub - 1; }
+
+// One MFMA tile product on LDS / register operands, all in the layouts of v_mfma_f64_16x16x4_f64 (lane l: li = l & 15, lq = l >> 4):
+// an A operand is A[li][4 kk + lq], a B operand B[4 kk + lq][li], an accumulator register r holds C[lq + 4 r][li] — so an accumulator IS
+// the B operand of a following product (register r <-> k-step r): triangular solves chain without moving data.
 __global__ __launch_bounds__(256) void dense_potrf_panel_kernel(double* __restrict__ A, int n, int k0, int kw, int* fail_flag) {
   extern __shared__ double T[];   // [kwp][kPanelPitch], lower triangle; kwp = kw rounded up to the step width, padded with the identity
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ double Li[kSub][kSub + 1];   // inverse of the current diagonal sub-block
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
   const int kwp = (kw + kSub - 1) / kSub * kSub;
-  for (int e = tid; e < kwp * kwp; e += 256) {
-    const int r = e / kwp, c = e - r * kwp;
-    if (c <= r) T[r * kPanelPitch + c] = (r < kw) ? A[int64_t(k0 + r) * n + (k0 + c)] : (r == c ? 1.0 : 0.0);
+  {   // thread = column, two rows per sweep (coalesced, no division), 16 loads in flight per thread before the first is consumed
+    const int c = tid & 127;
+    for (int rb = tid >> 7; rb < kwp; rb += 32) {
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int r = rb + 2 * t;
+        v[t] = (c <= r && r < kw) ? A[int64_t(k0 + r) * n + (k0 + c)] : (r == c ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int r = rb + 2 * t;
+        if (c <= r && r < kwp) T[r * kPanelPitch + c] = v[t];
+      }
+    }
   }
   __syncthreads();
   for (int s0 = 0; s0 < kwp; s0 += kSub) {
-    if (tid < 64) {
+    if (wv == 0) {
       // lane r < 16 owns row r of the 16 x 16 diagonal sub-block; column by column, the pivot row's entries travel by shuffle
       double row[kSub];
 #pragma unroll
       for (int c = 0; c < kSub; ++c) row[c] = (lane < kSub && c <= lane) ? T[(s0 + lane) * kPanelPitch + s0 + c] : (c == lane ? 1.0 : 0.0);
+      // The pivot chain is 16 dependent steps per sub-block, 128 per panel: sqrt and divide (long software sequences in fp64) are
+      // replaced by ONE reciprocal square root per pivot — v_rsq_f64 refined by two Newton steps — and multiplications by it
+      // (L_jj = d y, column j *= y, and the inverse below multiplies by the same y = 1 / L_jj): a few ulps from the divided form.
       bool ok = true;
+      double ri[kSub];   // 1 / L[j][j]
 #pragma unroll
       for (int j = 0; j < kSub; ++j) {
         double d = __shfl(row[j], j, 64);   // T[j][j]
         if (!(d > 0.0)) { ok = false; d = 1.0; }
-        d = sqrt(d);
-        if (lane == j) row[j] = d;
-        else if (lane > j) row[j] /= d;
+        double y = __builtin_amdgcn_rsq(d);
+        y = y * (1.5 - 0.5 * d * y * y);
+        y = y * (1.5 - 0.5 * d * y * y);
+        ri[j] = y;
+        if (lane == j) row[j] = d * y;
+        else if (lane > j) row[j] *= y;
 #pragma unroll
         for (int c = j + 1; c < kSub; ++c) {
           const double tcj = __shfl(row[j], c, 64);   // T[c][j]
@@ -199,154 +232,182 @@ __global__ __launch_bounds__(256) void dense_potrf_panel_kernel(double* __restri
       if (!ok && lane == 0) atomicExch(fail_flag, 1);
 #pragma unroll
       for (int c = 0; c < kSub; ++c) if (lane < kSub && c <= lane) T[(s0 + lane) * kPanelPitch + s0 + c] = row[c];
+      // its inverse: lane j < 16 solves L x = e_j (column j), the entries of L travel by shuffle from the lanes that own their rows
+      double x[kSub];
+#pragma unroll
+      for (int r = 0; r < kSub; ++r) {
+        double v = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) v -= __shfl(row[k], r, 64) * x[k];   // L[r][k]
+        x[r] = v * ri[r];
+      }
+      if (lane < kSub) {
+#pragma unroll
+        for (int r = 0; r < kSub; ++r) Li[r][lane] = x[r];
+        if (kw == kPanel) {   // the rows under this block are solved against it by dense_trsm_mfma_kernel
+          const int s = s0 / kSub;
+          double* dst = A + int64_t(k0 + kSub * linv_block_row(s)) * n + (k0 + kSub * linv_block_col(s)) + lane;
+#pragma unroll
+          for (int r = 0; r < kSub; ++r) dst[int64_t(r) * n] = x[r];
+        }
+      }
     }
     __syncthreads();
     const int below = kwp - s0 - kSub;   // rows of the block under the sub-block (a multiple of 16)
-    if (tid < below) {                   // x L_ss^T = T[r, s0 : s0 + 16], one thread per row, L_ss read as broadcasts
-      double* tr = T + (s0 + kSub + tid) * kPanelPitch + s0;
-      const double* ls = T + s0 * kPanelPitch + s0;
-      double x[kSub];
+    const int nstrips = below / kSub;
+    // strips of 16 rows under the sub-block: X^T = L_ss^-1 A^T, one MFMA chain per strip (4 waves take them in turn)
+    for (int st = wv; st < nstrips; st += 4) {
+      double* base = T + (s0 + kSub + kSub * st + li) * kPanelPitch + s0;   // row (strip row li), column s0 + ..
+      v4f64 t = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < kSub; ++c) x[c] = tr[c];
+      for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[li][4 * kk + lq], base[4 * kk + lq], t, 0, 0, 0);
+      // (B operand of k-step kk = A^T[4 kk + lq][li] = the strip's row li, column 4 kk + lq: read straight from its place)
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < kSub; ++c) {
-        double v = x[c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) v -= x[q] * ls[c * kPanelPitch + q];
-        x[c] = v / ls[c * kPanelPitch + c];
-      }
-#pragma unroll
-      for (int c = 0; c < kSub; ++c) tr[c] = x[c];
+      for (int r = 0; r < 4; ++r) base[lq + 4 * r] = t[r];   // X^T[lq + 4 r][li] back to row li, column lq + 4 r
     }
     __syncthreads();
-    // the block's own trailing update, lower triangle, in 4 x 4 patches: patch (pr, pc), pc <= pr, of the (below / 4)^2 grid
-    const int P = below / 4, n_patches = P * (P + 1) / 2;
-    for (int e = tid; e < n_patches; e += 256) {
-      int pr = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
-      while (pr * (pr + 1) / 2 > e) --pr;
-      while ((pr + 1) * (pr + 2) / 2 <= e) ++pr;
-      const int pc = e - pr * (pr + 1) / 2;
-      const double* ra = T + (s0 + kSub + 4 * pr) * kPanelPitch + s0;
-      const double* rb = T + (s0 + kSub + 4 * pc) * kPanelPitch + s0;
-      double acc[4][4];
+    // the block's own trailing update, lower triangle, in 16 x 16 tiles (tr, tc), tc <= tr: C -= X_tr X_tc^T
+    const int n_tiles = nstrips * (nstrips + 1) / 2;
+    for (int e = wv; e < n_tiles; e += 4) {
+      int tr = int((sqrtf(8.0f * float(e) + 1.0f) - 1.0f) * 0.5f);
+      while (tr * (tr + 1) / 2 > e) --tr;
+      while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
+      const int tc = e - tr * (tr + 1) / 2;
+      const double* xa = T + (s0 + kSub + kSub * tr + li) * kPanelPitch + s0;
+      const double* xb = T + (s0 + kSub + kSub * tc + li) * kPanelPitch + s0;
+      double* cp = T + (s0 + kSub + kSub * tr + lq) * kPanelPitch + s0 + kSub + kSub * tc + li;
+      v4f64 c;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 4; ++r) c[r] = cp[4 * r * kPanelPitch];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+      for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[4 * kk + lq], xb[4 * kk + lq], c, 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < kSub; ++q) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = ra[i * kPanelPitch + q]; b[i] = rb[i * kPanelPitch + q]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
-      }
-      double* out = T + (s0 + kSub + 4 * pr) * kPanelPitch + s0 + kSub + 4 * pc;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) out[i * kPanelPitch + j] -= acc[i][j];   // (entries above the diagonal inside a diagonal patch are never read)
+      for (int r = 0; r < 4; ++r) cp[4 * r * kPanelPitch] = c[r];   // (entries above the diagonal inside a diagonal tile are never read)
     }
     __syncthreads();
   }
-  for (int e = tid; e < kw * kw; e += 256) {
-    const int r = e / kw, c = e - r * kw;
+  for (int r = tid >> 7; r < kw; r += 2) {
+    const int c = tid & 127;
     if (c <= r) A[int64_t(k0 + r) * n + (k0 + c)] = T[r * kPanelPitch + c];
   }
 }
 
-// Rows i >= k0 + kw: A[i, k0 : k0 + kw] <- A[i, k0 : k0 + kw] L_kk^-T.  One thread per row; L_kk in LDS (every lane reads the same
-// entry: a broadcast); the row is solved 32 columns at a time in registers, finished columns are re-read from the row itself.
-__global__ __launch_bounds__(64) void dense_trsm_panel_kernel(double* __restrict__ A, int n, int k0, int kw) {
-  extern __shared__ double L[];   // [kw][kPanelPitch], lower triangle
-  for (int e = threadIdx.x; e < kw * kw; e += 64) {
-    const int r = e / kw, c = e - r * kw;
-    if (c <= r) L[r * kPanelPitch + c] = A[int64_t(k0 + r) * n + (k0 + c)];
+// Rows i >= k0 + kPanel: A[i, k0 : k0 + kPanel] <- A[i, k0 : k0 + kPanel] L_kk^-T, in the transposed form X^T = L_kk^-1 A^T: one
+// wavefront per strip of 16 rows, 16 columns at a time — R_s = A_s^T - sum_{s' < s} L[s][s'] X_s'^T (MFMA, the X_s'^T are this wave's
+// own accumulators), X_s^T = L_ss^-1 R_s (MFMA, the inverted diagonal sub-blocks left by dense_potrf_panel_kernel).  144 MFMAs per strip.
+__global__ __launch_bounds__(256) void dense_trsm_mfma_kernel(double* __restrict__ A, int n, int k0) {
+  constexpr int kS = kPanel / kSub;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const int i0 = k0 + kPanel + kSub * (blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (i0 >= n) return;
+  const bool live = i0 + li < n;
+  double* arow = A + int64_t(min(i0 + li, n - 1)) * n + k0;
+  const double* Lb = A + int64_t(k0) * n + k0;
+  v4f64 X[kS];
+#pragma unroll
+  for (int s = 0; s < kS; ++s) {
+    v4f64 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = arow[kSub * s + lq + 4 * r];
+#pragma unroll
+    for (int sp = 0; sp < s; ++sp) {
+      const double* lp = Lb + int64_t(kSub * s + li) * n + kSub * sp + lq;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[4 * kk], X[sp][kk], acc, 0, 0, 0);
+    }
+    const double* ip = Lb + int64_t(kSub * linv_block_row(s) + li) * n + kSub * linv_block_col(s) + lq;
+    v4f64 t = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ip[4 * kk], acc[kk], t, 0, 0, 0);
+    X[s] = t;
   }
-  __syncthreads();
-  const int i = k0 + kw + blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  double* row = A + int64_t(i) * n + k0;
-  for (int c0 = 0; c0 < kw; c0 += 32) {
-    double x[32];
+  if (live) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) x[c] = c0 + c < kw ? row[c0 + c] : 0.0;
-    for (int q0 = 0; q0 < c0; q0 += 32) {   // columns finished in earlier rounds
-      double xq[32];
+    for (int s = 0; s < kS; ++s)
 #pragma unroll
-      for (int q = 0; q < 32; ++q) xq[q] = row[q0 + q];
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        if (c0 + c < kw) {
-          const double* lc = L + (c0 + c) * kPanelPitch + q0;
-          double v = 0.0;
-#pragma unroll
-          for (int q = 0; q < 32; ++q) v += xq[q] * lc[q];
-          x[c] -= v;
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      if (c0 + c < kw) {
-        const double* lc = L + (c0 + c) * kPanelPitch + c0;
-        double v = x[c];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) if (q < c) v -= x[q] * lc[q];
-        x[c] = v / lc[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) if (c0 + c < kw) row[c0 + c] = x[c];
+      for (int r = 0; r < 4; ++r) arow[kSub * s + lq + 4 * r] = X[s][r];
   }
 }
 
-// Trailing update of the LOWER triangle: A[i, j] -= sum_p X[i, p] X[j, p], X = A[:, k0 : k0 + kw], i >= j >= k0 + kw.
-// Workgroup = 128 x 128 outputs, wavefront = 64 x 64 = 4 x 4 MFMA tiles.  v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][l >> 4] and
-// B[l >> 4][l & 15] — for X X^T both are "row (l & 15) of the operand's 16 rows, column p + (l >> 4) of the panel" — and holds
-// C[(l >> 4) + 4 r][l & 15], r = 0..3.  Operands come straight from memory (the panel is L2-resident: n x kw doubles), one k-step ahead.
-__global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict__ A, int n, int k0) {
-  constexpr int kw = kPanel;   // a trailing update follows full panels only (a narrower last panel has nothing below it)
-  const int first = k0 + kw;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj > bi) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = first + 128 * bi + 64 * (wv >> 1), j0 = first + 128 * bj + 64 * (wv & 1);
-  if (i0 >= n || j0 >= n || j0 > i0 + 63) return;   // outside the matrix, or entirely above the diagonal
-  const int lr = lane & 15, lk = lane >> 4;
-  const double *ap[4], *bp[4];
+// Trailing update of the LOWER triangle: A[i, j] -= sum_p X[i, p] X[j, p], X = A[:, k0 : k0 + kPanel], i >= j >= k0 + kPanel.
+// Workgroup = 128 x 128 outputs, wavefront = 64 x 64 = 4 x 4 MFMA tiles (16 accumulators in AGPRs).  The two 128-row operand strips
+// go through LDS 32 panel columns at a time — coalesced loads into registers while the previous chunk multiplies, two LDS buffers,
+// one barrier per chunk — and every k-step takes its eight operands (A[li][4 ks + lq] / B[4 ks + lq][li]: both "row li of the strip,
+// column 4 ks + lq") from there: row pitch 36 doubles = the 64 lanes of a read fall two to a bank, the floor for 8-byte reads.
+// (The first version read its operands straight from memory, one wavefront per SIMD: 4 x the MFMA-bound time, waiting for loads.)
+constexpr int kSyrkChunk = 32;
+constexpr int kSyrkPitch = 36;
+constexpr int kSyrkOperand = 128 * kSyrkPitch;   // doubles of one operand strip in one buffer
+// kw = 128 or 256 panel columns [k0, k0 + kw) at once (full panels only: a narrower last panel has nothing below it); rows from
+// `first` on, 128-wide block columns [cb0, ncb) counted from `first` (ncb = 0: to the end).  Two panels per update halve the traffic on C — at K = 128 the
+// 16 bytes read and written per entry per 256 flops put the update on the HBM roof (16 flop / B x 5 TB/s = the MFMA peak), at 256 under it.
+__global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict__ A, int n, int k0, int kw, int first, int cb0, int ncb) {
+  extern __shared__ double sh[];   // [2 buffers][A strip | B strip][128][kSyrkPitch]
+  const int bi = blockIdx.y, bj = blockIdx.x + cb0;   // block columns [cb0, ncb) of the trailing matrix (ncb = 0: to the end)
+  if (bj > bi || (ncb > 0 && bj >= ncb)) return;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ib = first + 128 * bi, jb = first + 128 * bj;
+  const int i0 = ib + 64 * (wv >> 1), j0 = jb + 64 * (wv & 1);
+  const bool active = i0 < n && j0 < n && j0 <= i0 + 63;   // inside the matrix and not entirely above the diagonal
+  const int li = lane & 15, lq = lane >> 4;
+  // staging: element e = tid + 256 j of a 128 x 32 chunk, row e >> 5, column e & 31 (a wavefront = two 256-byte row segments)
+  const int srow = tid >> 5, scol = tid & 31;
+  const double* ga[16];
+  const double* gb[16];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {   // rows past the end are clamped: their results are never stored
-    ap[t] = A + int64_t(min(i0 + 16 * t + lr, n - 1)) * n + k0 + lk;
-    bp[t] = A + int64_t(min(j0 + 16 * t + lr, n - 1)) * n + k0 + lk;
+  for (int j = 0; j < 16; ++j) {   // rows past the end are clamped: their results are never stored
+    ga[j] = A + int64_t(min(ib + srow + 8 * j, n - 1)) * n + k0 + scol;
+    gb[j] = A + int64_t(min(jb + srow + 8 * j, n - 1)) * n + k0 + scol;
   }
+  double ra[16], rb[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ra[j] = ga[j][0]; rb[j] = gb[j][0]; }
   v4f64 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
-  // two k-steps (8 panel columns) per round, the operands of the NEXT round in flight while this one multiplies: a load has two
-  // steps = 32 MFMAs of 64 cycles to arrive
-  double a0[4], b0[4], a1[4], b1[4], c0[4], d0[4], c1[4], d1[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { a0[t] = ap[t][0]; b0[t] = bp[t][0]; a1[t] = ap[t][4]; b1[t] = bp[t][4]; }
-  for (int p = 0; p < kw; p += 8) {
-    const int pn = p + 8 < kw ? p + 8 : p;   // the last round re-loads itself: no branch in the loop
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { c0[t] = ap[t][pn]; d0[t] = bp[t][pn]; c1[t] = ap[t][pn + 4]; d1[t] = bp[t][pn + 4]; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[a], b0[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[a], b1[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { a0[t] = c0[t]; b0[t] = d0[t]; a1[t] = c1[t]; b1[t] = d1[t]; }
+  for (int j = 0; j < 16; ++j) {
+    sh[(srow + 8 * j) * kSyrkPitch + scol] = ra[j];
+    sh[kSyrkOperand + (srow + 8 * j) * kSyrkPitch + scol] = rb[j];
   }
+  __syncthreads();
+  const int nch = kw / kSyrkChunk;
+#pragma unroll 1
+  for (int ch = 0; ch < nch; ++ch) {
+    const double* cur = sh + (ch & 1) * 2 * kSyrkOperand;
+    double* nxt = sh + ((ch + 1) & 1) * 2 * kSyrkOperand;
+    const bool more = ch + 1 < nch;
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { ra[j] = ga[j][kSyrkChunk * (ch + 1)]; rb[j] = gb[j][kSyrkChunk * (ch + 1)]; }
+    }
+    if (active) {
+      const double* pa = cur + (64 * (wv >> 1) + li) * kSyrkPitch + lq;
+      const double* pb = cur + kSyrkOperand + (64 * (wv & 1) + li) * kSyrkPitch + lq;
+#pragma unroll
+      for (int ks = 0; ks < kSyrkChunk / 4; ++ks) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { av[t] = pa[16 * t * kSyrkPitch + 4 * ks]; bv[t] = pb[16 * t * kSyrkPitch + 4 * ks]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        nxt[(srow + 8 * j) * kSyrkPitch + scol] = ra[j];
+        nxt[kSyrkOperand + (srow + 8 * j) * kSyrkPitch + scol] = rb[j];
+      }
+    }
+    __syncthreads();   // the next buffer is complete, and nobody still reads the one the round after next overwrites
+  }
+  if (!active) return;
   // C -= acc, one row of tiles at a time: 16 loads in flight, then 16 predicated stores (addresses clamped into the matrix)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -355,42 +416,47 @@ __global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = min(i0 + 16 * a + lk + 4 * r, n - 1), j = min(j0 + 16 * b + lr, n - 1);
+        const int i = min(i0 + 16 * a + lq + 4 * r, n - 1), j = min(j0 + 16 * b + li, n - 1);
         c[b][r] = A[int64_t(i) * n + j];
       }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = i0 + 16 * a + lk + 4 * r, j = j0 + 16 * b + lr;
+        const int i = i0 + 16 * a + lq + 4 * r, j = j0 + 16 * b + li;
         if (i < n && j <= i) A[int64_t(i) * n + j] = c[b][r] - acc[a][b][r];
       }
   }
 }
 
 // Triangular solves with the factor, one right-hand side, blocked by kNb: x <- L^-1 x then x <- L^-T x.
-__global__ __launch_bounds__(kNb) void dense_trsv_diag_kernel(const double* __restrict__ A, int n, int k0, int nb, double* __restrict__ x, int transposed) {
-  __shared__ double xs[kNb];
+__global__ __launch_bounds__(64) void dense_trsv_diag_kernel(const double* __restrict__ A, int n, int k0, int nb, double* __restrict__ x, int transposed) {
+  // the nb x nb diagonal block through LDS (coalesced rows), lane r owns x[k0 + r]; column by column, the solved entry travels by shuffle
+  // (a single thread walking the block in global memory, as this kernel first did, took 35 us per call: 18 ms of a solve at n = 8192)
+  __shared__ double Ls[kNb][kNb + 1];
   const int t = threadIdx.x;
-  if (t < nb) xs[t] = x[k0 + t];
-  __syncthreads();
-  if (t == 0) {
-    if (!transposed) {
-      for (int r = 0; r < nb; ++r) {
-        double s = xs[r];
-        for (int c = 0; c < r; ++c) s -= A[int64_t(k0 + r) * n + (k0 + c)] * xs[c];
-        xs[r] = s / A[int64_t(k0 + r) * n + (k0 + r)];
-      }
-    } else {
-      for (int r = nb - 1; r >= 0; --r) {
-        double s = xs[r];
-        for (int c = r + 1; c < nb; ++c) s -= A[int64_t(k0 + c) * n + (k0 + r)] * xs[c];
-        xs[r] = s / A[int64_t(k0 + r) * n + (k0 + r)];
-      }
-    }
+  for (int e = t; e < kNb * kNb; e += 64) {
+    const int r = e / kNb, c = e % kNb;
+    Ls[r][c] = (r < nb && c <= r) ? A[int64_t(k0 + r) * n + (k0 + c)] : (r == c ? 1.0 : 0.0);
   }
   __syncthreads();
-  if (t < nb) x[k0 + t] = xs[t];
+  double v = t < nb ? x[k0 + t] : 0.0;
+  if (!transposed) {
+#pragma unroll
+    for (int c = 0; c < kNb; ++c) {
+      if (t == c) v /= Ls[c][c];
+      const double xc = __shfl(v, c, 64);
+      if (t > c && t < kNb) v -= Ls[t][c] * xc;
+    }
+  } else {
+#pragma unroll
+    for (int c = kNb - 1; c >= 0; --c) {
+      if (t == c) v /= Ls[c][c];
+      const double xc = __shfl(v, c, 64);
+      if (t < c) v -= Ls[c][t] * xc;
+    }
+  }
+  if (t < nb) x[k0 + t] = v;
 }
 // forward: x[i] -= sum_c L[i, k0 + c] x[k0 + c] for i >= k0 + nb;  backward (transposed): x[i] -= sum_c L[k0 + c, i] x[k0 + c] for i < k0
 __global__ __launch_bounds__(kB) void dense_trsv_update_kernel(const double* __restrict__ A, int n, int k0, int nb, double* __restrict__ x, int transposed) {
@@ -425,27 +491,88 @@ hipError_t LaunchSchurSparseDiag(const GenStructure& G, const SchurPairs& P, con
   return hipGetLastError();
 }
 
+// A side stream and two events per device for the look-ahead below (created once, shared by every factorisation on the device:
+// calls that overlap in time still order correctly through their event waits, they just share the side stream).
+namespace {
+struct LookAhead { hipStream_t side = nullptr; hipEvent_t panels = nullptr, bulk = nullptr; bool ok = false; };
+LookAhead* look_ahead_for_current_device() {
+  static std::mutex mu;
+  static LookAhead per_device[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  LookAhead& L = per_device[dev];
+  if (!L.ok) {
+    if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&L.panels, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&L.bulk, hipEventDisableTiming) != hipSuccess) return nullptr;
+    L.ok = true;
+  }
+  return &L;
+}
+}  // namespace
+
 // In-place Cholesky of the symmetric n x n matrix whose UPPER triangle is authoritative; L is left in the lower triangle.
+// Panels go in PAIRS (P0, P1 = 256 columns).  After P0 only P1's 128 columns are updated; everything behind the pair takes both panels
+// in ONE update with K = 256.  That update is split: the 256 columns of the NEXT pair first, on the caller's stream, which then goes
+// straight on to factor them; the bulk behind them on a side stream, concurrently (look-ahead) — the chain potrf / trsm / potrf / trsm
+// of a pair is latency-bound on one or a few CUs and as long as the bulk update of the pair before it.
 hipError_t LaunchDenseCholesky(double* A, int n, int* fail_flag, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  static const hipError_t lds_ok = [] {   // the panel kernels keep a kPanel x kPanel block in LDS (132 KB)
+  static const hipError_t lds_ok = [] {   // the panel kernel keeps a kPanel x kPanel block in LDS (132 KB), the update two operand strips twice (147 KB)
     const int bytes = kPanel * kPanelPitch * int(sizeof(double));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dense_trsm_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(dense_syrk_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(4 * kSyrkOperand * sizeof(double)));
   }();
   if (lds_ok != hipSuccess) return lds_ok;
   hipLaunchKernelGGL(dense_mirror_upper_kernel, dim3(blocks_for(int64_t(n) * n)), dim3(kB), 0, s, A, n);
-  for (int k0 = 0; k0 < n; k0 += kPanel) {
-    const int kw = n - k0 < kPanel ? n - k0 : kPanel;
+  const size_t syrk_lds = 4 * kSyrkOperand * sizeof(double);
+  LookAhead* la = n >= 24 * kPanel ? look_ahead_for_current_device() : nullptr;   // below ~3000 columns the event traffic costs more than it hides (n = 2052: 2.7 vs 3.9 ms)
+  // (the side stream and its events are shared per device: one factorisation ENQUEUES at a time — a wait captures the record that
+  // precedes it in enqueue order, so whole sequences must not interleave)
+  static std::mutex enqueue_mu;
+  std::unique_lock<std::mutex> enqueue_lock(enqueue_mu, std::defer_lock);
+  if (la) enqueue_lock.lock();
+  bool bulk_pending = false;
+  auto panel = [&](int k0, int kw) {
     const size_t lds = size_t((kw + kSub - 1) / kSub * kSub) * kPanelPitch * sizeof(double);
     hipLaunchKernelGGL(dense_potrf_panel_kernel, dim3(1), dim3(256), lds, s, A, n, k0, kw, fail_flag);
     const int rest = n - k0 - kw;
-    if (rest <= 0) break;
-    hipLaunchKernelGGL(dense_trsm_panel_kernel, dim3((rest + 63) / 64), dim3(64), lds, s, A, n, k0, kw);
-    const unsigned blocks = unsigned((rest + 127) / 128);
-    hipLaunchKernelGGL(dense_syrk_mfma_kernel, dim3(blocks, blocks), dim3(256), 0, s, A, n, k0);
+    if (rest > 0) hipLaunchKernelGGL(dense_trsm_mfma_kernel, dim3((rest + 63) / 64), dim3(256), 0, s, A, n, k0);   // (rest > 0: a full panel)
+    return rest;
+  };
+  for (int k0 = 0; k0 < n; k0 += 2 * kPanel) {
+    // ---- the pair's two panels, on the caller's stream
+    const int kw0 = n - k0 < kPanel ? n - k0 : kPanel;
+    const int rest0 = panel(k0, kw0);
+    if (rest0 <= 0) break;
+    const unsigned blocks0 = unsigned((rest0 + 127) / 128);
+    // P1's columns (block column 0 behind P0) take P0 now; if nothing lies behind P1 this is the whole trailing matrix
+    hipLaunchKernelGGL(dense_syrk_mfma_kernel, dim3(1, blocks0), dim3(256), syrk_lds, s, A, n, k0, kPanel, k0 + kPanel, 0, 1);
+    const int k1 = k0 + kPanel;
+    const int kw1 = n - k1 < kPanel ? n - k1 : kPanel;
+    const int rest1 = panel(k1, kw1);
+    if (rest1 <= 0) break;
+    // ---- everything behind the pair takes both panels at once: K = 256 from k0, rows and columns from k1 + 128 on
+    const int first = k1 + kPanel;
+    const unsigned blocks = unsigned((rest1 + 127) / 128);
+    if (la && blocks > 2) {
+      if (hipError_t e = hipEventRecord(la->panels, s); e != hipSuccess) return e;
+      // the next pair's columns (they were part of the previous pair's bulk update: wait for it), then straight on to factor them
+      if (bulk_pending) if (hipError_t e = hipStreamWaitEvent(s, la->bulk, 0); e != hipSuccess) return e;
+      hipLaunchKernelGGL(dense_syrk_mfma_kernel, dim3(2, blocks), dim3(256), syrk_lds, s, A, n, k0, 2 * kPanel, first, 0, 2);
+      // the bulk behind them, concurrently (the side stream is in order: this pair's bulk follows the previous pair's)
+      if (hipError_t e = hipStreamWaitEvent(la->side, la->panels, 0); e != hipSuccess) return e;
+      hipLaunchKernelGGL(dense_syrk_mfma_kernel, dim3(blocks - 2, blocks), dim3(256), syrk_lds, la->side, A, n, k0, 2 * kPanel, first, 2, 0);
+      if (hipError_t e = hipEventRecord(la->bulk, la->side); e != hipSuccess) return e;
+      bulk_pending = true;
+    } else {
+      if (bulk_pending) { if (hipError_t e = hipStreamWaitEvent(s, la->bulk, 0); e != hipSuccess) return e; bulk_pending = false; }
+      hipLaunchKernelGGL(dense_syrk_mfma_kernel, dim3(blocks, blocks), dim3(256), syrk_lds, s, A, n, k0, 2 * kPanel, first, 0, 0);
+    }
   }
+  if (bulk_pending) if (hipError_t e = hipStreamWaitEvent(s, la->bulk, 0); e != hipSuccess) return e;   // join
   return hipGetLastError();
 }
 // x <- (L L^T)^-1 x
@@ -453,14 +580,14 @@ hipError_t LaunchDenseCholeskySolve(const double* A, int n, double* x, hipStream
   if (n <= 0) return hipSuccess;
   for (int k0 = 0; k0 < n; k0 += kNb) {
     const int nb = n - k0 < kNb ? n - k0 : kNb;
-    hipLaunchKernelGGL(dense_trsv_diag_kernel, dim3(1), dim3(kNb), 0, s, A, n, k0, nb, x, 0);
+    hipLaunchKernelGGL(dense_trsv_diag_kernel, dim3(1), dim3(64), 0, s, A, n, k0, nb, x, 0);
     const int rest = n - k0 - nb;
     if (rest > 0) hipLaunchKernelGGL(dense_trsv_update_kernel, dim3(blocks_for(rest)), dim3(kB), 0, s, A, n, k0, nb, x, 0);
   }
   const int last = ((n - 1) / kNb) * kNb;
   for (int k0 = last; k0 >= 0; k0 -= kNb) {
     const int nb = n - k0 < kNb ? n - k0 : kNb;
-    hipLaunchKernelGGL(dense_trsv_diag_kernel, dim3(1), dim3(kNb), 0, s, A, n, k0, nb, x, 1);
+    hipLaunchKernelGGL(dense_trsv_diag_kernel, dim3(1), dim3(64), 0, s, A, n, k0, nb, x, 1);
     if (k0 > 0) hipLaunchKernelGGL(dense_trsv_update_kernel, dim3(blocks_for(k0)), dim3(kB), 0, s, A, n, k0, nb, x, 1);
   }
   return hipGetLastError();
