@@ -231,75 +231,83 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
 
   // HYBRID camera accumulation (more cameras than LDS holds; needs the freedom to renumber the points).  The tile pass runs
   // hyb.groups workgroups, each with hyb.rows accumulator rows (9 doubles) in LDS:
-  //   rows [0, K_h)        the K_h most popular cameras — the same in every workgroup;
-  //   rows [K_h, K_h+K_w)  the workgroup's WINDOW: K_w cameras that no other workgroup holds.
-  // Every point is handed to a workgroup whose window holds one of its (cold) cameras, so of a point's k observations the hot ones
-  // and at least one cold one are summed in LDS; the others are SPILLED (a 72-byte row F_o^T z_o into a ring, summed by the
-  // camera-major second pass, which also collects the rows every workgroup flushes at its end).  A spill-everything pass moves
-  // 72 + ~200 bytes per observation on top of the 204 it reads (the second pass fetches whole lines around its 72-byte rows); with
-  // three observations per point and 50 000 cameras 58 % of the observations stay in LDS.  Windows are built from runs of
-  // kHybBlock consecutive camera ids (cameras of neighbouring ids see the same points in real scenes) dealt to the least loaded
-  // window, heaviest run first; a point goes to the least loaded of its candidate workgroups, or — above a load cap — to the
-  // least loaded workgroup overall (all its cold observations then spill: balance before locality).
+  //   rows [0, K_h)   the POPULAR cameras (at least twice the mean number of observations, at most as many as leave room for the
+  //                   windows to cover everything) — the same in every workgroup;
+  //   rows [K_h, K)   the workgroup's WINDOW: K_w = K - K_h consecutive ids of the other ("cold") cameras, starting stride g cameras
+  //                   in: windows overlap wherever groups x K_w exceeds the number of cold cameras, i.e. a camera may have a row in
+  //                   several workgroups (cameras of neighbouring ids see the same points in real scenes: a scene whose cameras fit
+  //                   a window keeps whole tracks in LDS).
+  // Every point is handed to the workgroup whose window holds most of its cold cameras (the least loaded of them; above a load cap:
+  // the least loaded workgroup overall — balance before locality), so of a point's k observations the popular ones and at least one
+  // cold one are summed in LDS; the others are SPILLED (a 72-byte row F_o^T z_o into a ring, summed by the camera-major second pass,
+  // which also collects the rows every workgroup flushes at its end).  A spill-everything pass moves 72 + ~200 bytes per observation
+  // on top of the 204 it reads (the second pass fetches whole lines around its 72-byte rows); with three observations per point on
+  // 50 000 cameras of random visibility 56 % of the observations stay in LDS, on the replicated libmv graphs (long tracks over
+  // consecutive cameras, tests/golden/libmv_problems.npz) all of them.
   bool hybrid = reorder_points && !P.cameras_in_lds && hyb.groups >= 2 && hyb.rows >= 64 && chunk_mib <= 0 && hyb.rows < kSlotSpill;
   if (const char* e = getenv("CERES_HIP_HYBRID")) hybrid = hybrid && atoi(e) != 0;
-  std::vector<int32_t> cam_row;                 // camera -> accumulator row (hot: < K_h; windowed: >= K_h)
-  std::vector<int32_t> cam_group;               // camera -> the workgroup whose window holds it (-1: hot, or in no window)
+  std::vector<int32_t> hot_row;                 // camera -> accumulator row < K_h, or -1
+  std::vector<int32_t> cold_rank;               // camera -> its rank among the cold cameras (id order), or -1
+  std::vector<int32_t> win_start;               // group -> cold rank of its window's first camera (non-decreasing)
   std::vector<std::vector<int32_t>> grp_points; // caller-order points of each group
-  int K_h = 0, K_w = 0;
+  int K_h = 0, K_w = 0, n_cold = 0;
+  // groups whose window holds the cold camera of rank q: [first, last]
+  auto groups_of = [&](int q, int* first, int* last) {
+    *last = int(std::upper_bound(win_start.begin(), win_start.end(), q) - win_start.begin()) - 1;
+    *first = int(std::upper_bound(win_start.begin(), win_start.end(), q - K_w) - win_start.begin());
+  };
   if (hybrid) {
     const int G = hyb.groups, K = hyb.rows;
-    K_w = std::min(K, std::max(1, (P.n_cameras - K + (G - 2)) / (G - 1)));   // (G - 1) K_w >= n_c - K  <=>  G K_w >= n_c - K_h
-    K_h = K - K_w;
     std::vector<int64_t> deg(P.n_cameras, 0);
     for (int i = 0; i < n_conf; ++i) ++deg[row_cam[i]];
-    cam_row.assign(P.n_cameras, -1);
-    cam_group.assign(P.n_cameras, -1);
-    {
-      std::vector<int32_t> by_deg(P.n_cameras);
-      std::iota(by_deg.begin(), by_deg.end(), 0);
-      std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
-      for (int r = 0; r < K_h; ++r) cam_row[by_deg[r]] = r;
-    }
-    // cold cameras in id order, cut into runs of kHybBlock; runs sorted by weight, each to the least loaded window with room
-    constexpr int kHybBlock = 8;
-    std::vector<int32_t> cold;
-    for (int c = 0; c < P.n_cameras; ++c) if (cam_row[c] < 0) cold.push_back(c);
-    const int n_runs = (int(cold.size()) + kHybBlock - 1) / kHybBlock;
-    std::vector<int64_t> run_w(n_runs, 0);
-    for (size_t i = 0; i < cold.size(); ++i) run_w[i / kHybBlock] += deg[cold[i]];
-    std::vector<int32_t> run_order(n_runs);
-    std::iota(run_order.begin(), run_order.end(), 0);
-    std::stable_sort(run_order.begin(), run_order.end(), [&](int a, int b) { return run_w[a] > run_w[b]; });
-    std::vector<int64_t> win_w(G, 0);
-    std::vector<int32_t> win_n(G, 0);
-    for (int r : run_order) {
-      const int lo = r * kHybBlock, hi = std::min<int>(int(cold.size()), lo + kHybBlock);
-      int best = -1;
-      for (int g = 0; g < G; ++g)
-        if (win_n[g] + (hi - lo) <= K_w && (best < 0 || win_w[g] < win_w[best])) best = g;
-      if (best < 0) continue;   // more cameras than G windows hold: this run always spills
-      for (int i = lo; i < hi; ++i) { cam_group[cold[i]] = best; cam_row[cold[i]] = K_h + win_n[best]++; }
-      win_w[best] += run_w[r];
-    }
+    // most rows the popular cameras may take: the windows must still cover the others, (G - 1) stride + K_w >= n_cold with stride <= K_w
+    const int max_hot = K - std::min(K, std::max(1, (P.n_cameras - K + (G - 2)) / (G - 1)));
+    std::vector<int32_t> by_deg(P.n_cameras);
+    std::iota(by_deg.begin(), by_deg.end(), 0);
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+    const double popular = 2.0 * double(n_conf) / double(P.n_cameras);
+    while (K_h < max_hot && double(deg[by_deg[K_h]]) >= popular) ++K_h;
+    if (const char* e = getenv("CERES_HIP_HYB_HOT")) K_h = std::max(0, std::min(atoi(e), max_hot));   // (experiments)
+    K_w = K - K_h;
+    hot_row.assign(P.n_cameras, -1);
+    cold_rank.assign(P.n_cameras, -1);
+    for (int r = 0; r < K_h; ++r) hot_row[by_deg[r]] = r;
+    for (int c = 0; c < P.n_cameras; ++c) if (hot_row[c] < 0) cold_rank[c] = n_cold++;
+    const int last_start = std::max(0, n_cold - K_w);
+    const int stride = (last_start + (G - 2)) / (G - 1);
+    win_start.resize(G);
+    for (int g = 0; g < G; ++g) win_start[g] = int(std::min<int64_t>(int64_t(g) * stride, last_start));
     // points -> groups
     grp_points.assign(G, {});
+    // load in tile slots: a point of more than 64 observations owns whole tiles
+    auto slots_of = [&](int p) { return track[p] > kTile ? int64_t((track[p] + kTile - 1) / kTile) * kTile : int64_t(track[p]); };
     std::vector<int64_t> load(G, 0);
-    const int64_t cap = (int64_t(n_conf) * 103 / 100 + G - 1) / G + kTile;
+    int64_t total_slots = 0;
+    for (int p = 0; p < P.n_points; ++p) total_slots += slots_of(p);
+    const int64_t cap = (total_slots * 103 / 100 + G - 1) / G + kTile;
     int least = 0, since_scan = 0;
+    std::vector<int32_t> votes(G, 0), touched;
     for (int p = 0; p < P.n_points; ++p) {
       if ((since_scan++ & 1023) == 0) least = int(std::min_element(load.begin(), load.end()) - load.begin());
-      int best = -1;
+      touched.clear();
       for (int q = row_start[p]; q < row_start[p + 1]; ++q) {
-        const int g = cam_group[row_cam[order[q]]];
-        if (g >= 0 && (best < 0 || load[g] < load[best])) best = g;
+        const int r = cold_rank[row_cam[order[q]]];
+        if (r < 0) continue;
+        int g0, g1;
+        groups_of(r, &g0, &g1);
+        for (int g = g0; g <= g1; ++g) if (votes[g]++ == 0) touched.push_back(g);
       }
-      if (best < 0 || load[best] >= cap) {
+      int best = -1;
+      for (int g : touched) {   // most of the point's cameras, then the lighter load
+        if (load[g] < cap && (best < 0 || votes[g] > votes[best] || (votes[g] == votes[best] && load[g] < load[best]))) best = g;
+      }
+      for (int g : touched) votes[g] = 0;
+      if (best < 0) {
         if (load[least] >= cap) least = int(std::min_element(load.begin(), load.end()) - load.begin());
         best = least;
       }
       grp_points[best].push_back(p);
-      load[best] += track[p];
+      load[best] += slots_of(p);
     }
   }
 
@@ -512,7 +520,14 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       const int c = P.slot_cam[s];
       if (c < 0) continue;
       int row = kSlotSpill;
-      if (hybrid && cam_row[c] >= 0 && (cam_group[c] < 0 || cam_group[c] == tile_group[s / kTile])) { row = cam_row[c]; ++n_local; }
+      if (hybrid) {
+        if (hot_row[c] >= 0) row = hot_row[c];
+        else {
+          const int st = win_start[tile_group[s / kTile]], r = cold_rank[c];
+          if (r >= st && r < st + K_w) row = K_h + (r - st);
+        }
+        if (row != kSlotSpill) ++n_local;
+      }
       P.slot_word[s] = int32_t(uint32_t(c) | (uint32_t(row) << kSlotCamBits));
     }
     P.n_local_obs = n_local;
@@ -547,8 +562,12 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       if (hybrid) {
         P.z_flush_row0 = flush_row0;
         row += int64_t(G) * K;
-        for (int c = 0; c < P.n_cameras; ++c)
-          if (cam_row[c] >= 0) count[c + 1] += cam_group[c] < 0 ? G : 1;   // hot: a row in every workgroup; windowed: in one
+        for (int c = 0; c < P.n_cameras; ++c) {   // popular: a row in every workgroup; cold: in every workgroup whose window holds it
+          if (hot_row[c] >= 0) { count[c + 1] += G; continue; }
+          int g0, g1;
+          groups_of(cold_rank[c], &g0, &g1);
+          count[c + 1] += std::max(0, g1 - g0 + 1);
+        }
       }
       if (row >= (int64_t(1) << 31)) return no("F^T z ring beyond 2^31 rows");
       P.z_ring_rows = std::max<int64_t>(P.z_ring_rows, row);
@@ -570,9 +589,13 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
         if (slot_zrow[s] >= 0) P.zc_slot[base + cur[P.slot_cam[s]]++] = slot_zrow[s];
       if (hybrid)
         for (int c = 0; c < P.n_cameras; ++c) {
-          if (cam_row[c] < 0) continue;
-          if (cam_group[c] >= 0) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(cam_group[c]) * K + cam_row[c]);
-          else for (int g = 0; g < G; ++g) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(g) * K + cam_row[c]);
+          if (hot_row[c] >= 0) {
+            for (int g = 0; g < G; ++g) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(g) * K + hot_row[c]);
+            continue;
+          }
+          int g0, g1;
+          groups_of(cold_rank[c], &g0, &g1);
+          for (int g = g0; g <= g1; ++g) P.zc_slot[base + cur[c]++] = int32_t(flush_row0 + int64_t(g) * K + K_h + (cold_rank[c] - win_start[g]));
         }
       base += start[P.n_cameras];
       P.zc_unit_ptr.push_back(int32_t(P.zu_cam.size()));

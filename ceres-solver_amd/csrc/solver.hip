@@ -1795,6 +1795,12 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
   info->world_size = s->world; info->rank = s->rank;
   info->p2p_enabled = s->p2p ? 1 : 0;
   info->p2p_fine_grained = s->p2p_fine_grained ? 1 : 0;
+  if (s->path == CERES_HIP_PATH_BAL) {
+    info->camera_accum_hybrid = s->plan.hybrid ? 1 : 0;
+    info->hybrid_popular_rows = s->plan.hybrid ? s->plan.hyb_hot : 0;
+    info->num_observations_in_lds = s->lds_mode ? s->plan.n_obs : s->plan.n_local_obs;
+    info->points_renumbered = s->plan.renumbered ? 1 : 0;
+  }
   return 0;
 }
 

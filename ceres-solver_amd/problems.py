@@ -306,6 +306,34 @@ def bal_from_tracks(track_lengths, num_cameras, layout="schur", seed=0, with_val
     return _assemble_bal(rng, int(num_cameras), int(k.shape[0]), point_of_obs, cam_of_obs[order], layout, with_values)
 
 
+LIBMV_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "libmv_problems.npz")
+
+
+def libmv_visibility(problem=2):
+    """(num_cameras, num_points, camera_of_marker, point_of_marker) of one of the three bundle-adjustment problems the reference
+    ships (data/libmv-ba-problems/problem_0{1,2,3}.bin, read by examples/libmv_bundle_adjuster.cc:376-455; committed as
+    tests/golden/libmv_problems.npz by tests/golden/make_libmv_fixture.py): REAL visibility — a few dozen tracks followed through
+    hundreds of consecutive frames, i.e. every point is seen by far more than 64 cameras and neighbouring cameras see the same points."""
+    z = np.load(LIBMV_FIXTURE)
+    img, trk = z[f"p{problem}_marker_image"].astype(np.int64), z[f"p{problem}_marker_track"].astype(np.int64)
+    cams, cam_of = np.unique(img, return_inverse=True)
+    pts, pt_of = np.unique(trk, return_inverse=True)
+    assert np.isin(cams, z[f"p{problem}_camera_image"]).all() and np.isin(pts, z[f"p{problem}_point_track"]).all()
+    return int(cams.shape[0]), int(pts.shape[0]), cam_of.astype(np.int64), pt_of.astype(np.int64)
+
+
+def libmv_bal(problem=2, copies=1, layout="schur", seed=38401, with_values=True) -> LinearProblem:
+    """<2,3,9> Jacobian with the visibility graph of a libmv problem, `copies` disjoint replicas of it side by side (cameras and points
+    of replica j follow those of replica j - 1: the graph "replicated to size"), values / b ~ N(0,1) like the synthetic workloads."""
+    n_c, n_p, cam_of, pt_of = libmv_visibility(problem)
+    rng = np.random.default_rng(seed)
+    reps = np.arange(copies, dtype=np.int64)
+    point_of_obs = (pt_of[None, :] + n_p * reps[:, None]).reshape(-1)
+    cam_of_obs = (cam_of[None, :] + n_c * reps[:, None]).reshape(-1)
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    return _assemble_bal(rng, n_c * copies, n_p * copies, point_of_obs[order], cam_of_obs[order], layout, with_values)
+
+
 def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_values) -> LinearProblem:
     n_obs = int(point_of_obs.shape[0])
     r = np.arange(n_obs, dtype=np.int64)

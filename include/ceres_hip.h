@@ -163,6 +163,13 @@ typedef struct ceres_hip_info {
   int32_t p2p_enabled;      /* the one-shot peer-to-peer all-reduce is connected AND passed its self-test */
   int32_t p2p_fine_grained; /* its receive buffer is a fine-grained allocation (0: the runtime could only export a
                                coarse-grained one — fine between ranks that share a device, self-tested otherwise)  */
+  /* BAL path with more cameras than LDS rows (camera_accum_in_lds == 0): hybrid accumulation (csrc/plan.cc) — the popular cameras
+   * in every workgroup's LDS, every other camera in the windows of a few workgroups, points grouped accordingly                  */
+  int32_t camera_accum_hybrid;        /* 1: hybrid plan; 0: every observation's F^T z is spilled (or camera_accum_in_lds)          */
+  int32_t hybrid_popular_rows;        /* accumulator rows every workgroup gives to the popular cameras                             */
+  int64_t num_observations_in_lds;    /* observations summed in LDS by the tile pass (the others are spilled to the ring)          */
+  int32_t points_renumbered;          /* 1: the tiles hold the points in an internal order (fuller tiles, hybrid groups)           */
+  int32_t reserved0;
 } ceres_hip_info;
 
 typedef struct ceres_hip_solver ceres_hip_solver; /* opaque */

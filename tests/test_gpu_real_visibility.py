@@ -1,0 +1,52 @@
+"""REAL visibility on the GPU: the three bundle-adjustment problems the reference ships (data/libmv-ba-problems/problem_0{1,2,3}.bin, read by
+examples/libmv_bundle_adjuster.cc; committed as tests/golden/libmv_problems.npz) — 26-71 tracks followed through 333-500 consecutive frames,
+so EVERY point has more than 64 observations (it owns whole tiles: the two-sweep long-point path of the fused kernels) and neighbouring
+cameras see the same points.  Values are N(0,1) like the synthetic workloads; every operator of both solvers and the LM-style solves are
+checked against the oracle (tests/test_gpu_fullsize.py's checkers).  Replicated side by side the cameras outgrow LDS: the hybrid plan then
+keeps (nearly) whole tracks in one workgroup's window — windows of consecutive camera ids that overlap."""
+import numpy as np
+import pytest
+
+from test_gpu_fullsize import check_cgnr_side, check_schur_side, oracle_threads  # noqa: F401  (module fixture)
+from test_gpu_operators import make_solver
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("problem", [1, 2, 3])
+def test_libmv_problem_against_the_oracle(hip, oracle, problems, problem):
+    p = problems.libmv_bal(problem, 1)
+    track = np.bincount(p.point_of_row)
+    assert track.min() > 64          # long points only
+    check_schur_side(hip, oracle, p, True)
+    check_cgnr_side(hip, oracle, p, True)
+
+
+@pytest.mark.parametrize("problem,copies", [(2, 6), (3, 8)])
+def test_replicated_libmv_problem_in_the_hybrid_regime(hip, oracle, problems, problem, copies):
+    """2640 / 4000 cameras: more than LDS holds.  No camera is popular here (every row of a workgroup goes to its window), windows
+    overlap, and a copy's cameras fit one window: (nearly) every observation is summed in LDS — against 56 % on random visibility."""
+    p = problems.libmv_bal(problem, copies)
+    for typ, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        s = make_solver(hip, p, typ, pre, max_it=500)
+        info = s.info()
+        assert info.kernel_path == hip.PATH_BAL and info.camera_accum_in_lds == 0 and info.camera_accum_hybrid == 1
+        assert info.points_renumbered == 1 and info.hybrid_popular_rows == 0
+        assert info.num_observations_in_lds >= 0.9 * info.num_observations, (info.num_observations_in_lds, info.num_observations)
+        s.close()
+    check_schur_side(hip, oracle, p, False)
+    check_cgnr_side(hip, oracle, p, False)
+
+
+def test_many_camera_regime_is_hybrid_with_popular_cameras(hip, problems):
+    """The synthetic many-camera shape: skewed popularity -> the popular cameras take most rows, windows do not overlap; more than half of
+    the observations stay in LDS (the parity checks of this shape are test_gpu_fullsize.py::test_many_camera_regime_against_the_oracle)."""
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=50000, num_points=400000, num_observations=1200000, seed=38401, skew=0.6,
+                               with_values=False)
+    for typ, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        s = hip.HipLinearSolver(hip.LinearSolverOptions(type=typ, preconditioner_type=pre, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=10))
+        s.set_structure(p.bs)
+        info = s.info()
+        assert info.camera_accum_hybrid == 1 and info.hybrid_popular_rows > 1000
+        assert 0.5 * info.num_observations < info.num_observations_in_lds < 0.7 * info.num_observations
+        s.close()

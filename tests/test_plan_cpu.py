@@ -293,13 +293,14 @@ def simulate_camera_accumulation(pl, n_cameras, groups, rng):
         accs = np.zeros(groups * K)
         np.add.at(accs, slot_group[loc] * K + acc[loc], v[loc])
         ring[pl["flush_row0"]: pl["flush_row0"] + groups * K] = accs
-        # a row of the shared (popular) part means the same camera in every group; a window row belongs to ONE group
+        # a row of the shared (popular) part means the same camera in every group; inside a group a window row means one camera and a
+        # camera has one row (windows of different groups may overlap: the same camera, a row in each)
         hot = loc & (acc < pl["hot_rows"])
         pairs = np.unique(np.stack([acc[hot], cam[hot]], 1), axis=0)
         assert len(np.unique(pairs[:, 0])) == len(pairs)
         win = loc & (acc >= pl["hot_rows"])
-        trip = np.unique(np.stack([cam[win], slot_group[win], acc[win]], 1), axis=0)
-        assert len(np.unique(trip[:, 0])) == len(trip)
+        trip = np.unique(np.stack([slot_group[win], cam[win], acc[win]], 1), axis=0)
+        assert len(np.unique(trip[:, :2], axis=0)) == len(trip) and len(np.unique(trip[:, [0, 2]], axis=0)) == len(trip)
     else:
         assert not (valid & ~spill).any()
     assert not np.isnan(ring).any()
@@ -340,3 +341,30 @@ def test_hybrid_camera_accumulation_plan(problems, kw, groups, rows, min_local):
 def test_cameras_that_fit_in_lds_have_no_ring(problems):
     p = problems.synthetic_bal("ladybug1723", layout="schur", seed=5, with_values=False)
     assert pkg.hip_solver.debug_hybrid_plan(p.bs, p.num_eliminate_blocks, 256, 1728) is None
+
+
+@pytest.mark.parametrize("problem,copies", [(1, 1), (2, 1), (3, 1), (2, 8)])
+def test_plan_of_real_visibility(problems, problem, copies, monkeypatch):
+    """The three bundle-adjustment problems the reference ships (data/libmv-ba-problems, committed as tests/golden/libmv_problems.npz):
+    26-71 tracks followed through 333-500 consecutive frames — every point is a LONG point (more than 64 observations: it owns whole
+    tiles), the opposite corner of the plan from the BAL shapes."""
+    p = problems.libmv_bal(problem, copies, with_values=False)
+    plan = plan_of(p)
+    check_plan_invariants(p, plan)
+    assert (plan["tile_kind"] != 0).mean() > 0.9
+    monkeypatch.setenv("CERES_HIP_DEBUG_PLAN_REORDER", "1")
+    plan2 = plan_of(p)
+    assert plan2["eligible"] and plan2["n_tiles"] <= plan["n_tiles"]
+    assert np.array_equal(np.sort(plan2["slot_row"][plan2["valid"].astype(bool)]), np.arange(p.bs.num_row_blocks))
+
+
+def test_hybrid_plan_keeps_real_tracks_in_lds(problems):
+    """Replicated to 13 200 cameras (30 copies of problem_02 side by side) the cameras no longer fit in LDS; a copy's 440 cameras fit one
+    window and windows overlap, so nearly every observation of a track is summed in its workgroup's LDS (random visibility: 56 %)."""
+    p = problems.libmv_bal(2, 30, with_values=False)
+    n_c = p.bs.num_col_blocks - p.num_eliminate_blocks
+    pl = pkg.hip_solver.debug_hybrid_plan(p.bs, p.num_eliminate_blocks, 64, 1728)
+    assert pl is not None and pl["hybrid"] and pl["hot_rows"] == 0     # no camera is "popular" here: every row goes to the windows
+    local = simulate_camera_accumulation(pl, n_c, 64, np.random.default_rng(2))
+    print(f"summed in LDS: {local:.3f}")
+    assert local > 0.9
