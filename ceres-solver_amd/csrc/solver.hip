@@ -147,6 +147,7 @@ struct ceres_hip_solver {
   double* cg_rhs = nullptr;
   double* cg_pq_parts = nullptr;   // kMaxPqParts partial sums of p.q left by the operator's kernels
   bool cg_fused = true;            // CERES_HIP_CG_FUSED=0: the five-kernel iteration (A/B measurements)
+  int last_cg_iterations = 2;      // of the previous solve: the length of the next solve's first batch of iterations (run_cg)
   int nine_wide_from = 0;          // column blocks [nine_wide_from, ncb) are all 9 wide (BAL: the cameras)
   CgScalars* h_scalars = nullptr;  // pinned
   double* h_pinned = nullptr;      // pinned scratch, 2 * kMaxVecGrid + 8 doubles (scalar read-backs of the LM step)
@@ -965,7 +966,10 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
   // for it, otherwise 2, 4, 8, 16, 16, ... (short solves do not pay for no-op launches,
   // long ones poll rarely).
   const bool adaptive = s->opt.cg_check_interval <= 0;
-  int interval = adaptive ? 2 : s->opt.cg_check_interval;
+  // The FIRST batch is as long as the previous solve of this instance was (consecutive trust-region steps need about the same number
+  // of iterations: no surplus launches, one poll); then 2, 4, 8, 16, 16, ...
+  int interval = adaptive ? std::max(2, std::min(s->last_cg_iterations, 64)) : s->opt.cg_check_interval;
+  bool first_batch = true;
 
   // Fused iteration: operator (+ p.q where its kernels have p and q in registers) -> cg_update (alpha, x, r, M^-1 r)
   // -> cg_finalize_direction (tests, beta, p): 2 launches after the operator instead of 5.  Needs a block-diagonal
@@ -1056,13 +1060,14 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
     }
     if (spec.before_poll) TRY(spec.before_poll());
     TRY(poll_scalars(s));
-    if (adaptive) interval = std::min(16, interval * 2);
+    if (adaptive) { interval = first_batch ? 2 : std::min(16, interval * 2); first_batch = false; }
     if (it > max_it && s->h_scalars->status == kCgRunning)
       return fail(s, CERES_HIP_E_INVALID, "CG did not terminate after max_num_iterations (device status 0)");
   }
   (void)status;
   if (s->h_scalars->status == kCgZeroRhs && spec.x0_nonzero) HIP_TRY(s, hipMemsetAsync(B.x, 0, sizeof(double) * B.n, st));
   fill_summary(*s->h_scalars, s->h_scalars->status, summary);
+  s->last_cg_iterations = summary->num_iterations;
   return 0;
 }
 

