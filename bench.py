@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--extra-synthetic10m", type=int, default=1,
                     help="default venice1778 run at N=1: also run `--workload synthetic10M` (BASELINE.json configs[4]) in a child process and put a "
                          "condensed result under extra.synthetic10M (0: skip)")
+    ap.add_argument("--extra-real-graph", type=int, default=1, help="default line: S.x / JtJx on the replicated libmv visibility graph (extra.real_graph)")
+    ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=0, help="many-camera workloads: also time the fp32-tile storage mode (extra.fp32_tiles)")
     return ap.parse_args()
 
@@ -499,6 +501,52 @@ def main():
             except Exception as ex:  # the default line must not depend on the child
                 extra["synthetic10M"] = {"error": repr(ex)[:300]}
 
+    # ---- REAL visibility next to the synthetic shapes: the libmv problems the reference ships, replicated to size (tools/real_graph_times.py) ----
+    if world == 1 and args.extra_real_graph and args.workload == "venice1778" and not storage:
+        try:
+            rg = {"what": "S.x / JtJx (HIP events, as roofline) on the visibility graph of data/libmv-ba-problems/problem_02.bin (tests/golden/libmv_problems.npz: 71 tracks "
+                          "through 440 consecutive frames) replicated side by side, N(0,1) values: every point has far more than 64 observations (it owns whole tiles), "
+                          "neighbouring cameras see the same points", "cases": []}
+            for copies in (4, 120):
+                rp = pkg.problems.libmv_bal(2, copies)
+                r_np = rp.num_eliminate_blocks
+                r_nc, r_no = rp.bs.num_col_blocks - r_np, rp.bs.num_row_blocks
+                case = {"copies": copies, "cameras": r_nc, "points": r_np, "observations": r_no}
+                for sv, kd in (("iterative_schur", "sx"), ("cgnr", "jtjx")):
+                    rs = make_solver(hs, rp.bs, r_np, sv, local_rank, None, 0)
+                    ri = rs.info()
+                    rs.load(rp.values, rp.b, rp.D)
+                    rms = min(rs.time_op(hs.TIMED_SX if kd == "sx" else hs.TIMED_JTJX, 20) for _ in range(3))
+                    case[kd] = {"ms": round(rms, 5), "frac": round(algorithmic_bytes(kd, r_no, r_np, r_nc, 8) / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    case.update({"accumulators_in_lds": int(ri.camera_accum_in_lds), "hybrid": int(ri.camera_accum_hybrid),
+                                 "observations_summed_in_lds": round(ri.num_observations_in_lds / float(r_no), 4)})
+                    rs.close()
+                rg["cases"].append(case)
+            extra["real_graph"] = rg
+        except Exception as ex:  # the default line must not depend on it
+            extra["real_graph"] = {"error": repr(ex)[:300]}
+
+    # ---- DENSE_SCHUR's factorisation on the matrix pipe (the one real contraction of the path: SURVEY §8 f2) ----
+    if world == 1 and args.extra_dense_cholesky and args.workload == "venice1778" and not storage:
+        try:
+            n_dc = 8190   # 910 cameras x 9
+            rng_dc = np.random.default_rng(8190)
+            Bm = rng_dc.standard_normal((n_dc, n_dc)) * 0.5
+            Am = (Bm + Bm.T) / 2 + n_dc * 0.6 * np.eye(n_dc)
+            xt = rng_dc.standard_normal(n_dc)
+            xs, ms_dc, failed_dc = solver.dense_cholesky_solve(np.triu(Am), Am @ xt, repeats=3)
+            tf = n_dc ** 3 / 3.0 / ms_dc / 1e9
+            extra["dense_schur_cholesky"] = {
+                "what": "DenseCholesky::FactorAndSolve of a random SPD matrix the size of a 910-camera reduced system (blocked, 128-wide panels, "
+                        "trailing update on v_mfma_f64_16x16x4_f64; csrc/kernels_schur.hip)", "n": n_dc, "factor_ms": round(ms_dc, 3),
+                "TFLOPs": round(tf, 2), "peak_TFLOPs_datasheet_fp64_matrix": 78.6, "frac_of_datasheet_peak": round(tf / 78.6, 4),
+                "mfma_f64_sustained_TFLOPs_probe": 35.6, "frac_of_probe": round(tf / 35.6, 4),
+                "probe": "tools/probes/mfma_f64_probe.hip, profiles/r03j_mfma_f64_probe.txt: 16 independent accumulator chains per wave, no memory traffic",
+                "failed": bool(failed_dc), "rel_err_of_solve": float(np.linalg.norm(xs - xt) / np.linalg.norm(xt))}
+            del Bm, Am
+        except Exception as ex:
+            extra["dense_schur_cholesky"] = {"error": repr(ex)[:300]}
+
     # ---- CPU baseline: the oracle (a restatement of Ceres' algorithm, "port") on this box's cores ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -558,7 +606,7 @@ def main():
         except Exception:
             pass
         cpu = {"value": round(n_done / cpu_t, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_done} full {args.workload}-shaped {args.solver} " + ("LM steps (diag, solve, model cost)" if args.step == "lm_step" else "solves") + " (same inputs, eta={args.eta}), "
+               "sample": f"{n_done} full {args.workload}-shaped {args.solver} " + ("LM steps (diag, solve, model cost)" if args.step == "lm_step" else "solves") + f" (same inputs, eta={args.eta}), "
                          f"oracle/libceres_oracle.so with OpenMP over {cores} threads, {cpu_t:.1f} s; "
                          f"one-step probe seconds by thread count: { {k: round(v, 2) for k, v in probe.items()} } on {ncpu} host cpus" + probe_txt,
                "cg_iterations": cpu_iters, "step_rel_diff_vs_gpu": parity}

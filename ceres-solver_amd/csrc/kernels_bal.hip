@@ -262,6 +262,10 @@ __device__ __forceinline__ void issue_idx(const BalArgs& A, int64_t tile, int la
   i.cam = stream_load<4>(A.slot_cam + sl);
   i.seg = stream_load<4>(A.slot_seg + sl);
 }
+// NT: the tile stream is larger than the Infinity Cache (non-temporal loads, see stream_load); a problem whose tiles fit there — and in
+// the L2s, whose workgroup -> tile mapping is the same in every pass — is better off with plain loads: the next pass finds them on die
+// (Ladybug shape: S.x 49 -> 41 us, Dubrovnik 13.0 -> 11.7; profiles/r03n_small_shapes_nt_loads_ab.txt).
+template <bool NT = true>
 __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int lane, Slot& s) {
   s.slot = tile * kTile + lane;
   s.zbase = A.tile_zbase ? A.tile_zbase[tile] : 0;
@@ -269,7 +273,7 @@ __device__ __forceinline__ void issue_pairs(const BalArgs& A, int64_t tile, int 
   const double2* J = A.J + tile * kTilePitch + lane;
   double2 p[kPairsPerSlot];
 #pragma unroll
-  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = stream_load<1>(J + j * kTile);
+  for (int j = 0; j < kPairsPerSlot; ++j) p[j] = NT ? stream_load<1>(J + j * kTile) : J[j * kTile];
   s.e[0] = p[0].x; s.e[1] = p[0].y; s.e[2] = p[1].x; s.e[3] = p[1].y; s.e[4] = p[2].x; s.e[5] = p[2].y;
 #pragma unroll
   for (int j = 0; j < 9; ++j) { s.f[2 * j] = p[3 + j].x; s.f[2 * j + 1] = p[3 + j].y; }
@@ -967,7 +971,7 @@ __device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int l
   }
 }
 
-template <int MODE, bool LDS>
+template <int MODE, bool LDS, bool NT>
 __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   constexpr int BLOCK = 512;
   extern __shared__ double lds_acc[];
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     __builtin_amdgcn_sched_barrier(0);
     issue_idx(A, min(tile + nwaves, last), lane, i1);
     __builtin_amdgcn_sched_barrier(0);
-    issue_pairs(A, tile, lane, sa);
+    issue_pairs<NT>(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
     sa.cam = i2.cam; sa.seg = i2.seg;
     finish_slot(sa, lane, A.tile_pt0[tile]);
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       naux = A.tile_aux[next];
       issue_idx(A, min(next + nwaves, last), lane, i2);
       __builtin_amdgcn_sched_barrier(0);
-      issue_pairs(A, next, lane, n);
+      issue_pairs<NT>(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);
       n.cam = i1.cam; n.seg = i1.seg;
       finish_slot(n, lane, A.tile_pt0[next]);
@@ -1566,18 +1570,24 @@ int BalBlockFor(int mode) {
   return 1024;
 }
 
-template <int MODE>
-static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+template <int MODE, bool NT>
+static hipError_t launch_stream2(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   if (lds) {
-    auto k = bal_stream_kernel<MODE, true>;
+    auto k = bal_stream_kernel<MODE, true, NT>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
   } else {
-    auto k = bal_stream_kernel<MODE, false>;
+    auto k = bal_stream_kernel<MODE, false, NT>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), (size_t(A.hyb_rows) * 9 + size_t(512 / 64) * kTile * 9) * sizeof(double), stream, A);
   }
   return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_stream(const BalArgs& A, bool lds, int grid, hipStream_t stream) {
+  // tiles that fit the 256 MiB Infinity Cache are read with plain loads (see issue_pairs)
+  const bool nt = A.n_tiles * int64_t(kTilePitch) * int64_t(sizeof(double2)) > (int64_t(200) << 20);
+  return nt ? launch_stream2<MODE, true>(A, lds, grid, stream) : launch_stream2<MODE, false>(A, lds, grid, stream);
 }
 
 // CERES_HIP_PIPELINE=0 falls back to the unpipelined kernels (A/B measurements).
