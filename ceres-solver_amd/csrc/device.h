@@ -348,7 +348,8 @@ hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, dou
 
 // ---- one-shot peer-to-peer all-reduce (kernels_cg.hip) ----
 constexpr int kP2pMaxWorld = 8;   // one node: 8 GPUs on the xGMI mesh
-constexpr int kP2pChunk = 2048;   // doubles per workgroup
+constexpr int kP2pChunk = 2048;   // doubles per workgroup and round
+constexpr int kP2pMaxGrid = 256;  // workgroups of one all-reduce (each takes every kP2pMaxGrid-th chunk): never the whole device spinning
 struct P2pPeers {
   double* slots[kP2pMaxWorld];               // rank q's receive slots [2][world][cap], as mapped into THIS process
   unsigned long long* flags[kP2pMaxWorld];   // rank q's arrival flags [2][world][chunks_cap]

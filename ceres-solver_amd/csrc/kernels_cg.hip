@@ -823,61 +823,68 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
   // timeout again (error_seen: device memory, a cheap load; error_flag: mapped host memory for the host)
   if (threadIdx.x == 0) timed_out = __hip_atomic_load(error_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (timed_out) {
-    for (int k = 0; k < kP2pChunk / 256; ++k) {
-      const int64_t i = int64_t(blockIdx.x) * kP2pChunk + threadIdx.x + 256 * k;
-      if (i < n) out[i] = __builtin_nan("");
-    }
-    return;
-  }
   const int parity = int(epoch & 1ull);
-  const int c = blockIdx.x;
-  const int64_t lo = int64_t(c) * kP2pChunk;
   constexpr int kPer = kP2pChunk / 256;
-  double v[kPer];
+  const int n_chunks = int((n + kP2pChunk - 1) / kP2pChunk);
+  // A workgroup takes every gridDim.x-th chunk, in the same order on every rank (the grid is a function of n alone): a long vector
+  // — the step's merged sum is 99 doubles per camera — must not fill the GPU with spinning workgroups.  Ranks that SHARE a device
+  // (the one-GPU validation runs) would otherwise starve each other's kernels, whose data the spinners are waiting for.
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t lo = int64_t(c) * kP2pChunk;
+    if (timed_out) {   // an earlier chunk of this workgroup timed out
 #pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int64_t i = lo + threadIdx.x + 256 * k;
-    v[k] = i < n ? in[i] : 0.0;
-  }
-  for (int q = 0; q < world; ++q) {
-    double* dst = P.slots[q] + (int64_t(parity) * world + rank) * cap;
+      for (int k = 0; k < kPer; ++k) {
+        const int64_t i = lo + threadIdx.x + 256 * k;
+        if (i < n) out[i] = __builtin_nan("");
+      }
+      continue;
+    }
+    double v[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int64_t i = lo + threadIdx.x + 256 * k;
-      if (i < n) dst[i] = v[k];
+      v[k] = i < n ? in[i] : 0.0;
     }
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (int(threadIdx.x) < world) {
-    const int q = threadIdx.x;
-    __hip_atomic_store(P.flags[q] + (int64_t(parity) * world + rank) * chunks_cap + c, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long* f = P.flags[rank] + (int64_t(parity) * world + q) * chunks_cap + c;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: do not hang the GPU
-        __hip_atomic_store(error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // mapped host memory: the host reads it after its next synchronisation
-        __hip_atomic_store(error_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        timed_out = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-  }
-  __syncthreads();
-  __threadfence_system();
-  const double* mine = P.slots[rank] + int64_t(parity) * world * cap;
+    for (int q = 0; q < world; ++q) {
+      double* dst = P.slots[q] + (int64_t(parity) * world + rank) * cap;
 #pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int64_t i = lo + threadIdx.x + 256 * k;
-    if (i < n) {
-      double s = 0.0;
-      for (int q = 0; q < world; ++q) s += mine[q * cap + i];
-      // an incomplete sum must not be consumed: NaN flows into the CG scalars, whose tests then end the solve (rho / alpha not finite), and
-      // the host reports CERES_HIP_E_COMM at its next poll
-      out[i] = timed_out ? __builtin_nan("") : s;
+      for (int k = 0; k < kPer; ++k) {
+        const int64_t i = lo + threadIdx.x + 256 * k;
+        if (i < n) dst[i] = v[k];
+      }
     }
+    __threadfence_system();
+    __syncthreads();
+    if (int(threadIdx.x) < world) {
+      const int q = threadIdx.x;
+      __hip_atomic_store(P.flags[q] + (int64_t(parity) * world + rank) * chunks_cap + c, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned long long* f = P.flags[rank] + (int64_t(parity) * world + q) * chunks_cap + c;
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: do not hang the GPU
+          __hip_atomic_store(error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // mapped host memory: the host reads it after its next synchronisation
+          __hip_atomic_store(error_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          timed_out = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const double* mine = P.slots[rank] + int64_t(parity) * world * cap;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int64_t i = lo + threadIdx.x + 256 * k;
+      if (i < n) {
+        double s = 0.0;
+        for (int q = 0; q < world; ++q) s += mine[q * cap + i];
+        // an incomplete sum must not be consumed: NaN flows into the CG scalars, whose tests then end the solve (rho / alpha not finite), and
+        // the host reports CERES_HIP_E_COMM at its next poll
+        out[i] = timed_out ? __builtin_nan("") : s;
+      }
+    }
+    __syncthreads();   // `timed_out` is read above and may be written in the next round
   }
 }
 }  // namespace
@@ -886,7 +893,7 @@ hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2
                               unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, int* error_seen, double timeout_seconds,
                               hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  const int grid = int((n + kP2pChunk - 1) / kP2pChunk);
+  const int grid = int(std::min<int64_t>((n + kP2pChunk - 1) / kP2pChunk, kP2pMaxGrid));
   const long long ticks = (long long)(timeout_seconds * 1e8);  // wall_clock64 counts at 100 MHz
   hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(grid), dim3(256), 0, stream, in, out, n, peers, rank, world, epoch, cap, chunks_cap,
                      error_flag, error_seen, ticks);

@@ -61,12 +61,11 @@ def assemble(partition_mod, recs, num_cols, key):
     return x
 
 
-@pytest.fixture(scope="module")
-def bal_case(hip, oracle, problems):
-    """The problem of the sharded BAL test and everything the oracle says about it (computed once for all world sizes)."""
-    kw = dict(kind="bal", seed=31, nc=37, np=6000, no=26000, skew=0.5,
+def make_bal_case(hip, oracle, problems, nc, npts, nobs):
+    """A problem of the sharded BAL tests and everything the oracle says about it (computed once for all world sizes)."""
+    kw = dict(kind="bal", seed=31, nc=nc, np=npts, no=nobs, skew=0.5,
               solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)])
-    p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=37, num_points=6000, num_observations=26000)
+    p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=nc, num_points=npts, num_observations=nobs)
     m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
     m0 = oracle.Matrix(p.bs, 0)
     ref = {}
@@ -84,9 +83,30 @@ def bal_case(hip, oracle, problems):
     return kw, p, m0, ref
 
 
+@pytest.fixture(scope="module")
+def bal_case(hip, oracle, problems):
+    return make_bal_case(hip, oracle, problems, 37, 6000, 26000)
+
+
+@pytest.fixture(scope="module")
+def many_camera_case(hip, oracle, problems):
+    # 2600 cameras: more than LDS holds — every rank builds a hybrid plan for its shard (popular cameras + windows, the rest spilled),
+    # CGNR runs on internally numbered points, and the step's merged all-reduce is 99 x 2600 doubles = 126 chunks of the one-shot kernel
+    return make_bal_case(hip, oracle, problems, 2600, 9000, 30000)
+
+
 @pytest.mark.parametrize("world", WORLDS)
 def test_sharded_bal_both_solvers_against_the_oracle(hip, bal_case, world):
-    kw, p, m0, ref = bal_case
+    check_sharded_case(hip, bal_case, world)
+
+
+@pytest.mark.parametrize("world", (2, 4))
+def test_sharded_many_camera_regime_against_the_oracle(hip, many_camera_case, world):
+    check_sharded_case(hip, many_camera_case, world)
+
+
+def check_sharded_case(hip, case, world):
+    kw, p, m0, ref = case
     res = run_ranks([("bal", kw)], world)
     for solver_type, pre in kw["solvers"]:
         recs = [res[r][("bal", solver_type, pre)] for r in range(world)]
