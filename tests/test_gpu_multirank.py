@@ -92,7 +92,7 @@ def bal_case(hip, oracle, problems):
 def many_camera_case(hip, oracle, problems):
     # 2600 cameras: more than LDS holds — every rank builds a hybrid plan for its shard (popular cameras + windows, the rest spilled),
     # CGNR runs on internally numbered points, and the step's merged all-reduce is 99 x 2600 doubles = 126 chunks of the one-shot kernel
-    return make_bal_case(hip, oracle, problems, 2600, 9000, 30000)
+    return make_bal_case(hip, oracle, problems, 2600, 20000, 90000)
 
 
 @pytest.mark.parametrize("world", WORLDS)
