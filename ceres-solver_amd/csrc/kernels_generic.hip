@@ -369,20 +369,91 @@ inline unsigned blocks_for(int64_t n) { return unsigned((n + kB - 1) / kB); }
 // out[81 c + 9 a + b] = sum over the remainder cells of camera c of (F^T F)(a, b): what SchurEliminator::NoEBlockRowsUpdate adds to
 // the diagonal cell of S (I/schur_eliminator_impl.h:574-666) and UpdateBlockDiagonalFtF's second loop to blockdiag(F^T F)
 // (I/partitioned_matrix_view_impl.h:617-658).  One thread per entry through the transpose list of the camera's column block.
+// One WAVEFRONT per camera, one LANE per cell (64 cells per round): a lane forms its cell's F^T F — the 45 upper-triangle entries, every
+// load of a row in flight at once — and the wave adds the lanes' results up by shuffles.  (Thread per entry, as this kernel first was,
+// and then wave per camera with every lane walking all the cells, are one long chain of dependent loads: 131 / 140 us for 50 k prior rows
+// on 1778 cameras.)
+template <int RS>   // rows of a cell known at compile time (9: priors on whole cameras), or 0: read from the structure
+__device__ __forceinline__ void cell_ftf_upper(const double* __restrict__ m, int rs, double (&u)[45]) {
+  const int n = RS > 0 ? RS : rs;
+#pragma unroll
+  for (int r = 0; r < (RS > 0 ? RS : 1); ++r) {
+    for (int rr = r; rr < n; rr += (RS > 0 ? RS : 1)) {
+      double f[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) f[k] = m[rr * 9 + k];
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b2 = a; b2 < 9; ++b2) u[idx++] += f[a] * f[b2];
+    }
+  }
+}
 __global__ __launch_bounds__(kB) void rem_camera_blocks_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
                                                                int n_cameras, double* __restrict__ out) {
-  const int64_t e = int64_t(blockIdx.x) * kB + threadIdx.x;
-  if (e >= int64_t(81) * n_cameras) return;
-  const int c = int(e / 81), a = int(e % 81) / 9, b = int(e % 9);
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
+  if (c >= n_cameras) return;
   const int j = cam_block[c];
-  double s = 0;
-  for (int t = R.tptr[j]; t < R.tptr[j + 1]; ++t) {
-    const int i = R.trow[t], k = R.tcell[t];
-    const double* m = v + R.cval[k];
-    const int rs = R.rsz[i];
-    for (int r = 0; r < rs; ++r) s += m[r * 9 + a] * m[r * 9 + b];
+  double u[45];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) u[i] = 0.0;
+  for (int t = R.tptr[j] + lane; t < R.tptr[j + 1]; t += 64) {
+    const int rs = R.rsz[R.trow[t]];
+    const double* m = v + R.cval[R.tcell[t]];
+    if (rs == 9) cell_ftf_upper<9>(m, rs, u);
+    else cell_ftf_upper<0>(m, rs, u);
   }
-  out[e] = s;
+  double* o = out + 81 * int64_t(c);
+  int idx = 0;
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int b2 = a; b2 < 9; ++b2) {
+      double x = u[idx++];
+#pragma unroll
+      for (int w = 32; w >= 1; w >>= 1) x += __shfl_xor(x, w, 64);
+      if (lane == 0) { o[9 * a + b2] = x; o[9 * b2 + a] = x; }
+    }
+}
+// y_f[pos(c) + k] += sum over the remainder cells of camera c of sum_r F[r][k] t[row + r]: F_R^T t on the 9-wide camera blocks, one
+// WAVEFRONT per camera — lane = (cell slot 0..6, column k 0..8), seven cells per round, the seven partial sums of a column combined by
+// shuffles; a 9-row cell's loads are all issued before the first is used.  (gen_left_multiply_kernel's thread per output scalar walks a
+// camera's cells alone: 111 us per call on the same problem, three calls per solve: a Venice-shaped problem with 1 % prior rows ran 1.32x
+// the pure one.)
+__global__ __launch_bounds__(kB) void rem_left_multiply9_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
+                                                                const int32_t* __restrict__ cam_pos, int n_cameras, const double* __restrict__ t_rows,
+                                                                double* __restrict__ y_f, const int* __restrict__ status) {
+  if (status && *status != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
+  if (c >= n_cameras) return;
+  const int j = cam_block[c];
+  const int cs = lane / 9, k = lane - 9 * cs;   // lane 63: cs = 7, idle
+  double acc = 0;
+  const int t0 = R.tptr[j], t1 = R.tptr[j + 1];
+  for (int t = t0 + cs; t < t1 && cs < 7; t += 7) {
+    const int i = R.trow[t];
+    const double* m = v + R.cval[R.tcell[t]] + k;
+    const double* tr = t_rows + R.rpos[i];
+    const int rs = R.rsz[i];
+    if (rs == 9) {
+      double a[9], x[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) { a[r] = m[r * 9]; x[r] = tr[r]; }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) acc += a[r] * x[r];
+    } else {
+      for (int r = 0; r < rs; ++r) acc += m[r * 9] * tr[r];
+    }
+  }
+  double u = __shfl_down(acc, 36, 64);
+  if (lane < 27) acc += u;
+  u = __shfl_down(acc, 18, 64);
+  if (lane < 18) acc += u;
+  u = __shfl_down(acc, 9, 64);
+  if (lane < 9) y_f[(cam_pos ? cam_pos[c] : 9 * c) + k] += acc + u;
 }
 // y[pos(c) + k] += blocks[81 c + 10 k]: the remainder's share of the camera columns' squared norms
 __global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int n_cameras,
@@ -410,7 +481,13 @@ __global__ __launch_bounds__(kB) void rem_model_cost_kernel(const double* __rest
 }  // namespace
 
 hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, double* out, hipStream_t s) {
-  if (n_cameras > 0) hipLaunchKernelGGL(rem_camera_blocks_kernel, dim3(blocks_for(int64_t(81) * n_cameras)), dim3(kB), 0, s, R, values, cam_block, n_cameras, out);
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_camera_blocks_kernel, dim3((n_cameras + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, R, values, cam_block, n_cameras, out);
+  return hipGetLastError();
+}
+hipError_t LaunchRemLeftMultiply9(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras,
+                                  const double* t_rows, double* y_f, const int* status, hipStream_t s) {
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_left_multiply9_kernel, dim3((n_cameras + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, R, values, cam_block, cam_pos,
+                                        n_cameras, t_rows, y_f, status);
   return hipGetLastError();
 }
 hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, double* y, hipStream_t s) {

@@ -359,10 +359,10 @@ int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f,
     case kBalSx: case kBalJtJx:   // F_R^T (F_R x)
       HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
       HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, status, st));
-      HIP_TRY(s, LaunchGenLeftMultiply(s->GR, s->values, kF, s->rem_tmp, y_f, status, st));
+      HIP_TRY(s, LaunchRemLeftMultiply9(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->rem_tmp, y_f, status, st));
       return 0;
     case kBalInit: case kBalJtb: case kBalCgnrInit:   // F_R^T b_R
-      if (s->have_b) HIP_TRY(s, LaunchGenLeftMultiply(s->GR, s->values, kF, s->b + s->rem_b0, y_f, status, st));
+      if (s->have_b) HIP_TRY(s, LaunchRemLeftMultiply9(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->b + s->rem_b0, y_f, status, st));
       return 0;
     case kBalColNorm:   // diag(F_R^T F_R)
       TRY(ensure_rem_blocks(s));

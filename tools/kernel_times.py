@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the dominant operators on a cached Venice-shaped problem (GPU box helper).
-usage: kernel_times.py [workload] ; honours CERES_HIP_BAL_BLOCK."""
+usage: kernel_times.py [workload] [--force-generic] ; honours CERES_HIP_BAL_BLOCK.  --force-generic: the thread-per-scalar generic kernels
+(any block sizes; one reference operator per launch) on the same problem, so that their cost is a number."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +9,9 @@ import torch
 import __graft_entry__ as entry
 pkg = entry.load_package()
 hs = pkg.hip_solver
-wl = sys.argv[1] if len(sys.argv) > 1 else "venice1778"
+force_generic = "--force-generic" in sys.argv
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+wl = args_[0] if args_ else "venice1778"
 cache = f"/tmp/{wl}.npz"
 P = pkg.problems
 if os.path.exists(cache):
@@ -23,7 +26,7 @@ else:
 n_c, n_p, n_o = P.BAL_SHAPES[wl]
 B_jtjx = n_o * 200 + (3 * n_p + 9 * n_c) * 32
 B_sx = n_o * 200 + n_p * 72 + n_c * 288
-out = {"block": os.environ.get("CERES_HIP_BAL_BLOCK", "default"), "workload": wl}
+out = {"block": os.environ.get("CERES_HIP_BAL_BLOCK", "default"), "workload": wl, "kernel_path": "generic" if force_generic else "fused<2,3,9>"}
 skew = 0.6
 for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JTJX, B_jtjx), ("block_jacobi", hs.TIMED_BLOCK_JACOBI, None), ("cgnr_setup", hs.TIMED_CGNR_SETUP, None)]),
                               ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, [("sx", hs.TIMED_SX, B_sx), ("schur_init", hs.TIMED_SCHUR_INIT, None),
@@ -33,14 +36,16 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
     out["storage"] = "fp32" if storage else "fp64"
     if storage:
         ops = [o for o in ops if o[0] not in ("read_stream",)]
+    if force_generic:
+        ops = [o for o in ops if o[0] in ("jtjx", "block_jacobi", "sx", "schur_init", "schur_jacobi", "back_substitute")]
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
-                                                  elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage))
+                                                  elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage, force_generic_path=force_generic))
     s.set_structure(prob.bs)
     s.load(prob.values, prob.b, prob.D)
     for name, op, nbytes in ops:
         if nbytes == "tiles":
             nbytes = int(s.info().num_tiles) * 12288
-        ms = min(s.time_op(op, 30) for _ in range(3))
+        ms = min(s.time_op(op, 5 if force_generic else 30) for _ in range(2 if force_generic else 3))
         out[name + "_ms"] = round(ms, 4)
         if nbytes:
             out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
