@@ -9,7 +9,8 @@ import pytest
 
 from conftest import ROOT
 
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")) +
+               [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -36,7 +37,7 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "under_rocprof" not in path and "fp32" not in path and not two_ranks:   # profiled / fp32-storage / validation runs skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
-    if os.path.basename(path).startswith("r02"):   # round 2: what the traffic figure is, and the probe for real Ceres
+    if os.path.basename(path).startswith(("r02", "r03")):   # since round 2: what the traffic figure is, and the probe for real Ceres
         assert r["traffic"] is None or "profiles/" in r["traffic_source"]
         if cpu:
             assert "tools/probe.sh" in cpu["sample"]
@@ -66,3 +67,21 @@ def test_synthetic10m_lines_name_the_many_camera_configuration():
         d = json.loads(open(os.path.join(ROOT, "profiles", f"r02x_bench_synthetic10M_{storage}.json")).read())
         assert d["config"]["workload"].startswith("synthetic10M") and d["config"]["jacobian_storage"].startswith(storage)
         assert d["config"]["camera_accumulators_in_lds"] is False and d["dtype"] == "f64"
+
+
+def test_round3_default_line_carries_the_configurations_the_review_asked_for():
+    """VERDICT r02 "next" 1d / 3c / 4 / 8 / 9: BASELINE.json configs[4] (synthetic10M) on the driver-style line, the roofline of the WHOLE step,
+    the scene-valued steps at both eta, S.x / JtJx on real visibility, DENSE_SCHUR's factorisation with the ceiling it is measured against."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03n_bench_default_iterative_schur.json")).read())
+    e = d["extra"]
+    s10 = e["synthetic10M"]
+    assert s10["workload"].startswith("synthetic10M") and s10["sx"]["frac"] >= 0.40 and s10["jtjx"]["frac"] >= 0.40
+    sr = d["step_roofline"]
+    assert sr["bound"] == "hbm" and 0.3 < sr["frac"] < 1.0 and sr["frac"] == pytest.approx(sr["achieved"] / sr["peak"], abs=1e-3)
+    assert set(d["scene_step"]) >= {"eta_0.1", "eta_0.01"}
+    rg = e["real_graph"]["cases"]
+    assert [c["hybrid"] for c in rg] == [0, 1] and rg[1]["observations_summed_in_lds"] > 0.9 and rg[1]["cameras"] > 50000
+    dc = e["dense_schur_cholesky"]
+    assert dc["n"] == 8190 and not dc["failed"] and dc["rel_err_of_solve"] < 1e-12
+    assert dc["frac_of_datasheet_peak"] == pytest.approx(dc["TFLOPs"] / 78.6, abs=1e-3) and dc["frac_of_datasheet_peak"] < 0.30   # said plainly: the 30 % is not met
+    assert d["roofline"]["frac"] >= 0.65 and d["roofline_jtjx"]["frac"] >= 0.60

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 GPU-box session (run through gpurun).  usage: tools/gpu_r03.sh TAG stage [stage ...]
-# new stages: bench_n8 (bench.py's N = 8 code path, eight ranks on ONE GPU: validation only), bench_n4, ab (A/B libraries:
+# new stages: dense realgraph leftover generic small_ab; bench_n8 (bench.py's N = 8 code path, eight ranks on ONE GPU: validation only), bench_n4, ab (A/B libraries:
 # VARIANTS="base xent ..." REPS=3 WL=venice1778), longcg_ab, pytest_multirank; every other stage is tools/gpu_r02.sh's.
 TAG=$1; shift
 REPO=$(cd $(dirname $0)/.. && pwd)
@@ -37,6 +37,26 @@ import json,sys; d=json.loads(sys.stdin.read()); print({k:d.get(k) for k in ('jt
     pytest_multirank)
       echo "===== $STAGE ($(date +%T))"
       timeout 1800 python -m pytest tests/test_gpu_multirank.py -m gpu -q --timeout 900 2>&1 | tail -40 | tee $OUT/pytest_multirank_$TAG.log | tail -15 ;;
+    dense)     # DENSE_SCHUR's factorisation: MFMA probe + times at 228 / 456 / 910 cameras (+ kernel stats at n = 8190)
+      echo "===== $STAGE ($(date +%T))"
+      timeout 120 ./tools/probes/mfma_f64_probe | tee $OUT/mfma_f64_probe_$TAG.txt
+      timeout 300 python tools/dense_cholesky_times.py 2052 4104 8190 2>&1 | grep "^{" | tee $OUT/dense_cholesky_$TAG.jsonl
+      cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_dc
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dc -o dc -- python $REPO/tools/dense_cholesky_times.py 8190 > /dev/null 2>&1
+      F=$(find /tmp/prof_dc -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/kernel_stats_dense_cholesky_8190_$TAG.csv && head -8 $F | cut -c1-200
+      cd $REPO ;;
+    realgraph) # S.x / JtJx on the replicated libmv visibility graphs
+      echo "===== $STAGE ($(date +%T))"
+      timeout 600 python tools/real_graph_times.py 2>/dev/null | tee $OUT/real_graph_$TAG.jsonl ;;
+    leftover)  # Venice shape + 1 % prior rows against the pure problem
+      echo "===== $STAGE ($(date +%T))"
+      timeout 600 python tools/leftover_rows_times.py 2>/dev/null | tee $OUT/leftover_rows_$TAG.json ;;
+    generic)   # the generic path, timed once (Ladybug shape)
+      echo "===== $STAGE ($(date +%T))"
+      timeout 300 python tools/kernel_times.py ladybug1723 --force-generic 2>/dev/null | tail -1 | tee $OUT/ktimes_generic_ladybug_$TAG.json ;;
+    small_ab)  # launch- / latency-bound shapes per library variant
+      echo "===== $STAGE ($(date +%T))"
+      bash tools/gpu_small_ab.sh 2>&1 | tee $OUT/small_ab_$TAG.txt ;;
     *) bash tools/gpu_r02.sh $TAG $STAGE ;;
   esac
 done
