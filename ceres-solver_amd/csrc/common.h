@@ -31,6 +31,7 @@ constexpr int kPairsPerSlot = 12;   // 24 Jacobian doubles per observation as 12
 #endif
 constexpr int kTilePitch = CERES_HIP_AB_TILE_ROWS * 64;
 constexpr size_t kLdsBytesPerCu = 160 * 1024;  // LDS per CU on gfx950
+constexpr int kSchurItem = 128;        // max triples of one work item of the explicit Schur elimination
 constexpr int kZUnit = 64;             // max entries of one work unit of the chunked camera-major pass (cameras not in LDS)
 constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalars per tile (two per lane)
 // The per-slot index word of the tiles: camera id in the low kSlotCamBits bits, LDS accumulator row above them (kSlotSpill = none)
@@ -130,7 +131,14 @@ struct SchurStorage {
   std::vector<int64_t> trip_ptr;            // npairs + 1
   std::vector<int32_t> trip_e, trip_k1, trip_k2;  // E block of the chunk (-1: an E-free row), cell of block i, cell of block j
   std::vector<int32_t> cell_row;            // row block of every cell
+  // Work ITEMS of the elimination: at most kSchurItem consecutive triples of ONE pair (a popular camera's diagonal block sums
+  // thousands: one wavefront walking that list alone was the whole kernel's duration); items of a pair are consecutive
+  std::vector<int32_t> item_pair;           // n_items
+  std::vector<int64_t> item_t0, item_t1;    // triples [t0, t1)
+  std::vector<int64_t> item_off;            // n_items + 1: where an item's partial block (n_i x n_j values) sits in the scratch
+  std::vector<int32_t> pair_item_ptr;       // npairs + 1
   int64_t num_values() const { return pair_off.empty() ? 0 : pair_off.back(); }
+  int64_t scratch_values() const { return item_off.empty() ? 0 : item_off.back(); }
 };
 void BuildSchurStorage(const HostStructure& hs, SchurStorage* out);
 

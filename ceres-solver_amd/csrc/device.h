@@ -202,10 +202,19 @@ struct SchurPairs {  // device image of SchurStorage (common.h)
   const int32_t *pair_i = nullptr, *pair_j = nullptr, *row_ptr = nullptr, *col_ptr = nullptr, *col_pair = nullptr;
   const int64_t *pair_off = nullptr, *trip_ptr = nullptr;
   const int32_t *trip_e = nullptr, *trip_k1 = nullptr, *trip_k2 = nullptr, *cell_row = nullptr;
+  // work items of the elimination (common.h): item -> pair, triples [t0, t1), offset of its partial block in `scratch`
+  int n_items = 0;
+  const int32_t *item_pair = nullptr, *pair_item_ptr = nullptr;
+  const int64_t *item_t0 = nullptr, *item_t1 = nullptr, *item_off = nullptr;
+  double* scratch = nullptr;
+  int64_t total_values = 0;   // values of the block-sparse S
 };
 // S (block-sparse, upper block triangle) = SchurEliminator::Eliminate; D may be nullptr (then no D_f^2 on the diagonal)
 hipError_t LaunchSchurSparseEliminate(const GenStructure& G, const SchurPairs& P, const double* values, const double* ete_inv,
                                       const double* D, double* S, hipStream_t stream);
+// dense lhs (num_cols_f^2, zeroed by the caller) <- the stored blocks of S (`total` values): DENSE_SCHUR eliminates into the block-sparse
+// storage (a gather per block) and factors the dense image
+hipError_t LaunchSchurBlocksToDense(const GenStructure& G, const SchurPairs& P, const double* S, int64_t total, double* lhs, hipStream_t stream);
 // y (+)= S x   BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate
 hipError_t LaunchSchurSparseSymv(const GenStructure& G, const SchurPairs& P, const double* S, const double* x, double* y,
                                  const int* status, int accumulate, hipStream_t stream);

@@ -661,6 +661,20 @@ void BuildSchurStorage(const HostStructure& h, SchurStorage* out) {
     if (!diag_done) emit(i);
   }
   S.row_ptr[S.nf] = int32_t(S.pair_i.size());
+  // work items: <= kSchurItem triples of one pair (a pair without triples still gets one: its block is written, D^2 joins the diagonal)
+  S.pair_item_ptr.assign(1, 0);
+  S.item_off.assign(1, 0);
+  for (size_t p = 0; p < S.pair_i.size(); ++p) {
+    const int64_t nent = S.pair_off[p + 1] - S.pair_off[p];
+    int64_t t0 = S.trip_ptr[p];
+    do {
+      const int64_t t1 = std::min<int64_t>(S.trip_ptr[p + 1], t0 + kSchurItem);
+      S.item_pair.push_back(int32_t(p)); S.item_t0.push_back(t0); S.item_t1.push_back(t1);
+      S.item_off.push_back(S.item_off.back() + nent);
+      t0 = t1;
+    } while (t0 < S.trip_ptr[p + 1]);
+    S.pair_item_ptr.push_back(int32_t(S.item_pair.size()));
+  }
   // transpose half: for block i the pairs (j, i), j < i
   S.col_ptr.assign(S.nf + 1, 0);
   const int np = int(S.pair_i.size());

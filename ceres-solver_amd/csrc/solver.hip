@@ -135,6 +135,12 @@ struct ceres_hip_solver {
   double* precond = nullptr;
   double* d_S = nullptr;          // explicit Schur complement: dense num_cols_f^2 (DENSE_SCHUR, sharded explicit), or block-sparse values
   bool sparse_S = false;          // use_explicit_schur_complement on one rank: BlockRandomAccessSparseMatrix storage
+  // DENSE_SCHUR on one rank: SchurEliminator::Eliminate as the same gather per block into block-sparse storage (d_Sblk), expanded into
+  // the dense matrix the Cholesky factors — the thread-per-entry dense elimination took 447 ms for 456 cameras / 500 k observations,
+  // against 9 ms of factorisation.  On <2,3,9> problems the fused tile passes do Init / rhs / back-substitution (etei_dense: the
+  // point inverses expanded to the dense E-block store the eliminator reads).
+  bool dense_from_blocks = false;
+  double *d_Sblk = nullptr, *etei_dense = nullptr;
   SchurStorage schur_storage;
   SchurPairs schur_pairs;
   bool precond_valid = false;
@@ -1177,8 +1183,19 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       // DenseSchurComplementSolver (I/schur_complement_solver.cc:163-222): S dense by elimination, Cholesky of its upper
       // triangle (DenseCholesky::FactorAndSolve), back-substitution on SUCCESS.
       const int64_t nf = h.num_cols_f;
-      HIP_TRY(s, LaunchGenSchurDense(s->G, s->values, s->etei, (s->world > 1 && s->rank != 0) ? nullptr : s->D, s->d_S, st));
-      if (s->world > 1) TRY(allreduce(s, s->d_S, size_t(nf * nf)));
+      if (s->dense_from_blocks) {
+        const double* ei = s->etei;
+        if (s->path == CERES_HIP_PATH_BAL) {  // packed 6-per-point inverses (internal point order) -> the dense E-block store
+          HIP_TRY(s, LaunchExpandSym3(s->etei, s->etei_dense, s->d_pt_eoff, s->plan.n_points, st));
+          ei = s->etei_dense;
+        }
+        HIP_TRY(s, LaunchSchurSparseEliminate(s->G, s->schur_pairs, s->values, ei, s->D, s->d_Sblk, st));
+        HIP_TRY(s, hipMemsetAsync(s->d_S, 0, sizeof(double) * size_t(nf) * size_t(nf), st));
+        HIP_TRY(s, LaunchSchurBlocksToDense(s->G, s->schur_pairs, s->d_Sblk, s->schur_storage.num_values(), s->d_S, st));
+      } else {
+        HIP_TRY(s, LaunchGenSchurDense(s->G, s->values, s->etei, (s->world > 1 && s->rank != 0) ? nullptr : s->D, s->d_S, st));
+        if (s->world > 1) TRY(allreduce(s, s->d_S, size_t(nf * nf)));
+      }
       HIP_TRY(s, hipEventRecord(s->ev[4], st));
       HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
       HIP_TRY(s, LaunchDenseCholesky(s->d_S, int(nf), s->d_fail_flag, st));
@@ -1572,7 +1589,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     // Schur solvers: no CG vector lives in point space; CGNR: only where its CG vectors can be the caller's with the points renumbered
     BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
   }
-  s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !is_dense_schur(s)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);
   s->cgnr_internal = !is_schur(s) && s->path == CERES_HIP_PATH_BAL && s->plan.renumbered;
@@ -1618,7 +1636,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), s->stream));
   TRY(dev_alloc(s, &s->rhs_f, size_t(h.num_cols_f)));
   if (dense_S) TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(h.num_cols_f) * size_t(h.num_cols_f))));
-  if (s->sparse_S) {
+  if (s->sparse_S || s->dense_from_blocks) {
     SchurStorage& Q = s->schur_storage;
     BuildSchurStorage(h, &Q);
     SchurPairs& P = s->schur_pairs;
@@ -1635,7 +1653,16 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &q32, Q.trip_k1)); P.trip_k1 = q32;
     TRY(dev_upload(s, &q32, Q.trip_k2)); P.trip_k2 = q32;
     TRY(dev_upload(s, &q32, Q.cell_row)); P.cell_row = q32;
-    TRY(dev_alloc(s, &s->d_S, std::max<size_t>(1, size_t(Q.num_values()))));
+    P.n_items = int(Q.item_pair.size());
+    P.total_values = Q.num_values();
+    TRY(dev_upload(s, &q32, Q.item_pair)); P.item_pair = q32;
+    TRY(dev_upload(s, &q32, Q.pair_item_ptr)); P.pair_item_ptr = q32;
+    TRY(dev_upload(s, &q64, Q.item_t0)); P.item_t0 = q64;
+    TRY(dev_upload(s, &q64, Q.item_t1)); P.item_t1 = q64;
+    TRY(dev_upload(s, &q64, Q.item_off)); P.item_off = q64;
+    { double* sc = nullptr; TRY(dev_alloc(s, &sc, std::max<size_t>(1, size_t(Q.scratch_values())))); P.scratch = sc; }
+    TRY(dev_alloc(s, s->sparse_S ? &s->d_S : &s->d_Sblk, std::max<size_t>(1, size_t(Q.num_values()))));
+    if (s->dense_from_blocks && s->path == CERES_HIP_PATH_BAL) TRY(dev_alloc(s, &s->etei_dense, size_t(h.diag_off_e.back())));
   }
   const int64_t cg_n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(dev_alloc(s, &s->cg.x, size_t(cg_n)));
@@ -2067,7 +2094,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   // (the point block's own diagonal; the camera columns' norms in the camera-major pass): then D
   // is formed inside them and no separate column-norm pass runs.
   const bool fresh = !o->reuse_diagonal || !s->have_lm_diag;
-  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->opt.preconditioner_type != CERES_HIP_IDENTITY;
+  // (DENSE_SCHUR forms no preconditioner blocks: nobody would form the camera part of a fused diagonal)
+  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->opt.preconditioner_type != CERES_HIP_IDENTITY && !is_dense_schur(s);
   s->lm_opts = *o;
   if (fresh && !s->lm_fuse_active) TRY(op_squared_column_norm(s, s->lm_diag));
   if (!s->lm_fuse_active)

@@ -204,7 +204,8 @@ def test_dense_schur_solver(hip, oracle, problems, kind):
     o = hip.LinearSolverOptions(type=hip.DENSE_SCHUR, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=1)
     s = hip.HipLinearSolver(o)
     s.set_structure(p.bs)
-    assert s.info().kernel_path == hip.PATH_GENERIC
+    # <2,3,9> problems: Init / rhs / back-substitution on the fused tile passes; the elimination is a gather per block either way
+    assert s.info().kernel_path == (hip.PATH_BAL if kind.startswith("bal") else hip.PATH_GENERIC)
     x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
     assert summ.termination_type == hip.SUCCESS and summ.num_iterations == 1, summ
     ref = dense_reference(p) if p.num_cols <= 4000 else None
