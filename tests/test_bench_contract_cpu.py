@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")) +
-               [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
+               [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03zb_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
