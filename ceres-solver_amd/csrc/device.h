@@ -134,7 +134,7 @@ struct CamGather {
 // Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].
 struct ZUnits {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr, *shared = nullptr;  // units [first, first + count)
-  const int32_t* slot = nullptr;                                                       // entry -> ring-relative slot
+  const int32_t* slot = nullptr;                                                       // entry -> ring row (chunk-relative)
   int first = 0, count = 0;
 };
 hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
