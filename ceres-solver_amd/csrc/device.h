@@ -68,6 +68,7 @@ struct BalArgs {
   double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
   const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => 9*p
   double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 pad (kInit)
+  const int32_t* mo_index = nullptr;      // record of each slot in Mo (nullptr: the slot itself; hybrid plans: the slot's row)
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_f9]   (LDS mode)

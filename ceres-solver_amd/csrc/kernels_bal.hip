@@ -489,7 +489,7 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     double q0[3], q1[3];
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
-    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * sl);  // [slot][4]: m00 m01 m11 pad, 32 B per slot
+    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * (A.mo_index ? int64_t(A.mo_index[sl]) : sl));  // [record][4]: m00 m01 m11 pad, 32 B
     tile_store<2>(mo, make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2])));
     tile_store<2>(mo + 1, make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0));
   }

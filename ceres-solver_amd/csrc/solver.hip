@@ -62,6 +62,7 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
+  int32_t* d_mo_index = nullptr;                               // hybrid plans: M_o record of each slot
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
@@ -267,6 +268,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.tile_zbase = s->d_tile_zbase; A.grp_tile_ptr = s->d_grp_tile_ptr;
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
+  A.mo_index = s->d_mo_index;
   A.n_f9 = 9 * s->plan.n_cameras;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
@@ -1738,6 +1740,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     if (!s->lds_mode) {
       TRY(dev_upload(s, &s->d_tile_zbase, P.tile_zbase));
       if (P.hybrid) TRY(dev_upload(s, &s->d_grp_tile_ptr, P.grp_tile_ptr));
+      if (!P.mo_index.empty()) TRY(dev_upload(s, &s->d_mo_index, P.mo_index));
       int32_t *uc = nullptr, *ub = nullptr, *ue = nullptr, *us = nullptr, *zs = nullptr;
       TRY(dev_upload(s, &uc, P.zu_cam)); TRY(dev_upload(s, &ub, P.zu_begin)); TRY(dev_upload(s, &ue, P.zu_end));
       TRY(dev_upload(s, &us, P.zu_shared)); TRY(dev_upload(s, &zs, P.zc_slot));
@@ -2684,7 +2687,7 @@ int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_elimin
   const int64_t n_slots = P.n_tiles * kTile;
   if (slot_capacity < n_slots) return 0;  // caller only wanted the counts
   for (int64_t i = 0; i < n_slots; ++i) {
-    slot_row_out[i] = P.slot_bpos[i] < 0 ? -1 : P.slot_bpos[i] / 2;
+    slot_row_out[i] = P.slot_row[i];
     slot_cam_out[i] = P.slot_cam[i];
     slot_pt_out[i] = P.slot_pt[i];
     slot_seg_out[i] = P.slot_seg[i];
@@ -2759,7 +2762,7 @@ int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num
   if (slot_capacity < n_slots || entry_capacity < n_entries || unit_capacity < n_units) return 0;  // the caller only wanted the counts
   for (int64_t i = 0; i < n_slots; ++i) {
     slot_word[i] = P.slot_cam[i] < 0 ? -1 : P.slot_word[i];
-    slot_row[i] = P.slot_bpos[i] < 0 ? -1 : P.slot_bpos[i] / 2;
+    slot_row[i] = P.slot_row[i];
   }
   std::copy(P.tile_zbase.begin(), P.tile_zbase.end(), tile_zbase);
   if (P.hybrid) std::copy(P.grp_tile_ptr.begin(), P.grp_tile_ptr.end(), grp_tile_ptr);
