@@ -543,7 +543,8 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
       return 0;
     }
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
-    HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->fused_grid, st));
+    // (cameras not in LDS: the scattering modes walk the hybrid groups, one workgroup each — chunk_grid, never fused_grid)
+    HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->lds_mode ? s->fused_grid : s->chunk_grid, st));
     return g.commit(0);
   }
   // block diagonal of E^T E + D_e^2, inverted in place

@@ -50,3 +50,17 @@ def test_many_camera_regime_is_hybrid_with_popular_cameras(hip, problems):
         assert info.camera_accum_hybrid == 1 and info.hybrid_popular_rows > 1000
         assert 0.5 * info.num_observations < info.num_observations_in_lds < 0.7 * info.num_observations
         s.close()
+
+
+def test_preconditioner_without_residuals_in_the_hybrid_regime(hip, oracle, problems):
+    """Preconditioner::Update needs no residual vector: Init without b scatters nothing, but its tile pass still walks the hybrid groups
+    (one workgroup per group — a grid sized for the non-scattering passes once indexed past the group table here)."""
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=3000, num_points=12000, num_observations=60000, seed=4, skew=0.6)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    assert s.info().camera_accum_hybrid == 1
+    s.load(p.values, None, p.D)
+    s.schur_jacobi_update()
+    inv, raw = m.schur_jacobi(p.values, p.D)
+    assert np.linalg.norm(s.preconditioner_blocks() - inv) <= 1e-11 * np.linalg.norm(inv)
+    s.close()
