@@ -83,8 +83,14 @@ struct BalPlan {
   std::vector<int32_t> mo_index;                         // hybrid plans: where a slot's M_o record lives (its row: plan.cc); empty: at the slot
   // first | last<<8 | valid<<16 | tailA<<17 | hasA<<23 | tailB<<24 | hasB<<30   (tails: see plan.cc)
   std::vector<uint32_t> slot_seg;
-  // per tile: 0 normal (tile_aux = longest track | #points<<8), 1 head of a long point (tile_aux = #tiles), 2 continuation
+  // per tile: 0 normal (tile_aux = longest track | #points<<8), 1 / 3 head of a long point (tile_aux = #tiles; 3: the streaming
+  // kernels take it in a round), 2 continuation
   std::vector<int32_t> tile_kind, tile_aux;
+  // Long points sit behind the normal tiles of their range (a hybrid group, or everything): long_ptr[g] = first long tile of range g.
+  // round_word: kRoundWaves words per round (plan.cc), rounds [round_ptr[g], round_ptr[g + 1]) belong to range g.
+  bool long_behind = false;
+  std::vector<int32_t> long_ptr, round_ptr;
+  std::vector<uint32_t> round_word;
   std::vector<int32_t> tile_pt0;  // point id of lane 0 of each tile (every tile's lane 0 is a valid slot)
   // camera-major lists
   std::vector<int32_t> cam_ptr;    // n_cameras+1
@@ -149,6 +155,8 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
 // Decides whether the fused <2,3,9> path applies and, if so, builds the packing plan.
 // hyb: the workgroups and LDS accumulator rows of the tile pass (hybrid camera accumulation when the cameras do not fit in LDS;
 // needs reorder_points; groups = 0: never)
+constexpr int kRoundWaves = 8;               // waves of a streaming workgroup = tiles of a round of long points (plan.cc)
+constexpr uint32_t kRoundIdle = 0xFFFFFFFFu;  // round word of a wave without a tile
 struct HybridRequest { int groups = 0, rows = 0; };
 // reorder_mode: renumber the points (fuller tiles; hybrid groups) never / always (Schur solvers: no CG vector lives in point space) /
 // only if the caller's layout is points-then-cameras back to back (CGNR: its CG vectors then ARE the caller's with the points renumbered)

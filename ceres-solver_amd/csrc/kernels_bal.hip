@@ -971,6 +971,55 @@ __device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int l
   }
 }
 
+// One tile of a long point inside a ROUND (plan.cc): the kRoundWaves waves of the workgroup each hold one tile in registers, the waves
+// [w0, w0 + cnt) of one point leave their tile sums in LDS (`red`, double-buffered by round parity: one barrier per round), every
+// wave adds them up in the same order and finishes its own tile.  A point of up to 512 observations is read ONCE, a tile per wave in
+// flight, where one wave walked the point's tiles twice with nothing in flight (process_long_point: 0.20 - 0.25 of the HBM peak on
+// graphs of long tracks).  `word`: the wave's round word (kRoundIdle: no tile — every lane is invalid, the loads were issued anyway).
+template <int MODE, bool LDS>
+__device__ __forceinline__ void compute_long_round(const BalArgs& A, const Slot& s, int lane, const StreamAux& x, uint32_t word, int wave,
+                                                   double (*red)[3], double* acc, double& dot) {
+  const bool active = word != kRoundIdle;
+  const int w0 = active ? int((word >> 26) & 7u) : wave, cnt = active ? int((word >> 29) & 7u) + 1 : 1;
+  if constexpr (MODE == kSx || MODE == kSpseZ) {
+    double t0, t1;
+    f_times(s, x.xc, t0, t1);
+    double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
+    if (!s.valid) { u[0] = u[1] = u[2] = 0; }
+    wave_allreduce<3>(u);
+    if (lane == 0) { red[wave][0] = u[0]; red[wave][1] = u[1]; red[wave][2] = u[2]; }
+    __syncthreads();
+    u[0] = u[1] = u[2] = 0;
+    for (int k = 0; k < cnt; ++k) { u[0] += red[w0 + k][0]; u[1] += red[w0 + k][1]; u[2] += red[w0 + k][2]; }
+    double v[3];
+    sym3_mul(x.ei, u, v);
+    const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+    const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+    scatter_ft<LDS>(A, s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
+  } else {
+    static_assert(MODE == kJtJx, "streaming modes");
+    // issue_aux with one point: lanes 0..2 hold the point's x_e and D_e
+    const double xp[3] = {shfl_idx(x.xa, 0), shfl_idx(x.xa, 1), shfl_idx(x.xa, 2)};
+    double z0, z1;
+    f_times(s, x.xc, z0, z1);
+    z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
+    z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
+    scatter_ft<LDS>(A, s, acc, z0, z1);
+    double w[3] = {s.e[0] * z0 + s.e[3] * z1, s.e[1] * z0 + s.e[4] * z1, s.e[2] * z0 + s.e[5] * z1};
+    if (!s.valid) { w[0] = w[1] = w[2] = 0; }
+    wave_allreduce<3>(w);
+    if (lane == 0) { red[wave][0] = w[0]; red[wave][1] = w[1]; red[wave][2] = w[2]; }
+    __syncthreads();
+    if (active && wave == w0 && lane < 3) {   // the point's first wave stores y_e
+      double t = 0;
+      for (int k = 0; k < cnt; ++k) t += red[w0 + k][lane];
+      const double yv = t + x.da * x.da * x.xa;
+      A.y_e[x.base + lane] = yv;
+      dot += x.xa * yv;
+    }
+  }
+}
+
 template <int MODE, bool LDS, bool NT>
 __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   constexpr int BLOCK = 512;
@@ -989,9 +1038,14 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   const int64_t nwaves = grouped ? BLOCK / 64 : int64_t(gridDim.x) * (BLOCK / 64);
   // wave-uniform by construction; readfirstlane tells the compiler, so that the tile words are
   // scalar loads and the branches on them scalar branches
-  const int64_t tile_end = grouped ? A.grp_tile_ptr[blockIdx.x + 1] : (A.tile_end > 0 ? A.tile_end : A.n_tiles);
-  const int64_t wave0 = (grouped ? int64_t(A.grp_tile_ptr[blockIdx.x]) : A.tile_begin + logical_workgroup() * (BLOCK / 64)) +
-                        __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int range = grouped ? int(blockIdx.x) : 0;   // the hybrid group, or everything (plan.cc)
+  const int64_t range_end = grouped ? A.grp_tile_ptr[blockIdx.x + 1] : (A.tile_end > 0 ? A.tile_end : A.n_tiles);
+  // long points sit behind the normal tiles of their range (unless the ring is chunked): the pipeline ends where they begin
+  const int64_t long_begin = A.long_behind ? int64_t(A.long_ptr[range]) : range_end;
+  const int64_t tile_end = min(range_end, long_begin);
+  const int64_t wave_first = (grouped ? 0 : logical_workgroup() * (BLOCK / 64)) + wave;
+  const int64_t wave0 = (grouped ? int64_t(A.grp_tile_ptr[blockIdx.x]) : A.tile_begin) + wave_first;
   const int64_t last = tile_end - 1;
   if (wave0 < tile_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
@@ -1041,9 +1095,68 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
       if (!more) break;
     }
   }
-  // Points with more than 64 observations own whole tiles (kind 1 = head, 2 = continuation);
-  // they are rare and are handled outside the pipelined loop to keep its register footprint down.
-  for (int64_t tile = wave0; tile < tile_end; tile += nwaves) {
+  // Points with more than 64 observations own whole tiles (kind 3 / 1 = head, 2 = continuation).  Those of up to kRoundWaves
+  // tiles (kind 3) are taken in ROUNDS, one tile per wave, with the same one-stage-ahead pipeline as above.
+  __shared__ double round_red[2][kRoundWaves][3];
+  if (A.round_word) {
+    const int64_t rb = A.round_ptr[range], re = A.round_ptr[range + 1];
+    const int64_t rstride = grouped ? 1 : int64_t(gridDim.x);
+    int64_t r = grouped ? rb : rb + logical_workgroup();
+    if (r < re) {   // (workgroup-uniform: the rounds have barriers)
+      const int64_t rlast = r + ((re - 1 - r) / rstride) * rstride;
+      Slot sa, sb;
+      StreamAux xa, xb;
+      SlotIdx i1, i2;
+      // an idle wave issues the loads of the round's first tile (same load count on every path), with every lane invalid
+      auto word_at = [&](int64_t q) { return A.round_word[q * kRoundWaves + wave]; };
+      auto tile_at = [&](int64_t q, uint32_t w) { return int64_t((w != kRoundIdle ? w : A.round_word[q * kRoundWaves]) & 0x3FFFFFFu); };
+      auto finish = [&](Slot& c, const SlotIdx& i, int64_t tile, uint32_t w) {
+        c.cam = i.cam; c.seg = i.seg;
+        finish_slot(c, lane, A.tile_pt0[tile]);
+        if (w == kRoundIdle) { c.valid = false; c.cam = 0; c.pt = 0; c.acc = kSlotSpill; }
+      };
+      uint32_t wa = word_at(r), wb = kRoundIdle;
+      int64_t tile = tile_at(r, wa);
+      int par = 0;
+      issue_idx(A, tile, lane, i2);
+      __builtin_amdgcn_sched_barrier(0);
+      { const int64_t q = min(r + rstride, rlast); issue_idx(A, tile_at(q, word_at(q)), lane, i1); }
+      __builtin_amdgcn_sched_barrier(0);
+      issue_pairs<NT>(A, tile, lane, sa);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(sa, i2, tile, wa);
+      issue_aux<MODE>(A, sa, lane, 1, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      bool more = true;
+      auto stage = [&](Slot& c, StreamAux& cx, uint32_t cw, Slot& n, StreamAux& nx, uint32_t& nw) {
+        const int64_t q = min(r + rstride, rlast), q2 = min(q + rstride, rlast);
+        more = r + rstride < re;
+        nw = word_at(q);
+        const int64_t next = tile_at(q, nw);
+        issue_idx(A, tile_at(q2, word_at(q2)), lane, i2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pairs<NT>(A, next, lane, n);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(n, i1, next, nw);
+        issue_aux<MODE>(A, n, lane, 1, nx);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_long_round<MODE, LDS>(A, c, lane, cx, cw, wave, round_red[par], acc, dot);
+        __builtin_amdgcn_sched_barrier(0);
+        par ^= 1;
+        i1 = i2;
+        r = q;
+      };
+      while (true) {
+        stage(sa, xa, wa, sb, xb, wb);
+        if (!more) break;
+        stage(sb, xb, wb, sa, xa, wa);
+        if (!more) break;
+      }
+    }
+  }
+  // Longer ones still (kind 1; and every long point when the ring is chunked: they sit among the normal tiles then): one wave per
+  // point, two sweeps (process_long_point).
+  for (int64_t tile = (A.long_behind ? long_begin + wave_first : wave0); tile < range_end; tile += nwaves) {
     if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, dot);
   }
   if (MODE == kJtJx && A.pq_out) {  // one partial of x_e . y_e per workgroup

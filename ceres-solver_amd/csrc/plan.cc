@@ -318,18 +318,27 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // next point does not fit, the largest point among the next kReorderWindow ones that does fit is pulled forward (best fit in a
   // window: the gathers from the caller's layout stay local).  seq[i] = caller-order point of internal point i.  Hybrid: group by
   // group, every group starting a tile of its own (grp_pt_ptr = first internal point of each group).
+  // Points of more than one tile ("long": they own whole tiles) come BEHIND the others — of their group, or of everything: the
+  // streaming kernels pipeline over the normal tiles and then take the long points in cooperative ROUNDS (below).  Not with a
+  // chunked ring (a chunk is a tile range of its own launch).
+  const bool segregate = chunk_mib <= 0;
   constexpr int kReorderWindow = 96;
   std::vector<int32_t> seq;
   seq.reserve(P.n_points);
   std::vector<int32_t> grp_pt_ptr;
   auto pack_order = [&](const int32_t* pts, int n) {   // appends pts[0 .. n) in packing order; starts on a fresh tile
     std::vector<uint8_t> taken(n, 0);
+    std::vector<int32_t> longs;   // points of more than a tile: behind the others (they own their tiles; see the rounds below)
     int next = 0, placed = 0, used = kTile, npts = 0;
     auto put = [&](int i) { taken[i] = 1; seq.push_back(pts[i]); ++placed; };
     while (placed < n) {
       while (taken[next]) ++next;
       const int k = track[pts[next]];
-      if (k > kTile) { put(next); used = kTile; npts = 0; continue; }   // a long point owns its tiles
+      if (k > kTile) {
+        if (segregate) { taken[next] = 1; ++placed; longs.push_back(pts[next]); }
+        else { put(next); used = kTile; npts = 0; }   // a long point owns its tiles
+        continue;
+      }
       if (used + k <= kTile && npts < kMaxPointsPerTile) { put(next); used += k; ++npts; continue; }
       int best = -1;
       const int room = kTile - used;
@@ -345,6 +354,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       if (best >= 0) { put(best); used += track[pts[best]]; ++npts; continue; }
       put(next); used = k; npts = 1;   // new tile
     }
+    seq.insert(seq.end(), longs.begin(), longs.end());
   };
   if (!reorder_points) {
     seq.resize(P.n_points);
@@ -394,10 +404,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   int64_t tile = -1;
   int used = kTile;  // slots used in the current tile (kTile forces a new one)
   int npts_in_tile = 0;
-  size_t next_group = 0;
-  for (int p = 0; p < P.n_points; ++p) {
-    // hybrid: a group's tiles are its own (empty groups own none)
-    while (next_group < grp_pt_ptr.size() && grp_pt_ptr[next_group] == p) { P.grp_tile_ptr.push_back(int32_t(P.tile_kind.size())); used = kTile; ++next_group; }
+  auto emit_point = [&](int p) {
     const int k = track[p];
     int idx = row_start[seq[p]];   // the point's rows, in the caller's order
     if (k > kTile) {
@@ -414,7 +421,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
         }
       }
       used = kTile;  // nothing shares a tile with a long point
-      continue;
+      return;
     }
     // A normal tile holds at most kMaxPointsPerTile points: the cooperative point-space path of the
     // fused JtJx (kernels_bal.hip, compute_stream / issue_aux) gives lane L the scalars L and 64 + L of
@@ -430,9 +437,35 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       P.slot_seg[s] = uint32_t(used) | (uint32_t(used + k - 1) << 8) | (1u << 16);
     }
     used += k;
+  };
+  // one range of points = one hybrid group (whose tiles are its own), or everything.  segregate: the normal tiles first (a tile
+  // still ends where a long point sat: the points of a tile are consecutive ids), then the long points' (long_ptr = where they begin)
+  std::vector<int32_t> long_ptr;
+  auto emit_range = [&](int p0, int p1) {
+    used = kTile;
+    if (!segregate) {
+      for (int p = p0; p < p1; ++p) emit_point(p);
+      long_ptr.push_back(int32_t(P.tile_kind.size()));
+      return;
+    }
+    for (int p = p0; p < p1; ++p) {
+      if (track[p] > kTile) used = kTile;
+      else emit_point(p);
+    }
+    long_ptr.push_back(int32_t(P.tile_kind.size()));
+    for (int p = p0; p < p1; ++p) if (track[p] > kTile) emit_point(p);
+    used = kTile;
+  };
+  if (grp_pt_ptr.empty()) {
+    emit_range(0, P.n_points);
+  } else {
+    for (size_t g = 0; g + 1 < grp_pt_ptr.size(); ++g) {   // hybrid: a group's tiles are its own (empty groups own none)
+      P.grp_tile_ptr.push_back(int32_t(P.tile_kind.size()));
+      emit_range(grp_pt_ptr[g], grp_pt_ptr[g + 1]);
+    }
+    P.grp_tile_ptr.push_back(int32_t(P.tile_kind.size()));
   }
   P.n_tiles = int64_t(P.tile_kind.size());
-  while (next_group < grp_pt_ptr.size()) { P.grp_tile_ptr.push_back(int32_t(P.n_tiles)); ++next_group; }  // trailing empty groups + the end
   P.tile_pt0.resize(P.n_tiles);
   for (int64_t t = 0; t < P.n_tiles; ++t) P.tile_pt0[t] = P.slot_pt[t * kTile];
   // Normal tiles: tile_aux = longest track in the tile (bounds the segmented-scan steps).
@@ -463,6 +496,44 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // Padding slots form singleton segments so that shuffles stay in range.
   for (int64_t s = 0; s < P.n_tiles * kTile; ++s)
     if (!(P.slot_seg[s] & (1u << 16))) { const uint32_t l = uint32_t(s % kTile); P.slot_seg[s] |= l | (l << 8); }
+
+  // ROUNDS of long points.  A streaming kernel's workgroup has kRoundWaves waves; in a round each of them takes ONE tile, the waves
+  // of a point exchange their tile sums through LDS, and every wave finishes its tile from registers: a long point is read once,
+  // with a tile per wave in flight, instead of one wave walking all its tiles twice.  A round holds whole points (first fit,
+  // longest first); word = tile | first wave of the point << 26 | (waves of the point - 1) << 29, kRoundIdle for a wave without a
+  // tile.  Points of more than kRoundWaves tiles keep kind 1 (one wave, two sweeps); the others get kind 3.  Hybrid: rounds per group.
+  P.long_ptr = long_ptr;
+  P.long_behind = segregate;
+  P.round_ptr.assign(1, 0);
+  if (segregate && P.n_tiles < (int64_t(1) << 26)) {
+    const size_t n_ranges = long_ptr.size();
+    for (size_t g = 0; g < n_ranges; ++g) {
+      const int64_t t0 = long_ptr[g], t1 = P.grp_tile_ptr.empty() ? P.n_tiles : int64_t(P.grp_tile_ptr[g + 1]);
+      std::vector<std::pair<int, int64_t>> heads;   // (tiles, head tile)
+      for (int64_t t = t0; t < t1; ++t)
+        if (P.tile_kind[t] == 1 && P.tile_aux[t] <= kRoundWaves) heads.emplace_back(P.tile_aux[t], t);
+      std::stable_sort(heads.begin(), heads.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+      const size_t round0 = P.round_word.size() / kRoundWaves;
+      std::vector<int> fill;                        // waves taken in each round of this range
+      std::vector<size_t> open_by_room[kRoundWaves + 1];   // rounds with exactly `room` free waves (stacks)
+      for (const auto& hd : heads) {
+        const int nt = hd.first;
+        size_t r = size_t(-1);
+        for (int room = nt; room <= kRoundWaves && r == size_t(-1); ++room)   // tightest fit
+          if (!open_by_room[room].empty()) { r = open_by_room[room].back(); open_by_room[room].pop_back(); }
+        if (r == size_t(-1)) { r = fill.size(); fill.push_back(0); P.round_word.resize(P.round_word.size() + kRoundWaves, kRoundIdle); }
+        const int w0 = fill[r];
+        for (int t = 0; t < nt; ++t)
+          P.round_word[(round0 + r) * kRoundWaves + w0 + t] = uint32_t(hd.second + t) | (uint32_t(w0) << 26) | (uint32_t(nt - 1) << 29);
+        fill[r] += nt;
+        if (fill[r] < kRoundWaves) open_by_room[kRoundWaves - fill[r]].push_back(r);
+        P.tile_kind[hd.second] = 3;
+      }
+      P.round_ptr.push_back(int32_t(P.round_word.size() / kRoundWaves));
+    }
+  } else {
+    P.round_ptr.resize(long_ptr.size() + 1, 0);
+  }
 
   // Camera-major lists (counting sort over slots keeps point order inside a camera).
   P.cam_ptr.assign(P.n_cameras + 1, 0);

@@ -30,6 +30,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// read-back image: 2 kMaxVecGrid partial sums, one double holding the two int flags, one spare, then the CG scalars
+constexpr int kScalarsOffset = 2 * kMaxVecGrid + 2;
+constexpr int kReadbackDoubles = kScalarsOffset + int((sizeof(CgScalars) + sizeof(double) - 1) / sizeof(double));
+
 struct Buf {  // device allocation owned by a solver
   void* p = nullptr;
   size_t bytes = 0;
@@ -62,6 +66,8 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
+  int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr;       // long points: where they begin, their rounds (plan.cc)
+  uint32_t* d_round_word = nullptr;
   int32_t* d_mo_index = nullptr;                               // hybrid plans: M_o record of each slot
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
@@ -156,8 +162,10 @@ struct ceres_hip_solver {
   bool cg_fused = true;            // CERES_HIP_CG_FUSED=0: the five-kernel iteration (A/B measurements)
   int last_cg_iterations = 2;      // of the previous solve: the length of the next solve's first batch of iterations (run_cg)
   int nine_wide_from = 0;          // column blocks [nine_wide_from, ncb) are all 9 wide (BAL: the cameras)
-  CgScalars* h_scalars = nullptr;  // pinned
-  double* h_pinned = nullptr;      // pinned scratch, 2 * kMaxVecGrid + 8 doubles (scalar read-backs of the LM step)
+  // ONE pinned buffer, the image of the device's [scalar_partials | flags | CgScalars] (kReadbackDoubles doubles): a poll of the CG
+  // status word brings the LM step's partial sums and flags along in the same copy (two copies per poll before: 4.7 us each)
+  double* h_pinned = nullptr;
+  CgScalars* h_scalars = nullptr;  // = h_pinned + kScalarsOffset
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
   // comm: RCCL communicator and / or the one-shot peer-to-peer all-reduce over hipIpc-mapped buffers
   ncclComm_t comm = nullptr;
@@ -267,6 +275,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.tile_zbase = s->d_tile_zbase; A.grp_tile_ptr = s->d_grp_tile_ptr;
+  A.long_ptr = s->d_long_ptr; A.round_ptr = s->d_round_ptr; A.round_word = s->d_round_word; A.long_behind = s->plan.long_behind ? 1 : 0;
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.mo_index = s->d_mo_index;
   A.n_f9 = 9 * s->plan.n_cameras;
@@ -936,7 +945,7 @@ int check_comm_error(ceres_hip_solver* s) {  // after a stream synchronisation
 }
 
 int poll_scalars(ceres_hip_solver* s) {
-  HIP_TRY(s, hipMemcpyAsync(s->h_scalars, s->cg.S, sizeof(CgScalars), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * kReadbackDoubles, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return check_comm_error(s);
 }
@@ -1368,8 +1377,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         const int rc = op_back_substitute(s, s->cg.x, x);
         s->gate_on_cg_status = false;
         if (rc) return rc;
-        HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, s->stream));
-        s->spec_tail_done = true;
+        s->spec_tail_done = true;   // (the poll that follows copies the partial sums and flags together with the CG scalars)
         return 0;
       };
     }
@@ -1436,8 +1444,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       s->nonfinite_clean = false;
       HIP_TRY(s, LaunchCgnrModelCost(s->cg.x, s->cg_rhs, s->cg.r, s->D, 0, hh.num_cols, s->scalar_partials, &s->spec_cgnr_parts, s->stream,
                                      x, s->d_nonfinite, &s->cg.S->status, point_perm(s)));
-      HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, s->stream));
-      s->spec_tail_done = true;
+      s->spec_tail_done = true;   // (the poll that follows copies the partial sums and flags together with the CG scalars)
       return 0;
     };
   }
@@ -1537,15 +1544,12 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
     return nullptr;
   }
   for (auto& e : s->ev) (void)hipEventCreate(&e);
-  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), sizeof(CgScalars), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_pinned), sizeof(double) * (kReadbackDoubles + 8), hipHostMallocDefault) != hipSuccess) {
     fail(nullptr, CERES_HIP_E_HIP, "hipHostMalloc failed");
     return nullptr;
   }
-  memset(s->h_scalars, 0, sizeof(CgScalars));
-  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_pinned), sizeof(double) * (2 * kMaxVecGrid + 8), hipHostMallocDefault) != hipSuccess) {
-    fail(nullptr, CERES_HIP_E_HIP, "hipHostMalloc failed");
-    return nullptr;
-  }
+  memset(s->h_pinned, 0, sizeof(double) * (kReadbackDoubles + 8));
+  s->h_scalars = reinterpret_cast<CgScalars*>(s->h_pinned + kScalarsOffset);
   return s.release();
 }
 
@@ -1559,7 +1563,6 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   if (s->h_comm_error) (void)hipHostFree(s->h_comm_error);
   if (s->d_comm_error_seen) (void)hipFree(s->d_comm_error_seen);
   free_all(s);
-  if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -1633,7 +1636,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->lm_D, size_t(h.num_cols)));
   // [0, 2 kMaxVecGrid) partial sums, then two int flags in one double: one memset clears both flags, one D2H copy at the
   // end of an LM step brings {model-cost partials, finite-step flag} back
-  TRY(dev_alloc(s, &s->scalar_partials, size_t(2 * kMaxVecGrid + 2)));
+  TRY(dev_alloc(s, &s->scalar_partials, size_t(kReadbackDoubles)));   // [partial sums | flags | CgScalars]: one read-back (poll_scalars)
   s->d_nonfinite = reinterpret_cast<int*>(s->scalar_partials + 2 * kMaxVecGrid);
   s->d_fail_flag = s->d_nonfinite + 1;
   HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), s->stream));
@@ -1678,7 +1681,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   TRY(dev_alloc(s, &s->cg_pq_parts, size_t(kMaxPqParts)));
   { const char* e = getenv("CERES_HIP_CG_FUSED"); s->cg_fused = !(e && atoi(e) == 0); }
   { const char* e = getenv("CERES_HIP_SPECULATE"); s->speculate = !(e && atoi(e) == 0); }
-  TRY(dev_alloc(s, &s->cg.S, 1));
+  s->cg.S = reinterpret_cast<CgScalars*>(s->scalar_partials + kScalarsOffset);
   HIP_TRY(s, hipMemsetAsync(s->cg.S, 0, sizeof(CgScalars), s->stream));
   // (+ 18 doubles per F block: room for the step's other camera-space sums right behind the blocks, see merged_layout)
   TRY(dev_alloc(s, &s->precond, size_t(is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back()) + 2 * size_t(h.num_cols_f)));
@@ -1697,6 +1700,10 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
     TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));
+    TRY(dev_upload(s, &s->d_long_ptr, P.long_ptr));
+    TRY(dev_upload(s, &s->d_round_ptr, P.round_ptr));
+    s->d_round_word = nullptr;
+    if (!P.round_word.empty()) TRY(dev_upload(s, &s->d_round_word, P.round_word));
     TRY(dev_upload(s, &s->d_tile_aux, P.tile_aux));
     TRY(dev_upload(s, &s->d_pt_pos, P.pt_pos));
     TRY(dev_upload(s, &s->d_cam_pos, P.cam_pos));
@@ -2771,6 +2778,31 @@ int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num
   std::copy(P.zu_cam.begin(), P.zu_cam.end(), unit_cam);
   std::copy(P.zu_begin.begin(), P.zu_begin.end(), unit_begin);
   std::copy(P.zu_end.begin(), P.zu_end.end(), unit_end);
+  return 0;
+}
+
+int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t renumber, int32_t groups,
+                                int32_t rows, int64_t counts[4], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
+                                int32_t* long_ptr, int32_t* round_ptr, uint32_t* round_word, int64_t tile_capacity,
+                                int64_t range_capacity, int64_t round_capacity) {
+  if (!bs || !counts) return CERES_HIP_E_INVALID;
+  HostStructure h;
+  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
+  BalPlan P;
+  HybridRequest hyb;
+  hyb.groups = groups; hyb.rows = rows;
+  BuildBalPlan(h, renumber ? kReorderAlways : kReorderNever, hyb, &P);
+  if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
+  const int64_t n_ranges = int64_t(P.long_ptr.size()), n_rounds = int64_t(P.round_word.size()) / kRoundWaves;
+  counts[0] = P.n_tiles; counts[1] = n_ranges; counts[2] = n_rounds; counts[3] = P.long_behind ? 1 : 0;
+  if (tile_capacity < P.n_tiles || range_capacity < n_ranges || round_capacity < n_rounds) return 0;  // the caller only wanted the counts
+  std::copy(P.tile_kind.begin(), P.tile_kind.end(), tile_kind);
+  std::copy(P.tile_aux.begin(), P.tile_aux.end(), tile_aux);
+  if (P.grp_tile_ptr.empty()) { range_tile_ptr[0] = 0; range_tile_ptr[1] = int32_t(P.n_tiles); }
+  else std::copy(P.grp_tile_ptr.begin(), P.grp_tile_ptr.end(), range_tile_ptr);
+  std::copy(P.long_ptr.begin(), P.long_ptr.end(), long_ptr);
+  std::copy(P.round_ptr.begin(), P.round_ptr.end(), round_ptr);
+  std::copy(P.round_word.begin(), P.round_word.end(), round_word);
   return 0;
 }
 

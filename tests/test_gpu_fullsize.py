@@ -44,7 +44,7 @@ def check_schur_side(hip, oracle, p, expect_lds, solve=True):
     isc = oracle.ImplicitSchurComplement(m)
     isc.init(p.values, p.D, p.b)
     s.schur_init()
-    errs = {"rhs": rel(s.schur_rhs(), isc.rhs()), "ete_inverse": rel(s.ete_inverse(), isc.ete_inverse())}
+    errs = {"rhs": rel(s.schur_rhs(), isc.rhs()), "ete_inv": rel(s.ete_inverse(), isc.ete_inverse())}
     xf = rng.standard_normal(m.num_cols_f)
     errs["sx"] = rel(s.schur_sx(xf), isc.sx(xf))
     errs["back_substitute"] = rel(s.back_substitute(xf), isc.back_substitute(xf))

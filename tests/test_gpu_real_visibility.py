@@ -64,3 +64,22 @@ def test_preconditioner_without_residuals_in_the_hybrid_regime(hip, oracle, prob
     inv, raw = m.schur_jacobi(p.values, p.D)
     assert np.linalg.norm(s.preconditioner_blocks() - inv) <= 1e-11 * np.linalg.norm(inv)
     s.close()
+
+
+MIXED_TRACKS = ([3, 70, 2, 2, 129, 64, 65, 5, 513, 1, 300, 512, 7, 449, 200, 100, 66] + [4] * 50 + [90, 1000, 3] + [2, 9, 130] * 40 +
+                [640, 65, 448, 384, 1, 1, 63, 64, 65])
+
+
+@pytest.mark.parametrize("cameras,expect_lds", [(1100, True), (2600, False)])
+def test_every_track_length_against_the_oracle(hip, oracle, problems, cameras, expect_lds):
+    """Points of 1 .. 1000 observations side by side: normal tiles (pipelined), points of 2 .. 8 tiles (taken in ROUNDS: one tile per
+    wave of a workgroup, tile sums exchanged through LDS; rounds with idle waves among them) and points of more than 8 tiles (one wave,
+    two sweeps) in one plan — with every camera's accumulator in LDS, and in the hybrid regime (rounds per group)."""
+    p = problems.bal_from_tracks(MIXED_TRACKS, cameras, seed=11)
+    r = hip.debug_long_rounds(p.bs, p.num_eliminate_blocks, True)
+    kinds = np.bincount(r["tile_kind"], minlength=4)
+    assert kinds[3] >= 50 and kinds[1] == 3 and (r["round_word"] == 0xFFFFFFFF).any()
+    check_schur_side(hip, oracle, p, expect_lds)
+    check_cgnr_side(hip, oracle, p, expect_lds)
+    # the same problem with its columns in CGNR's caller order (points not renumbered: the long points' tiles still move behind)
+    check_cgnr_side(hip, oracle, problems.bal_from_tracks(MIXED_TRACKS, cameras, layout="cgnr", seed=11), expect_lds)

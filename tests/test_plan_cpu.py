@@ -55,8 +55,9 @@ def check_plan_invariants(p, plan):
     # a long point owns its tiles
     t = 0
     while t < nt:
-        if kind[t] == 1:
+        if kind[t] in (1, 3):   # 3: at most 8 tiles, the streaming kernels take it in a round (test_long_point_rounds)
             n = aux[t]
+            assert (n <= 8) == (kind[t] == 3)
             assert n >= 2 and (kind[t + 1:t + n] == 2).all()
             sl = slice(t * 64, (t + n) * 64)
             q = np.unique(pt[sl][valid[sl]])
@@ -85,7 +86,59 @@ def test_plan_long_points(problems):
     p = problems.synthetic_bal(None, num_cameras=220, num_points=300, num_observations=9000, seed=9, skew=0.0)
     plan = plan_of(p)
     track = check_plan_invariants(p, plan)
-    assert (plan["tile_kind"] == 1).sum() == (track > 64).sum()
+    assert np.isin(plan["tile_kind"], (1, 3)).sum() == (track > 64).sum()
+
+
+def check_long_rounds(r):
+    """The long points sit behind the normal tiles of their range, and every one of up to 8 tiles is in exactly one round."""
+    kind, aux = r["tile_kind"], r["tile_aux"]
+    assert r["long_behind"]
+    seen = np.zeros(r["n_tiles"], int)
+    for g in range(len(r["long_ptr"])):
+        t0, tl, t1 = r["range_tile_ptr"][g], r["long_ptr"][g], r["range_tile_ptr"][g + 1]
+        assert t0 <= tl <= t1
+        assert (kind[t0:tl] == 0).all() and (kind[tl:t1] != 0).all()
+        for q in range(r["round_ptr"][g], r["round_ptr"][g + 1]):
+            words = r["round_word"][q]
+            w = 0
+            assert words[0] != 0xFFFFFFFF                     # (an idle wave issues the loads of the round's first tile)
+            while w < 8:
+                if words[w] == 0xFFFFFFFF:
+                    assert (words[w:] == 0xFFFFFFFF).all()    # idle waves come last
+                    break
+                tile, w0, n = int(words[w] & 0x3FFFFFF), int((words[w] >> 26) & 7), int((words[w] >> 29) & 7) + 1
+                assert w0 == w and w + n <= 8 and kind[tile] == 3 and aux[tile] == n and tl <= tile < t1
+                for k in range(n):
+                    assert words[w + k] == np.uint32((tile + k) | (w0 << 26) | ((n - 1) << 29))
+                    seen[tile + k] += 1
+                w += n
+    in_round = np.zeros(r["n_tiles"], bool)
+    for t in np.flatnonzero(kind == 3):
+        in_round[t:t + aux[t]] = True
+    assert np.array_equal(seen, in_round.astype(int))
+    assert (aux[kind == 1] > 8).all()
+
+
+@pytest.mark.parametrize("renumber", [False, True])
+def test_long_point_rounds(problems, renumber):
+    tracks = [3, 70, 2, 2, 129, 64, 65, 5, 513, 1, 300, 512, 7, 449, 200, 100, 66] + [4] * 50 + [90, 1000, 3]
+    p = problems.bal_from_tracks(tracks, 1100, seed=3)
+    r = pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, renumber)
+    check_long_rounds(r)
+    assert (r["tile_kind"] == 3).sum() == 10 and (r["tile_kind"] == 1).sum() == 2   # 513 and 1000 observations: one wave each
+    # tightest fit, longest first: (8) (8) (5, 3) (4, 2, 2) (2, 2, 2 + two idle waves) tiles
+    assert len(r["round_word"]) == 5 and (r["round_word"] == 0xFFFFFFFF).sum() == 2
+    p = problems.synthetic_bal(None, num_cameras=220, num_points=300, num_observations=9000, seed=9, skew=0.0)
+    check_long_rounds(pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, renumber))
+
+
+def test_long_point_rounds_of_hybrid_groups(problems):
+    # real tracks (every point a long one) on more cameras than LDS holds: rounds per group
+    p = problems.libmv_bal(2, 8, with_values=False)
+    r = pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, True, groups=16, rows=400)
+    assert len(r["long_ptr"]) == 16
+    check_long_rounds(r)
+    assert (r["round_ptr"][1:] > r["round_ptr"][:-1]).sum() >= 8   # the groups have points, hence rounds
 
 
 def test_plan_caps_points_per_tile(problems):
@@ -198,7 +251,7 @@ def test_point_ids_are_recoverable_from_the_segment_words(problems, seed, nc, np
     # valid slots are a prefix of the tile (no holes), so the heads seen below a lane are exactly its predecessors
     assert (np.diff(valid.astype(int), axis=1) <= 0).all()
     if nc >= 100:
-        assert (plan["tile_kind"] == 1).any()        # the long-point case is exercised
+        assert np.isin(plan["tile_kind"], (1, 3)).any()        # the long-point case is exercised
 
 
 @pytest.mark.parametrize("layout", ["schur", "cgnr"])
