@@ -87,9 +87,10 @@ struct BalPlan {
   // kernels take it in a round), 2 continuation
   std::vector<int32_t> tile_kind, tile_aux;
   // Long points sit behind the normal tiles of their range (a hybrid group, or everything): long_ptr[g] = first long tile of range g.
-  // round_word: kRoundWaves words per round (plan.cc), rounds [round_ptr[g], round_ptr[g + 1]) belong to range g.
+  // round_word: kRoundWaves words per round, round_flag: kRoundSum / kRoundApply / kRoundLast (plan.cc); sequence q = the rounds
+  // [seq_ptr[q], seq_ptr[q + 1]) that ONE workgroup takes in order; sequences [round_ptr[g], round_ptr[g + 1]) belong to range g.
   bool long_behind = false;
-  std::vector<int32_t> long_ptr, round_ptr;
+  std::vector<int32_t> long_ptr, round_ptr, seq_ptr, round_flag;
   std::vector<uint32_t> round_word;
   std::vector<int32_t> tile_pt0;  // point id of lane 0 of each tile (every tile's lane 0 is a valid slot)
   // camera-major lists
@@ -157,6 +158,7 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
 // needs reorder_points; groups = 0: never)
 constexpr int kRoundWaves = 8;               // waves of a streaming workgroup = tiles of a round of long points (plan.cc)
 constexpr uint32_t kRoundIdle = 0xFFFFFFFFu;  // round word of a wave without a tile
+constexpr int kRoundSum = 1, kRoundApply = 2, kRoundLast = 4;   // round flags of a point of more than kRoundWaves tiles (plan.cc)
 struct HybridRequest { int groups = 0, rows = 0; };
 // reorder_mode: renumber the points (fuller tiles; hybrid groups) never / always (Schur solvers: no CG vector lives in point space) /
 // only if the caller's layout is points-then-cameras back to back (CGNR: its CG vectors then ARE the caller's with the points renumbered)

@@ -46,10 +46,13 @@ struct BalArgs {
   const int32_t* grp_tile_ptr = nullptr;
   int hyb_rows = 0;
   // long points (plan.cc): the tiles of range g (the hybrid group, or 0 = everything) from long_ptr[g] on belong to points of more
-  // than 64 observations; the streaming kernels take them in rounds [round_ptr[g], round_ptr[g + 1]) of kRoundWaves words
+  // than 64 observations; the streaming kernels take them in rounds of kRoundWaves words, sequence by sequence (common.h, plan.cc)
   int long_behind = 0;   // 0: long points sit among the normal tiles (chunked ring), no rounds
   const int32_t* long_ptr = nullptr;
-  const int32_t* round_ptr = nullptr;
+  const int32_t* round_ptr = nullptr;    // per range: its sequences
+  const int32_t* seq_ptr = nullptr;      // per sequence: its rounds
+  int n_seq = 0;                         // sequences of all ranges
+  const int32_t* round_flag = nullptr;
   const uint32_t* round_word = nullptr;
   int64_t z_flush_row0 = 0;
   int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)

@@ -863,6 +863,203 @@ __device__ __forceinline__ void process_long_point(const BalArgs& A, int64_t til
   }
 }
 
+// The long points of the unpipelined kernels, in the same ROUNDS as the streaming kernels' (plan.cc, compute_long_round): the waves of
+// a workgroup — in sub-workgroups of kRoundWaves — take one tile each, exchange the tile's sums (3 or 9 doubles) through LDS and finish
+// the tile from registers; a point of more than kRoundWaves tiles runs sum rounds, then (where the per-observation result needs the
+// sums: S.x, Init's M_o and rhs, the model cost of the back-substitution) apply rounds that re-read its tiles.  Every wave of the
+// workgroup runs the same number of rounds (the barriers are the workgroup's): a sub-workgroup out of rounds idles.
+template <int MODE, bool LDS, int BLOCK, bool F32>
+__device__ __forceinline__ void fused_long_rounds(const BalArgs& A, int lane, bool grouped, int range, double* acc, double& lane_acc) {
+  constexpr int NX = (MODE == kInit || MODE == kEte || MODE == kCgnrInit) ? 9 : 3;
+  constexpr int SUBS = BLOCK / 64 / kRoundWaves;
+  constexpr bool kTwoPhase = (MODE == kSx || MODE == kSpseZ || MODE == kInit || MODE == kBackSub);
+  static_assert(SUBS >= 1, "a workgroup holds at least one round");
+  __shared__ double xr[SUBS][kRoundWaves][NX];
+  const int wave_all = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int sub = wave_all / kRoundWaves, wave = wave_all % kRoundWaves;
+  // a workgroup that owns a hybrid group takes the group's sequences; otherwise the workgroups share ALL sequences (also those of a
+  // hybrid plan: the passes that scatter nothing walk every tile)
+  const int64_t qe = grouped ? int64_t(A.round_ptr[range + 1]) : int64_t(A.n_seq);
+  const int64_t qstride = grouped ? 1 : int64_t(gridDim.x) * SUBS;
+  const int64_t q_first = grouped ? int64_t(A.round_ptr[range]) : logical_workgroup() * SUBS;
+  // rounds of the busiest sub-workgroup (a hybrid group's sequences all go to sub-workgroup 0: scattering modes run 8 waves there)
+  int64_t n_iter = 0;
+  for (int j = 0; j < (grouped ? 1 : SUBS); ++j) {
+    int64_t n = 0;
+    if (grouped) { if (q_first < qe) n = A.seq_ptr[qe] - A.seq_ptr[q_first]; }
+    else for (int64_t q = q_first + j; q < qe; q += qstride) n += A.seq_ptr[q + 1] - A.seq_ptr[q];
+    n_iter = max(n_iter, n);
+  }
+  int64_t it_q = q_first + (grouped ? 0 : sub);
+  bool it_real = grouped ? (sub == 0 && it_q < qe) : it_q < qe;
+  int64_t it_r = 0, it_end = 0;
+  if (it_real) { it_r = A.seq_ptr[it_q]; it_end = A.seq_ptr[grouped ? qe : it_q + 1]; if (grouped) it_q = qe - 1; }
+  double carry[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) carry[i] = 0.0;
+  for (int64_t iter = 0; iter < n_iter; ++iter) {
+    uint32_t word = kRoundIdle, word0 = kRoundIdle;
+    int flag = 0;
+    if (it_real) {
+      word = A.round_word[it_r * kRoundWaves + wave];
+      word0 = A.round_word[it_r * kRoundWaves];
+      flag = A.round_flag[it_r];
+      if (it_r + 1 < it_end) ++it_r;
+      else if (it_q + qstride < qe) { it_q += qstride; it_r = A.seq_ptr[it_q]; it_end = A.seq_ptr[it_q + 1]; }
+      else it_real = false;
+    }
+    const bool active = word != kRoundIdle;
+    const int64_t tile = int64_t(word & 0x3FFFFFFu);
+    const int w0 = flag ? 0 : (active ? int((word >> 26) & 7u) : wave);
+    const int cnt = flag ? (word0 != kRoundIdle ? int((word0 >> 29) & 7u) + 1 : 1) : (active ? int((word >> 29) & 7u) + 1 : 1);
+    const bool apply_round = (flag & kRoundApply) != 0;
+    Slot s;
+    s.valid = false; s.pt = 0; s.cam = 0; s.acc = kSlotSpill; s.b0 = s.b1 = 0.0; s.zbase = 0; s.slot = 0;
+    double part[NX], t0 = 0.0, t1 = 0.0, xp[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) part[i] = 0.0;
+    int pt = 0, po = 0;
+    if (active && (!apply_round || kTwoPhase)) {
+      // (an apply round re-reads the tiles the sum rounds wrote: never a gather)
+      load_slot<kCanGather<MODE>, F32>(A, tile, lane, s, kWantsB<MODE>, !apply_round);
+      pt = __builtin_amdgcn_readfirstlane(s.pt);   // one segment: every valid lane holds the point
+      po = pt_off(A, pt);
+    }
+    // ---- this tile's share of the point's sums
+    if (active && !apply_round) {
+      if constexpr (MODE == kColNorm) {
+        scatter_f_squares(s, acc);
+        if (s.valid) { part[0] = s.e[0] * s.e[0] + s.e[3] * s.e[3]; part[1] = s.e[1] * s.e[1] + s.e[4] * s.e[4]; part[2] = s.e[2] * s.e[2] + s.e[5] * s.e[5]; }
+      } else if constexpr (MODE == kSx || MODE == kSpseZ || MODE == kBackSub) {
+        double xc[9];
+        load_xc(A, s.cam, xc);
+        f_times(s, xc, t0, t1);
+        if constexpr (MODE == kBackSub) { t0 = s.b0 - t0; t1 = s.b1 - t1; }
+        if (s.valid) { part[0] = s.e[0] * t0 + s.e[3] * t1; part[1] = s.e[1] * t0 + s.e[4] * t1; part[2] = s.e[2] * t0 + s.e[5] * t1; }
+      } else if constexpr (MODE == kJtJx || MODE == kJtb) {
+        double z0 = s.b0, z1 = s.b1;
+        if constexpr (MODE == kJtJx) {
+          xp[0] = A.x_e[po]; xp[1] = A.x_e[po + 1]; xp[2] = A.x_e[po + 2];
+          double xc[9];
+          load_xc(A, s.cam, xc);
+          f_times(s, xc, z0, z1);
+          z0 += s.e[0] * xp[0] + s.e[1] * xp[1] + s.e[2] * xp[2];
+          z1 += s.e[3] * xp[0] + s.e[4] * xp[1] + s.e[5] * xp[2];
+        }
+        scatter_ft<LDS>(A, s, acc, z0, z1);
+        if (s.valid) { part[0] = s.e[0] * z0 + s.e[3] * z1; part[1] = s.e[1] * z0 + s.e[4] * z1; part[2] = s.e[2] * z0 + s.e[5] * z1; }
+      } else {
+        static_assert(MODE == kInit || MODE == kEte || MODE == kCgnrInit, "set-up modes");
+        if constexpr (MODE == kCgnrInit) scatter_ft<LDS>(A, s, acc, s.b0, s.b1);
+        if (s.valid) {
+          double a[6];
+          ete_of(s, a);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) part[i] = a[i];
+          part[6] = s.e[0] * s.b0 + s.e[3] * s.b1; part[7] = s.e[1] * s.b0 + s.e[4] * s.b1; part[8] = s.e[2] * s.b0 + s.e[5] * s.b1;
+        }
+      }
+      wave_allreduce<NX>(part);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xr[sub][wave][i] = part[i];
+      }
+    }
+    __syncthreads();
+    double tot[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) tot[i] = 0.0;
+    if (it_real || active || flag) {   // (a sub-workgroup out of rounds has nothing to add up)
+      if (!apply_round)
+        for (int k = 0; k < cnt; ++k) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) tot[i] += xr[sub][w0 + k][i];
+        }
+    }
+    __syncthreads();
+    if (flag & kRoundSum) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { carry[i] += tot[i]; tot[i] = carry[i]; }
+      if (!(flag & kRoundLast)) continue;
+      if constexpr (!kTwoPhase) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) carry[i] = 0.0;
+      }
+    } else if (apply_round) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) tot[i] = carry[i];
+      if (flag & kRoundLast) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) carry[i] = 0.0;
+      }
+      if constexpr (!kTwoPhase) continue;
+    }
+    if (!active) continue;
+    // ---- the point's sums are in tot.  `finish`: what is stored once per point (first wave of the point; a point of more than
+    // kRoundWaves tiles: in its last sum round).  `apply`: what every tile does with the sums (such a point: in its apply rounds).
+    const bool finish = wave == w0 && lane == 0 && !apply_round;
+    const bool apply = flag == 0 || apply_round;
+    if constexpr (MODE == kColNorm || MODE == kJtb) {
+      if (finish) { A.y_e[po] = tot[0]; A.y_e[po + 1] = tot[1]; A.y_e[po + 2] = tot[2]; }
+    } else if constexpr (MODE == kJtJx) {
+      if (finish) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double d = 0;
+          if (A.D_e) { d = A.D_e[po + j]; d = d * d * xp[j]; }
+          A.y_e[po + j] = tot[j] + d;
+          lane_acc += xp[j] * (tot[j] + d);
+        }
+      }
+    } else if constexpr (MODE == kSx || MODE == kSpseZ || MODE == kBackSub) {
+      double ei[6], v[3];
+      load_ete_inverse(A, pt, ei);
+      const double u[3] = {tot[0], tot[1], tot[2]};
+      sym3_mul(ei, u, v);
+      if constexpr (MODE == kBackSub) {
+        if (finish) {
+          const double sg = A.negate_out ? -1.0 : 1.0;
+          A.y_e[po] = sg * v[0]; A.y_e[po + 1] = sg * v[1]; A.y_e[po + 2] = sg * v[2];
+          if (A.negate_out && !isfinite(v[0] + v[1] + v[2])) atomicAdd(A.nonfinite, 1);
+        }
+        if (!A.scalar_out || !apply) continue;
+      } else if (!apply) continue;
+      if (apply_round) {   // the sums came from earlier rounds: this tile's F x again
+        double xc[9];
+        load_xc(A, s.cam, xc);
+        f_times(s, xc, t0, t1);
+        if constexpr (MODE == kBackSub) { t0 = s.b0 - t0; t1 = s.b1 - t1; }
+      }
+      const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
+      const double ev1 = s.e[3] * v[0] + s.e[4] * v[1] + s.e[5] * v[2];
+      if constexpr (MODE == kBackSub) {   // fused model cost change: J x = F z + E x_e with F z = b - t
+        const double m0 = (s.b0 - t0) + ev0, m1 = (s.b1 - t1) + ev1;
+        if (s.valid) lane_acc += m0 * (s.b0 - 0.5 * m0) + m1 * (s.b1 - 0.5 * m1);
+      } else {
+        scatter_ft<LDS>(A, s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
+      }
+    } else {
+      double a[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, ei[6];
+      add_e_diagonal(A, pt, po, a, finish);
+      invert_spd3(a, ei);
+      if constexpr (MODE == kCgnrInit) {
+        if (finish) {
+          A.y_e[po] = tot[6]; A.y_e[po + 1] = tot[7]; A.y_e[po + 2] = tot[8];
+          if (A.point_blocks) store_ete_inverse(A, pt, ei);
+        }
+      } else {
+        if (finish) store_ete_inverse(A, pt, ei);
+      }
+      if constexpr (MODE == kInit) {
+        if (apply) {
+          const double g[3] = {tot[6], tot[7], tot[8]};
+          init_apply<LDS>(A, s, tile * kTile + lane, s.b0, s.b1, ei, g, acc);
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, bool LDS, int BLOCK, bool F32>
 __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
   extern __shared__ double lds_acc[];
@@ -898,10 +1095,13 @@ __global__ __launch_bounds__(BLOCK) void bal_fused_kernel(BalArgs A) {
     if constexpr (MODE == kJx) {
       process_tile<MODE, LDS, F32>(A, tile, lane, 1, 0, acc, lane_acc);
     } else {
-      if (kind == 2) continue;
+      if (kind == 2 || kind == 3) continue;   // 3: the head of a long point that is taken in rounds (below)
       if (kind == 0) process_tile<MODE, LDS, F32>(A, tile, lane, aux & 0xff, aux >> 8, acc, lane_acc);
       else process_long_point<MODE, LDS, F32>(A, tile, aux, lane, acc, lane_acc);
     }
+  }
+  if constexpr (MODE != kJx) {
+    if (A.round_word) fused_long_rounds<MODE, LDS, BLOCK, F32>(A, lane, grouped, grouped ? int(blockIdx.x) : 0, acc, lane_acc);   // (workgroup-uniform)
   }
   double* const scalar_dst = MODE == kJtJx ? A.pq_out : A.scalar_out;
   if ((MODE == kJx || MODE == kBackSub || MODE == kJtJx) && scalar_dst) {  // one partial per workgroup, summed in fixed order by the caller
@@ -976,21 +1176,33 @@ __device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int l
 // wave adds them up in the same order and finishes its own tile.  A point of up to 512 observations is read ONCE, a tile per wave in
 // flight, where one wave walked the point's tiles twice with nothing in flight (process_long_point: 0.20 - 0.25 of the HBM peak on
 // graphs of long tracks).  `word`: the wave's round word (kRoundIdle: no tile — every lane is invalid, the loads were issued anyway).
+// A point of more than kRoundWaves tiles (flag != 0, the round is its own: waves [0, cnt0), cnt0 from the round's first word): in its
+// kRoundSum rounds every wave adds the round's total to `carry`; its kRoundApply rounds finish the (L2-warm) tiles with that sum.
+// JtJx has nothing to finish: its sum rounds do all the work, the last one stores y_e.
 template <int MODE, bool LDS>
-__device__ __forceinline__ void compute_long_round(const BalArgs& A, const Slot& s, int lane, const StreamAux& x, uint32_t word, int wave,
-                                                   double (*red)[3], double* acc, double& dot) {
+__device__ __forceinline__ void compute_long_round(const BalArgs& A, const Slot& s, int lane, const StreamAux& x, uint32_t word, uint32_t word0,
+                                                   int flag, int wave, double (*red)[3], double (&carry)[3], double* acc, double& dot) {
   const bool active = word != kRoundIdle;
-  const int w0 = active ? int((word >> 26) & 7u) : wave, cnt = active ? int((word >> 29) & 7u) + 1 : 1;
+  const int w0 = flag ? 0 : (active ? int((word >> 26) & 7u) : wave);
+  const int cnt = flag ? int((word0 >> 29) & 7u) + 1 : (active ? int((word >> 29) & 7u) + 1 : 1);
   if constexpr (MODE == kSx || MODE == kSpseZ) {
     double t0, t1;
     f_times(s, x.xc, t0, t1);
     double u[3] = {s.e[0] * t0 + s.e[3] * t1, s.e[1] * t0 + s.e[4] * t1, s.e[2] * t0 + s.e[5] * t1};
     if (!s.valid) { u[0] = u[1] = u[2] = 0; }
-    wave_allreduce<3>(u);
-    if (lane == 0) { red[wave][0] = u[0]; red[wave][1] = u[1]; red[wave][2] = u[2]; }
+    if (!(flag & kRoundApply)) {
+      wave_allreduce<3>(u);
+      if (lane == 0) { red[wave][0] = u[0]; red[wave][1] = u[1]; red[wave][2] = u[2]; }
+    }
     __syncthreads();
-    u[0] = u[1] = u[2] = 0;
-    for (int k = 0; k < cnt; ++k) { u[0] += red[w0 + k][0]; u[1] += red[w0 + k][1]; u[2] += red[w0 + k][2]; }
+    if (flag & kRoundApply) {
+      u[0] = carry[0]; u[1] = carry[1]; u[2] = carry[2];
+      if (flag & kRoundLast) { carry[0] = carry[1] = carry[2] = 0; }
+    } else {
+      u[0] = u[1] = u[2] = 0;
+      for (int k = 0; k < cnt; ++k) { u[0] += red[w0 + k][0]; u[1] += red[w0 + k][1]; u[2] += red[w0 + k][2]; }
+      if (flag & kRoundSum) { carry[0] += u[0]; carry[1] += u[1]; carry[2] += u[2]; return; }
+    }
     double v[3];
     sym3_mul(x.ei, u, v);
     const double ev0 = s.e[0] * v[0] + s.e[1] * v[1] + s.e[2] * v[2];
@@ -998,6 +1210,7 @@ __device__ __forceinline__ void compute_long_round(const BalArgs& A, const Slot&
     scatter_ft<LDS>(A, s, acc, MODE == kSx ? t0 - ev0 : ev0, MODE == kSx ? t1 - ev1 : ev1);
   } else {
     static_assert(MODE == kJtJx, "streaming modes");
+    if (flag & kRoundApply) { __syncthreads(); return; }
     // issue_aux with one point: lanes 0..2 hold the point's x_e and D_e
     const double xp[3] = {shfl_idx(x.xa, 0), shfl_idx(x.xa, 1), shfl_idx(x.xa, 2)};
     double z0, z1;
@@ -1010,9 +1223,19 @@ __device__ __forceinline__ void compute_long_round(const BalArgs& A, const Slot&
     wave_allreduce<3>(w);
     if (lane == 0) { red[wave][0] = w[0]; red[wave][1] = w[1]; red[wave][2] = w[2]; }
     __syncthreads();
-    if (active && wave == w0 && lane < 3) {   // the point's first wave stores y_e
-      double t = 0;
+    double t = 0;   // lane j < 3: component j of the point's sum
+    if (lane < 3) {
       for (int k = 0; k < cnt; ++k) t += red[w0 + k][lane];
+    }
+    bool store = active && wave == w0 && lane < 3;   // the point's first wave stores y_e
+    if (flag & kRoundSum) {
+      const double c = (lane == 0 ? carry[0] : (lane == 1 ? carry[1] : carry[2])) + t;
+      if (lane == 0) carry[0] = c; else if (lane == 1) carry[1] = c; else if (lane == 2) carry[2] = c;
+      store = store && (flag & kRoundLast);
+      t = c;
+      if (flag & kRoundLast) { carry[0] = carry[1] = carry[2] = 0; }
+    }
+    if (store) {
       const double yv = t + x.da * x.da * x.xa;
       A.y_e[x.base + lane] = yv;
       dot += x.xa * yv;
@@ -1099,63 +1322,87 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   // tiles (kind 3) are taken in ROUNDS, one tile per wave, with the same one-stage-ahead pipeline as above.
   __shared__ double round_red[2][kRoundWaves][3];
   if (A.round_word) {
-    const int64_t rb = A.round_ptr[range], re = A.round_ptr[range + 1];
-    const int64_t rstride = grouped ? 1 : int64_t(gridDim.x);
-    int64_t r = grouped ? rb : rb + logical_workgroup();
-    if (r < re) {   // (workgroup-uniform: the rounds have barriers)
-      const int64_t rlast = r + ((re - 1 - r) / rstride) * rstride;
+    // this workgroup's SEQUENCES of rounds (plan.cc): one packed round, or all rounds of one point of more than kRoundWaves tiles
+    const int64_t qe = grouped ? int64_t(A.round_ptr[range + 1]) : int64_t(A.n_seq);
+    const int64_t qstride = grouped ? 1 : int64_t(gridDim.x);
+    int64_t it_q = grouped ? int64_t(A.round_ptr[range]) : logical_workgroup();
+    if (it_q < qe) {   // (workgroup-uniform: the rounds have barriers)
+      // (a hybrid group's sequences are all its workgroup's: one run of rounds, no table look-up on the way)
+      int64_t it_r = A.seq_ptr[it_q], it_end = A.seq_ptr[grouped ? qe : it_q + 1];
+      if (grouped) it_q = qe - 1;
+      bool it_real = true;
+      // the iterator's round, then one step on; past the end it keeps returning the last round (same load count on every path)
+      auto next_round = [&](bool* real) {
+        const int64_t r = it_r;
+        *real = it_real;
+        if (it_real) {
+          if (it_r + 1 < it_end) ++it_r;
+          else if (it_q + qstride < qe) { it_q += qstride; it_r = A.seq_ptr[it_q]; it_end = A.seq_ptr[it_q + 1]; }
+          else it_real = false;
+        }
+        return r;
+      };
       Slot sa, sb;
       StreamAux xa, xb;
       SlotIdx i1, i2;
-      // an idle wave issues the loads of the round's first tile (same load count on every path), with every lane invalid
-      auto word_at = [&](int64_t q) { return A.round_word[q * kRoundWaves + wave]; };
-      auto tile_at = [&](int64_t q, uint32_t w) { return int64_t((w != kRoundIdle ? w : A.round_word[q * kRoundWaves]) & 0x3FFFFFFu); };
+      double carry[3] = {0, 0, 0};
+      // an idle wave issues the loads of the round's first tile, with every lane invalid
+      auto word_at = [&](int64_t r) { return A.round_word[r * kRoundWaves + wave]; };
+      auto tile_at = [&](int64_t r, uint32_t w) { return int64_t((w != kRoundIdle ? w : A.round_word[r * kRoundWaves]) & 0x3FFFFFFu); };
       auto finish = [&](Slot& c, const SlotIdx& i, int64_t tile, uint32_t w) {
         c.cam = i.cam; c.seg = i.seg;
         finish_slot(c, lane, A.tile_pt0[tile]);
         if (w == kRoundIdle) { c.valid = false; c.cam = 0; c.pt = 0; c.acc = kSlotSpill; }
       };
-      uint32_t wa = word_at(r), wb = kRoundIdle;
-      int64_t tile = tile_at(r, wa);
+      bool real_c, real_n, real_nn;
+      int64_t rc = next_round(&real_c), rn = next_round(&real_n);
+      uint32_t wa = word_at(rc), wb = kRoundIdle;
+      // the round's first word and flag travel with the pipeline (scalar loads a stage ahead of their use)
+      uint32_t w0a = A.round_word[rc * kRoundWaves], w0b = kRoundIdle;
+      int fa = A.round_flag[rc], fb = 0;
       int par = 0;
-      issue_idx(A, tile, lane, i2);
-      __builtin_amdgcn_sched_barrier(0);
-      { const int64_t q = min(r + rstride, rlast); issue_idx(A, tile_at(q, word_at(q)), lane, i1); }
-      __builtin_amdgcn_sched_barrier(0);
-      issue_pairs<NT>(A, tile, lane, sa);
-      __builtin_amdgcn_sched_barrier(0);
-      finish(sa, i2, tile, wa);
-      issue_aux<MODE>(A, sa, lane, 1, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      bool more = true;
-      auto stage = [&](Slot& c, StreamAux& cx, uint32_t cw, Slot& n, StreamAux& nx, uint32_t& nw) {
-        const int64_t q = min(r + rstride, rlast), q2 = min(q + rstride, rlast);
-        more = r + rstride < re;
-        nw = word_at(q);
-        const int64_t next = tile_at(q, nw);
-        issue_idx(A, tile_at(q2, word_at(q2)), lane, i2);
+      {
+        const int64_t tile = tile_at(rc, wa);
+        issue_idx(A, tile, lane, i2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_idx(A, tile_at(rn, word_at(rn)), lane, i1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pairs<NT>(A, tile, lane, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(sa, i2, tile, wa);
+        issue_aux<MODE>(A, sa, lane, 1, xa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      auto stage = [&](Slot& c, StreamAux& cx, uint32_t cw, uint32_t cw0, int cf, Slot& n, StreamAux& nx, uint32_t& nw, uint32_t& nw0, int& nf) {
+        const int64_t rnn = next_round(&real_nn);
+        nw = word_at(rn);
+        nw0 = A.round_word[rn * kRoundWaves];
+        nf = A.round_flag[rn];
+        const int64_t next = int64_t((nw != kRoundIdle ? nw : nw0) & 0x3FFFFFFu);
+        issue_idx(A, tile_at(rnn, word_at(rnn)), lane, i2);
         __builtin_amdgcn_sched_barrier(0);
         issue_pairs<NT>(A, next, lane, n);
         __builtin_amdgcn_sched_barrier(0);
         finish(n, i1, next, nw);
         issue_aux<MODE>(A, n, lane, 1, nx);
         __builtin_amdgcn_sched_barrier(0);
-        compute_long_round<MODE, LDS>(A, c, lane, cx, cw, wave, round_red[par], acc, dot);
+        compute_long_round<MODE, LDS>(A, c, lane, cx, cw, cw0, cf, wave, round_red[par], carry, acc, dot);
         __builtin_amdgcn_sched_barrier(0);
         par ^= 1;
         i1 = i2;
-        r = q;
+        rc = rn; real_c = real_n;
+        rn = rnn; real_n = real_nn;
       };
       while (true) {
-        stage(sa, xa, wa, sb, xb, wb);
-        if (!more) break;
-        stage(sb, xb, wb, sa, xa, wa);
-        if (!more) break;
+        stage(sa, xa, wa, w0a, fa, sb, xb, wb, w0b, fb);
+        if (!real_c) break;
+        stage(sb, xb, wb, w0b, fb, sa, xa, wa, w0a, fa);
+        if (!real_c) break;
       }
     }
   }
-  // Longer ones still (kind 1; and every long point when the ring is chunked: they sit among the normal tiles then): one wave per
-  // point, two sweeps (process_long_point).
+  // Long points outside the rounds (kind 1: the ring is chunked — they sit among the normal tiles then — or the plan has more
+  // tiles than a round word holds): one wave per point, two sweeps (process_long_point).
   for (int64_t tile = (A.long_behind ? long_begin + wave_first : wave0); tile < range_end; tile += nwaves) {
     if (A.tile_kind[tile] == 1) process_long_point<MODE, LDS, false>(A, tile, A.tile_aux[tile], lane, acc, dot);
   }

@@ -224,7 +224,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   P.renumbered = reorder_points;
 
   // Cameras whose 9-double accumulators do not fit in LDS (decided here: the point order below depends on it).
-  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 512;
+  // (1 KiB of the 160 stays free for the kernels' static LDS: workgroup reductions, the exchange area of the long points' rounds)
+  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 1024;
   int64_t chunk_mib = 0;  // CERES_HIP_Z_CHUNK_MIB=<n>: bound the F^T z ring to n MiB (memory-constrained runs)
   if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
   if (!P.cameras_in_lds && P.n_cameras >= (1 << kSlotCamBits)) return no("more cameras than the slot word holds");
@@ -499,37 +500,59 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
 
   // ROUNDS of long points.  A streaming kernel's workgroup has kRoundWaves waves; in a round each of them takes ONE tile, the waves
   // of a point exchange their tile sums through LDS, and every wave finishes its tile from registers: a long point is read once,
-  // with a tile per wave in flight, instead of one wave walking all its tiles twice.  A round holds whole points (first fit,
+  // with a tile per wave in flight, instead of one wave walking all its tiles twice.  A round holds whole points (tightest fit,
   // longest first); word = tile | first wave of the point << 26 | (waves of the point - 1) << 29, kRoundIdle for a wave without a
-  // tile.  Points of more than kRoundWaves tiles keep kind 1 (one wave, two sweeps); the others get kind 3.  Hybrid: rounds per group.
+  // tile.  A point of MORE than kRoundWaves tiles has rounds of its own, twice: kRoundSum rounds (every wave keeps the running sum of
+  // the rounds' totals) and then kRoundApply rounds over the same tiles (L2-warm), which finish them with that sum; kRoundLast marks
+  // the last round of either phase.  The workgroup-level unit of work is the SEQUENCE (one packed round, or all rounds of one such
+  // point): a workgroup takes whole sequences, those of range g (the hybrid group, or everything) are [round_ptr[g], round_ptr[g + 1]),
+  // the longest first.  Every head tile in a round has kind 3 (kind 1: no rounds — a chunked ring, or more tiles than a word holds).
   P.long_ptr = long_ptr;
   P.long_behind = segregate;
   P.round_ptr.assign(1, 0);
+  P.seq_ptr.assign(1, 0);
   if (segregate && P.n_tiles < (int64_t(1) << 26)) {
     const size_t n_ranges = long_ptr.size();
+    auto new_round = [&](int flag) {
+      P.round_word.resize(P.round_word.size() + kRoundWaves, kRoundIdle);
+      P.round_flag.push_back(flag);
+      return P.round_word.size() / kRoundWaves - 1;
+    };
     for (size_t g = 0; g < n_ranges; ++g) {
       const int64_t t0 = long_ptr[g], t1 = P.grp_tile_ptr.empty() ? P.n_tiles : int64_t(P.grp_tile_ptr[g + 1]);
       std::vector<std::pair<int, int64_t>> heads;   // (tiles, head tile)
       for (int64_t t = t0; t < t1; ++t)
-        if (P.tile_kind[t] == 1 && P.tile_aux[t] <= kRoundWaves) heads.emplace_back(P.tile_aux[t], t);
+        if (P.tile_kind[t] == 1) { heads.emplace_back(P.tile_aux[t], t); P.tile_kind[t] = 3; }
       std::stable_sort(heads.begin(), heads.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-      const size_t round0 = P.round_word.size() / kRoundWaves;
-      std::vector<int> fill;                        // waves taken in each round of this range
+      size_t h = 0;
+      for (; h < heads.size() && heads[h].first > kRoundWaves; ++h) {   // rounds of its own, two phases
+        const int nt = heads[h].first;
+        for (int phase = 0; phase < 2; ++phase) {
+          for (int t = 0; t < nt; t += kRoundWaves) {
+            const int n = std::min(kRoundWaves, nt - t);
+            const size_t r = new_round((phase == 0 ? kRoundSum : kRoundApply) | (t + n == nt ? kRoundLast : 0));
+            for (int w = 0; w < n; ++w) P.round_word[r * kRoundWaves + w] = uint32_t(heads[h].second + t + w) | (uint32_t(n - 1) << 29);
+          }
+        }
+        P.seq_ptr.push_back(int32_t(P.round_flag.size()));
+      }
+      const size_t round0 = P.round_flag.size();
+      std::vector<int> fill;                               // waves taken in each packed round of this range
       std::vector<size_t> open_by_room[kRoundWaves + 1];   // rounds with exactly `room` free waves (stacks)
-      for (const auto& hd : heads) {
-        const int nt = hd.first;
+      for (; h < heads.size(); ++h) {
+        const int nt = heads[h].first;
         size_t r = size_t(-1);
         for (int room = nt; room <= kRoundWaves && r == size_t(-1); ++room)   // tightest fit
           if (!open_by_room[room].empty()) { r = open_by_room[room].back(); open_by_room[room].pop_back(); }
-        if (r == size_t(-1)) { r = fill.size(); fill.push_back(0); P.round_word.resize(P.round_word.size() + kRoundWaves, kRoundIdle); }
+        if (r == size_t(-1)) { r = fill.size(); fill.push_back(0); new_round(0); }
         const int w0 = fill[r];
         for (int t = 0; t < nt; ++t)
-          P.round_word[(round0 + r) * kRoundWaves + w0 + t] = uint32_t(hd.second + t) | (uint32_t(w0) << 26) | (uint32_t(nt - 1) << 29);
+          P.round_word[(round0 + r) * kRoundWaves + w0 + t] = uint32_t(heads[h].second + t) | (uint32_t(w0) << 26) | (uint32_t(nt - 1) << 29);
         fill[r] += nt;
         if (fill[r] < kRoundWaves) open_by_room[kRoundWaves - fill[r]].push_back(r);
-        P.tile_kind[hd.second] = 3;
       }
-      P.round_ptr.push_back(int32_t(P.round_word.size() / kRoundWaves));
+      for (size_t r = 0; r < fill.size(); ++r) P.seq_ptr.push_back(int32_t(round0 + r + 1));
+      P.round_ptr.push_back(int32_t(P.seq_ptr.size() - 1));
     }
   } else {
     P.round_ptr.resize(long_ptr.size() + 1, 0);

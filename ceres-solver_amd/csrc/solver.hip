@@ -66,7 +66,7 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
-  int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr;       // long points: where they begin, their rounds (plan.cc)
+  int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr, *d_seq_ptr = nullptr, *d_round_flag = nullptr;  // long points: where they begin, their rounds (plan.cc)
   uint32_t* d_round_word = nullptr;
   int32_t* d_mo_index = nullptr;                               // hybrid plans: M_o record of each slot
   CamItems cam_items;
@@ -275,7 +275,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.etei = s->etei;
   A.partials = s->d_partials; A.zbuf = s->d_zbuf;
   A.tile_zbase = s->d_tile_zbase; A.grp_tile_ptr = s->d_grp_tile_ptr;
-  A.long_ptr = s->d_long_ptr; A.round_ptr = s->d_round_ptr; A.round_word = s->d_round_word; A.long_behind = s->plan.long_behind ? 1 : 0;
+  A.long_ptr = s->d_long_ptr; A.round_ptr = s->d_round_ptr; A.round_word = s->d_round_word; A.seq_ptr = s->d_seq_ptr; A.round_flag = s->d_round_flag; A.n_seq = int(s->plan.seq_ptr.size()) - 1; A.long_behind = s->plan.long_behind ? 1 : 0;
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.mo_index = s->d_mo_index;
   A.n_f9 = 9 * s->plan.n_cameras;
@@ -1703,7 +1703,11 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_long_ptr, P.long_ptr));
     TRY(dev_upload(s, &s->d_round_ptr, P.round_ptr));
     s->d_round_word = nullptr;
-    if (!P.round_word.empty()) TRY(dev_upload(s, &s->d_round_word, P.round_word));
+    if (!P.round_word.empty()) {
+      TRY(dev_upload(s, &s->d_round_word, P.round_word));
+      TRY(dev_upload(s, &s->d_seq_ptr, P.seq_ptr));
+      TRY(dev_upload(s, &s->d_round_flag, P.round_flag));
+    }
     TRY(dev_upload(s, &s->d_tile_aux, P.tile_aux));
     TRY(dev_upload(s, &s->d_pt_pos, P.pt_pos));
     TRY(dev_upload(s, &s->d_cam_pos, P.cam_pos));
@@ -2782,9 +2786,9 @@ int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num
 }
 
 int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t renumber, int32_t groups,
-                                int32_t rows, int64_t counts[4], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
-                                int32_t* long_ptr, int32_t* round_ptr, uint32_t* round_word, int64_t tile_capacity,
-                                int64_t range_capacity, int64_t round_capacity) {
+                                int32_t rows, int64_t counts[5], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
+                                int32_t* long_ptr, int32_t* round_ptr, int32_t* seq_ptr, int32_t* round_flag, uint32_t* round_word,
+                                int64_t tile_capacity, int64_t range_capacity, int64_t round_capacity) {
   if (!bs || !counts) return CERES_HIP_E_INVALID;
   HostStructure h;
   if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
@@ -2794,7 +2798,7 @@ int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num
   BuildBalPlan(h, renumber ? kReorderAlways : kReorderNever, hyb, &P);
   if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
   const int64_t n_ranges = int64_t(P.long_ptr.size()), n_rounds = int64_t(P.round_word.size()) / kRoundWaves;
-  counts[0] = P.n_tiles; counts[1] = n_ranges; counts[2] = n_rounds; counts[3] = P.long_behind ? 1 : 0;
+  counts[0] = P.n_tiles; counts[1] = n_ranges; counts[2] = n_rounds; counts[3] = P.long_behind ? 1 : 0; counts[4] = int64_t(P.seq_ptr.size()) - 1;
   if (tile_capacity < P.n_tiles || range_capacity < n_ranges || round_capacity < n_rounds) return 0;  // the caller only wanted the counts
   std::copy(P.tile_kind.begin(), P.tile_kind.end(), tile_kind);
   std::copy(P.tile_aux.begin(), P.tile_aux.end(), tile_aux);
@@ -2803,6 +2807,8 @@ int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num
   std::copy(P.long_ptr.begin(), P.long_ptr.end(), long_ptr);
   std::copy(P.round_ptr.begin(), P.round_ptr.end(), round_ptr);
   std::copy(P.round_word.begin(), P.round_word.end(), round_word);
+  std::copy(P.seq_ptr.begin(), P.seq_ptr.end(), seq_ptr);
+  std::copy(P.round_flag.begin(), P.round_flag.end(), round_flag);
   return 0;
 }
 

@@ -149,7 +149,7 @@ ABI = [
     ("ceres_hip_debug_hybrid_plan", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, POINTER(c_int64)] + [POINTER(c_int32)] * 8 +
      [c_int64, c_int64, c_int64]),
     ("ceres_hip_debug_long_rounds", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, c_int32, POINTER(c_int64)] +
-     [POINTER(c_int32)] * 5 + [POINTER(c_uint32), c_int64, c_int64, c_int64]),
+     [POINTER(c_int32)] * 7 + [POINTER(c_uint32), c_int64, c_int64, c_int64]),
 ]
 
 _lib = None
@@ -706,22 +706,24 @@ def debug_long_rounds(bs: BlockStructure, num_eliminate_blocks: int, renumber: b
     (csrc/plan.cc; no device needed).  Returns None when the structure is not <2,3,9>-shaped."""
     lib = load_library()
     c = bs.as_ctypes()
-    counts = (c_int64 * 4)()
+    counts = (c_int64 * 5)()
     n32, nu = POINTER(c_int32)(), POINTER(c_uint32)()
     fn = lib.ceres_hip_debug_long_rounds
     args = (byref(c), c_int32(num_eliminate_blocks), c_int32(1 if renumber else 0), c_int32(groups), c_int32(rows), counts)
-    if fn(*args, n32, n32, n32, n32, n32, nu, c_int64(0), c_int64(0), c_int64(0)) != 0:
+    if fn(*args, n32, n32, n32, n32, n32, n32, n32, nu, c_int64(0), c_int64(0), c_int64(0)) != 0:
         return None
-    nt, nr, nrounds, behind = (int(v) for v in counts)
+    nt, nr, nrounds, behind, nseq = (int(v) for v in counts)
     kind, aux = np.zeros(nt, np.int32), np.zeros(nt, np.int32)
     rtp, lp, rp = np.zeros(nr + 1, np.int32), np.zeros(nr, np.int32), np.zeros(nr + 1, np.int32)
+    sp, flag = np.zeros(nrounds + 1, np.int32), np.zeros(max(nrounds, 1), np.int32)
     words = np.zeros(max(nrounds, 1) * 8, np.uint32)
     ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
-    rc = fn(*args, ip(kind), ip(aux), ip(rtp), ip(lp), ip(rp), words.ctypes.data_as(POINTER(c_uint32)), c_int64(nt), c_int64(nr),
-            c_int64(nrounds))
+    rc = fn(*args, ip(kind), ip(aux), ip(rtp), ip(lp), ip(rp), ip(sp), ip(flag), words.ctypes.data_as(POINTER(c_uint32)), c_int64(nt),
+            c_int64(nr), c_int64(nrounds))
     assert rc == 0
     return {"n_tiles": nt, "tile_kind": kind, "tile_aux": aux, "range_tile_ptr": rtp, "long_ptr": lp, "round_ptr": rp,
-            "round_word": words[:nrounds * 8].reshape(nrounds, 8), "long_behind": bool(behind)}
+            "seq_ptr": sp[:nseq + 1], "round_flag": flag[:nrounds], "round_word": words[:nrounds * 8].reshape(nrounds, 8),
+            "long_behind": bool(behind)}
 
 
 CONVERGENCE, MINIMIZER_NO_CONVERGENCE, MINIMIZER_FAILURE = 0, 1, 2

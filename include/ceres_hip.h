@@ -502,14 +502,17 @@ int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num
 /* Debug: where the plan (csrc/plan.cc; pure host code) puts the points of more than 64 observations, and the ROUNDS the streaming
  * kernels take them in.  renumber != 0: the plan of a Schur solver (points renumbered); groups >= 2: the hybrid plan.  The tiles of
  * range g (a hybrid group, or range 0 = everything) are [range_tile_ptr[g], range_tile_ptr[g+1]); from long_ptr[g] on they belong to
- * long points (tile_kind 3 or 1 = head, tile_aux = its number of tiles; 2 = continuation).  Round r of range g, r in
- * [round_ptr[g], round_ptr[g+1]), gives wave w the tile round_word[8 r + w] & 0x3FFFFFF (0xFFFFFFFF: none); bits 26..28 = first wave
- * of the point, bits 29..31 = its number of waves - 1.  counts[4] = {n_tiles, ranges, rounds, long points behind the others (0/1)}.
- * Call once with capacities 0 for the counts.                                                                                     */
+ * long points (tile_kind 3 = head of a point that is in the rounds, 1 = of one that is not, tile_aux = its number of tiles;
+ * 2 = continuation).  A workgroup takes whole SEQUENCES of rounds: those of range g are [round_ptr[g], round_ptr[g+1]), sequence q is
+ * the rounds [seq_ptr[q], seq_ptr[q+1]).  Round r gives wave w the tile round_word[8 r + w] & 0x3FFFFFF (0xFFFFFFFF: none); bits
+ * 26..28 = first wave of the point, bits 29..31 = its number of waves - 1; round_flag[r]: 0 = a round of whole points, else 1 (sum)
+ * or 2 (apply), + 4 on the last round of the phase: the rounds of ONE point of more than 8 tiles.  counts[5] = {n_tiles, ranges,
+ * rounds, long points behind the others (0/1), sequences}.  seq_ptr holds sequences + 1 entries within round_capacity + 1.  Call
+ * once with capacities 0 for the counts.                                                                                          */
 int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t renumber, int32_t groups,
-                                int32_t rows, int64_t counts[4], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
-                                int32_t* long_ptr, int32_t* round_ptr, uint32_t* round_word, int64_t tile_capacity,
-                                int64_t range_capacity, int64_t round_capacity);
+                                int32_t rows, int64_t counts[5], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
+                                int32_t* long_ptr, int32_t* round_ptr, int32_t* seq_ptr, int32_t* round_flag, uint32_t* round_word,
+                                int64_t tile_capacity, int64_t range_capacity, int64_t round_capacity);
 
 /* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
  * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */

@@ -30,7 +30,7 @@ CASES = [("bal_schur", 5, 2), ("bal_schur", 6, 1), ("bal_cgnr", 6, 1), ("general
 def test_lm_compute_step_matches_reference(hip, oracle, problems, kind, solver_type, pre):
     if kind == "bal_schur":
         p = problems.synthetic_bal(None, layout="schur", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
-    elif kind == "bal_many_cameras":  # > 2275 cameras: the camera accumulators leave LDS (per-slot F^T z + camera-major pass)
+    elif kind == "bal_many_cameras":  # > 2261 cameras: the camera accumulators leave LDS (per-slot F^T z + camera-major pass)
         p = problems.synthetic_bal(None, layout="schur", num_cameras=2500, num_points=12000, num_observations=62000, seed=43, skew=0.4)
     elif kind == "bal_cgnr":
         p = problems.synthetic_bal(None, layout="cgnr", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)

@@ -167,7 +167,7 @@ def test_bal_fused_kernels_cgnr(hip, oracle, problems, case, layout):
 
 
 def test_bal_without_regulariser_and_global_accumulators(hip, oracle, problems):
-    # D == NULL, and enough cameras (> 2275) that the camera accumulators leave LDS
+    # D == NULL, and enough cameras (> 2261) that the camera accumulators leave LDS
     p = problems.synthetic_bal(None, num_cameras=2600, num_points=14000, num_observations=70000, seed=4)
     p.D = None
     s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)

@@ -55,9 +55,8 @@ def check_plan_invariants(p, plan):
     # a long point owns its tiles
     t = 0
     while t < nt:
-        if kind[t] in (1, 3):   # 3: at most 8 tiles, the streaming kernels take it in a round (test_long_point_rounds)
+        if kind[t] == 3:        # the streaming kernels take it in rounds (test_long_point_rounds)
             n = aux[t]
-            assert (n <= 8) == (kind[t] == 3)
             assert n >= 2 and (kind[t + 1:t + n] == 2).all()
             sl = slice(t * 64, (t + n) * 64)
             q = np.unique(pt[sl][valid[sl]])
@@ -90,16 +89,39 @@ def test_plan_long_points(problems):
 
 
 def check_long_rounds(r):
-    """The long points sit behind the normal tiles of their range, and every one of up to 8 tiles is in exactly one round."""
-    kind, aux = r["tile_kind"], r["tile_aux"]
+    """The long points sit behind the normal tiles of their range; every one of up to 8 tiles is in exactly one round, every longer
+    one has a sequence of rounds of its own: sum rounds over its tiles, then apply rounds over the same tiles."""
+    kind, aux, flag, seq = r["tile_kind"], r["tile_aux"], r["round_flag"], r["seq_ptr"]
     assert r["long_behind"]
+    assert seq[0] == 0 and seq[-1] == len(flag) and (np.diff(seq) >= 1).all()
     seen = np.zeros(r["n_tiles"], int)
     for g in range(len(r["long_ptr"])):
         t0, tl, t1 = r["range_tile_ptr"][g], r["long_ptr"][g], r["range_tile_ptr"][g + 1]
         assert t0 <= tl <= t1
         assert (kind[t0:tl] == 0).all() and (kind[tl:t1] != 0).all()
+        lengths = []
         for q in range(r["round_ptr"][g], r["round_ptr"][g + 1]):
-            words = r["round_word"][q]
+            rounds = range(seq[q], seq[q + 1])
+            lengths.append(len(rounds))
+            if len(rounds) > 1 or flag[rounds[0]] != 0:       # ONE point of more than 8 tiles
+                head = int(r["round_word"][rounds[0]][0] & 0x3FFFFFF)
+                n = aux[head]
+                assert kind[head] == 3 and n > 8 and len(rounds) == 2 * ((n + 7) // 8)
+                tiles = {1: [], 2: []}
+                for i, q_r in enumerate(rounds):
+                    phase = 1 if i < len(rounds) // 2 else 2
+                    last = (i + 1) % (len(rounds) // 2) == 0
+                    assert flag[q_r] == phase + (4 if last else 0)
+                    words = r["round_word"][q_r]
+                    act = words != 0xFFFFFFFF
+                    k = int(act.sum())
+                    assert act[:k].all() and k == (8 if not last else n - 8 * ((n - 1) // 8))
+                    assert ((words[:k] >> 29) & 7 == k - 1).all() and ((words[:k] >> 26) & 7 == 0).all()
+                    tiles[phase] += [int(w & 0x3FFFFFF) for w in words[:k]]
+                assert tiles[1] == tiles[2] == list(range(head, head + n))
+                seen[head:head + n] += 1
+                continue
+            words = r["round_word"][rounds[0]]
             w = 0
             assert words[0] != 0xFFFFFFFF                     # (an idle wave issues the loads of the round's first tile)
             while w < 8:
@@ -112,11 +134,12 @@ def check_long_rounds(r):
                     assert words[w + k] == np.uint32((tile + k) | (w0 << 26) | ((n - 1) << 29))
                     seen[tile + k] += 1
                 w += n
+        assert lengths == sorted(lengths, reverse=True)        # the longest sequences first
     in_round = np.zeros(r["n_tiles"], bool)
     for t in np.flatnonzero(kind == 3):
         in_round[t:t + aux[t]] = True
     assert np.array_equal(seen, in_round.astype(int))
-    assert (aux[kind == 1] > 8).all()
+    assert not (kind == 1).any()
 
 
 @pytest.mark.parametrize("renumber", [False, True])
@@ -125,9 +148,10 @@ def test_long_point_rounds(problems, renumber):
     p = problems.bal_from_tracks(tracks, 1100, seed=3)
     r = pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, renumber)
     check_long_rounds(r)
-    assert (r["tile_kind"] == 3).sum() == 10 and (r["tile_kind"] == 1).sum() == 2   # 513 and 1000 observations: one wave each
-    # tightest fit, longest first: (8) (8) (5, 3) (4, 2, 2) (2, 2, 2 + two idle waves) tiles
-    assert len(r["round_word"]) == 5 and (r["round_word"] == 0xFFFFFFFF).sum() == 2
+    assert (r["tile_kind"] == 3).sum() == 12
+    # 1000 observations: 2 x (8 + 8) tiles, 513: 2 x (8 + 1); then tightest fit, longest first: (8) (8) (5, 3) (4, 2, 2) (2, 2, 2 + two idle waves)
+    assert np.diff(r["seq_ptr"]).tolist() == [4, 4, 1, 1, 1, 1, 1]
+    assert (r["round_word"][r["round_flag"] == 0] == 0xFFFFFFFF).sum() == 2
     p = problems.synthetic_bal(None, num_cameras=220, num_points=300, num_observations=9000, seed=9, skew=0.0)
     check_long_rounds(pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, renumber))
 

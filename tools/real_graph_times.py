@@ -9,15 +9,22 @@ import numpy as np
 import __graft_entry__ as entry
 pkg = entry.load_package()
 hs, P = pkg.hip_solver, pkg.problems
-cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(2, 4), (2, 120), (3, 100)]
+cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(2, 4), (2, 120), (3, 100), (0, 1778)]
 for problem, copies in cases:
-    prob = P.libmv_bal(problem, copies)
+    if problem == 0:
+        # heavy-tailed tracks, as internet photo collections have them: 2 (1 + Pareto(1.6)) observations per point capped at 1000 (mean 5,
+        # an eighth of the observations in tracks of more than 64), random cameras: "0:<cameras>", 1 M points
+        rng = np.random.default_rng(38401)
+        lengths = np.minimum(np.floor(2.0 * (1.0 + rng.pareto(1.6, 1000000))), min(1000, copies)).astype(np.int64)
+        prob = P.bal_from_tracks(lengths, copies, seed=38401)
+    else:
+        prob = P.libmv_bal(problem, copies)
     n_p = prob.num_eliminate_blocks
     n_c = prob.bs.num_col_blocks - n_p
     n_o = prob.bs.num_row_blocks
     B_jtjx = n_o * 200 + (3 * n_p + 9 * n_c) * 32
     B_sx = n_o * 200 + n_p * 72 + n_c * 288
-    out = {"graph": f"libmv problem_0{problem} x {copies}", "cameras": n_c, "points": n_p, "observations": n_o}
+    out = {"graph": f"libmv problem_0{problem} x {copies}" if problem else f"power-law tracks on {copies} cameras", "cameras": n_c, "points": n_p, "observations": n_o}
     for solver, typ, pre, op, nbytes in (("cgnr", hs.CGNR, hs.JACOBI, hs.TIMED_JTJX, B_jtjx), ("schur", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI, hs.TIMED_SX, B_sx)):
         s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                       elimination_groups=[n_p]))
