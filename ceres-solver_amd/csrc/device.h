@@ -76,7 +76,7 @@ struct BalArgs {
   double* etei = nullptr;
   double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
   const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => 9*p
-  double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 pad (kInit)
+  double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 m01 (kInit)
   const int32_t* mo_index = nullptr;      // record of each slot in Mo (nullptr: the slot itself; hybrid plans: the slot's row)
   int have_b = 0;
   // camera accumulation
@@ -123,6 +123,7 @@ struct LmFuse {
 struct CamItems {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;
   int count = 0;
+  int64_t observations = 0;   // of all items together (the launcher picks the kernel by the mean item length)
 };
 // Per-camera 9x9 blocks in two steps: every item (<= kCamChunk observations of one camera) leaves 45 upper-triangle sums + 9
 // column square sums in parts[item][kCamPart]; the items of a camera (cam_item_ptr) are then added in list order either by
@@ -139,6 +140,7 @@ struct CamGather {
   const double* D_f = nullptr;            // added squared to the diagonal (indexed through cam_pos)
   const int32_t* cam_pos = nullptr;
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
+  int few = 0;                            // every camera has a handful of items at most: seven cameras per wavefront gather their own
   const double* extra = nullptr;          // [81 c + 9 a + b] raw sums added to the camera's block (rows outside the tiles: LaunchRemCameraBlocks)
 };
 // Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].

@@ -489,9 +489,11 @@ __device__ __forceinline__ void init_apply(const BalArgs& A, const Slot& s, int6
     double q0[3], q1[3];
     sym3_mul(ei, r0, q0);
     sym3_mul(ei, r1, q1);
-    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * (A.mo_index ? int64_t(A.mo_index[sl]) : sl));  // [record][4]: m00 m01 m11 pad, 32 B
+    double2* mo = reinterpret_cast<double2*>(A.Mo + 4 * (A.mo_index ? int64_t(A.mo_index[sl]) : sl));  // [record][4]: m00 m01 m11 m01, 32 B
     tile_store<2>(mo, make_double2(1.0 - (r0[0] * q0[0] + r0[1] * q0[1] + r0[2] * q0[2]), -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2])));
-    tile_store<2>(mo + 1, make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), 0.0));
+
+    const double m01 = -(r0[0] * q1[0] + r0[1] * q1[1] + r0[2] * q1[2]);
+    tile_store<2>(mo + 1, make_double2(1.0 - (r1[0] * q1[0] + r1[1] * q1[1] + r1[2] * q1[2]), m01));   // (m01 again: bal_camera_items_mfma_kernel)
   }
 }
 
@@ -1649,6 +1651,79 @@ __global__ __launch_bounds__(256) void bal_camera_items_kernel(const double* __r
   }
 }
 
+// The same item sums on the matrix pipe: a camera's block IS a contraction, F^T (W F) with F the (2 n) x 9 stack of the item's
+// observations and W = diag(M_o) (SCHUR_JACOBI) or I.  One v_mfma_f64_16x16x4_f64 takes four rows = two observations: lane l holds
+// column l & 15 (zero beyond 9) of row l >> 4, which is both its A operand (F^T[col][row]) and, after the 2 x 2 weight mixes it
+// with the observation's other row (lane l ^ 16), its B operand ((W F)[row][col]).  Against the lane-per-observation form above:
+// a load instruction reads whole 72-byte rows of two records instead of one 8-byte word of 64 records (4 instead of 18 line
+// look-ups per observation), and there is no 54-value wavefront reduction at the end — the sums ARE the accumulator, entry
+// (a, b) in register a / 4 of lane 16 (a % 4) + b.  What short items (a camera of a video-like scene has tens of observations) and
+// launch-bound shapes spent their time on.  LaunchBalCameraItems picks the kernel by the mean item length.
+typedef double cam_v4f64 __attribute__((ext_vector_type(4)));
+template <bool SCHUR>
+__global__ __launch_bounds__(256) void bal_camera_items_mfma_kernel(const double* __restrict__ values, CamItems items,
+                                                                    const int32_t* __restrict__ cam_fpos,
+                                                                    const int32_t* __restrict__ cam_slot,
+                                                                    const double* __restrict__ Mo, double* __restrict__ parts) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items.count) return;
+  const int beg = items.begin[item], end = items.end[item];
+  const int col = lane & 15, kk = lane >> 4, ob = kk >> 1, r = kk & 1;
+  const bool cv = col < 9;
+  constexpr int U = 8;  // matrix instructions (pairs of observations) per iteration: their loads are all in flight together
+  cam_v4f64 acc = cam_v4f64{0.0, 0.0, 0.0, 0.0}, acc1 = cam_v4f64{0.0, 0.0, 0.0, 0.0};   // two chains: the pipe need not wait for its own result
+  double sq = 0.0;
+  int fp[U], sl[U];
+  auto load_idx = [&](int q0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 2 * u + ob;
+      const bool ok = q < end;
+      fp[u] = ok ? cam_fpos[q] : -1;
+      if constexpr (SCHUR) sl[u] = ok ? cam_slot[q] : 0;
+    }
+  };
+  load_idx(beg);
+  for (int q0 = beg; q0 < end; q0 += 2 * U) {
+    double a[U], wd[U], wo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = (fp[u] >= 0 && cv) ? values[fp[u] + 9 * r + col] : 0.0;
+      if constexpr (SCHUR) {
+        // record [m00 m01 | m11 m01]: one 16-byte load gives row r its diagonal and off-diagonal weight
+        const double2 m = *reinterpret_cast<const double2*>(Mo + 4 * int64_t(sl[u]) + 2 * r);
+        wd[u] = m.x;
+        wo[u] = m.y;
+      }
+    }
+    load_idx(q0 + 2 * U);   // the next iteration's index words travel while this one computes
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double b = a[u];
+      if constexpr (SCHUR) {
+        const double other = __shfl_xor(a[u], 16, 64);   // the observation's other row, same column
+        b = wd[u] * a[u] + wo[u] * other;
+        sq += a[u] * a[u];
+      }
+      if (u & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b, acc1, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b, acc, 0, 0, 0);
+    }
+  }
+  acc += acc1;
+  double* out = parts + int64_t(item) * kCamPart;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = kk + 4 * i;
+    if (ra <= col && col < 9) out[ra * (19 - ra) / 2 + (col - ra)] = acc[i];
+  }
+  if constexpr (SCHUR) {
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (kk == 0 && cv) out[45 + col] = sq;
+  }
+}
+
 // Row `i` of camera c's block from the per-item partial sums (packed upper triangle: entry (a, b), a <= b, at a (19 - a) / 2 + b - a),
 // items of a camera in list order; sqsum = the camera's column-i square sum (SCHUR items only).
 __device__ __forceinline__ void gather_camera_row(const double* __restrict__ parts, int item_lo, int item_hi, int i, double (&row)[9],
@@ -1752,14 +1827,35 @@ __global__ __launch_bounds__(64 * kInvertGatherWaves) void bal_invert9_kernel(do
   // workgroup of kInvertGatherWaves wavefronts, whose 54 lanes each add up every kInvertGatherWaves-th item of the camera entry by
   // entry (coalesced 432-byte rows) — the kernel lasts as long as its most popular camera, whose item list one wavefront alone
   // walked for 46 us on the Venice shape —, then wave 0 combines the partial sums in a fixed order and lanes 0..8 take the rows
-  const bool gathering = gather.parts != nullptr;
+  // gather.few: cameras of a handful of items each (tens of thousands of cameras with tens of observations: video-like scenes) — seven
+  // cameras per wavefront here too, every lane adding up its row over the camera's items (a workgroup per camera was 206 us for
+  // 52 800 cameras of one item each, latency from end to end)
+  const bool few = gather.parts != nullptr && gather.few != 0;
+  const bool gathering = gather.parts != nullptr && !few;
   const int c = gathering ? int(blockIdx.x) : int(blockIdx.x) * 7 + grp;
   const bool active = (gathering ? grp == 0 : grp < 7) && c < n_cameras;
   const int cc = active ? c : 0;
   const int g0 = 9 * ((!gathering && grp < 7) ? grp : 0);        // first lane of the group
   double* a = blocks + (cam_diag_off ? cam_diag_off[cc] : int64_t(81) * cc);
   double row[9], sq_from_items = 0.0;
-  if (gathering) {  // the blocks are still per-item partial sums: combine them here (bal_camera_items_kernel)
+  if (few) {
+    if (active) {
+      gather_camera_row(gather.parts, gather.cam_item_ptr[c], gather.cam_item_ptr[c + 1], i, row, sq_from_items, gather.want_sq != 0);
+      if (gather.extra) {
+        const double* x = gather.extra + 81 * int64_t(c) + 9 * i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { row[k] += x[k]; if (k == i) sq_from_items += x[k]; }
+      }
+      if (gather.D_f) {
+        const double d = gather.D_f[(gather.cam_pos ? gather.cam_pos[c] : 9 * c) + i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) if (k == i) row[k] += d * d;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) row[k] = (k == i ? 1.0 : 0.0);
+    }
+  } else if (gathering) {  // the blocks are still per-item partial sums: combine them here (bal_camera_items_kernel)
     const int item_lo = gather.cam_item_ptr[blockIdx.x], item_hi = gather.cam_item_ptr[blockIdx.x + 1];
     if (lane < kCamPart) {
       double s0 = 0.0, s1 = 0.0;
@@ -2023,7 +2119,8 @@ hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* s
 
 hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
                             const CamGather& gather, hipStream_t stream) {
-  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3(gather.parts ? n_cameras : (n_cameras + 6) / 7), dim3(gather.parts ? 64 * kInvertGatherWaves : 64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
+  const bool wg_per_camera = gather.parts && !gather.few;
+  if (n_cameras > 0) hipLaunchKernelGGL(bal_invert9_kernel, dim3(wg_per_camera ? n_cameras : (n_cameras + 6) / 7), dim3(wg_per_camera ? 64 * kInvertGatherWaves : 64), 0, stream, blocks, cam_diag_off, n_cameras, fail_flag, lm, gather);
   return hipGetLastError();
 }
 
@@ -2031,8 +2128,20 @@ hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems
                                 const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream) {
   if (items.count == 0) return hipSuccess;
   const dim3 grid((items.count + 3) / 4);
-  if (schur) hipLaunchKernelGGL((bal_camera_items_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
-  else hipLaunchKernelGGL((bal_camera_items_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  // Items of a few hundred observations at most (small problems: plan.cc cuts them short so that they spread over the chip; cameras
+  // of video-like scenes: tens of observations): the matrix-pipe kernel — Ladybug shape 0.079 -> 0.060 ms, Dubrovnik 0.034 -> 0.026,
+  // 52 800 cameras of 38 observations 0.42 -> 0.19 (profiles/r03zj_*).  Full-length items (kCamChunk = 512 observations, the Venice
+  // shape): the lane-per-observation kernel keeps 64 records in flight per wavefront and is 8 % ahead there.
+  // CERES_HIP_CAM_ITEMS_MFMA=0 / 1 forces one of them (A/B).
+  static const int forced = [] { const char* e = getenv("CERES_HIP_CAM_ITEMS_MFMA"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool mfma = forced >= 0 ? forced == 1 : items.observations < int64_t(384) * items.count;
+  if (mfma) {
+    if (schur) hipLaunchKernelGGL((bal_camera_items_mfma_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+    else hipLaunchKernelGGL((bal_camera_items_mfma_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  } else {
+    if (schur) hipLaunchKernelGGL((bal_camera_items_kernel<true>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+    else hipLaunchKernelGGL((bal_camera_items_kernel<false>), grid, dim3(256), 0, stream, values, items, cam_fpos, cam_slot, Mo, parts);
+  }
   return hipGetLastError();
 }
 

@@ -594,10 +594,12 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       P.cam_slot[q] = i;
     }
   }
-  // Item size: kCamChunk at scale; smaller problems get shorter items so that they too spread over the chip, but never
-  // fewer than 256 observations (4 per lane): an item ends in a 54-value wavefront reduction, and items of 64-128
-  // observations spent more time reducing than accumulating.
-  const int chunk = int(std::max<int64_t>(256, std::min<int64_t>(kCamChunk, ((P.n_obs / 8192 + kTile - 1) / kTile) * kTile)));
+  // Item size: kCamChunk at scale; smaller problems get shorter items so that they too spread over the chip, down to one tile's
+  // worth (short items go to the matrix-pipe kernel, whose sums need no wavefront reduction: LaunchBalCameraItems; with the
+  // lane-per-observation kernel alone, items under 256 observations spent more time reducing than accumulating).
+  int64_t chunk_min = kTile;
+  if (const char* e = getenv("CERES_HIP_CAM_CHUNK_MIN")) chunk_min = std::max<int64_t>(kTile, atoll(e));   // (experiments)
+  const int chunk = int(std::max<int64_t>(chunk_min, std::min<int64_t>(kCamChunk, ((P.n_obs / 8192 + kTile - 1) / kTile) * kTile)));
   P.cam_item_ptr.assign(P.n_cameras + 1, 0);
   for (int c = 0; c < P.n_cameras; ++c) {
     int b = P.cam_ptr[c];

@@ -66,6 +66,7 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
+  bool cam_items_few = false;   // no camera has more than a handful of items: bal_invert9_kernel gathers seven cameras per wavefront
   int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr, *d_seq_ptr = nullptr, *d_round_flag = nullptr;  // long points: where they begin, their rounds (plan.cc)
   uint32_t* d_round_word = nullptr;
   int32_t* d_mo_index = nullptr;                               // hybrid plans: M_o record of each slot
@@ -636,7 +637,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
         CamGather g;
-        g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.want_sq = (fuse && schur) ? 1 : 0;
+        g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.want_sq = (fuse && schur) ? 1 : 0;
         g.extra = rem_extra_blocks(s);
         g.D_f = fuse ? nullptr : D_f;
         HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
@@ -687,7 +688,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
     TRY(ensure_rem_blocks(s));
     CamGather g;
-    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.D_f = D_f;
+    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.D_f = D_f;
     g.extra = rem_extra_blocks(s);
     g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
     HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
@@ -739,7 +740,7 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   TRY(ensure_rem_blocks(s));
   if (s->world <= 1) {
     CamGather g;
-    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.cam_pos = cam_pos;
+    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.cam_pos = cam_pos;
     g.extra = rem_extra_blocks(s);
     g.D_f = s->lm_fuse_active ? nullptr : D_f;  // fused LM diagonal: bal_invert9_kernel forms D_f from the block's own diagonal and adds it
     HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
@@ -1721,7 +1722,13 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       TRY(dev_upload(s, &ie, P.item_end));
       s->cam_items.cam = ic; s->cam_items.begin = ib; s->cam_items.end = ie;
       s->cam_items.count = int(P.item_cam.size());
+      s->cam_items.observations = P.n_obs;
       TRY(dev_upload(s, &s->d_cam_item_ptr, P.cam_item_ptr));
+      {
+        int most = 0;
+        for (int c = 0; c < P.n_cameras; ++c) most = std::max(most, P.cam_item_ptr[c + 1] - P.cam_item_ptr[c]);
+        s->cam_items_few = most <= 4 && P.n_cameras >= 1024;
+      }
       TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * kCamPart));
     }
     std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
