@@ -18,6 +18,25 @@ constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
 enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8, kBalSpseZ = 9 };
 
+struct CgScalars;
+// The rest of a CG iteration at the end of the S.x pass, for camera spaces of at most kCgTailMax scalars (run_cg, solver.hip): the
+// workgroup that flushes its partial sums LAST (an atomic ticket; nobody waits for anybody) adds the partials up, and does what
+// bal_reduce_partials_kernel, cg_update_kernel and cg_finalize_direction_kernel do for such a vector in three more launches of
+// ~5 us each — most of a CG iteration on a problem like problem-16-22106 (BASELINE.json configs[0]: 144 camera scalars).
+constexpr int kCgTailMax = 512;     // 56 cameras: at least one thread of the last workgroup per camera scalar
+constexpr int kCgTailLoads = 64;    // partial sums one thread of the last workgroup adds up (all in flight at once): workgroups <=
+                                    // kCgTailLoads * (512 / camera scalars), or the iteration runs as the usual three kernels
+struct CgTail {
+  int enabled = 0, it = 0;
+  unsigned int* ticket = nullptr;   // zero between launches
+  double *x = nullptr, *r = nullptr, *p = nullptr;   // (q = S p arrives in BalArgs::y_f... the caller's z, which becomes M^-1 r)
+  double* z = nullptr;
+  const double* rhs = nullptr;
+  const double* blocks = nullptr;   // M^-1: 81 doubles per camera, back to back
+  const double* D_f = nullptr;
+  CgScalars* S = nullptr;
+};
+
 struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][12][64]
@@ -97,9 +116,12 @@ struct BalArgs {
   const int* run_after_cg = nullptr;
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
+  CgTail tail;                   // kSx, pipelined kernel, every camera's accumulator in LDS: finish the CG iteration (see CgTail)
 };
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
+// whether LaunchBalFused(kBalSx, A, lds, ..) runs the pipelined kernel — the one that can finish a CG iteration (A.tail)
+bool BalSxRunsPipelined(const BalArgs& A);
 // pq_out != nullptr: also partial x_f . y_f, one per workgroup (*n_pq of them; needs x_f)
 hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
                                    const double* D_f, const double* x_f, double* y_f, const int* status,

@@ -1173,6 +1173,161 @@ __device__ __forceinline__ void issue_aux(const BalArgs& A, const Slot& s, int l
   }
 }
 
+// The rest of CG iteration `it` by ONE workgroup, for a camera space of at most kCgTailMax scalars (CgTail, device.h): q = S p from the
+// workgroups' partial sums (+ D_f^2 p), then ConjugateGradientsSolver's step exactly as cg_update_kernel and
+// cg_finalize_direction_kernel split it (I/conjugate_gradients_solver.h:190-290): p.q, alpha, x += alpha p, r -= alpha q, z = M^-1 r,
+// Q1, |r|, the termination tests, beta, p = z + beta p — same scalars, same failure codes, same double-buffered rho / Q0.
+// `lds`: the workgroup's accumulator array (n_f9 doubles, flushed already): scratch for q, then for the new r.
+template <int BLOCK>
+__device__ __forceinline__ void cg_iteration_tail(const BalArgs& A, double* lds) {
+  constexpr int PER = (kCgTailMax + BLOCK - 1) / BLOCK;
+  __shared__ double sh[3][BLOCK / 64];
+  const CgTail& T = A.tail;
+  CgScalars& S = *T.S;
+  const int n = A.n_f9, it = T.it, nparts = int(gridDim.x);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto sum3 = [&](double& a, double& b, double& c) {   // over the workgroup, fixed order; every thread gets the sums
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); c += __shfl_xor(c, m, 64); }
+    __syncthreads();
+    if (lane == 0) { sh[0][wv] = a; sh[1][wv] = b; sh[2][wv] = c; }
+    __syncthreads();
+    a = b = c = 0.0;
+    for (int w = 0; w < BLOCK / 64; ++w) { a += sh[0][w]; b += sh[1][w]; c += sh[2][w]; }
+  };
+  // everything this kernel reads of S, before anything of it is written
+  const int staged = S.fail_dir;
+  const double rho = S.rho_pp[it & 1], Q0 = S.Q0_pp[it & 1], q_tol = S.q_tol, tol_r = S.tol_r;
+  const int min_it = S.min_it, max_it = S.max_it;
+  // everything the step reads of the CG vectors and of M^-1 is requested first, in one go with the partial sums: the tail is a chain
+  // of memory round trips otherwise (11 us, as long as the three launches it replaces)
+  double pv[PER], dv[PER], xo[PER], ro[PER], bv[PER], mrow[PER][9];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * BLOCK;
+    const bool in = i < n;
+    const int ii = in ? i : 0;
+    pv[k] = T.p[ii]; dv[k] = T.D_f ? T.D_f[ii] : 0.0; xo[k] = T.x[ii]; ro[k] = T.r[ii]; bv[k] = T.rhs[ii];
+    const double* m = T.blocks + int64_t(9) * ii;   // row (i % 9) of camera i / 9: 81 c + 9 a = 9 i
+#pragma unroll
+    for (int j = 0; j < 9; ++j) mrow[k][j] = m[j];
+    if (!in) pv[k] = 0.0;
+  }
+  // the partial sums, all threads at once and every load of a thread independent of the others: (element i, subset sp) adds up the
+  // partials sp, sp + ns, ... (at most kCgTailLoads of them: run_cg's condition) — ONE memory round trip; a thread per element walking
+  // the partials alone was 35 us, batches of four dependent on each other 6 us
+  const int ns = max(1, BLOCK / n);
+  double* part = lds + n;   // [ns][n], behind the accumulator array (launch_stream2 sizes the LDS for it)
+  {
+    const int idx = threadIdx.x;
+    const bool mine = idx < ns * n;
+    const int sp = mine ? idx / n : 0, i = mine ? idx - sp * n : 0;
+    double v[kCgTailLoads];
+#pragma unroll
+    for (int j = 0; j < kCgTailLoads; ++j) {
+      const int w = sp + j * ns;
+      v[j] = (mine && w < nparts) ? A.partials[int64_t(w) * n + i] : 0.0;
+    }
+#pragma unroll
+    for (int h = kCgTailLoads / 2; h >= 1; h >>= 1) {
+#pragma unroll
+      for (int j = 0; j < h; ++j) v[j] += v[j + h];
+    }
+    if (mine) part[idx] = v[0];
+  }
+  __syncthreads();
+  double qv[PER];
+  double pq = 0, unused0 = 0, unused1 = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * BLOCK;
+    qv[k] = 0.0;
+    if (i < n) {
+      double q = 0;
+      for (int sp = 0; sp < ns; ++sp) q += part[sp * n + i];
+      q += dv[k] * dv[k] * pv[k];
+      qv[k] = q;
+      pq += pv[k] * q;
+    }
+  }
+  sum3(pq, unused0, unused1);
+  if (staged) pq = 1.0;
+  int fail = staged;
+  double alpha = 0;
+  if (!fail) {
+    if (pq <= 0 || isinf(pq)) fail = kCgIndefinite;
+    else { alpha = rho / pq; if (isinf(alpha)) fail = kCgFailAlpha; }
+  }
+  if (threadIdx.x == 0) { S.pq = pq; S.alpha = alpha; S.rho_new = rho; S.fail_step = fail; }
+  if (fail) {
+    if (threadIdx.x == 0) S.status = fail;
+    return;
+  }
+  double q1 = 0, rr = 0, rz = 0, rn[PER], zv[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * BLOCK;
+    rn[k] = 0.0;
+    if (i < n) {
+      const double xv = xo[k] + alpha * pv[k];
+      const double rv = ro[k] - alpha * qv[k];
+      T.x[i] = xv; T.r[i] = rv;
+      rn[k] = rv;
+      lds[i] = rv;
+      q1 -= xv * (bv[k] + rv);
+      rr += rv * rv;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * BLOCK;
+    zv[k] = 0.0;
+    if (i < n) {
+      const int c = i / 9;
+      double t = 0;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t += mrow[k][j] * lds[9 * c + j];
+      zv[k] = t;
+      T.z[i] = t;
+      rz += rn[k] * t;
+    }
+  }
+  sum3(q1, rr, rz);
+  const double Q1 = q1, rho_next = rz;
+  const double norm_r = sqrt(rr);
+  const double zeta = it * (Q1 - Q0) / Q1;
+  int status = kCgRunning;
+  if (zeta < q_tol && it >= min_it) status = kCgConvergedZeta;
+  else if (norm_r <= tol_r && it >= min_it) status = kCgConvergedResidual;
+  else if (it >= max_it) status = kCgMaxIterations;
+  int fail_dir = 0;
+  double beta = 0.0;
+  if (status == kCgRunning) {
+    auto zero_or_inf = [](double v) { return v == 0.0 || isinf(v); };
+    if (zero_or_inf(rho_next)) fail_dir = kCgFailRho;
+    else { beta = rho_next / rho; if (zero_or_inf(beta)) fail_dir = kCgFailBeta; }
+    if (!fail_dir) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + k * BLOCK;
+        if (i < n) T.p[i] = zv[k] + beta * pv[k];
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    S.Q1 = Q1; S.zeta = zeta; S.norm_r = norm_r;
+    if (status == kCgConvergedZeta) { S.status = status; return; }   // Q0 keeps its value, as in the reference (:273-284)
+    S.Q0 = Q1;
+    S.Q0_pp[(it + 1) & 1] = Q1;
+    if (status != kCgRunning) { S.status = status; return; }
+    S.rho = rho; S.rho_new = rho_next; S.beta = beta;
+    S.rho_pp[(it + 1) & 1] = rho_next;
+    S.fail_dir = fail_dir;
+    S.iter = it + 1;
+  }
+}
+
 // One tile of a long point inside a ROUND (plan.cc): the kRoundWaves waves of the workgroup each hold one tile in registers, the waves
 // [w0, w0 + cnt) of one point leave their tile sums in LDS (`red`, double-buffered by round parity: one barrier per round), every
 // wave adds them up in the same order and finishes its own tile.  A point of up to 512 observations is read ONCE, a tile per wave in
@@ -1424,7 +1579,28 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   if constexpr (LDS) {
     __syncthreads();
     double* out = A.partials + int64_t(blockIdx.x) * A.n_f9;
-    for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
+    const bool tail = MODE == kSx && A.tail.enabled;   // (launch-uniform)
+    if (!tail) {
+      for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) out[i] = acc[i];
+    } else {
+      // write-through stores (device scope): the partial sums must be readable from another XCD when the ticket is taken, and a
+      // release fence instead — an L2 write-back per workgroup, queued behind those of the XCD's other workgroups — cost 12 us
+      for (int i = threadIdx.x; i < A.n_f9; i += BLOCK) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(out + i), "v"(acc[i]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    }
+    if constexpr (MODE == kSx) {
+      if (tail) {
+        __shared__ int last;
+        __syncthreads();      // the workgroup's partial sums are out ...
+        if (threadIdx.x == 0) last = atomicAdd(A.tail.ticket, 1u) == gridDim.x - 1 ? 1 : 0;   // ... before its ticket is
+        __syncthreads();
+        if (last) {
+          __threadfence();    // and every other workgroup's are in before they are read
+          cg_iteration_tail<BLOCK>(A, acc);
+          if (threadIdx.x == 0) *A.tail.ticket = 0u;
+        }
+      }
+    }
   } else {
     if (A.hyb_rows > 0) {  // this workgroup's accumulator rows join the spilled rows in the ring: the second pass sums both
       __syncthreads();
@@ -2031,7 +2207,9 @@ static hipError_t launch_stream2(const BalArgs& A, bool lds, int grid, hipStream
   if (lds) {
     auto k = bal_stream_kernel<MODE, true, NT>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double), stream, A);
+    // (+ the scratch of the CG iteration tail: cg_iteration_tail)
+    const size_t tail_bytes = (MODE == kSx && A.tail.enabled) ? size_t(512 + kCgTailMax) * sizeof(double) : 0;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), size_t(A.n_f9) * sizeof(double) + tail_bytes, stream, A);
   } else {
     auto k = bal_stream_kernel<MODE, false, NT>;
     if (hipError_t e = allow_max_lds(reinterpret_cast<const void*>(k)); e != hipSuccess) return e;
@@ -2051,6 +2229,8 @@ static bool UsePipeline() {
   static int v = [] { const char* e = getenv("CERES_HIP_PIPELINE"); return e ? atoi(e) : 1; }();
   return v != 0;
 }
+
+bool BalSxRunsPipelined(const BalArgs& A) { return UsePipeline() && !A.Jf && !A.src_values && !A.cam_pos && !(A.flags & 1); }
 
 hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream) {
   const bool big = BalBlockFor(mode) == 1024;

@@ -66,6 +66,8 @@ struct ceres_hip_solver {
   int32_t *d_tile_kind = nullptr, *d_tile_aux = nullptr, *d_pt_pos = nullptr, *d_cam_pos = nullptr;
   int32_t *d_cam_ptr = nullptr, *d_cam_fpos = nullptr, *d_cam_slot = nullptr;
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
+  unsigned int* d_cg_ticket = nullptr;   // CgTail: the S.x pass of a small camera space finishes the CG iteration (device.h)
+  bool cg_tail_enabled = [] { const char* e = getenv("CERES_HIP_CG_TAIL"); return !e || atoi(e) != 0; }();   // (A/B switch)
   bool cam_items_few = false;   // no camera has more than a handful of items: bal_invert9_kernel gathers seven cameras per wavefront
   int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr, *d_seq_ptr = nullptr, *d_round_flag = nullptr;  // long points: where they begin, their rounds (plan.cc)
   uint32_t* d_round_word = nullptr;
@@ -885,6 +887,9 @@ struct CgSpec {
   // sharded: *extra = device pointer to the shard's share of x . y, already summed over ranks (nullptr if not produced)
   std::function<int(const double*, double*, double*, int*, const double**)> apply_dot;
   std::function<int()> before_poll;                     // enqueued before every poll of the status word (speculative LM tail)
+  // optional (small camera spaces, CgTail in device.h): q = A p AND the rest of fused iteration `it` in one launch; returns 1 if it
+  // did, 0 if this launch cannot (the caller then runs the iteration the usual way), < 0 on error
+  std::function<int(int)> iteration;
   bool shard_fused = false;                             // sharded CG vectors, and apply_dot + the block layout support the fused iteration
   std::function<int(const double*, double*)> precondition;  // z = M^-1 r as an operator (SPSE); empty = block diagonal
   bool x0_nonzero = false;                              // B.x holds an initial guess
@@ -1036,6 +1041,11 @@ int run_cg(ceres_hip_solver* s, const CgSpec& spec, double q_tol, double r_tol, 
     const int batch_end = std::min(max_it, it + interval - 1);
     for (; it <= batch_end; ++it) {
       const int reset = (it % reset_period == 0) ? 1 : 0;
+      if (fused && spec.iteration && !reset) {
+        const int done = spec.iteration(it);
+        if (done < 0) return CERES_HIP_E_HIP;
+        if (done > 0) { ++s->timing.operator_applications; continue; }
+      }
       if (fused) {
         int n_pq = 0;
         const double* extra = nullptr;
@@ -1364,6 +1374,26 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     spec.col_begin = h.num_cols_e;
     spec.diag_off = s->G.diag_off_f;
     spec.blocks = (pre == CERES_HIP_IDENTITY || spse_pre) ? nullptr : s->precond;
+    if (s->path == CERES_HIP_PATH_BAL && s->world <= 1 && s->lds_mode && !has_remainder(s) && spec.blocks && s->plan.cameras_contiguous &&
+        h.num_cols_f == 9 * s->plan.n_cameras && h.num_cols_f <= kCgTailMax && s->fused_grid <= kCgTailLoads * (512 / std::max(1, h.num_cols_f)) && s->cg_tail_enabled) {
+      // a camera space this small: the S.x pass finishes the CG iteration itself (one launch instead of four)
+      spec.iteration = [s, status](int it) -> int {
+        if (ensure_packed(s)) return -1;
+        BalArgs A = bal_args(s);
+        if (!BalSxRunsPipelined(A)) return 0;
+        CgBuffers& B = s->cg;
+        A.x_f = B.p;
+        A.status = status;
+        A.tail.enabled = 1; A.tail.it = it; A.tail.ticket = s->d_cg_ticket;
+        A.tail.x = B.x; A.tail.r = B.r; A.tail.p = B.p; A.tail.z = B.z; A.tail.rhs = B.rhs;
+        A.tail.blocks = s->precond; A.tail.D_f = s->D ? s->D + s->hs.num_cols_e : nullptr; A.tail.S = B.S;
+        if (hipError_t e = LaunchBalFused(kBalSx, A, true, s->fused_grid, s->stream); e != hipSuccess) {
+          fail(s, CERES_HIP_E_HIP, "S.x + CG iteration launch: %s", hipGetErrorString(e));
+          return -1;
+        }
+        return 1;
+      };
+    }
     if (defer_check && spec.blocks) spec.setup_fail = s->d_fail_flag;
     if (spse_pre)  // tolerance 0: the preconditioner must stay fixed during CG (:178-186)
       spec.precondition = [s, spse_iters, status](const double* in, double* out) { return op_spse_apply(s, in, out, spse_iters, 0.0, status); };
@@ -1701,6 +1731,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
     TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));
+    TRY(dev_alloc(s, &s->d_cg_ticket, 1));
+    HIP_TRY(s, hipMemsetAsync(s->d_cg_ticket, 0, sizeof(unsigned int), s->stream));
     TRY(dev_upload(s, &s->d_long_ptr, P.long_ptr));
     TRY(dev_upload(s, &s->d_round_ptr, P.round_ptr));
     s->d_round_word = nullptr;
