@@ -267,6 +267,16 @@ bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HI
 // ---------------------------------------------------------------------------
 // Operators.  All take device pointers and enqueue on s->stream.
 // ---------------------------------------------------------------------------
+// Camera space small enough for the S.x pass to finish the CG iteration itself (CgTail, device.h)?  ITERATIVE_SCHUR on the fused path,
+// one rank, every camera's accumulator in LDS, no rows outside the tiles, camera blocks back to back, and few enough workgroups for
+// one thread of the last one to have all its partial sums in flight at once.
+bool cg_tail_possible(const ceres_hip_solver* s) {
+  const HostStructure& h = s->hs;
+  return s->cg_tail_enabled && s->opt.solver_type == CERES_HIP_ITERATIVE_SCHUR && s->path == CERES_HIP_PATH_BAL && s->world <= 1 &&
+         s->lds_mode && s->plan.n_rem_rows == 0 && s->plan.cameras_contiguous && h.num_cols_f == 9 * s->plan.n_cameras &&
+         h.num_cols_f > 0 && h.num_cols_f <= kCgTailMax && s->fused_grid <= kCgTailLoads * (512 / std::max(1, h.num_cols_f));
+}
+
 BalArgs bal_args(ceres_hip_solver* s) {
   BalArgs A;
   A.J = s->d_J; A.Jf = s->d_Jf; A.b = s->d_bt;
@@ -1374,8 +1384,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     spec.col_begin = h.num_cols_e;
     spec.diag_off = s->G.diag_off_f;
     spec.blocks = (pre == CERES_HIP_IDENTITY || spse_pre) ? nullptr : s->precond;
-    if (s->path == CERES_HIP_PATH_BAL && s->world <= 1 && s->lds_mode && !has_remainder(s) && spec.blocks && s->plan.cameras_contiguous &&
-        h.num_cols_f == 9 * s->plan.n_cameras && h.num_cols_f <= kCgTailMax && s->fused_grid <= kCgTailLoads * (512 / std::max(1, h.num_cols_f)) && s->cg_tail_enabled) {
+    if (cg_tail_possible(s) && spec.blocks) {
       // a camera space this small: the S.x pass finishes the CG iteration itself (one launch instead of four)
       spec.iteration = [s, status](int it) -> int {
         if (ensure_packed(s)) return -1;
@@ -1886,6 +1895,7 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
     info->hybrid_popular_rows = s->plan.hybrid ? s->plan.hyb_hot : 0;
     info->num_observations_in_lds = s->lds_mode ? s->plan.n_obs : s->plan.n_local_obs;
     info->points_renumbered = s->plan.renumbered ? 1 : 0;
+    info->cg_iteration_in_operator = (cg_tail_possible(s) && s->opt.preconditioner_type != CERES_HIP_IDENTITY) ? 1 : 0;
   }
   return 0;
 }

@@ -169,7 +169,7 @@ typedef struct ceres_hip_info {
   int32_t hybrid_popular_rows;        /* accumulator rows every workgroup gives to the popular cameras                             */
   int64_t num_observations_in_lds;    /* observations summed in LDS by the tile pass (the others are spilled to the ring)          */
   int32_t points_renumbered;          /* 1: the tiles hold the points in an internal order (fuller tiles, hybrid groups)           */
-  int32_t reserved0;
+  int32_t cg_iteration_in_operator; /* 1: camera space of at most 512 scalars — the S.x pass finishes the CG iteration itself (one launch) */
 } ceres_hip_info;
 
 typedef struct ceres_hip_solver ceres_hip_solver; /* opaque */

@@ -221,3 +221,40 @@ def test_sharded_code_paths_in_loopback(hip, oracle, problems, solver_type, pre,
         assert rel(loop.jtb(), ref.jtb()) <= 1e-12
     ref.close()
     loop.close()
+
+
+@pytest.mark.parametrize("pre", ["JACOBI", "SCHUR_JACOBI"])
+def test_cg_iteration_finished_by_the_operator_pass(hip, oracle, problems, monkeypatch, pre):
+    """Camera spaces of at most 512 scalars: the S.x pass's last workgroup adds up the partial sums and runs the rest of the CG iteration
+    (csrc/kernels_bal.hip::cg_iteration_tail) — one launch instead of four.  Same iterates as the four-kernel iteration
+    (CERES_HIP_CG_TAIL=0) and as the oracle: iteration by iteration for a fixed count, at convergence, and across a residual reset
+    (iteration 10, 20, ..: the operator pass then leaves the iteration to the usual kernels)."""
+    pre = getattr(hip, pre)
+    p = problems.synthetic_bal(None, num_cameras=40, num_points=3000, num_observations=14000, seed=21, skew=0.4)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    runs = {}
+    for tail in ("1", "0"):
+        monkeypatch.setenv("CERES_HIP_CG_TAIL", tail)
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, max_it=200)
+        assert s.info().kernel_path == hip.PATH_BAL and s.info().cg_iteration_in_operator == int(tail)
+        out = []
+        for its in (1, 2, 3, 7, 12, 23):   # fixed iteration counts: min = max
+            s2 = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, min_it=its, max_it=its)
+            x, summ = s2.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=-1.0))
+            xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=pre, min_it=its, max_it=its, q_tol=-1.0, r_tol=-1.0)
+            assert summ.num_iterations == so.num_iterations == its and rel(x, xo) <= 1e-9, (tail, its, rel(x, xo))
+            out.append(x)
+            s2.close()
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-12))
+        xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=200, q_tol=-1.0, r_tol=1e-12)
+        assert summ.termination_type == so.termination_type == hip.SUCCESS and abs(summ.num_iterations - so.num_iterations) <= 1
+        assert rel(x, xo) <= 1e-9
+        x2, summ2 = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))   # LM-style, twice on one handle
+        x3, summ3 = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+        assert summ2.num_iterations == summ3.num_iterations and np.array_equal(x2, x3)
+        out += [x, x2]
+        runs[tail] = (out, summ.num_iterations, summ2.num_iterations)
+        s.close()
+    assert runs["1"][1:] == runs["0"][1:]
+    for a, b in zip(runs["1"][0], runs["0"][0]):
+        assert rel(a, b) <= 1e-12
