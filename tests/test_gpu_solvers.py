@@ -251,7 +251,8 @@ def test_cg_iteration_finished_by_the_operator_pass(hip, oracle, problems, monke
         assert rel(x, xo) <= 1e-9
         x2, summ2 = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))   # LM-style, twice on one handle
         x3, summ3 = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
-        assert summ2.num_iterations == summ3.num_iterations and np.array_equal(x2, x3)
+        # (not bit for bit: the order of a workgroup's ds_add_f64 into its LDS accumulators is not fixed)
+        assert summ2.num_iterations == summ3.num_iterations and rel(x2, x3) <= 1e-12
         out += [x, x2]
         runs[tail] = (out, summ.num_iterations, summ2.num_iterations)
         s.close()
