@@ -971,12 +971,11 @@ __device__ __forceinline__ void fused_long_rounds(const BalArgs& A, int lane, bo
     double tot[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) tot[i] = 0.0;
-    if (it_real || active || flag) {   // (a sub-workgroup out of rounds has nothing to add up)
-      if (!apply_round)
-        for (int k = 0; k < cnt; ++k) {
+    if ((active || flag) && !apply_round) {   // (an idle wave of a sum round adds up too: it may hold a tile in the apply rounds)
+      for (int k = 0; k < cnt; ++k) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) tot[i] += xr[sub][w0 + k][i];
-        }
+        for (int i = 0; i < NX; ++i) tot[i] += xr[sub][w0 + k][i];
+      }
     }
     __syncthreads();
     if (flag & kRoundSum) {
@@ -1426,20 +1425,28 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
   const int64_t tile_end = min(range_end, long_begin);
   const int64_t wave_first = (grouped ? 0 : logical_workgroup() * (BLOCK / 64)) + wave;
   const int64_t wave0 = (grouped ? int64_t(A.grp_tile_ptr[blockIdx.x]) : A.tile_begin) + wave_first;
-  const int64_t last = tile_end - 1;
-  if (wave0 < tile_end) {
+  // The pipelined loop's walk.  Default: grid-strided (all workgroups stream through one region of memory together).  BLOCKED
+  // (A.flags & 2, experiment: CERES_HIP_TILE_WALK=blocked): workgroup b takes the tiles [b C, (b + 1) C), its waves in turn — the
+  // point-space range a workgroup writes (JtJx's y_e) is then one contiguous run.
+  const bool blocked = !grouped && (A.flags & 2) != 0;
+  const int64_t chunk = blocked ? ((tile_end - A.tile_begin + gridDim.x - 1) / gridDim.x + 7) / 8 * 8 : 0;
+  const int64_t pipe_end = blocked ? min(tile_end, A.tile_begin + (logical_workgroup() + 1) * chunk) : tile_end;
+  const int64_t pipe0 = blocked ? A.tile_begin + logical_workgroup() * chunk + wave : wave0;
+  const int64_t pstep = blocked ? BLOCK / 64 : nwaves;
+  const int64_t last = pipe_end - 1;
+  if (pipe0 < pipe_end) {
     // Two register sets in ping-pong: copying "next" into "current" would need the loaded
     // values to have arrived, which is exactly the wait this kernel exists to avoid.  (The
     // three index words are the exception: they are copied a stage after they were issued.)
     Slot sa, sb;
     StreamAux xa, xb;
     SlotIdx i1, i2;
-    int64_t tile = wave0;
+    int64_t tile = pipe0;
     int kind_a = A.tile_kind[tile], aux_a = A.tile_aux[tile], kind_b = 2, aux_b = 0;
     // prologue in the steady-state issue order: index words (1), pairs (0), aux (0)
     issue_idx(A, tile, lane, i2);
     __builtin_amdgcn_sched_barrier(0);
-    issue_idx(A, min(tile + nwaves, last), lane, i1);
+    issue_idx(A, min(tile + pstep, last), lane, i1);
     __builtin_amdgcn_sched_barrier(0);
     issue_pairs<NT>(A, tile, lane, sa);
     __builtin_amdgcn_sched_barrier(0);
@@ -1450,11 +1457,11 @@ __global__ __launch_bounds__(512) void bal_stream_kernel(BalArgs A) {
     bool more = true;
     // one pipeline stage: everything of the next tile is issued, then this one is computed from `c`
     auto stage = [&](Slot& c, StreamAux& cx, int ckind, int caux, Slot& n, StreamAux& nx, int& nkind, int& naux) {
-      const int64_t next = min(tile + nwaves, last);  // past the end: re-issue, the load count stays the same
-      more = tile + nwaves < tile_end;
+      const int64_t next = min(tile + pstep, last);  // past the end: re-issue, the load count stays the same
+      more = tile + pstep < pipe_end;
       nkind = A.tile_kind[next];
       naux = A.tile_aux[next];
-      issue_idx(A, min(next + nwaves, last), lane, i2);
+      issue_idx(A, min(next + pstep, last), lane, i2);
       __builtin_amdgcn_sched_barrier(0);
       issue_pairs<NT>(A, next, lane, n);
       __builtin_amdgcn_sched_barrier(0);

@@ -1860,6 +1860,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
       s->bal_flags = (e && atoi(e) == 0) ? 1 : 0;
+      const char* w = getenv("CERES_HIP_TILE_WALK");  // "blocked": a workgroup of the pipelined kernels takes one contiguous run of tiles (experiment)
+      if (w && strcmp(w, "blocked") == 0) s->bal_flags |= 2;
     }
   } else {
     TRY(dev_alloc(s, &s->etei, size_t(h.diag_off_e.back())));
