@@ -156,6 +156,82 @@ def test_long_point_rounds(problems, renumber):
     check_long_rounds(pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, renumber))
 
 
+def test_rounds_schedule_computes_the_schur_product(oracle, problems):
+    """S x computed by walking the plan the way a workgroup of the streaming kernel does (csrc/kernels_bal.hip: the pipelined loop over
+    the normal tiles, then sequence by sequence, round by round: a tile per wave, the waves [w0, w0 + cnt) of a point exchange their
+    tile sums; a point of more than 8 tiles: sum rounds into a running total, then apply rounds with it) equals the oracle's product —
+    the contract between the plan's round words / flags / sequences and the kernel, on CPU."""
+    tracks = [3, 70, 2, 129, 64, 65, 5, 513, 1, 300, 512, 7, 449, 200, 66] + [4] * 30 + [90, 1000, 3] + [130, 2] * 6
+    p = problems.bal_from_tracks(tracks, 1100, seed=5)
+    n_o, n_p, n_c = p.bs.num_row_blocks, p.num_eliminate_blocks, 1100
+    plan = plan_of(p)                                               # (caller order: debug_plan's default)
+    r = pkg.hip_solver.debug_long_rounds(p.bs, p.num_eliminate_blocks, False)
+    assert r["n_tiles"] == plan["n_tiles"] and np.array_equal(r["tile_kind"], plan["tile_kind"])
+    nt = plan["n_tiles"]
+    valid = plan["valid"].astype(bool).reshape(nt, 64)
+    row, pt, cam = (plan[k].reshape(nt, 64) for k in ("slot_row", "slot_pt", "slot_cam"))
+    E = p.values[: 6 * n_o].reshape(n_o, 2, 3)
+    F = p.values[6 * n_o:].reshape(n_o, 2, 9)
+    De, Df = p.D[: 3 * n_p].reshape(n_p, 3), p.D[3 * n_p:]
+    ete = np.einsum("pi,ij->pij", De ** 2, np.eye(3))
+    np.add.at(ete, p.point_of_row, np.einsum("oki,okj->oij", E, E))
+    einv = np.linalg.inv(ete)
+    x = np.random.default_rng(3).standard_normal(9 * n_c).reshape(n_c, 9)
+    y = np.zeros((n_c, 9))
+
+    def tile_parts(t):            # what a wave has after loading tile t: rows, F x per slot, its share of E^T F x
+        v = valid[t]
+        rows, cams = row[t][v], cam[t][v]
+        tx = np.einsum("oij,oj->oi", F[rows], x[cams])
+        return rows, cams, tx, np.einsum("oij,oi->j", E[rows], tx)
+
+    def finish(t, parts, u):      # the tile from "registers", with the point's sum u
+        rows, cams, tx, _ = parts
+        point = pt[t][0]
+        z = tx - E[rows] @ (einv[point] @ u)
+        np.add.at(y, cams, np.einsum("oij,oi->oj", F[rows], z))
+
+    done = np.zeros(nt, int)
+    for t in np.flatnonzero(r["tile_kind"] == 0):                   # the pipelined loop: a tile holds whole points
+        rows, cams, tx, _ = tile_parts(t)
+        pts = pt[t][valid[t]]
+        u = np.zeros((n_p, 3))
+        np.add.at(u, pts, np.einsum("oij,oi->oj", E[rows], tx))
+        z = tx - np.einsum("oij,oj->oi", E[rows], np.einsum("oij,oj->oi", einv[pts], u[pts]))
+        np.add.at(y, cams, np.einsum("oij,oi->oj", F[rows], z))
+        done[t] += 1
+    seq, flag, words = r["seq_ptr"], r["round_flag"], r["round_word"]
+    for q in range(len(seq) - 1):                                   # one workgroup per sequence, its rounds in order
+        carry = np.zeros(3)
+        for rd in range(seq[q], seq[q + 1]):
+            w = words[rd]
+            act = w != 0xFFFFFFFF
+            tiles = (w & 0x3FFFFFF).astype(int)
+            w0s, cnts = ((w >> 26) & 7).astype(int), ((w >> 29) & 7).astype(int) + 1
+            if flag[rd] & 2:                                        # apply round: the running total of the sum rounds
+                for k in np.flatnonzero(act):
+                    finish(tiles[k], tile_parts(tiles[k]), carry)
+                    done[tiles[k]] += 1
+                if flag[rd] & 4:
+                    carry = np.zeros(3)
+                continue
+            parts = {k: tile_parts(tiles[k]) for k in np.flatnonzero(act)}
+            red = {k: parts[k][3] for k in parts}                   # the exchange area
+            if flag[rd] & 1:                                        # sum round: every wave adds the round's total to its carry
+                carry = carry + sum(red[k] for k in range(cnts[0]))
+                continue
+            for k in parts:
+                finish(tiles[k], parts[k], sum(red[j] for j in range(w0s[k], w0s[k] + cnts[k])))
+                done[tiles[k]] += 1
+    assert (done == 1).all()
+    y = y.reshape(-1) + Df ** 2 * x.reshape(-1)
+    m = oracle.Matrix(p.bs, n_p)
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    ref = isc.sx(x.reshape(-1))
+    np.testing.assert_allclose(y, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+
+
 def test_long_point_rounds_of_hybrid_groups(problems):
     # real tracks (every point a long one) on more cameras than LDS holds: rounds per group
     p = problems.libmv_bal(2, 8, with_values=False)
