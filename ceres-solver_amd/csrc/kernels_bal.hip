@@ -14,14 +14,17 @@
 //
 // All per-point reductions (E^T·, (E^T E)^-1) are segmented wavefront scans over
 // __shfl_up — observations of a point are adjacent lanes by construction of the
-// plan (plan.cc); points longer than 64 observations own whole tiles and are
-// handled by the same wave in two sweeps.  Per-camera sums (F^T·) go to a
+// plan (plan.cc); points longer than 64 observations own whole tiles, which sit behind the
+// normal ones and are taken in ROUNDS: one tile per wave of a workgroup, the tile sums exchanged
+// through LDS, every tile finished from registers (compute_long_round, fused_long_rounds).  Per-camera sums (F^T·) go to a
 // workgroup-private accumulator in LDS (9 doubles per camera: 128 KB for Venice's
 // 1778 cameras, LDS is 160 KB) with ds_add_f64, flushed once per workgroup and
 // combined by bal_reduce_partials_kernel; when the cameras do not fit in LDS the tile pass leaves F_o^T z_o per slot
 // (72-byte rows, transposed through LDS into coalesced stores) and bal_camera_chunk_kernel sums them camera by camera.
-// Camera-major work on the Jacobian itself (the 9x9 preconditioner blocks) is bal_camera_items_kernel (per-item partial sums)
-// + bal_invert9_kernel (sums a camera's items, adds D^2 or the fused LM diagonal, inverts).
+// Camera-major work on the Jacobian itself (the 9x9 preconditioner blocks) is bal_camera_items_kernel / bal_camera_items_mfma_kernel
+// (per-item partial sums: lane per observation, or — short items — the matrix pipe) + bal_invert9_kernel (sums a camera's items,
+// adds D^2 or the fused LM diagonal, inverts).  For camera spaces of a few hundred scalars the S.x pass also finishes the CG
+// iteration (cg_iteration_tail).
 //
 // Reference operators restated by each MODE (file:line in include/ceres_hip.h):
 //   kSx        ImplicitSchurComplement::RightMultiplyAndAccumulate (4 passes there, 1 here)
