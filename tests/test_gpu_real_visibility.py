@@ -83,3 +83,36 @@ def test_every_track_length_against_the_oracle(hip, oracle, problems, cameras, e
     check_cgnr_side(hip, oracle, p, expect_lds)
     # the same problem with its columns in CGNR's caller order (points not renumbered: the long points' tiles still move behind)
     check_cgnr_side(hip, oracle, problems.bal_from_tracks(MIXED_TRACKS, cameras, layout="cgnr", seed=11), expect_lds)
+
+
+def test_every_track_length_with_fp32_tiles(hip, oracle, problems):
+    """The same mix of track lengths with the tiles rounded to fp32 (jacobian_storage = 1: the unpipelined kernels, whose long points
+    run the rounds of `fused_long_rounds` — also for S.x and JtJx).  An accuracy mode: exact against the oracle on the fp32-rounded
+    Jacobian, ~1e-7 against the fp64 one."""
+    p = problems.bal_from_tracks(MIXED_TRACKS, 1100, seed=11)
+    rounded = type(p)(p.bs, p.values.astype(np.float32).astype(np.float64), p.b, p.D, p.num_eliminate_blocks)
+    rng = np.random.default_rng(2)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for solver_type, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=200,
+                                    elimination_groups=[p.num_eliminate_blocks], jacobian_storage=1)
+        s = hip.HipLinearSolver(o)
+        s.set_structure(p.bs)
+        assert s.info().kernel_path == hip.PATH_BAL
+        s.load(p.values, p.b, p.D)
+        if solver_type == hip.ITERATIVE_SCHUR:
+            s.schur_init()
+            x = rng.standard_normal(m.num_cols_f)
+            got, rhs, back = s.schur_sx(x), s.schur_rhs(), s.back_substitute(x)
+            for prob, tol in ((p, 2e-6), (rounded, 1e-11)):
+                isc = oracle.ImplicitSchurComplement(m)
+                isc.init(prob.values, prob.D, prob.b)
+                assert rel(got, isc.sx(x)) <= tol and rel(rhs, isc.rhs()) <= tol and rel(back, isc.back_substitute(x)) <= tol
+        else:
+            x = rng.standard_normal(m.num_cols)
+            got, jtb = s.jtjx(x), s.jtb()
+            for prob, tol in ((p, 2e-6), (rounded, 1e-11)):
+                assert rel(got, m.left_multiply(prob.values, m.right_multiply(prob.values, x)) + p.D ** 2 * x) <= tol
+                assert rel(jtb, m.left_multiply(prob.values, prob.b)) <= tol
+        s.close()
