@@ -10,7 +10,8 @@ import pytest
 from conftest import ROOT
 
 LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")) +
-               [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03zb_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
+               [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03zb_bench_default_iterative_schur.json", "r03zm_bench_default_iterative_schur.json",
+                                                          "r03zq_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -85,3 +86,13 @@ def test_round3_default_line_carries_the_configurations_the_review_asked_for():
     assert dc["n"] == 8190 and not dc["failed"] and dc["rel_err_of_solve"] < 1e-12
     assert dc["frac_of_datasheet_peak"] == pytest.approx(dc["TFLOPs"] / 78.6, abs=1e-3) and dc["frac_of_datasheet_peak"] < 0.30   # said plainly: the 30 % is not met
     assert d["roofline"]["frac"] >= 0.65 and d["roofline_jtjx"]["frac"] >= 0.60
+
+
+def test_end_of_round3_line_has_the_long_points_in_rounds():
+    """The last default line of round 3: the real-visibility case (every point of the replicated libmv graph owns 3 - 7 tiles) runs with
+    the long points taken in cooperative rounds — S.x at twice the fraction of the HBM peak it had with one wave per point (0.20)."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03zq_bench_default_iterative_schur.json")).read())
+    rg = d["extra"]["real_graph"]["cases"]
+    assert rg[1]["hybrid"] == 1 and rg[1]["sx"]["frac"] >= 0.35 and rg[1]["jtjx"]["frac"] >= 0.30
+    assert d["roofline"]["frac"] >= 0.70 and d["extra"]["cgnr"]["jtjx_frac_hbm"] >= 0.60
+    assert d["extra"]["synthetic10M"]["sx"]["frac"] >= 0.40
