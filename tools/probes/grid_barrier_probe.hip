@@ -41,6 +41,42 @@ __global__ __launch_bounds__(256) void barrier_kernel(unsigned int* counter, int
   if (acc == 1.2345e-300) sink[0] = acc;
 }
 
+// Two cheaper barriers for comparison: `sleep` = the same single counter with s_sleep in the spin loop (less traffic against the
+// atomics), `tree` = per-XCD counters (workgroup b arrives at counter b % 8: the round-robin of workgroups over XCDs), the last
+// arrival of an XCD arrives at the global counter, the last of those raises a flag everybody spins on (with s_sleep).
+template <int KIND>   // 1 sleep, 2 tree
+__global__ __launch_bounds__(256) void barrier2_kernel(unsigned int* c, int nb, unsigned int* gave_up) {
+  __shared__ int ok;
+  unsigned int* xcd = c + 16 * (1 + blockIdx.x % 8);   // counters 64 bytes apart
+  unsigned int* global = c, *flag = c + 16 * 9;
+  const unsigned per_xcd = gridDim.x / 8;
+  for (int b = 0; b < nb; ++b) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      ok = 1;
+      int spins = 0;
+      if (KIND == 1) {
+        atomicAdd(global, 1u);
+        const unsigned target = unsigned(b + 1) * gridDim.x;
+        while (__hip_atomic_load(global, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > 1000000) { ok = 0; atomicAdd(gave_up, 1u); break; }
+        }
+      } else {
+        if (atomicAdd(xcd, 1u) == per_xcd * unsigned(b + 1) - 1u)
+          if (atomicAdd(global, 1u) == 8u * unsigned(b + 1) - 1u) __hip_atomic_store(flag, unsigned(b + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < unsigned(b + 1)) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > 1000000) { ok = 0; atomicAdd(gave_up, 1u); break; }
+        }
+      }
+    }
+    __syncthreads();
+    if (!ok) return;
+  }
+}
+
 int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int grid = prop.multiProcessorCount;   // one workgroup per CU
@@ -66,6 +102,27 @@ int main() {
       if (nb > 1) printf(", %.2f us per barrier beyond the first", (best - first) * 1e3 / (nb - 1));
       printf("\n");
       fflush(stdout);
+    }
+  }
+  {
+    unsigned int* c2 = nullptr; CK(hipMalloc(&c2, 4096));
+    for (int kind = 1; kind <= 2; ++kind) {
+      float t1 = 0;
+      for (int nb : {1, 1001}) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipMemset(c2, 0, 4096));
+          CK(hipEventRecord(e0));
+          if (kind == 1) hipLaunchKernelGGL((barrier2_kernel<1>), dim3(grid), dim3(256), 0, 0, c2, nb, gave_up);
+          else hipLaunchKernelGGL((barrier2_kernel<2>), dim3(grid), dim3(256), 0, 0, c2, nb, gave_up);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+          best = ms < best ? ms : best;
+        }
+        if (nb == 1) t1 = best;
+        else printf("%s: %.2f us per barrier (bare, %d workgroups)\n", kind == 1 ? "one counter + s_sleep in the spin" : "per-XCD counters -> global counter -> flag, s_sleep", (best - t1) * 1e3 / (nb - 1), grid);
+        fflush(stdout);
+      }
     }
   }
   unsigned int g = 0; CK(hipMemcpy(&g, gave_up, 4, hipMemcpyDeviceToHost));
