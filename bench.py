@@ -35,6 +35,48 @@ import os
 import sys
 import time
 
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (the driver's spelling of the 1-GPU
+    run must work for N GPUs too).  Ranks are `python -m torch.distributed.run --nproc-per-node N` children of this process; rank 0
+    prints the one JSON line, this process forwards their exit code.  On a box with fewer than N visible GPUs the ranks share device 0
+    (CERES_HIP_BENCH_ONE_GPU=1: a VALIDATION mode of the whole N > 1 code path — gloo + the peer-to-peer all-reduce — whose timings
+    mean nothing; the line says so in config.parallelism)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:], 1):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    try:
+        import torch
+        visible = torch.cuda.device_count()
+    except Exception:
+        visible = 0
+    if visible < n and env.get("CERES_HIP_BENCH_ONE_GPU", "0") != "1":
+        print(f"bench.py: {visible} GPU(s) visible for --gpus {n}: the ranks share device 0 (one-GPU validation mode, timings meaningless)",
+              file=sys.stderr, flush=True)
+        env["CERES_HIP_BENCH_ONE_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__":
+    _self_launch()
+
 if int(os.environ.get("WORLD_SIZE", "1")) == 1:
     # cpu_baseline leg (N = 1 only): keep the oracle's OpenMP threads next to each other and on the socket that holds the
     # data — 8 % on the two-socket host of the GPU boxes (tools/cpu_oracle_probe.py); must be set before any OpenMP
@@ -98,6 +140,10 @@ def parse():
     ap.add_argument("--extra-real-graph", type=int, default=1, help="default line: S.x / JtJx on the replicated libmv visibility graph (extra.real_graph)")
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=0, help="many-camera workloads: also time the fp32-tile storage mode (extra.fp32_tiles)")
+    ap.add_argument("--oracle-check", type=int, default=0,
+                    help="compare the step of the LAST timed solve with ONE oracle step on the same FULL-SIZE inputs (16 threads; N > 1: the ranks' "
+                         "shards of the step are gathered and assembled first) and report it as oracle_check.  Independent of --no-cpu-baseline: "
+                         "the synthetic10M child and the one-GPU N = 8 validation run use it")
     return ap.parse_args()
 
 
@@ -181,9 +227,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus:  # (a bare `python bench.py --gpus N` never gets here: _self_launch starts the ranks)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     pkg = entry.load_package()
     hs = pkg.hip_solver
     hs.load_library()
@@ -383,11 +428,33 @@ def main():
             per_step.append(time.perf_counter() - t0)
         th = float(np.median(per_step))  # the host side (page faults of the freshly allocated step vector) jitters by milliseconds
         tm = solver.last_timing()
+        # the retry after a REJECTED step (values_unchanged = 1: the minimizer has not re-evaluated, trust_region_minimizer.cc:832-837):
+        # nothing goes up, the step's first pass reads the resident tiles; radius halved as StepRejected does
+        retry = []
+        for k in range(nh):
+            t0 = time.perf_counter()
+            solver.lm_compute_step(None, None, RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True)
+            retry.append(time.perf_counter() - t0)
+        tr_ = solver.last_timing()
+        dev_retry_ms = None
+        if nh > 1:   # the same retry with J and f resident (the device evaluator's case)
+            solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS, 0.1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(nh):
+                solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True)
+            torch.cuda.synchronize()
+            dev_retry_ms = 1e3 * (time.perf_counter() - t0) / nh
         host_boundary = {"steps_per_s": round(1.0 / th, 3), "ms_per_step": round(1e3 * th, 3), "upload_ms": round(tm.upload_ms, 3),
                          "download_ms": round(tm.download_ms, 3), "bytes_h2d": int(8 * (prob.values.shape[0] + prob.b.shape[0])),
                          "h2d_GBs": round(8 * (prob.values.shape[0] + prob.b.shape[0]) / max(tm.upload_ms, 1e-9) / 1e6, 1),
                          "what": "ceres_hip_lm_compute_step with pinned host values/residuals (PCIe H2D + step + D2H), median of " + str(nh) + " steps",
-                         "ms_each_step": [round(1e3 * t, 2) for t in per_step]}
+                         "ms_each_step": [round(1e3 * t, 2) for t in per_step],
+                         "retry_after_rejection": {
+                             "what": "ceres_hip_lm_compute_step with values_unchanged = 1, reuse_diagonal = 1, radius / 2: the Jacobian the solver "
+                                     "already holds is neither re-sent nor re-laid-out (D2H of the step included)",
+                             "ms_per_step": round(1e3 * float(np.median(retry)), 3), "upload_ms": round(tr_.upload_ms, 3),
+                             "device_pointer_retry_ms_per_step": None if dev_retry_ms is None else round(dev_retry_ms, 3)}}
         del hv, hb
 
     # ---- the whole trust-region loop on the device, for the record (N = 1) ----------
@@ -482,10 +549,10 @@ def main():
             extra["synthetic10M"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the child wants 60"}
         else:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", "synthetic10M", "--steps", "5", "--warmup", "1", "--kernel-iters", "20",
-                   "--no-cpu-baseline", "--host-boundary-steps", "0", "--minimizer-iterations", "0", "--extra-synthetic10m", "0", "--also-fp32", "1",
+                   "--no-cpu-baseline", "--oracle-check", "1", "--host-boundary-steps", "0", "--minimizer-iterations", "0", "--extra-synthetic10m", "0", "--also-fp32", "1",
                    "--solver", args.solver, "--eta", str(args.eta)]
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 other = "cgnr" if args.solver == "iterative_schur" else "iterative_schur"
                 ro, rj = d["roofline"], d.get("roofline_jtjx") or d.get("roofline_sx") or {}
@@ -497,6 +564,7 @@ def main():
                     ("sx" if kind == "sx" else "jtjx"): {"frac": ro["frac"], "GBs": ro["achieved"], "ms": ro["avg_launch_ms"], "kernel": ro["kernel"]},
                     ("jtjx" if kind == "sx" else "sx"): {"frac": rj.get("frac"), "GBs": rj.get("achieved"), "ms": rj.get("avg_launch_ms")},
                     other: d["extra"].get(other), "fp32_tiles": d["extra"].get("fp32_tiles"),
+                    "step_rel_diff_vs_oracle": (d.get("oracle_check") or {}).get("step_rel_diff_vs_oracle"), "oracle_check": d.get("oracle_check"),
                     "child_wall_s": round(time.perf_counter() - t10, 1)}
             except Exception as ex:  # the default line must not depend on the child
                 extra["synthetic10M"] = {"error": repr(ex)[:300]}
@@ -546,6 +614,54 @@ def main():
             del Bm, Am
         except Exception as ex:
             extra["dense_schur_cholesky"] = {"error": repr(ex)[:300]}
+
+    # ---- full-size parity of the timed step itself (rungs 4 / 5 of the ladder at the size the line is quoted on) ----
+    oracle_check = None
+    if args.oracle_check and not (many_cameras and world > 1) and not storage:
+        xl = tx.cpu().numpy()
+        if world > 1:   # every rank's shard of the step -> rank 0, assembled through the shards' column maps
+            parts = [None] * world
+            dist.gather_object((xl, sh.col_index, int(bs.col_block_size[:nelim_local].sum())), parts if rank == 0 else None, dst=0)
+            if rank == 0:
+                xg_full = np.full(prob.bs.num_cols, np.nan)
+                for xl_r, ci_r, ne_r in parts:
+                    xg_full[ci_r[:ne_r]] = xl_r[:ne_r]
+                xg_full[parts[0][1][parts[0][2]:]] = parts[0][0][parts[0][2]:]
+        else:
+            xg_full = xl
+        if rank == 0:
+            oracle = entry.load_oracle()
+            oracle.set_num_threads(min(os.cpu_count() or 1, 16))
+            if many_cameras:
+                o_values, o_b = tv.cpu().numpy(), tb.cpu().numpy()
+            else:
+                o_values, o_b = prob.values, prob.b
+            o_nelim = prob.num_eliminate_blocks
+            mo_ = oracle.Matrix(prob.bs, o_nelim if args.solver == "iterative_schur" else 0)
+            mo_all = oracle.Matrix(prob.bs, 0)
+            fn_o = mo_.iterative_schur_solve if args.solver == "iterative_schur" else mo_.cgnr_solve
+            pre_o = 2 if args.solver == "iterative_schur" else 1
+            t_o = time.perf_counter()
+            if args.step == "lm_step":
+                D_o = np.sqrt(np.clip(mo_all.squared_column_norm(o_values), 1e-6, 1e32) / RADIUS)
+            else:
+                D_o = tD.cpu().numpy() if many_cameras else prob.D
+            xo_, so_ = fn_o(o_values, o_b, D_o, preconditioner=pre_o, min_it=0, max_it=500, q_tol=args.eta, r_tol=-1.0)
+            t_o = time.perf_counter() - t_o
+            k_gpu, k_or = int(iters[-1]), int(so_.num_iterations)
+            same_index = True
+            if k_gpu != k_or:   # zeta crossed the threshold one index apart: compare with the oracle's iterate of the SAME index (tests/step_check.py)
+                xo_, _ = fn_o(o_values, o_b, D_o, preconditioner=pre_o, min_it=k_gpu, max_it=k_gpu, q_tol=-1.0, r_tol=-1.0)
+                same_index = False
+            sign = -1.0 if args.step == "lm_step" else 1.0
+            oracle_check = {"what": "the step of the last timed solve against ONE oracle step on the same full-size inputs "
+                                    "(the oracle's CG iterate of the same iteration number; tolerance of the parity ladder: 1e-9)",
+                            "step_rel_diff_vs_oracle": float(np.linalg.norm(xg_full - sign * xo_) / np.linalg.norm(xo_)),
+                            "cg_iterations_gpu": k_gpu, "cg_iterations_oracle": k_or, "oracle_rerun_at_gpu_iteration_count": not same_index,
+                            "oracle_seconds": round(t_o, 2), "oracle_threads": min(os.cpu_count() or 1, 16), "ranks": world,
+                            "observations": int(prob.bs.num_row_blocks)}
+            oracle.set_num_threads(1)
+            del xo_, mo_, mo_all
 
     # ---- CPU baseline: the oracle (a restatement of Ceres' algorithm, "port") on this box's cores ----
     cpu = None
@@ -635,7 +751,7 @@ def main():
                        "jacobian_storage": "fp32 tiles, fp64 arithmetic (accuracy mode, not parity)" if storage else "fp64",
                        "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",
                        "camera_accumulators_in_lds": bool(info.camera_accum_in_lds)},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host_boundary, "scene_trust_region": scene_tr, "scene_step": scene_step,
+            "roofline": roofline, "cpu_baseline": cpu, "oracle_check": oracle_check, "host_boundary": host_boundary, "scene_trust_region": scene_tr, "scene_step": scene_step,
             "extra": extra,
         }
         if args.step == "lm_step":  # the whole step against ITS roofline: minimum bytes of all its passes / measured time / peak

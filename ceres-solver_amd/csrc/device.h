@@ -291,6 +291,8 @@ hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);
 hipError_t LaunchExpandSym3(const double* packed6, double* dense9, const int64_t* pt_diag_off, int n_points, hipStream_t stream);
+// out[off[p] + k] = in[9 p + k], k < 9 (in and out must not overlap)
+hipError_t LaunchScatterBlocks9(const double* in, double* out, const int64_t* off, int n_points, hipStream_t stream);
 
 // Status word values (device side) — 0 means "keep iterating".
 enum CgStatus {

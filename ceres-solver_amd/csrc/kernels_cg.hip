@@ -122,6 +122,14 @@ __global__ void expand_sym3_kernel(const double* p6, double* d9, const int64_t* 
   o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
 }
 
+// out[off[p] + k] = in[9 p + k]: the dense 3x3 point blocks of a CGNR solve (internal point order) into the caller's block order
+__global__ void scatter_blocks9_kernel(const double* in, double* out, const int64_t* off, int n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(9) * n) return;
+  const int p = int(i / 9), k = int(i - int64_t(9) * p);
+  out[off[p] + k] = in[i];
+}
+
 __global__ __launch_bounds__(kVecBlock) void lm_diagonal_kernel(double* diag, double lo, double hi, double radius, double* D, int64_t n) {
   for (int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x; i < n; i += int64_t(gridDim.x) * kVecBlock) {
     const double d = fmin(fmax(diag[i], lo), hi);
@@ -704,6 +712,11 @@ hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_
 }
 hipError_t LaunchExpandSym3(const double* p6, double* d9, const int64_t* off, int n, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(expand_sym3_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p6, d9, off, n);
+  return hipGetLastError();
+}
+
+hipError_t LaunchScatterBlocks9(const double* in, double* out, const int64_t* off, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(scatter_blocks9_kernel, dim3(unsigned((int64_t(9) * n + 255) / 256)), dim3(256), 0, s, in, out, off, n);
   return hipGetLastError();
 }
 

@@ -553,13 +553,27 @@ LookAhead* look_ahead_for_current_device() {
 // of a pair is latency-bound on one or a few CUs and as long as the bulk update of the pair before it.
 hipError_t LaunchDenseCholesky(double* A, int n, int* fail_flag, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  static const hipError_t lds_ok = [] {   // the panel kernel keeps a kPanel x kPanel block in LDS (132 KB), the update two operand strips twice (147 KB)
-    const int bytes = kPanel * kPanelPitch * int(sizeof(double));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_potrf_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(dense_syrk_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(4 * kSyrkOperand * sizeof(double)));
-  }();
-  if (lds_ok != hipSuccess) return lds_ok;
+  // The dynamic-LDS ceiling is an attribute of a (kernel, DEVICE) pair: raised once per device, under a lock (a process-wide "once" left
+  // the kernels of a second device — two handles with different options.device — at the default ceiling and their launches failed).
+  // The panel kernel keeps a kPanel x kPanel block in LDS (132 KB) next to its static arrays, the update two operand strips twice (147 KB).
+  {
+    static std::mutex lds_mu;
+    static unsigned long long lds_done = 0ull;   // mask of devices 0..63
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lock(lds_mu);
+    if (!(lds_done & bit)) {
+      const void* kernels[2] = {reinterpret_cast<const void*>(dense_potrf_panel_kernel), reinterpret_cast<const void*>(dense_syrk_mfma_kernel)};
+      for (const void* k : kernels) {
+        hipFuncAttributes fa;
+        if (hipError_t e = hipFuncGetAttributes(&fa, k); e != hipSuccess) return e;
+        const int dyn = int(kMaxLdsBytes) - int(fa.sharedSizeBytes);   // static + dynamic LDS must fit the CU's 160 KB
+        if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, dyn); e != hipSuccess) return e;
+      }
+      lds_done |= bit;
+    }
+  }
   hipLaunchKernelGGL(dense_mirror_upper_kernel, dim3(blocks_for(int64_t(n) * n)), dim3(kB), 0, s, A, n);
   const size_t syrk_lds = 4 * kSyrkOperand * sizeof(double);
   LookAhead* la = n >= 24 * kPanel ? look_ahead_for_current_device() : nullptr;   // below ~3000 columns the event traffic costs more than it hides (n = 2052: 2.7 vs 3.9 ms)

@@ -267,8 +267,9 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     std::iota(by_deg.begin(), by_deg.end(), 0);
     std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
     const double popular = 2.0 * double(n_conf) / double(P.n_cameras);
-    while (K_h < max_hot && double(deg[by_deg[K_h]]) >= popular) ++K_h;
-    if (const char* e = getenv("CERES_HIP_HYB_HOT")) K_h = std::max(0, std::min(atoi(e), max_hot));   // (experiments)
+    const int hot_cap = std::min(max_hot, P.n_cameras);   // (rows may exceed the cameras: ceres_hip_debug_hybrid_plan takes any `rows`)
+    while (K_h < hot_cap && double(deg[by_deg[K_h]]) >= popular) ++K_h;
+    if (const char* e = getenv("CERES_HIP_HYB_HOT")) K_h = std::max(0, std::min(atoi(e), hot_cap));   // (experiments)
     K_w = K - K_h;
     hot_row.assign(P.n_cameras, -1);
     cold_rank.assign(P.n_cameras, -1);

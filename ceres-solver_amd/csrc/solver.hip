@@ -362,6 +362,22 @@ int ensure_D_int(ceres_hip_solver* s) {
   s->D_int_valid = true;
   return 0;
 }
+// The JACOBI point blocks a CGNR solve left in CG's (internal) point order -> the caller's block order.  LOCAL work (a copy and a
+// scatter): the readers that call it are getters — recomputing the preconditioner there would issue an all-reduce on a sharded instance
+// (a hang unless every rank called the getter in lockstep) and would use the CURRENT D instead of the D of the solve.
+int precond_to_caller_order(ceres_hip_solver* s) {
+  if (!s->precond_internal) return 0;
+  const size_t n = size_t(9) * s->plan.n_points;
+  double* tmp = nullptr;
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * std::max<size_t>(1, n)));
+  hipError_t e = hipMemcpyAsync(tmp, s->precond, sizeof(double) * n, hipMemcpyDeviceToDevice, s->stream);
+  if (e == hipSuccess) e = LaunchScatterBlocks9(tmp, s->precond, s->d_pt_diag_off, s->plan.n_points, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(s, CERES_HIP_E_HIP, "permuting the point blocks failed: %s", hipGetErrorString(e));
+  s->precond_internal = false;
+  return 0;
+}
 // the solution of a CGNR solve (CG's order) -> the caller's
 int copy_out_cgnr_solution(ceres_hip_solver* s, double* x) {
   const HostStructure& h = s->hs;
@@ -1141,6 +1157,14 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   return 0;
 }
 
+// The retry after a rejected step: same values, same residuals (ceres_hip_lm_options::values_unchanged); only what contains D is stale.
+// The packed tiles, the remainder rows' blocks and the loaded pointers stay.
+void keep_loaded_values(ceres_hip_solver* s) {
+  s->precond_valid = false;
+  s->ftf_inv_valid = false;
+  s->D_int_valid = false;
+}
+
 int load_host(ceres_hip_solver* s, const double* hv, const double* hb, const double* hD) {
   if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
   if (!hv) return fail(s, CERES_HIP_E_INVALID, "values == NULL");
@@ -1162,7 +1186,13 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // The two LinearSolver::SolveImpl bodies.  x is a device pointer (num_cols).
 int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary);
 int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
-  const int rc = solve_loaded_impl(s, q_tol, r_tol, x, summary);
+  int rc = solve_loaded_impl(s, q_tol, r_tol, x, summary);
+  // a deferred rhs all-reduce nobody took along (an early return between op_schur_init and the preconditioner): pay it now, so that
+  // every rank issues the same collectives and a later op-level call does not find a stale promise
+  if (s->rhs_reduce_pending) {
+    s->rhs_reduce_pending = false;
+    if (rc == 0) rc = allreduce(s, s->rhs_f, size_t(s->hs.num_cols_f));
+  }
   // "the flags were cleared together at the start" holds INSIDE one solve only: paths that never consume the promise (DENSE_SCHUR,
   // explicit S, IDENTITY, early returns) clear and raise d_fail_flag themselves, and a later op-level call must not skip its memset
   s->fail_flag_clean = false;
@@ -1189,8 +1219,11 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     const int pre = s->opt.preconditioner_type;
     // sharded fused path, block-diagonal preconditioner from the camera-major pass: rhs, the blocks and the camera column norms go
     // through ONE all-reduce, issued by op_preconditioner
+    // (armed only where the code below REACHES that op_preconditioner call: the implicit iterative branch with F blocks — a direct or
+    // explicit-S solve, or the no-F-blocks shortcut, would otherwise factor / iterate on this rank's raw rhs)
+    const bool implicit_iterative = !is_dense_schur(s) && !s->sparse_S && !s->opt.use_explicit_schur_complement && h.ncb - h.nelim > 0;
     s->merge_step_reduce = s->world > 1 && s->path == CERES_HIP_PATH_BAL && (pre == CERES_HIP_SCHUR_JACOBI || pre == CERES_HIP_JACOBI) &&
-                           !s->opt.use_spse_initialization;
+                           !s->opt.use_spse_initialization && implicit_iterative;
     const int rc_init = op_schur_init(s, pre == CERES_HIP_SCHUR_JACOBI);
     s->merge_step_reduce = false;
     TRY(rc_init);
@@ -1897,7 +1930,9 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
     info->hybrid_popular_rows = s->plan.hybrid ? s->plan.hyb_hot : 0;
     info->num_observations_in_lds = s->lds_mode ? s->plan.n_obs : s->plan.n_local_obs;
     info->points_renumbered = s->plan.renumbered ? 1 : 0;
-    info->cg_iteration_in_operator = (cg_tail_possible(s) && s->opt.preconditioner_type != CERES_HIP_IDENTITY) ? 1 : 0;
+    // (the same condition solve_loaded applies: a block-diagonal preconditioner — not IDENTITY, not the power-series operator)
+    info->cg_iteration_in_operator = (cg_tail_possible(s) && s->opt.preconditioner_type != CERES_HIP_IDENTITY &&
+                                      s->opt.preconditioner_type != CERES_HIP_SCHUR_POWER_SERIES_EXPANSION) ? 1 : 0;
   }
   return 0;
 }
@@ -2127,6 +2162,37 @@ int ceres_hip_solve(ceres_hip_solver* s, const double* hv, const double* hb, con
   return 0;
 }
 
+int ceres_hip_solve_unchanged_values(ceres_hip_solver* s, const double* hD, double q_tol, double r_tol, double* hx, ceres_hip_summary* summary) {
+  if (!s || !summary || !hx) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  auto fatal = [&](int rc) {
+    summary->termination_type = CERES_HIP_FATAL_ERROR;
+    summary->residual_norm = -1;
+    snprintf(summary->message, sizeof(summary->message), "%s", s->err.c_str());
+    return rc;
+  };
+  if (!s->have_structure || !s->loaded || !s->have_b)
+    return fatal(fail(s, CERES_HIP_E_INVALID, "ceres_hip_solve_unchanged_values needs the values and b of a previous ceres_hip_solve / ceres_hip_load"));
+  (void)hipEventRecord(s->ev[0], s->stream);
+  const HostStructure& h = s->hs;
+  if (hD && hipMemcpyAsync(s->own_D, hD, sizeof(double) * h.num_cols, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+    return fatal(fail(s, CERES_HIP_E_HIP, "host-to-device copy failed"));
+  (void)hipEventRecord(s->ev[1], s->stream);
+  s->D = hD ? s->own_D : nullptr;
+  s->have_D = hD != nullptr;
+  keep_loaded_values(s);
+  int rc = solve_loaded(s, q_tol, r_tol, s->own_x, summary);
+  if (rc) return fatal(rc);
+  if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR) {
+    if (hipMemcpyAsync(hx, s->own_x, sizeof(double) * h.num_cols, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
+      return fatal(fail(s, CERES_HIP_E_HIP, "device-to-host copy failed"));
+  }
+  (void)hipEventRecord(s->ev[7], s->stream);
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
+  collect_timing(s);
+  return 0;
+}
+
 int ceres_hip_solve_device(ceres_hip_solver* s, const double* dv, const double* db, const double* dD, double q_tol,
                            double r_tol, double* dx, ceres_hip_summary* summary) {
   if (!s || !summary || !dx) return CERES_HIP_E_INVALID;
@@ -2284,7 +2350,9 @@ int ceres_hip_lm_compute_step_device(ceres_hip_solver* s, const double* dv, cons
   HIP_TRY(s, hipSetDevice(s->opt.device));
   (void)hipEventRecord(s->ev[0], s->stream);
   (void)hipEventRecord(s->ev[1], s->stream);
-  TRY(load_device(s, dv, db, nullptr));
+  if (o->values_unchanged && s->loaded && s->have_b && s->values == dv && s->b == db) keep_loaded_values(s);
+  else if (o->values_unchanged) return fail(s, CERES_HIP_E_INVALID, "values_unchanged = 1 but these are not the pointers of the previous load");
+  else TRY(load_device(s, dv, db, nullptr));
   TRY(lm_step_loaded(s, o, dx, res));
   (void)hipEventRecord(s->ev[7], s->stream);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -2297,7 +2365,13 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const doubl
   if (!s || !o || !hx || !res) return CERES_HIP_E_INVALID;
   HIP_TRY(s, hipSetDevice(s->opt.device));
   (void)hipEventRecord(s->ev[0], s->stream);
-  TRY(load_host(s, hv, hb, nullptr));
+  if (o->values_unchanged) {   // the copies of the previous call are still in HBM: nothing crosses PCIe but the step
+    if (!(s->loaded && s->have_b && s->values == s->own_values && s->b == s->own_b))
+      return fail(s, CERES_HIP_E_INVALID, "values_unchanged = 1 needs a previous ceres_hip_lm_compute_step / ceres_hip_load with host values and residuals");
+    keep_loaded_values(s);
+  } else {
+    TRY(load_host(s, hv, hb, nullptr));
+  }
   (void)hipEventRecord(s->ev[1], s->stream);
   TRY(lm_step_loaded(s, o, s->own_x, res));
   const int term = res->linear_solver.termination_type;
@@ -2544,7 +2618,7 @@ int ceres_hip_get_preconditioner_blocks(ceres_hip_solver* s, int32_t not_inverte
   if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
   if (!not_inverted) {
     if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
-    if (s->precond_internal) TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));  // a CGNR solve left its point blocks in CG's order
+    TRY(precond_to_caller_order(s));  // a CGNR solve left its point blocks in CG's order
     return down(s, blocks, s->precond, size_t(len));
   }
   // re-assemble without inverting, into a temporary
@@ -2563,7 +2637,7 @@ int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y) 
   TRY(require_loaded(s));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
-  if (s->precond_internal) TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));  // a CGNR solve left its point blocks in CG's order
+  TRY(precond_to_caller_order(s));  // a CGNR solve left its point blocks in CG's order
   const HostStructure& h = s->hs;
   const int n = is_schur(s) ? h.num_cols_f : h.num_cols;
   TRY(up(s, s->cg.p, x, n));

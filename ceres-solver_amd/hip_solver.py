@@ -77,7 +77,7 @@ class CTiming(ctypes.Structure):
 
 class CLmOptions(ctypes.Structure):
     _fields_ = [("radius", c_double), ("min_diagonal", c_double), ("max_diagonal", c_double), ("eta", c_double),
-                ("reuse_diagonal", c_int32), ("reserved", c_int32)]
+                ("reuse_diagonal", c_int32), ("values_unchanged", c_int32)]
 
 
 class CLmResult(ctypes.Structure):
@@ -104,6 +104,7 @@ ABI = [
     ("ceres_hip_debug_allreduce_timing", c_int32, [c_void_p, c_int64, c_int32, _DP]),
     ("ceres_hip_solve", c_int32, [c_void_p, _DP, _DP, _DP, c_double, c_double, _DP, POINTER(CSummary)]),
     ("ceres_hip_solve_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, POINTER(CSummary)]),
+    ("ceres_hip_solve_unchanged_values", c_int32, [c_void_p, _DP, c_double, c_double, _DP, POINTER(CSummary)]),
     ("ceres_hip_load", c_int32, [c_void_p, _DP, _DP, _DP]),
     ("ceres_hip_load_device", c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     ("ceres_hip_op_right_multiply", c_int32, [c_void_p, _DP, _DP]),
@@ -407,6 +408,21 @@ class HipLinearSolver:
             summary.message = self._lib.ceres_hip_last_error(self._h).decode()
         return x, summary
 
+    def solve_unchanged_values(self, per_solve: "PerSolveOptions"):
+        """LinearSolver::Solve again on the values and b of the previous solve() / load() with a new D (the retry after a rejected
+        trust-region step): only D crosses PCIe, the tiles are not rebuilt."""
+        n = self._info
+        D = None if per_solve.D is None else _f64(per_solve.D, n.num_cols, "D")
+        x = np.full(n.num_cols, np.nan)
+        s = CSummary()
+        rc = self._lib.ceres_hip_solve_unchanged_values(self._h, _p(D) if D is not None else None, per_solve.q_tolerance,
+                                                        per_solve.r_tolerance, _p(x), byref(s))
+        summary = Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace"))
+        if rc != 0:
+            summary.termination_type = FATAL_ERROR
+            summary.message = self._lib.ceres_hip_last_error(self._h).decode()
+        return x, summary
+
     def solve_device(self, d_values: int, d_b: int, d_D: int, d_x: int, q_tolerance=0.0, r_tolerance=0.0):
         """Same with raw device pointers (e.g. torch tensor .data_ptr()); nothing crosses PCIe."""
         s = CSummary()
@@ -419,23 +435,29 @@ class HipLinearSolver:
 
     # -- f1: one trust-region step's linear algebra on the device ----------------
     def lm_compute_step(self, values, residuals, radius, eta=0.1, min_diagonal=1e-6, max_diagonal=1e32,
-                        reuse_diagonal=False):
+                        reuse_diagonal=False, values_unchanged=False):
         """LevenbergMarquardtStrategy::ComputeStep + the model-cost bookkeeping of
-        TrustRegionMinimizer::ComputeTrustRegionStep.  Returns (step, Summary, model_cost_change)."""
+        TrustRegionMinimizer::ComputeTrustRegionStep.  Returns (step, Summary, model_cost_change).
+        values_unchanged: the retry after a rejected step — the solver keeps the Jacobian and residuals it holds (values / residuals
+        may be None): no host-to-device copy, no re-layout."""
         n = self._info
-        values = _f64(values, self._values_extent, "values")
-        residuals = _f64(residuals, n.num_rows, "residuals")
-        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), 0)
+        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), int(values_unchanged))
         r = CLmResult()
         step = np.full(n.num_cols, np.nan)
-        self._check(self._lib.ceres_hip_lm_compute_step(self._h, _p(values), _p(residuals), byref(o), _p(step), byref(r)))
+        if values_unchanged:
+            pv = pr = None
+        else:
+            values = _f64(values, self._values_extent, "values")
+            residuals = _f64(residuals, n.num_rows, "residuals")
+            pv, pr = _p(values), _p(residuals)
+        self._check(self._lib.ceres_hip_lm_compute_step(self._h, pv, pr, byref(o), _p(step), byref(r)))
         s = r.linear_solver
         return step, Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace")), \
             float(r.model_cost_change)
 
     def lm_compute_step_device(self, d_values: int, d_residuals: int, d_step: int, radius, eta=0.1, min_diagonal=1e-6,
-                               max_diagonal=1e32, reuse_diagonal=False):
-        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), 0)
+                               max_diagonal=1e32, reuse_diagonal=False, values_unchanged=False):
+        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), int(values_unchanged))
         r = CLmResult()
         self._check(self._lib.ceres_hip_lm_compute_step_device(self._h, d_values, d_residuals, byref(o), d_step, byref(r)))
         s = r.linear_solver

@@ -145,10 +145,11 @@ class HipLinearSolver final : public LinearSolver {
     bool step_is_finite = false;
   };
   LmStep ComputeLmStep(BlockSparseMatrix* jacobian, const double* residuals, double radius, double eta, double* step,
-                       bool reuse_diagonal = false, double min_diagonal = 1e-6, double max_diagonal = 1e32) {
+                       bool reuse_diagonal = false, double min_diagonal = 1e-6, double max_diagonal = 1e32,
+                       bool values_unchanged = false) {   // the retry after a rejected step: J and f are what the previous call received
     LmStep out;
     if (!EnsureStructure(jacobian, &out.summary)) return out;
-    ceres_hip_lm_options o{radius, min_diagonal, max_diagonal, eta, reuse_diagonal ? 1 : 0, 0};
+    ceres_hip_lm_options o{radius, min_diagonal, max_diagonal, eta, reuse_diagonal ? 1 : 0, values_unchanged ? 1 : 0};
     ceres_hip_lm_result r{};
     const int rc = ceres_hip_lm_compute_step(handle_, jacobian->values(), residuals, &o, step, &r);
     out.summary.residual_norm = r.linear_solver.residual_norm;

@@ -234,6 +234,11 @@ int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t ite
 int ceres_hip_solve(ceres_hip_solver* s, const double* host_values, const double* host_b,
                     const double* host_D, double q_tolerance, double r_tolerance,
                     double* host_x, ceres_hip_summary* summary);
+/* LinearSolver::Solve again on the values and b of the previous ceres_hip_solve / ceres_hip_load on this handle, with a new D (the
+ * retry after a rejected trust-region step: I/levenberg_marquardt_strategy.cc:164-176 shrinks the radius, the minimizer calls
+ * ComputeStep on the same Jacobian, I/trust_region_minimizer.cc:381-461).  Nothing but D goes up, the tiles are not rebuilt.      */
+int ceres_hip_solve_unchanged_values(ceres_hip_solver* s, const double* host_D, double q_tolerance, double r_tolerance,
+                                     double* host_x, ceres_hip_summary* summary);
 /* Same, all four arrays already resident in HBM (used by bench.py so that the
  * timed region holds no PCIe traffic; also the form a device evaluator uses). */
 int ceres_hip_solve_device(ceres_hip_solver* s, const double* dev_values, const double* dev_b,
@@ -354,7 +359,13 @@ typedef struct ceres_hip_lm_options {
   double max_diagonal;    /* Solver::Options::max_lm_diagonal (1e32)               */
   double eta;             /* q_tolerance of the linear solve                       */
   int32_t reuse_diagonal; /* 1 after a rejected step: keep the previous diag(J'J)  */
-  int32_t reserved;
+  /* 1: `values` and `residuals` are what the PREVIOUS ceres_hip_lm_compute_step* / ceres_hip_load* on this handle received — the
+   * Jacobian is re-evaluated only in HandleSuccessfulStep (I/trust_region_minimizer.cc:832-837), so the ComputeStep that follows a
+   * rejected or invalid step (I/levenberg_marquardt_strategy.cc:134,164,170: the calls that also set reuse_diagonal_) solves on the
+   * SAME matrix with a smaller radius.  The solver then keeps what it holds: no host-to-device copy (the host pointers may be NULL),
+   * no re-layout into tiles; the step's first pass reads the resident tiles.  A caller that re-evaluated says 0 (separate from
+   * reuse_diagonal: the two are independent statements).  Device entry point: the same device pointers, contents untouched.        */
+  int32_t values_unchanged;
 } ceres_hip_lm_options;
 typedef struct ceres_hip_lm_result {
   ceres_hip_summary linear_solver; /* FAILURE also when the step is not finite      */
