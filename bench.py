@@ -431,9 +431,10 @@ def main():
         # the retry after a REJECTED step (values_unchanged = 1: the minimizer has not re-evaluated, trust_region_minimizer.cc:832-837):
         # nothing goes up, the step's first pass reads the resident tiles; radius halved as StepRejected does
         retry = []
+        h_step = torch.empty(bs.num_cols, dtype=torch.float64).pin_memory()   # the caller's step vector (Ceres allocates it once per Solve())
         for k in range(nh):
             t0 = time.perf_counter()
-            solver.lm_compute_step(None, None, RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True)
+            solver.lm_compute_step(None, None, RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True, out=h_step.numpy())
             retry.append(time.perf_counter() - t0)
         tr_ = solver.last_timing()
         dev_retry_ms = None
@@ -455,7 +456,7 @@ def main():
                                      "already holds is neither re-sent nor re-laid-out (D2H of the step included)",
                              "ms_per_step": round(1e3 * float(np.median(retry)), 3), "upload_ms": round(tr_.upload_ms, 3),
                              "device_pointer_retry_ms_per_step": None if dev_retry_ms is None else round(dev_retry_ms, 3)}}
-        del hv, hb
+        del hv, hb, h_step
 
     # ---- the whole trust-region loop on the device, for the record (N = 1) ----------
     scene_tr = None

@@ -65,12 +65,37 @@ struct HostStructure {
   bool chunks_contiguous = true;
 };
 
+// SHAPES of the fused path.  A conforming row is 2 high and holds one point cell (2 x 3), at most ONE camera cell (2 x nf: the cameras
+// of a problem are all nf wide) and any cells on a few SHARED column blocks (libmv's intrinsics, examples/libmv_bundle_adjuster.cc:718-722:
+// AddResidualBlock(cost, NULL, camera_intrinsics, current_camera_R_t, &point->X(0)) = <2, 8, 6, 3>), which the tiles hold as a dense
+// 2 x ns STRIP per row (ns = the shared blocks' widths together, rounded up to a strip width that is compiled; zero where a row has no
+// cell).  The kernels are compiled once per (nf, ns) — kernels_bal.inc, one translation unit each — for the camera widths of the
+// reference's static specialisations with a 3-wide E block (internal/ceres/generate_template_specializations.py:55-75: (2,3,3), (2,3,4),
+// (2,3,6), (2,3,9)), 8 (its (2,4,8) camera), 10 (bundle_adjuster --use_quaternions: examples/snavely_reprojection_error.h:164), and strips
+// of 4 / 8 scalars next to the 6- and 9-wide cameras.
+constexpr int kMaxSharedScalars = 8;   // strip width limit (BalArgs::sh_pos)
+constexpr int kMaxSharedCellsPerRow = 2;
+inline bool BalShapeCompiled(int nf, int ns) {
+  if (ns == 0) return nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9 || nf == 10;
+  return (nf == 6 || nf == 9) && (ns == 4 || ns == 8);
+}
+inline int BalStripWidthFor(int ns_used) { return ns_used <= 0 ? 0 : (ns_used <= 4 ? 4 : (ns_used <= 8 ? 8 : -1)); }
+
 struct BalPlan {
   bool eligible = false;
   std::string why_not;         // reason the fused path was not selected
   int n_points = 0, n_cameras = 0;
+  int nf = 9;                  // width of the camera blocks
+  int ns_used = 0, ns = 0;     // shared strip: scalars in use, compiled strip width (BalStripWidthFor)
+  std::vector<int32_t> sh_block;   // shared column blocks, in strip order
+  std::vector<int32_t> sh_off;     // strip offset of each of them
+  std::vector<int32_t> sh_pos;     // ns_used entries: scalar position of each strip scalar in x (minus num_cols_e)
+  int cam_base = 0;                // cameras_contiguous: cam_pos[c] == cam_base + nf c
+  // per slot, per shared cell of its row (kMaxSharedCellsPerRow lists of n_tiles * 64): value offset (-1: none) and strip offset | width << 8
+  std::vector<int32_t> slot_hpos[kMaxSharedCellsPerRow], slot_hdesc[kMaxSharedCellsPerRow];
+  int64_t n_cam_cells = 0;         // observations WITH a camera cell (a locked camera leaves rows without one)
   int64_t n_obs = 0, n_tiles = 0;
-  bool contiguous_layout = false;  // pt_pos = 3p, cam_pos(F-relative) = 9c
+  bool contiguous_layout = false;  // pt_pos = 3p, cam_pos(F-relative) = cam_base + nf c
   bool points_contiguous = false, cameras_contiguous = false;  // each half of it (points may be renumbered: plan.cc)
   bool caller_contiguous = false;  // the CALLER's column layout is points-then-cameras back to back (before any renumbering)
   bool renumbered = false;         // internal point p is the caller's point of column block pt_block[p], at pt_pos[p]

@@ -134,26 +134,11 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   P = BalPlan();
   auto no = [&](const char* why) { P.eligible = false; P.why_not = why; };
   if (h.nrb == 0) return no("empty matrix");
-  // Classify column blocks.
-  P.pt_block.clear();
-  P.cam_block.clear();
-  std::vector<int32_t> id_of(h.ncb, -1);  // point id or camera id of a column block
-  for (int j = 0; j < h.ncb; ++j) {
-    const bool as_point = h.nelim > 0 ? (j < h.nelim) : (h.csz[j] == 3);
-    if (as_point) {
-      if (h.csz[j] != 3) return no("an eliminated block is not 3 wide");
-      id_of[j] = int(P.pt_block.size());
-      P.pt_block.push_back(j);
-    } else {
-      if (h.csz[j] != 9) return no("a non-eliminated block is not 9 wide");
-      id_of[j] = int(P.cam_block.size());
-      P.cam_block.push_back(j);
-    }
-  }
-  P.n_points = int(P.pt_block.size());
-  P.n_cameras = int(P.cam_block.size());
-  if (P.n_points == 0 || P.n_cameras == 0) return no("no point or no camera blocks");
+  // Classify column blocks: POINTS (the eliminated blocks; without an elimination order: the 3-wide ones), and among the others the
+  // CAMERAS (at most one cell per row, all of one width nf) and a few SHARED blocks (common.h: the strip).
   auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
+  for (int j = 0; j < h.ncb; ++j)
+    if (is_point(j) && h.csz[j] != 3) return no("an eliminated block is not 3 wide");
 
   // Remainder: the longest run of TRAILING rows that touch camera blocks only (no point cell; possibly no cell at all).  A conforming
   // row has a point cell, so the split is unambiguous.  Everything in front of it must conform.
@@ -169,22 +154,78 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (n_conf == 0) return no("no row with a point cell");
   P.rem_row0 = n_conf;
   P.n_rem_rows = h.nrb - n_conf;
-  // Every other row: 2 scalar rows, exactly one point cell and one camera cell.
-  std::vector<int32_t> row_pt(n_conf), row_cam(n_conf), row_epos(n_conf), row_fpos(n_conf);
+
+  // Shared blocks: as long as some row holds more than one cell outside the points and the shared set, the most referenced block
+  // among those rows' cells joins the shared set (libmv: the one intrinsics block every row references).
+  std::vector<uint8_t> shared(h.ncb, 0);
+  {
+    std::vector<int32_t> refs(h.ncb, 0);
+    for (int i = 0; i < n_conf; ++i)
+      for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) ++refs[h.ccol[k]];
+    int n_shared_scalars = 0;
+    for (int round = 0;; ++round) {
+      int pick = -1;
+      for (int i = 0; i < n_conf; ++i) {
+        int others = 0;
+        for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) others += !is_point(h.ccol[k]) && !shared[h.ccol[k]];
+        if (others < 2) continue;
+        for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
+          const int j = h.ccol[k];
+          if (!is_point(j) && !shared[j] && (pick < 0 || refs[j] > refs[pick])) pick = j;
+        }
+      }
+      if (pick < 0) break;
+      shared[pick] = 1;
+      n_shared_scalars += h.csz[pick];
+      if (n_shared_scalars > kMaxSharedScalars) return no("rows with several camera-side cells whose common blocks are wider than the shared strip");
+    }
+  }
+  P.pt_block.clear();
+  P.cam_block.clear();
+  std::vector<int32_t> id_of(h.ncb, -1);  // point id, camera id or shared-block index of a column block
+  for (int j = 0; j < h.ncb; ++j) {
+    if (is_point(j)) { id_of[j] = int(P.pt_block.size()); P.pt_block.push_back(j); }
+    else if (shared[j]) { id_of[j] = int(P.sh_block.size()); P.sh_off.push_back(P.ns_used); P.sh_block.push_back(j); P.ns_used += h.csz[j]; }
+    else { id_of[j] = int(P.cam_block.size()); P.cam_block.push_back(j); }
+  }
+  P.n_points = int(P.pt_block.size());
+  P.n_cameras = int(P.cam_block.size());
+  if (P.n_points == 0 || P.n_cameras == 0) return no("no point or no camera blocks");
+  P.nf = h.csz[P.cam_block[0]];
+  for (int c = 0; c < P.n_cameras; ++c)
+    if (h.csz[P.cam_block[c]] != P.nf) return no("camera blocks of different widths");
+  P.ns = BalStripWidthFor(P.ns_used);
+  if (P.ns < 0 || !BalShapeCompiled(P.nf, P.ns)) return no("no fused kernels are compiled for this camera width / shared strip");
+  for (size_t q = 0; q < P.sh_block.size(); ++q)
+    for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
+
+  // Every conforming row: 2 scalar rows, exactly one point cell, at most one camera cell, at most kMaxSharedCellsPerRow shared cells.
+  std::vector<int32_t> row_pt(n_conf), row_cam(n_conf, -1), row_epos(n_conf), row_fpos(n_conf, -1);
+  std::vector<int32_t> row_hpos[kMaxSharedCellsPerRow], row_hdesc[kMaxSharedCellsPerRow];
+  if (P.ns > 0)
+    for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { row_hpos[q].assign(n_conf, -1); row_hdesc[q].assign(n_conf, 0); }
   for (int i = 0; i < n_conf; ++i) {
     if (h.rsz[i] != 2) return no("row block that is not 2 high");
-    if (h.rptr[i + 1] - h.rptr[i] != 2) return no("row without exactly two cells");
-    const int k0 = h.rptr[i], k1 = k0 + 1;
-    int kp, kc;
-    if (is_point(h.ccol[k0]) && !is_point(h.ccol[k1])) { kp = k0; kc = k1; }
-    else if (!is_point(h.ccol[k0]) && is_point(h.ccol[k1])) {
-      if (h.nelim > 0) return no("E cell is not the first cell of its row");
-      kp = k1; kc = k0;
-    } else return no("row is not one point cell plus one camera cell");
-    row_pt[i] = id_of[h.ccol[kp]];
-    row_cam[i] = id_of[h.ccol[kc]];
-    row_epos[i] = h.cval[kp];
-    row_fpos[i] = h.cval[kc];
+    int n_pt = 0, n_cam = 0, n_sh = 0;
+    for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
+      const int j = h.ccol[k];
+      if (is_point(j)) {
+        if (h.nelim > 0 && k != h.rptr[i]) return no("E cell is not the first cell of its row");
+        if (n_pt++) return no("row with two point cells");
+        row_pt[i] = id_of[j]; row_epos[i] = h.cval[k];
+      } else if (shared[j]) {
+        if (n_sh >= kMaxSharedCellsPerRow) return no("row with more shared cells than the tiles take");
+        for (int q = 0; q < n_sh; ++q)
+          if ((row_hdesc[q][i] & 0xff) == P.sh_off[id_of[j]]) return no("row with two cells on one shared block");
+        row_hpos[n_sh][i] = h.cval[k];
+        row_hdesc[n_sh][i] = P.sh_off[id_of[j]] | (h.csz[j] << 8);
+        ++n_sh;
+      } else {
+        if (n_cam++) return no("row with two camera cells");   // (cannot happen: the shared set absorbed one of them)
+        row_cam[i] = id_of[j]; row_fpos[i] = h.cval[k];
+      }
+    }
+    if (n_pt != 1) return no("row is not one point cell plus camera-side cells");
   }
   if (h.nelim > 0 && !h.chunks_contiguous) return no("rows of one E block are not contiguous");
 
@@ -206,8 +247,10 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     std::vector<int32_t> last_point_of_cam(P.n_cameras, -1);
     for (int idx = 0; idx < n_conf; ++idx) {
       const int i = order[idx];
+      if (row_cam[i] < 0) continue;   // (a row without a camera cell: a locked camera, libmv_bundle_adjuster.cc:725-728)
       if (last_point_of_cam[row_cam[i]] == row_pt[i]) return no("a point observes one camera twice");
       last_point_of_cam[row_cam[i]] = row_pt[i];
+      ++P.n_cam_cells;
     }
   }
   P.n_obs = n_conf;
@@ -219,13 +262,16 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // the caller's column layout: points-then-cameras, back to back?
   P.caller_contiguous = true;
   for (int p = 0; p < P.n_points && P.caller_contiguous; ++p) P.caller_contiguous = h.cpos[P.pt_block[p]] == 3 * p;
-  for (int c = 0; c < P.n_cameras && P.caller_contiguous; ++c) P.caller_contiguous = h.cpos[P.cam_block[c]] - h.num_cols_e == 9 * c;
+  for (int c = 0; c < P.n_cameras && P.caller_contiguous; ++c) P.caller_contiguous = h.cpos[P.cam_block[c]] - h.num_cols_e == P.nf * c;
+  if (P.ns > 0) P.caller_contiguous = false;   // (a shared block sits somewhere among the camera-side columns)
   const bool reorder_points = reorder_mode == kReorderAlways || (reorder_mode == kReorderIfContiguous && P.caller_contiguous);
   P.renumbered = reorder_points;
 
   // Cameras whose 9-double accumulators do not fit in LDS (decided here: the point order below depends on it).
   // (1 KiB of the 160 stays free for the kernels' static LDS: workgroup reductions, the exchange area of the long points' rounds)
-  P.cameras_in_lds = size_t(9) * P.n_cameras * sizeof(double) <= kLdsBytesPerCu - 1024;
+  P.cameras_in_lds = (size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double) <= kLdsBytesPerCu - 1024;
+  // the shared strip's sums and rows without a camera cell live with the LDS accumulators only
+  if (!P.cameras_in_lds && (P.ns > 0 || P.n_cam_cells != n_conf)) return no("shared blocks / rows without a camera cell with more cameras than LDS holds");
   int64_t chunk_mib = 0;  // CERES_HIP_Z_CHUNK_MIB=<n>: bound the F^T z ring to n MiB (memory-constrained runs)
   if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
   if (!P.cameras_in_lds && P.n_cameras >= (1 << kSlotCamBits)) return no("more cameras than the slot word holds");
@@ -260,7 +306,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (hybrid) {
     const int G = hyb.groups, K = hyb.rows;
     std::vector<int64_t> deg(P.n_cameras, 0);
-    for (int i = 0; i < n_conf; ++i) ++deg[row_cam[i]];
+    for (int i = 0; i < n_conf; ++i) ++deg[row_cam[i]];   // (every row has a camera cell here: checked above)
     // most rows the popular cameras may take: the windows must still cover the others, (G - 1) stride + K_w >= n_cold with stride <= K_w
     const int max_hot = K - std::min(K, std::max(1, (P.n_cameras - K + (G - 2)) / (G - 1)));
     std::vector<int32_t> by_deg(P.n_cameras);
@@ -386,7 +432,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   }
   for (int c = 0; c < P.n_cameras; ++c) {
     P.cam_pos[c] = h.cpos[P.cam_block[c]] - h.num_cols_e;
-    if (P.cam_pos[c] != 9 * c) P.cameras_contiguous = false;
+    if (c == 0) P.cam_base = P.cam_pos[0];
+    if (P.cam_pos[c] != P.cam_base + P.nf * c) P.cameras_contiguous = false;
   }
   P.contiguous_layout = P.points_contiguous && P.cameras_contiguous;
 
@@ -401,11 +448,17 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     P.slot_pt.resize(P.slot_pt.size() + kTile, -1);
     P.slot_row.resize(P.slot_row.size() + kTile, -1);
     P.slot_seg.resize(P.slot_seg.size() + kTile, 0u);
+    if (P.ns > 0)
+      for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { P.slot_hpos[q].resize(P.slot_hpos[q].size() + kTile, -1); P.slot_hdesc[q].resize(P.slot_hdesc[q].size() + kTile, 0); }
     return int64_t(P.tile_kind.size()) - 1;
   };
   int64_t tile = -1;
   int used = kTile;  // slots used in the current tile (kTile forces a new one)
   int npts_in_tile = 0;
+  auto put_shared = [&](int64_t s, int i) {
+    if (P.ns == 0) return;
+    for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { P.slot_hpos[q][s] = row_hpos[q][i]; P.slot_hdesc[q][s] = row_hdesc[q][i]; }
+  };
   auto emit_point = [&](int p) {
     const int k = track[p];
     int idx = row_start[seq[p]];   // the point's rows, in the caller's order
@@ -418,7 +471,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
           const int i = order[idx++];
           const int64_t s = tile * kTile + l;
           P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
-          P.slot_cam[s] = row_cam[i]; P.slot_pt[s] = p; P.slot_row[s] = i;
+          P.slot_cam[s] = row_cam[i] >= 0 ? row_cam[i] : -2; P.slot_pt[s] = p; P.slot_row[s] = i;   // -2: a valid slot without a camera cell
+          put_shared(s, i);
           P.slot_seg[s] = 0u | (uint32_t(cnt - 1) << 8) | (1u << 16);
         }
       }
@@ -435,7 +489,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       const int i = order[idx++];
       const int64_t s = tile * kTile + used + l;
       P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
-      P.slot_cam[s] = row_cam[i]; P.slot_pt[s] = p; P.slot_row[s] = i;
+      P.slot_cam[s] = row_cam[i] >= 0 ? row_cam[i] : -2; P.slot_pt[s] = p; P.slot_row[s] = i;
+      put_shared(s, i);
       P.slot_seg[s] = uint32_t(used) | (uint32_t(used + k - 1) << 8) | (1u << 16);
     }
     used += k;
@@ -616,6 +671,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // The word the kernels read per slot: camera id | accumulator row << kSlotCamBits (kSlotSpill: no LDS row, the slot's F^T z is
   // spilled).  With the accumulators of ALL cameras in LDS the row is the camera id itself and the upper bits stay 0.
   P.slot_word.assign(P.slot_cam.begin(), P.slot_cam.end());
+  for (auto& w : P.slot_word) if (w == -2) w = 0;   // no camera cell: the tiles hold zeros for F, any camera's row takes the zero sums
   if (!P.cameras_in_lds) {
     // Camera-major second pass.  The tile pass leaves the spilled rows of a tile back to back in a ring (tile_zbase = the tile's
     // first row; a slot's row = tile_zbase + its rank among the tile's spilled slots), the hybrid workgroups append their accumulator
@@ -647,7 +703,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       P.slot_word[s] = int32_t(uint32_t(c) | (uint32_t(row) << kSlotCamBits));
     }
     P.n_local_obs = n_local;
-    const int64_t want_tiles = chunk_mib > 0 ? std::max<int64_t>(1, chunk_mib * (int64_t(1) << 20) / (int64_t(kTile) * 72)) : P.n_tiles;
+    const int64_t want_tiles = chunk_mib > 0 ? std::max<int64_t>(1, chunk_mib * (int64_t(1) << 20) / (int64_t(kTile) * 8 * P.nf)) : P.n_tiles;
     P.zc_tile_ptr.assign(1, 0);
     for (int64_t t = 0; t < P.n_tiles;) {
       int64_t e = std::min<int64_t>(P.n_tiles, t + want_tiles);

@@ -435,7 +435,7 @@ class HipLinearSolver:
 
     # -- f1: one trust-region step's linear algebra on the device ----------------
     def lm_compute_step(self, values, residuals, radius, eta=0.1, min_diagonal=1e-6, max_diagonal=1e32,
-                        reuse_diagonal=False, values_unchanged=False):
+                        reuse_diagonal=False, values_unchanged=False, out=None):
         """LevenbergMarquardtStrategy::ComputeStep + the model-cost bookkeeping of
         TrustRegionMinimizer::ComputeTrustRegionStep.  Returns (step, Summary, model_cost_change).
         values_unchanged: the retry after a rejected step — the solver keeps the Jacobian and residuals it holds (values / residuals
@@ -443,7 +443,7 @@ class HipLinearSolver:
         n = self._info
         o = CLmOptions(radius, min_diagonal, max_diagonal, eta, int(reuse_diagonal), int(values_unchanged))
         r = CLmResult()
-        step = np.full(n.num_cols, np.nan)
+        step = np.full(n.num_cols, np.nan) if out is None else _f64(out, n.num_cols, "out")   # out: a caller-owned (e.g. pinned) step buffer
         if values_unchanged:
             pv = pr = None
         else:
