@@ -10,8 +10,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libceres_hip.so")
-SOURCES = ["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal.hip", "kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"]
-HEADERS = ["common.h", "device.h", "bal_frontend.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
+# the fused kernels are compiled once per SHAPE (camera width, shared strip): kernels_bal.inc through kernels_bal_shape_*.hip (common.h)
+BAL_SHAPES = [(3, 0), (4, 0), (6, 0), (8, 0), (9, 0), (10, 0), (6, 4), (6, 8), (9, 4), (9, 8)]
+SOURCES = (["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal_common.hip"] + [f"kernels_bal_shape_f{nf}_s{ns}.hip" for nf, ns in BAL_SHAPES] +
+           ["kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"])
+HEADERS = ["common.h", "device.h", "bal_frontend.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
 HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")
 HOST_DRIVER = os.path.join(HERE, "host", "host_driver")
 
@@ -30,16 +33,22 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    objs, cmds = [], []
     for src in srcs:
         obj = os.path.splitext(src)[0] + ".o"
         objs.append(obj)
         if force or _stale(obj, [src] + [os.path.join(CSRC, h) for h in HEADERS]):
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                   "-x", "hip", "-c", src, "-o", obj]
+            cmds.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+                         "-x", "hip", "-c", src, "-o", obj])
+    if cmds:  # one hipcc per translation unit, a few at a time (the per-shape units take ~25 s each)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(cmds), (os.cpu_count() or 2)))) as ex:
+            list(ex.map(run, cmds))
     if force or _stale(OUT, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:

@@ -184,7 +184,7 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
 constexpr int kRoundWaves = 8;               // waves of a streaming workgroup = tiles of a round of long points (plan.cc)
 constexpr uint32_t kRoundIdle = 0xFFFFFFFFu;  // round word of a wave without a tile
 constexpr int kRoundSum = 1, kRoundApply = 2, kRoundLast = 4;   // round flags of a point of more than kRoundWaves tiles (plan.cc)
-struct HybridRequest { int groups = 0, rows = 0; };
+struct HybridRequest { int groups = 0, rows = 0; int64_t lds_bytes = 0; };   // rows == 0: as many as lds_bytes hold next to eight waves' spill strips, for the plan's camera width
 // reorder_mode: renumber the points (fuller tiles; hybrid groups) never / always (Schur solvers: no CG vector lives in point space) /
 // only if the caller's layout is points-then-cameras back to back (CGNR: its CG vectors then ARE the caller's with the points renumbered)
 constexpr int kReorderNever = 0, kReorderAlways = 1, kReorderIfContiguous = 2;

@@ -16,7 +16,8 @@ constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
-enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8, kBalSpseZ = 9 };
+enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8, kBalSpseZ = 9,
+               kBalShBlocks = 10 /* the strip's own diagonal block sums, per workgroup into BalArgs::scalar_out (shapes with a shared strip) */ };
 
 struct CgScalars;
 // The rest of a CG iteration at the end of the S.x pass, for camera spaces of at most kCgTailMax scalars (run_cg, solver.hip): the
@@ -39,14 +40,17 @@ struct CgTail {
 
 struct BalArgs {
   // packed problem
-  const double2* J = nullptr;   // [n_tiles][12][64]
+  const double2* J = nullptr;   // [n_tiles][3 + nf + ns][64]
   const float4* Jf = nullptr;   // [n_tiles][6][64]  fp32 storage mode (then J is unused)
   const double2* b = nullptr;   // [n_tiles][64]
   // fused re-layout: when src_values != nullptr the kernel gathers from the caller's layout and
   // writes the tiles (J_out, b_out) as it goes (first pass of a step)
   const double* src_values = nullptr;
   const double* src_b = nullptr;
-  const int32_t *slot_epos = nullptr, *slot_fpos = nullptr, *slot_bpos = nullptr;
+  const int32_t *slot_epos = nullptr, *slot_fpos = nullptr, *slot_bpos = nullptr;   // slot_fpos < 0: a row without a camera cell
+  // shapes with a shared strip: the row's shared cells (value offset, -1 none; strip offset | width << 8), common.h
+  const int32_t* slot_hpos[kMaxSharedCellsPerRow] = {};
+  const int32_t* slot_hdesc[kMaxSharedCellsPerRow] = {};
   double2* J_out = nullptr;
   float4* Jf_out = nullptr;
   double2* b_out = nullptr;
@@ -76,7 +80,9 @@ struct BalArgs {
   int64_t z_flush_row0 = 0;
   int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)
   const int32_t* pt_pos = nullptr;   // nullptr => 3*p
-  const int32_t* cam_pos = nullptr;  // nullptr => 9*c   (relative to the F base pointer)
+  const int32_t* cam_pos = nullptr;  // nullptr => cam_base + nf*c   (relative to the F base pointer)
+  int cam_base = 0;
+  int sh_pos[kMaxSharedScalars] = {};   // the strip's scalars in the F-space vectors (shapes with a shared strip)
   // CGNR on internally numbered points: x_e / y_e / point_blocks are internal (pt_pos == nullptr) while D_e, lm_diag_e, lm_D_e are the
   // caller's: d_pos[p] = the caller's offset of internal point p (nullptr: the same offsets as x_e); D_int_out: D_e in the internal order
   const int32_t* d_pos = nullptr;
@@ -99,9 +105,9 @@ struct BalArgs {
   const int32_t* mo_index = nullptr;      // record of each slot in Mo (nullptr: the slot itself; hybrid plans: the slot's row)
   int have_b = 0;
   // camera accumulation
-  double* partials = nullptr;    // [grid][n_f9]   (LDS mode)
+  double* partials = nullptr;    // [grid][n_acc]   (LDS mode)
   double* zbuf = nullptr;        // [rows][9]      (cameras do not fit in LDS: the ring of spilled / flushed F^T z rows, second pass by camera)
-  int n_f9 = 0;                  // 9 * n_cameras
+  int n_acc = 0;                 // nf * n_cameras + ns: the camera-space accumulator entries (the strip's behind the cameras')
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
   const double* copy_src = nullptr;
@@ -119,24 +125,12 @@ struct BalArgs {
   CgTail tail;                   // kSx, pipelined kernel, every camera's accumulator in LDS: finish the CG iteration (see CgTail)
 };
 
-hipError_t LaunchBalFused(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
-// whether LaunchBalFused(kBalSx, A, lds, ..) runs the pipelined kernel — the one that can finish a CG iteration (A.tail)
-bool BalSxRunsPipelined(const BalArgs& A);
-// pq_out != nullptr: also partial x_f . y_f, one per workgroup (*n_pq of them; needs x_f)
-hipError_t LaunchBalReducePartials(const double* partials, int nparts, int n_f9, const int32_t* cam_pos,
-                                   const double* D_f, const double* x_f, double* y_f, const int* status,
-                                   double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in = nullptr, int n_sum_in = 0,
-                                   double* sum_out = nullptr);  // sum_out: *sum_out = sum(sum_in[0 .. n_sum_in)), see the kernel
-hipError_t LaunchBalStreamProbe(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
-hipError_t LaunchBalAddFDiagonal(int n_f9, const int32_t* cam_pos, const double* D_f, const double* x_f, double* y_f,
-                                 const int* status, double* pq_out, int* n_pq, hipStream_t stream);
-hipError_t LaunchBalPack(const double* values, const double* b, const int32_t* slot_epos, const int32_t* slot_fpos,
-                         const int32_t* slot_bpos, int64_t n_tiles, double2* J, float4* Jf, double2* bt, hipStream_t stream);
-// Fused LM diagonal of the camera columns, applied by bal_invert9_kernel (radius > 0 to enable).
+// Fused LM diagonal of the camera columns, applied by bal_invert_kernel (radius > 0 to enable).
 struct LmFuse {
   double radius = 0.0, min_d = 0.0, max_d = 0.0;
-  const double* camsq = nullptr;     // [9 c + k] column norms; nullptr => the block's own diagonal (F^T F blocks)
-  const int32_t* cam_pos = nullptr;  // nullptr => 9 c
+  const double* camsq = nullptr;     // [nf c + k] column norms; nullptr => the block's own diagonal (F^T F blocks)
+  const int32_t* cam_pos = nullptr;  // nullptr => cam_base + nf c
+  int cam_base = 0;
   double* diag_f = nullptr;
   double* D_f = nullptr;
 };
@@ -147,33 +141,71 @@ struct CamItems {
   int count = 0;
   int64_t observations = 0;   // of all items together (the launcher picks the kernel by the mean item length)
 };
-// Per-camera 9x9 blocks in two steps: every item (<= kCamChunk observations of one camera) leaves 45 upper-triangle sums + 9
-// column square sums in parts[item][kCamPart]; the items of a camera (cam_item_ptr) are then added in list order either by
-// LaunchBalCameraFinish (raw sums to memory, + D_f^2 if given) or by the load phase of LaunchBalInvert9 (CamGather).
-constexpr int kCamPart = 54;
-hipError_t LaunchBalCameraItems(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos,
-                                const int32_t* cam_slot, const double* Mo, double* parts, hipStream_t stream);
-hipError_t LaunchBalCameraFinish(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos,
-                                 const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream,
-                                 const double* extra = nullptr);  // extra: as CamGather::extra
 struct CamGather {
   const double* parts = nullptr;          // nullptr: the blocks are already assembled in memory
   const int32_t* cam_item_ptr = nullptr;
   const double* D_f = nullptr;            // added squared to the diagonal (indexed through cam_pos)
   const int32_t* cam_pos = nullptr;
+  int cam_base = 0;                       // cam_pos == nullptr: camera c at cam_base + nf c
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
   int few = 0;                            // every camera has a handful of items at most: seven cameras per wavefront gather their own
-  const double* extra = nullptr;          // [81 c + 9 a + b] raw sums added to the camera's block (rows outside the tiles: LaunchRemCameraBlocks)
+  const double* extra = nullptr;          // [nf nf c + nf a + b] raw sums added to the camera's block (rows outside the tiles: LaunchRemCameraBlocks)
 };
-// Camera-major pass of one chunk (cameras not in LDS): acc[9 c + k] += sum over the unit's entries of ring[9 slot + k].
+// Camera-major pass of one chunk (cameras not in LDS): acc[nf c + k] += sum over the unit's entries of ring[nf slot + k].
 struct ZUnits {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr, *shared = nullptr;  // units [first, first + count)
   const int32_t* slot = nullptr;                                                       // entry -> ring row (chunk-relative)
   int first = 0, count = 0;
 };
-hipError_t LaunchBalCameraChunk(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
-hipError_t LaunchBalInvert9(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm,
-                            const CamGather& gather, hipStream_t stream);
+
+// accumulator entry -> place in the F-space vectors (bal_reduce_partials_kernel): camera c's scalars at cam_pos[c] (nullptr: cam_base +
+// nf c), behind them the shared strip's at sh_pos
+struct FMap {
+  const int32_t* cam_pos = nullptr;
+  int cam_base = 0, n_cam_scalars = 0;
+  int sh_pos[kMaxSharedScalars] = {};
+};
+
+// the shared column blocks of a plan: strip offset, width, where the block goes in the F-block store, the F-space position of its first scalar
+struct StripBlocks {
+  int count = 0;
+  int off[kMaxSharedScalars] = {}, width[kMaxSharedScalars] = {}, pos[kMaxSharedScalars] = {};
+  int64_t out[kMaxSharedScalars] = {};
+};
+
+// The fused kernels are compiled once per SHAPE (camera width nf, shared strip ns: common.h, kernels_bal.inc — one translation unit
+// per shape); this is one shape's launchers.
+struct BalOps {
+  int nf, ns, pairs, tile_pitch, cam_part, has_f32, has_cg_tail;   // tile_pitch: double2 elements per tile; cam_part: doubles per item of the camera-major pass
+  hipError_t (*fused)(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
+  // whether fused(kBalSx, A, lds, ..) runs the pipelined kernel — the one that can finish a CG iteration (A.tail)
+  bool (*sx_runs_pipelined)(const BalArgs& A);
+  // y_f[pos(i)] = sum over the workgroups' partials (+ D_f^2 x_f); pq_out != nullptr: also partial x_f . y_f, one per workgroup (*n_pq of
+  // them; needs x_f); sum_out: *sum_out = sum(sum_in[0 .. n_sum_in)), see the kernel
+  hipError_t (*reduce_partials)(const double* partials, int nparts, int n_acc, const FMap& map, const double* D_f, const double* x_f,
+                                double* y_f, const int* status, double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in,
+                                int n_sum_in, double* sum_out);
+  hipError_t (*stream_probe)(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
+  hipError_t (*add_f_diagonal)(int n_acc, const FMap& map, const double* D_f, const double* x_f, double* y_f, const int* status,
+                               double* pq_out, int* n_pq, hipStream_t stream);
+  hipError_t (*pack)(const BalArgs& A, hipStream_t stream);   // A.src_values / src_b / slot_* / J_out (Jf_out) / b_out set
+  hipError_t (*invert)(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm, const CamGather& gather,
+                       hipStream_t stream);
+  // Per-camera blocks in two steps: every item (<= kCamChunk observations of one camera) leaves its upper-triangle sums + nf column
+  // square sums in parts[item][cam_part]; the items of a camera (cam_item_ptr) are then added in list order either by camera_finish
+  // (raw sums to memory, + D_f^2 if given) or by the load phase of invert (CamGather).
+  hipError_t (*camera_items)(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos, const int32_t* cam_slot,
+                             const double* Mo, double* parts, hipStream_t stream);
+  hipError_t (*camera_finish)(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos, int cam_base,
+                              const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream, const double* extra);
+  hipError_t (*camera_chunk)(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
+  // shapes with a shared strip: the packed upper triangle of the strip's ns x ns matrix from the workgroups' partial sums (kBalShBlocks),
+  // cut into the shared blocks' dense diagonal blocks (+ D^2) in the F-block store
+  hipError_t (*strip_finish)(const double* parts, int nparts, const StripBlocks& sb, const double* D_f, double* blocks, hipStream_t stream);
+};
+const BalOps* GetBalOps(int nf, int ns);   // nullptr: not compiled (common.h: BalShapeCompiled)
+// the dynamic-LDS ceiling of a kernel, raised once per (kernel, device)
+hipError_t AllowMaxLds(const void* kernel);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------
 struct GenStructure {

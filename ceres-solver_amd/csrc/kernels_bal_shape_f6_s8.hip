@@ -1,0 +1,5 @@
+// The fused kernels for camera blocks 6 wide and a shared strip of 8 scalars (common.h: shapes; kernels_bal.inc: the kernels).
+#define CERES_HIP_NF 6
+#define CERES_HIP_NS 8
+#define CERES_HIP_SHAPE bal_f6_s8
+#include "kernels_bal.inc"

@@ -129,7 +129,7 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
   return "";
 }
 
-void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest& hyb, BalPlan* plan) {
+void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest& hyb_in, BalPlan* plan) {
   BalPlan& P = *plan;
   P = BalPlan();
   auto no = [&](const char* why) { P.eligible = false; P.why_not = why; };
@@ -196,6 +196,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     if (h.csz[P.cam_block[c]] != P.nf) return no("camera blocks of different widths");
   P.ns = BalStripWidthFor(P.ns_used);
   if (P.ns < 0 || !BalShapeCompiled(P.nf, P.ns)) return no("no fused kernels are compiled for this camera width / shared strip");
+  if (P.n_rem_rows > 0 && !(P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
   for (size_t q = 0; q < P.sh_block.size(); ++q)
     for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
 
@@ -291,6 +292,10 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // on top of the 204 it reads (the second pass fetches whole lines around its 72-byte rows); with three observations per point on
   // 50 000 cameras of random visibility 56 % of the observations stay in LDS, on the replicated libmv graphs (long tracks over
   // consecutive cameras, tests/golden/libmv_problems.npz) all of them.
+  HybridRequest hyb = hyb_in;
+  if (hyb.rows == 0 && hyb.lds_bytes > 0)
+    hyb.rows = int((hyb.lds_bytes - int64_t(512 / kTile) * kTile * P.nf * 8) / (int64_t(P.nf) * 8)) / kTile * kTile;
+  if (hyb.rows >= kSlotSpill) hyb.rows = (kSlotSpill - 1) / kTile * kTile;   // (narrow cameras: the slot word has 12 bits for the row)
   bool hybrid = reorder_points && !P.cameras_in_lds && hyb.groups >= 2 && hyb.rows >= 64 && chunk_mib <= 0 && hyb.rows < kSlotSpill;
   if (const char* e = getenv("CERES_HIP_HYBRID")) hybrid = hybrid && atoi(e) != 0;
   std::vector<int32_t> hot_row;                 // camera -> accumulator row < K_h, or -1

@@ -55,6 +55,11 @@ struct ceres_hip_solver {
   int path = CERES_HIP_PATH_GENERIC;
   HostStructure hs;
   BalPlan plan;
+  const BalOps* ops = nullptr;   // the fused kernels of the plan's shape (camera width, shared strip): kernels_bal.inc
+  int32_t* d_slot_hpos[kMaxSharedCellsPerRow] = {};   // shapes with a shared strip: the rows' shared cells (plan.cc)
+  int32_t* d_slot_hdesc[kMaxSharedCellsPerRow] = {};
+  double* d_strip_parts = nullptr; // [fused_grid][ns (ns + 1) / 2]: the workgroups' shares of the strip's own matrix (kBalShBlocks)
+  int64_t* d_cam_foff = nullptr;   // where camera c's block sits in the F-block store (diag_off_f), when not all F blocks are cameras
   std::vector<void*> allocs;
   int64_t device_bytes = 0;
 
@@ -273,7 +278,8 @@ bool is_schur(const ceres_hip_solver* s) { return s->opt.solver_type == CERES_HI
 bool cg_tail_possible(const ceres_hip_solver* s) {
   const HostStructure& h = s->hs;
   return s->cg_tail_enabled && s->opt.solver_type == CERES_HIP_ITERATIVE_SCHUR && s->path == CERES_HIP_PATH_BAL && s->world <= 1 &&
-         s->lds_mode && s->plan.n_rem_rows == 0 && s->plan.cameras_contiguous && h.num_cols_f == 9 * s->plan.n_cameras &&
+         s->ops->has_cg_tail && s->lds_mode && s->plan.n_rem_rows == 0 && s->plan.cameras_contiguous && s->plan.cam_base == 0 &&
+         h.num_cols_f == 9 * s->plan.n_cameras &&
          h.num_cols_f > 0 && h.num_cols_f <= kCgTailMax && s->fused_grid <= kCgTailLoads * (512 / std::max(1, h.num_cols_f));
 }
 
@@ -291,7 +297,9 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.long_ptr = s->d_long_ptr; A.round_ptr = s->d_round_ptr; A.round_word = s->d_round_word; A.seq_ptr = s->d_seq_ptr; A.round_flag = s->d_round_flag; A.n_seq = int(s->plan.seq_ptr.size()) - 1; A.long_behind = s->plan.long_behind ? 1 : 0;
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.mo_index = s->d_mo_index;
-  A.n_f9 = 9 * s->plan.n_cameras;
+  A.n_acc = s->plan.nf * s->plan.n_cameras + s->plan.ns;
+  A.cam_base = s->plan.cam_base;
+  for (int j = 0; j < kMaxSharedScalars; ++j) A.sh_pos[j] = j < s->plan.ns_used ? s->plan.sh_pos[j] : -1;
   A.have_b = s->have_b ? 1 : 0;
   A.flags = s->bal_flags;
   if (s->lm_fuse_active) {
@@ -300,6 +308,15 @@ BalArgs bal_args(ceres_hip_solver* s) {
   }
   return A;
 }
+
+FMap f_map(const ceres_hip_solver* s, const BalArgs& A) {
+  FMap m;
+  m.cam_pos = A.cam_pos; m.cam_base = A.cam_base; m.n_cam_scalars = s->plan.nf * s->plan.n_cameras;
+  for (int j = 0; j < kMaxSharedScalars; ++j) m.sh_pos[j] = A.sh_pos[j];
+  return m;
+}
+// where the camera blocks sit in a store of all F blocks (nullptr: back to back, nf * nf each — every F block is a camera)
+const int64_t* cam_f_offsets(const ceres_hip_solver* s) { return s->plan.ns > 0 ? s->d_cam_foff : nullptr; }
 
 // First pass over a step's Jacobian: let the kernel gather from the caller's layout and write
 // the tiles on the way (fused re-layout).  Call right before launching; marks the tiles valid.
@@ -321,6 +338,7 @@ struct PackGuard {
   A.src_values = s->values;
   A.src_b = s->b;
   A.slot_epos = s->d_slot_epos; A.slot_fpos = s->d_slot_fpos; A.slot_bpos = s->d_slot_bpos;
+  for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { A.slot_hpos[q] = s->d_slot_hpos[q]; A.slot_hdesc[q] = s->d_slot_hdesc[q]; }
   A.J_out = s->d_J; A.Jf_out = s->d_Jf; A.b_out = s->d_bt;
   s->packed = true;
   return PackGuard(s, true);
@@ -328,9 +346,10 @@ struct PackGuard {
 
 int ensure_packed(ceres_hip_solver* s) {
   if (s->path != CERES_HIP_PATH_BAL || s->packed) return 0;
-  HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_Jf, s->d_bt, s->stream));
-  s->packed = true;
-  return 0;
+  BalArgs A = bal_args(s);
+  PackGuard g = use_gather_if_unpacked(s, A);
+  HIP_TRY(s, s->ops->pack(A, s->stream));
+  return g.commit(0);
 }
 
 LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
@@ -339,6 +358,7 @@ LmFuse lm_fuse_for_cameras(ceres_hip_solver* s, bool schur_blocks) {
   f.radius = s->lm_opts.radius; f.min_d = s->lm_opts.min_diagonal; f.max_d = s->lm_opts.max_diagonal;
   f.camsq = schur_blocks ? s->d_camsq : nullptr;
   f.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
+  f.cam_base = s->plan.cam_base;
   f.diag_f = s->lm_diag + s->hs.num_cols_e;
   f.D_f = s->lm_D + s->hs.num_cols_e;
   return f;
@@ -435,9 +455,10 @@ int rem_model_cost(ceres_hip_solver* s, const double* x_f, int mode, double* out
 int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, double* y_f, bool add_diag,
                 const int* status, double* pq = nullptr, int* n_pq = nullptr, const double** pq_extra = nullptr,
                 bool defer_allreduce = false) {  // sharded: leave this rank's raw sums in y_f, the caller owes the all-reduce
-  const int n9 = A.n_f9;
+  const int n9 = A.n_acc;                 // accumulator entries (cameras, then the strip)
+  const int nfv = s->hs.num_cols_f;       // the F-space vectors themselves
+  const FMap map = f_map(s, A);
   const double* D_f = (add_diag && s->D) ? s->D + s->hs.num_cols_e : nullptr;
-  const int32_t* cam_pos = A.cam_pos;
   A.status = status;
   int n_first = 0;
   // cg_pq_parts holds kMaxPqParts partial sums: the tile pass's (one per workgroup) + the reduction's (<= kMaxVecGrid).  A grid that
@@ -445,7 +466,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   if (pq && (s->lds_mode ? s->fused_grid : s->chunk_grid) + kMaxVecGrid > kMaxPqParts) { pq = nullptr; if (n_pq) *n_pq = 0; }
   if (s->lds_mode) {
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
-    HIP_TRY(s, LaunchBalFused(mode, A, true, s->fused_grid, s->stream));
+    HIP_TRY(s, s->ops->fused(mode, A, true, s->fused_grid, s->stream));
   } else {
     // cameras do not fit in LDS: the tile pass sums what it can in LDS (hybrid plan) and leaves the other slots' F^T z, and at its
     // end its accumulator rows, in a ring; the camera-major pass adds the ring rows into the camera sums.  (Chunk by chunk when the
@@ -458,11 +479,11 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
       A.tile_begin = P.zc_tile_ptr[k];
       A.tile_end = P.zc_tile_ptr[k + 1];
       A.pq_accumulate = k > 0 ? 1 : 0;
-      HIP_TRY(s, LaunchBalFused(mode, A, false, s->chunk_grid, s->stream));
+      HIP_TRY(s, s->ops->fused(mode, A, false, s->chunk_grid, s->stream));
       ZUnits U = s->zunits;
       U.first = P.zc_unit_ptr[k];
       U.count = P.zc_unit_ptr[k + 1] - P.zc_unit_ptr[k];
-      HIP_TRY(s, LaunchBalCameraChunk(U, s->d_zbuf, s->d_global_acc, status, s->stream));
+      HIP_TRY(s, s->ops->camera_chunk(U, s->d_zbuf, s->d_global_acc, status, s->stream));
     }
   }
   const double* parts = s->lds_mode ? s->d_partials : s->d_global_acc;
@@ -470,22 +491,22 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   int n_second = 0;
   if (s->world <= 1 && has_remainder(s)) {
     // rows outside the tiles join the raw sums first; D_f^2 x_f and the camera part of x . y follow on the COMPLETE output
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream));
+    HIP_TRY(s, s->ops->reduce_partials(parts, nparts, n9, map, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream, nullptr, 0, nullptr));
     TRY(add_remainder(s, mode, x_f, y_f, status));
-    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
+    HIP_TRY(s, s->ops->add_f_diagonal(n9, map, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   } else if (s->world <= 1) {
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
+    HIP_TRY(s, s->ops->reduce_partials(parts, nparts, n9, map, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream, nullptr, 0, nullptr));
   } else {
     const bool pack = pq && pq_extra && n_first > 0;  // CGNR's p.q: the shard's share rides along as element n9 of the all-reduce
-    HIP_TRY(s, LaunchBalReducePartials(parts, nparts, n9, cam_pos, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream,
-                                       pack ? pq : nullptr, n_first, pack ? y_f + n9 : nullptr));
+    HIP_TRY(s, s->ops->reduce_partials(parts, nparts, n9, map, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream,
+                                       pack ? pq : nullptr, n_first, pack ? y_f + nfv : nullptr));
     TRY(add_remainder(s, mode, x_f, y_f, status));  // this rank's rows without a point cell (partition.py hands them to one rank)
     // camera scalars are contiguous in the Schur-ordered (sharded) layout
-    if (!defer_allreduce) TRY(allreduce(s, y_f, size_t(n9) + (pack ? 1 : 0)));
-    if (pack) { *pq_extra = y_f + n9; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
+    if (!defer_allreduce) TRY(allreduce(s, y_f, size_t(nfv) + (pack ? 1 : 0)));
+    if (pack) { *pq_extra = y_f + nfv; n_first = 0; }  // the tile pass's partials are consumed; the camera part goes to pq[0 ..)
     else if (n_first > 0) { pq = nullptr; n_first = 0; }  // the shard's point part without the packing: no complete p.q from here
     // (S.x has no point part: its p.q is the replicated camera part, formed below as on one rank)
-    HIP_TRY(s, LaunchBalAddFDiagonal(n9, cam_pos, D_f, x_f, y_f, status, pq, &n_second, s->stream));
+    HIP_TRY(s, s->ops->add_f_diagonal(n9, map, D_f, x_f, y_f, status, pq, &n_second, s->stream));
   }
   if (n_pq) *n_pq = n_first + n_second;
   return 0;
@@ -582,7 +603,7 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
     }
     // no residuals: only the inverses (and M_o) are needed; nothing is scattered
     // (cameras not in LDS: the scattering modes walk the hybrid groups, one workgroup each — chunk_grid, never fused_grid)
-    HIP_TRY(s, LaunchBalFused(kBalInit, A, s->lds_mode, s->lds_mode ? s->fused_grid : s->chunk_grid, st));
+    HIP_TRY(s, s->ops->fused(kBalInit, A, s->lds_mode, s->lds_mode ? s->fused_grid : s->chunk_grid, st));
     return g.commit(0);
   }
   // block diagonal of E^T E + D_e^2, inverted in place
@@ -625,7 +646,7 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
       A.negate_out = 1; A.nonfinite = s->d_nonfinite;
       s->lm_negated = true;
     }
-    HIP_TRY(s, LaunchBalFused(kBalBackSub, A, false, s->fused_grid, st));
+    HIP_TRY(s, s->ops->fused(kBalBackSub, A, false, s->fused_grid, st));
     if (s->backsub_cost_parts > 0 && has_remainder(s)) {  // the rows outside the tiles: one more partial sum behind the workgroups'
       TRY(rem_model_cost(s, z, 0, s->scalar_partials + s->backsub_cost_parts));
       ++s->backsub_cost_parts;
@@ -645,6 +666,37 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
   return 0;
 }
 
+// The diagonal blocks of the SHARED column blocks (shapes with a strip) into the F-block store `out`: the strip's NS x NS matrix
+// H^T H (JACOBI) or H^T H - sum over points G^T (E^T E)^-1 G, G = sum over the point's rows of E^T H (SCHUR_JACOBI: the rows of a point
+// all hold the shared cell, so the block is not a sum of per-observation terms like a camera's), from one tile pass (kBalShBlocks);
+// + D^2, inverted in place like every other block.
+int shared_preconditioner_blocks(ceres_hip_solver* s, bool schur, double* out, bool invert) {
+  const BalPlan& P = s->plan;
+  if (s->path != CERES_HIP_PATH_BAL || P.ns == 0) return 0;
+  const HostStructure& h = s->hs;
+  hipStream_t st = s->stream;
+  TRY(ensure_packed(s));
+  BalArgs A = bal_args(s);
+  if (!schur) A.etei = nullptr;   // JACOBI: blockdiag(F^T F) — the H^T H part alone
+  A.scalar_out = s->d_strip_parts;
+  HIP_TRY(s, s->ops->fused(kBalShBlocks, A, false, s->fused_grid, st));
+  StripBlocks sb;
+  sb.count = int(P.sh_block.size());
+  for (int q = 0; q < sb.count; ++q) {
+    const int j = P.sh_block[q];
+    sb.off[q] = P.sh_off[q]; sb.width[q] = h.csz[j]; sb.pos[q] = h.cpos[j] - h.num_cols_e;
+    sb.out[q] = is_schur(s) ? h.diag_off_f[j - h.nelim] : h.diag_off_all[j];
+  }
+  const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
+  HIP_TRY(s, s->ops->strip_finish(s->d_strip_parts, s->fused_grid, sb, D_f, out, st));
+  if (invert)
+    for (int q = 0; q < sb.count; ++q) {   // (the generic kernel addresses blocks relative to the first of its range)
+      const int j = P.sh_block[q];
+      HIP_TRY(s, LaunchGenInvertBlocks(s->G, j, 1, is_schur(s) ? s->G.diag_off_f + (j - h.nelim) : s->G.diag_off_all + j, out + sb.out[q], s->d_fail_flag, st));
+    }
+  return 0;
+}
+
 // Preconditioner blocks into `out`; invert = false leaves them as assembled.
 //   ITERATIVE_SCHUR: SCHUR_JACOBI (diag blocks of S) or JACOBI (blockdiag(F^T F + D_f^2)), F blocks
 //   CGNR:            JACOBI, all column blocks
@@ -660,7 +712,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     if (s->path == CERES_HIP_PATH_BAL) {
       const bool schur = type == CERES_HIP_SCHUR_JACOBI;
       const bool fuse = s->lm_fuse_active && invert;
-      HIP_TRY(s, LaunchBalCameraItems(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
+      HIP_TRY(s, s->ops->camera_items(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
       TRY(ensure_rem_blocks(s));  // rows without a point cell add their F^T F to the diagonal cells (NoEBlockRowsUpdate) and to the column norms
       if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
@@ -668,13 +720,17 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
         g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.want_sq = (fuse && schur) ? 1 : 0;
         g.extra = rem_extra_blocks(s);
         g.D_f = fuse ? nullptr : D_f;
-        HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
+        g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
+        g.cam_base = s->plan.cam_base;
+        HIP_TRY(s, s->ops->invert(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
+        TRY(shared_preconditioner_blocks(s, schur, out, true));
       } else {
         // raw sums in memory first (no diagonal when sharded: the ranks' sums are added up, then D_f^2 joins once)
-        HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f, nullptr, nullptr, out,
+        HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f,
+                                         s->plan.cameras_contiguous ? nullptr : s->d_cam_pos, s->plan.cam_base, cam_f_offsets(s), out,
                                          (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
         if (s->world > 1) {
-          const size_t n9c = size_t(9) * s->plan.n_cameras;
+          const size_t n9c = size_t(s->plan.nf) * s->plan.n_cameras;
           if (s->rhs_reduce_pending && out == s->precond && s->merged_layout) {
             // ONE collective for the step's camera-space sums: [blocks | rhs | column norms] are contiguous (set_structure)
             TRY(allreduce(s, out, size_t(len) + n9c + ((fuse && schur) ? n9c : 0)));
@@ -686,7 +742,8 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
           // fused LM diagonal: D_f does not exist yet, bal_invert9_kernel forms it from the reduced sums and adds it
           if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
         }
-        if (invert) HIP_TRY(s, LaunchBalInvert9(out, nullptr, s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), CamGather(), st));
+        if (invert) HIP_TRY(s, s->ops->invert(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), CamGather(), st));
+        TRY(shared_preconditioner_blocks(s, schur, out, invert));
       }
     } else {
       if (type == CERES_HIP_SCHUR_JACOBI) {
@@ -712,14 +769,16 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     A.D_e = s->D;
     A.point_blocks = out;
     A.pt_diag_off = s->d_pt_diag_off;
-    HIP_TRY(s, LaunchBalFused(kBalEte, A, false, s->fused_grid, st));
-    HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
+    HIP_TRY(s, s->ops->fused(kBalEte, A, false, s->fused_grid, st));
+    HIP_TRY(s, s->ops->camera_items(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
     TRY(ensure_rem_blocks(s));
     CamGather g;
     g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.D_f = D_f;
     g.extra = rem_extra_blocks(s);
     g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
-    HIP_TRY(s, LaunchBalInvert9(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
+    g.cam_base = s->plan.cam_base;
+    HIP_TRY(s, s->ops->invert(out, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, LmFuse(), g, st));
+    TRY(shared_preconditioner_blocks(s, false, out, true));
     return 0;
   }
   HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kAll, s->world > 1 ? nullptr : s->D, out, len, st));
@@ -764,20 +823,22 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   }
   if (!jacobi) return 0;
   const int32_t* cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
-  HIP_TRY(s, LaunchBalCameraItems(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
+  HIP_TRY(s, s->ops->camera_items(false, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, nullptr, s->d_cam_parts, st));
   TRY(ensure_rem_blocks(s));
   if (s->world <= 1) {
     CamGather g;
     g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.cam_pos = cam_pos;
+    g.cam_base = s->plan.cam_base;
     g.extra = rem_extra_blocks(s);
     g.D_f = s->lm_fuse_active ? nullptr : D_f;  // fused LM diagonal: bal_invert9_kernel forms D_f from the block's own diagonal and adds it
-    HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
+    HIP_TRY(s, s->ops->invert(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
+    TRY(shared_preconditioner_blocks(s, false, blocks, true));
     return 0;
   }
   // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
   // behind the point blocks in the Schur-ordered layout a sharded run requires)
-  HIP_TRY(s, LaunchBalCameraFinish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->d_cam_diag_off, blocks, nullptr, s->plan.n_cameras, st,
-                                   rem_extra_blocks(s)));
+  HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->plan.cam_base, s->d_cam_diag_off, blocks, nullptr,
+                                   s->plan.n_cameras, st, rem_extra_blocks(s)));
   const int64_t first = h.diag_off_all[h.nelim];
   if (merge) {
     TRY(allreduce(s, blocks + first, size_t(len - first) + size_t(h.num_cols_f)));
@@ -787,7 +848,7 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   }
   if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
     HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
-  HIP_TRY(s, LaunchBalInvert9(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), CamGather(), st));
+  HIP_TRY(s, s->ops->invert(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), CamGather(), st));
   return 0;
 }
 
@@ -888,7 +949,7 @@ int enqueue_model_cost_change(ceres_hip_solver* s, const double* x, const double
     A.scalar_out = s->scalar_partials;
     *nparts = std::min(s->fused_grid, kMaxVecGrid - 1);
     *dev_parts = s->scalar_partials;
-    HIP_TRY(s, LaunchBalFused(kBalJx, A, false, *nparts, st));
+    HIP_TRY(s, s->ops->fused(kBalJx, A, false, *nparts, st));
     if (has_remainder(s)) { TRY(rem_model_cost(s, x + h.num_cols_e, 1, s->scalar_partials + *nparts)); ++*nparts; }
     return 0;
   }
@@ -1422,14 +1483,14 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       spec.iteration = [s, status](int it) -> int {
         if (ensure_packed(s)) return -1;
         BalArgs A = bal_args(s);
-        if (!BalSxRunsPipelined(A)) return 0;
+        if (!s->ops->sx_runs_pipelined(A)) return 0;
         CgBuffers& B = s->cg;
         A.x_f = B.p;
         A.status = status;
         A.tail.enabled = 1; A.tail.it = it; A.tail.ticket = s->d_cg_ticket;
         A.tail.x = B.x; A.tail.r = B.r; A.tail.p = B.p; A.tail.z = B.z; A.tail.rhs = B.rhs;
         A.tail.blocks = s->precond; A.tail.D_f = s->D ? s->D + s->hs.num_cols_e : nullptr; A.tail.S = B.S;
-        if (hipError_t e = LaunchBalFused(kBalSx, A, true, s->fused_grid, s->stream); e != hipSuccess) {
+        if (hipError_t e = s->ops->fused(kBalSx, A, true, s->fused_grid, s->stream); e != hipSuccess) {
           fail(s, CERES_HIP_E_HIP, "S.x + CG iteration launch: %s", hipGetErrorString(e));
           return -1;
         }
@@ -1664,9 +1725,17 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     // more cameras than LDS rows: one workgroup per CU, each with the accumulator rows that fit next to its eight waves' spill strips
     HybridRequest hyb;
     hyb.groups = s->num_cus;
-    hyb.rows = int((kMaxLdsBytes - 512 - size_t(512 / kTile) * kTile * 9 * sizeof(double)) / (9 * sizeof(double))) / kTile * kTile;
+    // (sized for 9-wide cameras; the plan of another width that needs the rows — more cameras than LDS holds — resizes them below)
+    hyb.rows = 0;
+    hyb.lds_bytes = int64_t(kMaxLdsBytes) - 512;   // the plan sizes the rows for its camera width
     // Schur solvers: no CG vector lives in point space; CGNR: only where its CG vectors can be the caller's with the points renumbered
     BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
+  }
+  s->ops = s->plan.eligible ? GetBalOps(s->plan.nf, s->plan.ns) : nullptr;
+  if (s->plan.eligible && (!s->ops || (s->opt.jacobian_storage == 1 && !s->ops->has_f32) || (s->world > 1 && s->plan.ns > 0))) {
+    // (fp32 tiles exist for the 9-wide shape only; a sharded run with a shared strip has not been built)
+    s->plan.eligible = false;
+    s->plan.why_not = !s->ops ? "no kernels for this shape" : "option not available for this shape";
   }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
@@ -1769,6 +1838,12 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_upload(s, &s->d_slot_epos, P.slot_epos));
     TRY(dev_upload(s, &s->d_slot_fpos, P.slot_fpos));
     TRY(dev_upload(s, &s->d_slot_bpos, P.slot_bpos));
+    if (P.ns > 0) {
+      for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { TRY(dev_upload(s, &s->d_slot_hpos[q], P.slot_hpos[q])); TRY(dev_upload(s, &s->d_slot_hdesc[q], P.slot_hdesc[q])); }
+      std::vector<int64_t> cfo(P.n_cameras);
+      for (int c = 0; c < P.n_cameras; ++c) cfo[c] = h.diag_off_f[P.cam_block[c] - h.nelim];
+      TRY(dev_upload(s, &s->d_cam_foff, cfo));
+    }
     TRY(dev_upload(s, &s->d_slot_cam, P.slot_word));  // camera | accumulator row << kSlotCamBits
     TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
@@ -1796,14 +1871,14 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       TRY(dev_upload(s, &ie, P.item_end));
       s->cam_items.cam = ic; s->cam_items.begin = ib; s->cam_items.end = ie;
       s->cam_items.count = int(P.item_cam.size());
-      s->cam_items.observations = P.n_obs;
+      s->cam_items.observations = P.n_cam_cells;
       TRY(dev_upload(s, &s->d_cam_item_ptr, P.cam_item_ptr));
       {
         int most = 0;
         for (int c = 0; c < P.n_cameras; ++c) most = std::max(most, P.cam_item_ptr[c + 1] - P.cam_item_ptr[c]);
         s->cam_items_few = most <= 4 && P.n_cameras >= 1024;
       }
-      TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * kCamPart));
+      TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * s->ops->cam_part));
     }
     std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
     for (int p = 0; p < P.n_points; ++p) pdo[p] = h.diag_off_all[P.pt_block[p]];
@@ -1816,12 +1891,12 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       TRY(dev_upload(s, &s->d_pt_eoff, peo));
     }
     const size_t n_slots = size_t(P.n_tiles) * kTile;
-    if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));
-    else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * kTilePitch));
+    if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));   // (has_f32 shapes only: checked above)
+    else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * s->ops->tile_pitch));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
     TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
-    const size_t n9 = size_t(9) * P.n_cameras;
+    const size_t n9 = size_t(P.nf) * P.n_cameras + size_t(P.ns);   // accumulator entries: the cameras' scalars, then the strip
     s->lds_mode = P.cameras_in_lds;
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
     const int64_t tiles_per_wg = 512 / kTile;
@@ -1829,7 +1904,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->fused_grid = std::min(s->fused_grid, kMaxPqParts - kMaxVecGrid);  // one p.q partial per workgroup must fit cg_pq_parts (bal_scatter)
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
-    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_rows) * 9));  // ring of ONE chunk's F^T z rows
+    TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_rows) * P.nf));  // ring of ONE chunk's F^T z rows
     if (!s->lds_mode) {
       TRY(dev_upload(s, &s->d_tile_zbase, P.tile_zbase));
       if (P.hybrid) TRY(dev_upload(s, &s->d_grp_tile_ptr, P.grp_tile_ptr));
@@ -1845,8 +1920,9 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       s->chunk_grid = P.hybrid ? P.hyb_groups : int(std::max<int64_t>(1, std::min<int64_t>(s->num_cus, (chunk_tiles + 15) / 16)));
     }
     TRY(dev_alloc(s, &s->d_camsq, n9));
+    if (P.ns > 0) TRY(dev_alloc(s, &s->d_strip_parts, size_t(s->fused_grid) * size_t(P.ns * (P.ns + 1) / 2)));
     if (s->cgnr_internal) TRY(dev_alloc(s, &s->D_int, size_t(h.num_cols_e)));
-    if (s->world > 1 && (is_schur(s) ? P.cameras_contiguous : P.caller_contiguous) && int64_t(n9) == int64_t(h.num_cols_f)) {
+    if (s->world > 1 && (is_schur(s) ? (P.cameras_contiguous && P.cam_base == 0) : P.caller_contiguous) && int64_t(n9) == int64_t(h.num_cols_f)) {
       // one all-reduce per step for the camera-space sums: rhs and the column norms live right behind the preconditioner blocks
       s->merged_layout = true;
       if (is_schur(s)) {
@@ -1888,7 +1964,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       R.row_e_block = nullptr;
       TRY(dev_upload(s, &s->d_cam_block, P.cam_block));
       TRY(dev_alloc(s, &s->rem_tmp, size_t(s->rem_rows)));
-      TRY(dev_alloc(s, &s->rem_blocks, size_t(81) * P.n_cameras));
+      TRY(dev_alloc(s, &s->rem_blocks, size_t(81) * P.n_cameras));   // (the remainder kernels are 9-wide: plan.cc admits such rows for that shape only)
     }
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones
@@ -2227,7 +2303,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   // is formed inside them and no separate column-norm pass runs.
   const bool fresh = !o->reuse_diagonal || !s->have_lm_diag;
   // (DENSE_SCHUR forms no preconditioner blocks: nobody would form the camera part of a fused diagonal)
-  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->opt.preconditioner_type != CERES_HIP_IDENTITY && !is_dense_schur(s);
+  // (a shared strip's column norms are not formed by the set-up kernels: such shapes take the separate column-norm pass)
+  s->lm_fuse_active = fresh && s->path == CERES_HIP_PATH_BAL && s->opt.preconditioner_type != CERES_HIP_IDENTITY && !is_dense_schur(s) && s->plan.ns == 0;
   s->lm_opts = *o;
   if (fresh && !s->lm_fuse_active) TRY(op_squared_column_norm(s, s->lm_diag));
   if (!s->lm_fuse_active)
@@ -2775,20 +2852,20 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
       break;
     case CERES_HIP_TIMED_PACK:
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "pack exists on the <2,3,9> path only");
-      body = [&] { HIP_TRY(s, LaunchBalPack(s->values, s->b, s->d_slot_epos, s->d_slot_fpos, s->d_slot_bpos, s->plan.n_tiles, s->d_J, s->d_Jf, s->d_bt, st)); return 0; };
+      body = [&] { s->packed = false; return ensure_packed(s); };
       break;
     case CERES_HIP_TIMED_COPY:
       if (s->d_Jf) return fail(s, CERES_HIP_E_UNSUPPORTED, "copy probe needs the fp64 tile buffer");
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "copy probe uses the packed buffer of the <2,3,9> path");
       body = [&] {
-        HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * kTilePitch * 2), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(s, hipMemcpyAsync(s->d_J, s->values, sizeof(double) * std::min<int64_t>(h.values_extent, s->plan.n_tiles * int64_t(s->ops->tile_pitch) * 2), hipMemcpyDeviceToDevice, st));
         return 0;
       };
       break;
     case CERES_HIP_TIMED_READ_STREAM:
       if (s->d_Jf) return fail(s, CERES_HIP_E_UNSUPPORTED, "read-stream probe needs the fp64 tile buffer");
       if (s->path != CERES_HIP_PATH_BAL) return fail(s, CERES_HIP_E_INVALID, "read-stream probe uses the packed tiles of the <2,3,9> path");
-      body = [&] { HIP_TRY(s, LaunchBalStreamProbe(s->d_J, s->plan.n_tiles, std::min(s->num_cus, 9 * s->plan.n_cameras), s->d_global_acc, st)); return 0; };
+      body = [&] { HIP_TRY(s, s->ops->stream_probe(s->d_J, s->plan.n_tiles, std::min(s->num_cus, s->plan.nf * s->plan.n_cameras), s->d_global_acc, st)); return 0; };
       break;
     default:
       return fail(s, CERES_HIP_E_INVALID, "unknown timed op %d", op);

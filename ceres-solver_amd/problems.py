@@ -395,6 +395,114 @@ def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_
     return LinearProblem(bs, values, b, D, nelim, {}, cam_block, point_block)
 
 
+def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
+                   shared_of_obs=None, layout="schur", seed=38401, with_values=True) -> LinearProblem:
+    """Bundle-adjustment Jacobian of the structures the reference's examples produce beyond <2,3,9>: rows are 2 high and hold one point
+    cell (2 x 3), the observing camera's cell (2 x camera_width; none if the camera is in `locked_cameras`: SetParameterBlockConstant,
+    examples/libmv_bundle_adjuster.cc:725-728) and a cell on every SHARED block (`shared_widths`: libmv's camera intrinsics, <2, 8, 6, 3>,
+    examples/libmv_bundle_adjuster.cc:700-722; shared_of_obs: optional (n_obs, n_shared) mask of which shared blocks a row references).
+    Rows grouped by point (observations must come sorted by point).  layout "schur": column blocks = points, then the camera-side blocks in
+    program order (shared blocks first, like libmv's intrinsics, or last), values E|F-split, the F cells of a row back to back in column
+    order (internal/ceres/block_jacobian_writer.cc:68-167); "cgnr": the same column order, values row-sequential, no elimination.
+    camera_width 10 = bundle_adjuster --use_quaternions (examples/snavely_reprojection_error.h:164)."""
+    rng = np.random.default_rng(seed)
+    n_obs = int(point_of_obs.shape[0])
+    nsb = len(shared_widths)
+    locked = np.zeros(n_cams, dtype=bool)
+    locked[list(locked_cameras)] = True
+    # camera-side column blocks in program order
+    f_sizes = ([int(w) for w in shared_widths] if shared_first else []) + [int(camera_width)] * n_cams + ([] if shared_first else [int(w) for w in shared_widths])
+    sh0 = 0 if shared_first else n_cams          # F index of the first shared block
+    cam0 = nsb if shared_first else 0            # F index of camera 0
+    col_sizes = np.concatenate([np.full(n_points, 3, np.int64), np.asarray(f_sizes, np.int64)]).astype(np.int32)
+    col_pos = np.concatenate([[0], np.cumsum(col_sizes.astype(np.int64))[:-1]])
+    has_cam = ~locked[cam_of_obs]
+    sh_mask = np.ones((n_obs, nsb), dtype=bool) if shared_of_obs is None else np.asarray(shared_of_obs, dtype=bool)
+    # cells per row, in column order: point, [shared...], camera  (or camera before the shared blocks)
+    per_row = 1 + has_cam.astype(np.int64) + sh_mask.sum(axis=1)
+    ptr = np.concatenate([[0], np.cumsum(per_row)])
+    n_cells = int(ptr[-1])
+    cell_col = np.empty(n_cells, dtype=np.int64)
+    cell_w = np.empty(n_cells, dtype=np.int64)
+    cur = ptr[:-1].copy()
+    cell_col[cur] = point_of_obs; cell_w[cur] = 3; cur += 1
+
+    def put_shared():
+        for q in range(nsb):
+            m = sh_mask[:, q]
+            cell_col[cur[m]] = n_points + sh0 + q; cell_w[cur[m]] = shared_widths[q]; cur[m] += 1
+
+    def put_cameras():
+        m = has_cam
+        cell_col[cur[m]] = n_points + cam0 + cam_of_obs[m]; cell_w[cur[m]] = camera_width; cur[m] += 1
+    if shared_first:
+        put_shared(); put_cameras()
+    else:
+        put_cameras(); put_shared()
+    cell_len = 2 * cell_w
+    is_e = np.zeros(n_cells, dtype=bool)
+    is_e[ptr[:-1]] = True
+    cell_pos = np.empty(n_cells, dtype=np.int64)
+    if layout == "schur":
+        cell_pos[is_e] = 6 * np.arange(n_obs)
+        f_len = cell_len[~is_e]
+        cell_pos[~is_e] = 6 * n_obs + np.concatenate([[0], np.cumsum(f_len)[:-1]])
+        nelim = n_points
+    elif layout == "cgnr":
+        cell_pos[:] = np.concatenate([[0], np.cumsum(cell_len)[:-1]])
+        nelim = 0
+    else:
+        raise ValueError(layout)
+    nnz = int(cell_len.sum())
+    r = np.arange(n_obs, dtype=np.int64)
+    bs = BlockStructure(np.full(n_obs, 2, np.int32), 2 * r, col_sizes, col_pos, ptr, cell_col, cell_pos)
+    cam_block = np.where(has_cam, n_points + cam0 + cam_of_obs, -1)
+    if not with_values:
+        return LinearProblem(bs, np.zeros(0), np.zeros(0), None, nelim, {}, cam_block, point_of_obs.copy())
+    values = rng.standard_normal(nnz)
+    b = rng.standard_normal(2 * n_obs)
+    diag = np.zeros(bs.num_cols)
+    for w in np.unique(cell_w):   # column square sums, cells of one width at a time
+        idx = np.flatnonzero(cell_w == w)
+        v = values[(cell_pos[idx][:, None] + np.arange(2 * w)[None, :])].reshape(-1, 2, w)
+        sq = (v * v).sum(axis=1)
+        for c in range(int(w)):
+            diag += np.bincount(col_pos[cell_col[idx]] + c, weights=sq[:, c], minlength=bs.num_cols)
+    D = np.sqrt(np.clip(diag, 1e-6, 1e32) / 1e4)
+    return LinearProblem(bs, values, b, D, nelim, {}, cam_block, point_of_obs.copy())
+
+
+def synthetic_structured(num_cameras, num_points, num_observations, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
+                         layout="schur", seed=38401, skew=0.0, with_values=True) -> LinearProblem:
+    """structured_bal on the random visibility of synthetic_bal (every point seen by >= 2 distinct cameras)."""
+    rng = np.random.default_rng(seed)
+    k = _track_lengths(rng, num_cameras, num_points, num_observations)
+    point_of_obs = np.repeat(np.arange(num_points, dtype=np.int64), k)
+    weights = None
+    if skew > 0:
+        weights = np.arange(1, num_cameras + 1, dtype=np.float64) ** (-skew)
+        weights /= weights.sum()
+    cam_of_obs = _distinct_cameras(rng, num_cameras, point_of_obs, weights)
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    return structured_bal(num_cameras, num_points, point_of_obs, cam_of_obs[order], camera_width, shared_widths, shared_first, locked_cameras,
+                          None, layout, seed + 1, with_values)
+
+
+def libmv_structured(problem=2, copies=1, intrinsics_width=8, lock_first_camera=True, layout="schur", seed=38401, with_values=True) -> LinearProblem:
+    """The Jacobian STRUCTURE of examples/libmv_bundle_adjuster.cc on the real visibility of one of the reference's libmv problems:
+    AutoDiffCostFunction<OpenCVReprojectionError, 2, 8, 6, 3> (:697-722) — every row references the ONE shared intrinsics block (8 wide,
+    or the tangent size a SubsetManifold leaves, :754-771), the 6-wide pose of its camera and its 3-wide point; the first camera is
+    held constant (:725-728), so its rows have no pose cell; points are elimination group 0 (ordering, :775-790), the intrinsics block
+    is the first camera-side column block (it was added to the problem first).  N(0,1) values like the other synthetic workloads."""
+    n_c, n_p, cam_of, pt_of = libmv_visibility(problem)
+    reps = np.arange(copies, dtype=np.int64)
+    point_of_obs = (pt_of[None, :] + n_p * reps[:, None]).reshape(-1)
+    cam_of_obs = (cam_of[None, :] + n_c * reps[:, None]).reshape(-1)
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    return structured_bal(n_c * copies, n_p * copies, point_of_obs[order], cam_of_obs[order], 6, (intrinsics_width,), True,
+                          (0,) if lock_first_camera else (), None, layout, seed, with_values)
+
+
 def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair_fraction=0.0) -> LinearProblem:
     """Appends `num_rows` row blocks WITHOUT a point cell to a BAL-shaped problem (either layout): priors / regularisers on
     cameras — one `row_size` x 9 cell on camera i mod n_cameras, or (a `pair_fraction` of the rows) two cells coupling two

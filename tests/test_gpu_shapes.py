@@ -1,0 +1,106 @@
+"""The fused path beyond <2,3,9>: camera blocks of the widths the reference specialises for a 3-wide E block
+(internal/ceres/generate_template_specializations.py:55-75: 3, 4, 6, 9; 8 as in (2,4,8); 10 = bundle_adjuster --use_quaternions,
+examples/snavely_reprojection_error.h:164), rows with extra cells on SHARED blocks and rows without a camera cell
+(examples/libmv_bundle_adjuster.cc:697-728: <2, 8, 6, 3>, the first camera constant) — every operator against the oracle at 1e-12, the
+solvers on rungs (2) and (4) of the parity ladder, all on the FUSED kernels (kernel_path is asserted)."""
+import numpy as np
+import pytest
+
+from step_check import assert_lm_style_step
+from test_gpu_operators import assert_errs, check_cgnr_operators, check_schur_operators, make_solver, rel
+from test_gpu_lm_step import check_step
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "f3": dict(camera_width=3), "f4": dict(camera_width=4), "f6": dict(camera_width=6), "f8": dict(camera_width=8),
+    "f10_quaternion_cameras": dict(camera_width=10),
+    "f6_s8_libmv_like": dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
+    "f6_s3_subset_manifold": dict(camera_width=6, shared_widths=(3,), locked_cameras=(0, 5)),
+    "f9_s3_shared_last": dict(camera_width=9, shared_widths=(3,), shared_first=False),
+    "f9_s8_two_shared_blocks": dict(camera_width=9, shared_widths=(5, 3)),
+}
+
+
+def shaped(problems, name, layout="schur", seed=5, nc=40, npts=2500, nobs=11000):
+    return problems.synthetic_structured(nc, npts, nobs, layout=layout, seed=seed, skew=0.5, **SHAPES[name])
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_operators_of_every_shape_on_the_fused_path(hip, oracle, problems, name):
+    p = shaped(problems, name)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+    # CGNR sees no elimination order: points are the 3-wide blocks, so 3-wide cameras cannot be told from points (generic path)
+    q = shaped(problems, name, layout="cgnr")
+    assert_errs(check_cgnr_operators(hip, oracle, q, False, hip.PATH_GENERIC if SHAPES[name]["camera_width"] == 3 else hip.PATH_BAL))
+    # and CGNR on the Schur-ordered Jacobian (what a sharded run uses)
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_GENERIC if SHAPES[name]["camera_width"] == 3 else hip.PATH_BAL))
+
+
+@pytest.mark.parametrize("name", ["f10_quaternion_cameras", "f6", "f6_s8_libmv_like", "f9_s8_two_shared_blocks", "f3"])
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (5, 1), (6, 1)])
+def test_solvers_of_every_shape(hip, oracle, problems, name, solver_type, pre):
+    if solver_type == hip.CGNR and SHAPES[name]["camera_width"] == 3:
+        pytest.skip("CGNR cannot tell 3-wide cameras from points")
+    p = shaped(problems, name, seed=6)
+    if solver_type == hip.CGNR:
+        p = type(p)(p.bs, p.values, p.b, p.D, 0)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m.cgnr_solve
+    for k in (1, 7, 25):   # rung (2): fixed iteration counts (25 crosses two residual resets)
+        s = make_solver(hip, p, solver_type, pre, min_it=k, max_it=k)
+        assert s.info().kernel_path == hip.PATH_BAL
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=0.0))
+        s.close()
+        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=k, max_it=k, q_tol=-1.0, r_tol=0.0)
+        assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
+        assert rel(x, xo) <= 1e-9, (k, rel(x, xo))
+    # rung (4): the call LevenbergMarquardtStrategy issues
+    s = make_solver(hip, p, solver_type, pre, max_it=500)
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(x, summ, lambda lo, hi, q, r: fn(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r), 0.1, hip.SUCCESS)
+    # the whole LM step on the device (diag(J'J) by the fused column-norm pass incl. the strip's columns), and the retry after a rejection
+    radius = 1e4
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)
+    diag = np.clip(oracle.Matrix(p.bs, 0).squared_column_norm(p.values), 1e-6, 1e32)
+    assert rel(s.lm_diagonal(), np.sqrt(diag / radius)) <= 1e-13
+    check_step(oracle, hip, p, solver_type, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+    step, summ, mcc = s.lm_compute_step(None, None, radius / 2, 0.1, reuse_diagonal=True, values_unchanged=True)
+    check_step(oracle, hip, p, solver_type, pre, np.sqrt(diag / (radius / 2)), step, summ, mcc, 0.1)
+    s.close()
+
+
+def test_libmv_structure_on_the_real_visibility_graph(hip, oracle, problems):
+    """examples/libmv_bundle_adjuster.cc on data/libmv-ba-problems/problem_02.bin's visibility: shared intrinsics (8) + 6-wide pose +
+    point, first camera constant; every point has far more than 64 observations (long points: rounds) — on the fused path."""
+    p = problems.libmv_structured(2, 1)
+    errs = check_schur_operators(hip, oracle, p, False, hip.PATH_BAL)
+    assert_errs(errs)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    info = s.info()
+    assert info.kernel_path == hip.PATH_BAL and (info.row_block_size, info.e_block_size, info.f_block_size) == (2, 3, -1)   # DetectStructure: dynamic F
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(x, summ, lambda lo, hi, q, r: m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=2, min_it=lo, max_it=hi, q_tol=q, r_tol=r), 0.1, hip.SUCCESS)
+    s.close()
+    # a SubsetManifold leaves a narrower intrinsics block (:754-771): tangent size 3 (focal length, k1, k2)
+    p3 = problems.libmv_structured(2, 1, intrinsics_width=3)
+    assert_errs(check_schur_operators(hip, oracle, p3, False, hip.PATH_BAL))
+    # the CGNR solver on the same Jacobian
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+
+
+def test_narrow_cameras_beyond_lds(hip, oracle, problems):
+    # 30 000 6-wide cameras: the accumulators do not fit in LDS (hybrid plan: popular cameras + windows, the rest spilled to the ring)
+    p = problems.synthetic_structured(30000, 60000, 200000, camera_width=6, seed=8, skew=0.4)
+    errs = check_schur_operators(hip, oracle, p, False, hip.PATH_BAL)
+    assert_errs(errs)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    assert s.info().camera_accum_in_lds == 0
+    s.close()
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+
+
+def test_unsupported_widths_fall_back_to_the_generic_path(hip, oracle, problems):
+    p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_GENERIC))

@@ -257,9 +257,12 @@ def test_plan_caps_points_per_tile(problems):
 def test_plan_rejections(problems):
     hs = pkg.hip_solver
     assert not hs.debug_plan(problems.linear_least_squares_problem(2).bs, 2)["eligible"]
-    p = problems.random_schur_problem(static_sizes=(2, 3, 6), seed=1)
+    p = problems.random_schur_problem(static_sizes=(2, 3, 6), seed=1)   # rows with several 6-wide F cells on many blocks: no camera / shared split
     r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
-    assert not r["eligible"] and "9 wide" in r["why"]
+    assert not r["eligible"] and "shared strip" in r["why"]
+    p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)   # a camera width no kernels are compiled for
+    r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
+    assert not r["eligible"] and "no fused kernels" in r["why"]
     # a point that sees the same camera twice cannot use the fused SCHUR_JACOBI kernel
     q = problems.synthetic_bal(None, num_cameras=5, num_points=6, num_observations=14, seed=2)
     cc = q.bs.cell_col_block.copy()
@@ -269,6 +272,34 @@ def test_plan_rejections(problems):
                          cc, q.bs.cell_value_pos)
     r = hs.debug_plan(bad, q.num_eliminate_blocks)
     assert not r["eligible"] and "twice" in r["why"]
+
+
+@pytest.mark.parametrize("kw", [dict(camera_width=10), dict(camera_width=6), dict(camera_width=3), dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
+                                dict(camera_width=9, shared_widths=(5, 3), shared_first=False)])
+def test_plan_of_other_shapes(problems, kw):
+    """Camera widths other than 9, shared blocks and rows without a camera cell (common.h: shapes): the tiles still hold every row once,
+    grouped by point; a row without a camera cell is a valid slot whose camera is -2."""
+    hs = pkg.hip_solver
+    p = problems.synthetic_structured(25, 700, 3300, seed=11, with_values=False, **kw)
+    r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
+    assert r["eligible"], r
+    valid = r["valid"].astype(bool)
+    rows = r["slot_row"][valid]
+    assert np.array_equal(np.sort(rows), np.arange(p.bs.num_row_blocks))
+    cams = r["slot_cam"][valid]
+    want_cam = p.camera_of_row[rows]          # column block of the row's camera cell, -1: none (a locked camera)
+    locked = want_cam < 0
+    assert (cams[locked] == -2).all() and locked.sum() == (p.camera_of_row < 0).sum()
+    # camera ids = ranks of the camera blocks among the camera-side blocks that are not shared (structured_bal: cameras are contiguous blocks)
+    n_shared = len(kw.get("shared_widths", ()))
+    cam0 = p.num_eliminate_blocks + (n_shared if kw.get("shared_first", True) else 0)
+    assert np.array_equal(cams[~locked], want_cam[~locked] - cam0)
+    # rows of a point are adjacent slots of one tile (or whole tiles): slot_pt is non-decreasing inside a tile
+    pt = r["slot_pt"].reshape(-1, 64)
+    vm = valid.reshape(-1, 64)
+    for t in range(pt.shape[0]):
+        q = pt[t][vm[t]]
+        assert (np.diff(q) >= 0).all()
 
 
 def test_packed_formulation_matches_oracle(oracle, problems):
