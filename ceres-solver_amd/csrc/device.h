@@ -215,6 +215,12 @@ struct GenStructure {
   const int32_t *tptr = nullptr, *trow = nullptr, *tcell = nullptr;
   const int32_t *row_block_of = nullptr, *col_block_of = nullptr, *row_e_block = nullptr;
   const int64_t *diag_off_all = nullptr, *diag_off_e = nullptr, *diag_off_f = nullptr;
+  // chunk = the (contiguous) rows of one E block: SchurEliminator's unit of work (I/schur_eliminator_impl.h:87-181)
+  const int32_t *chunk_start = nullptr, *chunk_size = nullptr;
+  // hints for the GROUPED kernels (L lanes per column block / chunk, kernels_generic.hip): largest block sizes per part, lanes per group
+  // chosen from the average number of cells per block (power of two, 4 .. 64); 0 = use the thread-per-scalar kernels
+  int max_csz_e = 0, max_csz_f = 0, max_csz = 0, max_rsz = 0;
+  int lanes_e = 0, lanes_f = 0, lanes_all = 0, lanes_chunk = 0;
 };
 enum GenPart { kAll = 0, kE = 1, kF = 2 };
 
@@ -233,6 +239,13 @@ hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* value
 // [first_block, first_block + nblocks) of the column-block list, offsets relative to off[0].
 hipError_t LaunchGenInvertBlocks(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
                                  double* blocks, int* fail_flag, hipStream_t stream);
+// Per chunk (E block e, rows of the chunk): w = (E^T E + D^2)^-1 E^T t over the chunk's rows (ete_inv: the inverted blocks), then
+// t_r -= E_r w on those rows (update_t) and / or x_e[cpos(e) ..] = w (x_e != nullptr).  One launch for what LeftMultiplyE, the block
+// diagonal apply and RightMultiplyE do in ImplicitSchurComplement::RightMultiplyAndAccumulate / UpdateRhs / BackSubstitute
+// (I/implicit_schur_complement.cc:106-144, 208-276).  Returns hipErrorNotSupported when the block sizes exceed the grouped kernels'
+// (the caller then runs the separate passes).
+hipError_t LaunchGenChunkProject(const GenStructure& G, const double* values, const double* ete_inv, double* t_rows, int update_t,
+                                 double* x_e, const int* status, hipStream_t stream);
 // y += blockdiag x over column blocks [first_block, first_block+nblocks); vectors start at that block.
 hipError_t LaunchGenBlockDiagonalApply(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
                                        const double* blocks, const double* x, double* y, const int* status,

@@ -365,6 +365,252 @@ __global__ __launch_bounds__(kB) void gen_extract_diag_blocks_kernel(GenStructur
 
 inline unsigned blocks_for(int64_t n) { return unsigned((n + kB - 1) / kB); }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GROUPED kernels: L lanes (a power of two, 4 .. 64) per column block or chunk, striding over its cells / rows; every lane
+// accumulates the block's whole (small) result in registers, the group combines by butterfly shuffles (a fixed tree:
+// deterministic).  The thread-per-output-scalar kernels above walk a column block's cells ALONE: on the Ladybug shape a
+// camera's 394 cells are a 394-step dependent chain per thread with 15 507 threads in flight — S.x took 20.5 ms, 0.0009 of the
+// HBM peak (profiles/r03t_*).  MAXC / MAXE bound the block sizes a kernel is compiled for (predicated, fully unrolled register
+// arrays); larger blocks keep the old kernels.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int m = L / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// y[cpos(j) - ybase + c] += sum over the cells of column block j (in `part`) of sum_r A[r][c] x[rpos(i) + r],  j in [j0, j0 + nb)
+template <int L, int MAXC>
+__global__ __launch_bounds__(kB) void gen_left_multiply_grouped_kernel(GenStructure G, const double* __restrict__ v, int part, int j0, int nb,
+                                                                       int ybase, const double* __restrict__ x, double* __restrict__ y,
+                                                                       const int* status) {
+  if (status && *status != 0) return;
+  const int64_t grp = (int64_t(blockIdx.x) * kB + threadIdx.x) / L;
+  const int gl = threadIdx.x & (L - 1);
+  if (grp >= nb) return;
+  const int j = j0 + int(grp);
+  const int cs = G.csz[j];
+  double s[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) s[c] = 0.0;
+  for (int t = G.tptr[j] + gl; t < G.tptr[j + 1]; t += L) {
+    const int i = G.trow[t], k = G.tcell[t];
+    if (!cell_in_part(G, i, k, part)) continue;
+    const double* a = v + G.cval[k];
+    const double* xx = x + G.rpos[i];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) {
+      const double xr = xx[r];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+    }
+  }
+  double* out = y + G.cpos[j] - ybase;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const double t = group_sum<L>(s[c]);
+    if (c < cs && (c & (L - 1)) == gl) out[c] += t;
+  }
+}
+
+// One group per chunk: w = ete_inv(e) * sum over the chunk's rows of E_r^T t_r; then t_r -= E_r w (update_t) and / or x_e = w.
+template <int L, int MAXE>
+__global__ __launch_bounds__(kB) void gen_chunk_project_kernel(GenStructure G, const double* __restrict__ v, const double* __restrict__ ete_inv,
+                                                               double* __restrict__ t_rows, int update_t, double* __restrict__ x_e,
+                                                               const int* status) {
+  if (status && *status != 0) return;
+  const int64_t grp = (int64_t(blockIdx.x) * kB + threadIdx.x) / L;
+  const int gl = threadIdx.x & (L - 1);
+  if (grp >= G.nelim) return;
+  const int e = int(grp);
+  const int es = G.csz[e];
+  const int i0 = G.chunk_start[e], i1 = i0 + G.chunk_size[e];
+  double u[MAXE];
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) u[p] = 0.0;
+  for (int i = i0 + gl; i < i1; i += L) {
+    const double* E = v + G.cval[G.rptr[i]];
+    const double* tt = t_rows + G.rpos[i];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) {
+      const double tr = tt[r];
+#pragma unroll
+      for (int p = 0; p < MAXE; ++p) if (p < es) u[p] += E[r * es + p] * tr;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) u[p] = group_sum<L>(u[p]);
+  const double* inv = ete_inv + G.diag_off_e[e];
+  double w[MAXE];
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) if (p < es && q < es) a += inv[p * es + q] * u[q];
+    w[p] = a;
+  }
+  if (x_e) {
+#pragma unroll
+    for (int p = 0; p < MAXE; ++p) if (p < es && (p & (L - 1)) == gl) x_e[G.cpos[e] + p] = w[p];
+  }
+  if (update_t) {
+    for (int i = i0 + gl; i < i1; i += L) {
+      const double* E = v + G.cval[G.rptr[i]];
+      double* tt = t_rows + G.rpos[i];
+      const int rs = G.rsz[i];
+      for (int r = 0; r < rs; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int p = 0; p < MAXE; ++p) if (p < es) a += E[r * es + p] * w[p];
+        tt[r] -= a;
+      }
+    }
+  }
+}
+
+// blocks(j) = sum over the cells of column block j (in `part`) of A^T A (+ D^2), j in [j0, j0 + nb); off = the offsets of the store
+// the blocks live in, indexed by j - first (first = the store's first block)
+template <int L, int MAXC>
+__global__ __launch_bounds__(kB) void gen_block_diagonal_grouped_kernel(GenStructure G, const double* __restrict__ v, int part, int j0, int nb,
+                                                                        const int64_t* __restrict__ off, int first, const double* __restrict__ D,
+                                                                        double* __restrict__ blocks) {
+  constexpr int NT = MAXC * (MAXC + 1) / 2;
+  const int64_t grp = (int64_t(blockIdx.x) * kB + threadIdx.x) / L;
+  const int gl = threadIdx.x & (L - 1);
+  if (grp >= nb) return;
+  const int j = j0 + int(grp);
+  const int n = G.csz[j];
+  double acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = 0.0;
+  for (int t = G.tptr[j] + gl; t < G.tptr[j + 1]; t += L) {
+    const int i = G.trow[t], k = G.tcell[t];
+    if (!cell_in_part(G, i, k, part)) continue;
+    const double* m = v + G.cval[k];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) {
+      double row[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) row[c] = c < n ? m[r * n + c] : 0.0;
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+        for (int b = a; b < MAXC; ++b) acc[idx++] += row[a] * row[b];
+    }
+  }
+  double* o = blocks + (off[j - first] - off[0]);
+  int idx = 0;
+#pragma unroll
+  for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+    for (int b = a; b < MAXC; ++b) {
+      double s = group_sum<L>(acc[idx]);
+      if (a < n && b < n && (idx & (L - 1)) == gl) {
+        if (D && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+        o[a * n + b] = s;
+        o[b * n + a] = s;
+      }
+      ++idx;
+    }
+}
+
+// Diagonal blocks of the Schur complement, one group per F block j: its cells in row order; the cells of j inside ONE chunk are
+// adjacent in the transpose list, and the lane that meets the first of them takes the whole run:
+//   S_jj += sum over the run of F^T F - G^T (E^T E)^-1 G,  G = sum over the run of E_r^T F_r       (an E-free row: F^T F alone)
+// — ChunkDiagonalBlockAndGradient + ChunkOuterProduct + NoEBlockRowsUpdate restricted to the cell (j, j)
+// (I/schur_eliminator_impl.h:449-721).
+template <int L, int MAXE, int MAXC>
+__global__ __launch_bounds__(kB) void gen_schur_jacobi_grouped_kernel(GenStructure G, const double* __restrict__ v, const double* __restrict__ ete_inv,
+                                                                      const double* __restrict__ D, int add_f_diag, double* __restrict__ blocks) {
+  constexpr int NT = MAXC * (MAXC + 1) / 2;
+  const int nf = G.ncb - G.nelim;
+  const int64_t grp = (int64_t(blockIdx.x) * kB + threadIdx.x) / L;
+  const int gl = threadIdx.x & (L - 1);
+  if (grp >= nf) return;
+  const int j = G.nelim + int(grp);
+  const int n = G.csz[j];
+  double acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = 0.0;
+  const int t0 = G.tptr[j], t1 = G.tptr[j + 1];
+  for (int t = t0 + gl; t < t1; t += L) {
+    const int i = G.trow[t];
+    const int e = G.row_e_block[i];
+    if (e >= 0 && t > t0 && G.row_e_block[G.trow[t - 1]] == e) continue;   // not the first cell of j in its chunk
+    const int es = e >= 0 ? G.csz[e] : 0;
+    double g[MAXE][MAXC];
+#pragma unroll
+    for (int p = 0; p < MAXE; ++p)
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) g[p][c] = 0.0;
+    for (int tt = t; tt < t1; ++tt) {   // the run of j's cells in this chunk (an E-free row: itself alone)
+      const int ii = G.trow[tt];
+      if (tt > t && (e < 0 || G.row_e_block[ii] != e)) break;
+      const double* f = v + G.cval[G.tcell[tt]];
+      const double* E = e >= 0 ? v + G.cval[G.rptr[ii]] : nullptr;
+      const int rs = G.rsz[ii];
+      for (int r = 0; r < rs; ++r) {
+        double row[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) row[c] = c < n ? f[r * n + c] : 0.0;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+          for (int b = a; b < MAXC; ++b) acc[idx++] += row[a] * row[b];
+        if (e >= 0) {
+#pragma unroll
+          for (int p = 0; p < MAXE; ++p) {
+            const double ep = p < es ? E[r * es + p] : 0.0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) g[p][c] += ep * row[c];
+          }
+        }
+      }
+    }
+    if (e >= 0) {
+      const double* inv = ete_inv + G.diag_off_e[e];
+      double w[MAXE][MAXC];   // (E^T E)^-1 G
+#pragma unroll
+      for (int p = 0; p < MAXE; ++p)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          double a = 0.0;
+#pragma unroll
+          for (int q = 0; q < MAXE; ++q) if (p < es && q < es) a += inv[p * es + q] * g[q][c];
+          w[p][c] = a;
+        }
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+        for (int b = a; b < MAXC; ++b) {
+          double sub = 0.0;
+#pragma unroll
+          for (int p = 0; p < MAXE; ++p) sub += g[p][a] * w[p][b];
+          acc[idx++] -= sub;
+        }
+    }
+  }
+  double* o = blocks + G.diag_off_f[grp];
+  int idx = 0;
+#pragma unroll
+  for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+    for (int b = a; b < MAXC; ++b) {
+      double s = group_sum<L>(acc[idx]);
+      if (a < n && b < n && (idx & (L - 1)) == gl) {
+        if (D && add_f_diag && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+        o[a * n + b] = s;
+        o[b * n + a] = s;
+      }
+      ++idx;
+    }
+}
+
+
 // ---- remainder rows of the fused <2,3,9> path (rows without a point cell; R = their own GenStructure, compact row space) ----
 // out[81 c + 9 a + b] = sum over the remainder cells of camera c of (F^T F)(a, b): what SchurEliminator::NoEBlockRowsUpdate adds to
 // the diagonal cell of S (I/schur_eliminator_impl.h:574-666) and UpdateBlockDiagonalFtF's second loop to blockdiag(F^T F)
@@ -504,11 +750,60 @@ hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, i
   if (G.num_rows > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, part, x, y, status);
   return hipGetLastError();
 }
+// L lanes per group: dispatch of a grouped kernel over the compiled group widths
+#define GEN_DISPATCH_L(L_, CALL)            \
+  switch (L_) {                             \
+    case 4: { constexpr int L = 4; CALL; } break;   \
+    case 8: { constexpr int L = 8; CALL; } break;   \
+    case 16: { constexpr int L = 16; CALL; } break; \
+    case 32: { constexpr int L = 32; CALL; } break; \
+    default: { constexpr int L = 64; CALL; } break; \
+  }
+template <int L>
+static void launch_left_grouped(const GenStructure& G, const double* values, int part, int j0, int nb, int ybase, int max_c, const double* x,
+                                double* y, const int* status, hipStream_t s) {
+  const dim3 grid(blocks_for(int64_t(nb) * L));
+  if (max_c <= 4) hipLaunchKernelGGL((gen_left_multiply_grouped_kernel<L, 4>), grid, dim3(kB), 0, s, G, values, part, j0, nb, ybase, x, y, status);
+  else if (max_c <= 10) hipLaunchKernelGGL((gen_left_multiply_grouped_kernel<L, 10>), grid, dim3(kB), 0, s, G, values, part, j0, nb, ybase, x, y, status);
+  else hipLaunchKernelGGL((gen_left_multiply_grouped_kernel<L, kMaxGenericBlock>), grid, dim3(kB), 0, s, G, values, part, j0, nb, ybase, x, y, status);
+}
 hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
                                  const int* status, hipStream_t s) {
   const int n = part == kAll ? G.num_cols : (part == kE ? G.nce : G.ncf);
-  if (n > 0) hipLaunchKernelGGL(gen_left_multiply_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, part, x, y, status);
+  if (n <= 0) return hipSuccess;
+  if (G.lanes_all == 0) {   // no hints: the thread-per-scalar kernel
+    hipLaunchKernelGGL(gen_left_multiply_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, part, x, y, status);
+    return hipGetLastError();
+  }
+  // the E blocks (many, a few cells each) and the F blocks (few, many cells each) get their own group widths
+  const int ybase = part == kF ? G.nce : 0;
+  if (part != kF && G.nelim > 0) { GEN_DISPATCH_L(G.lanes_e, (launch_left_grouped<L>(G, values, part, 0, G.nelim, ybase, G.max_csz_e, x, y, status, s))) }
+  if (part != kE && G.ncb > G.nelim) {
+    if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_left_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, ybase, G.max_csz_f, x, y, status, s))) }
+    else { GEN_DISPATCH_L(G.lanes_all, (launch_left_grouped<L>(G, values, part, 0, G.ncb, ybase, G.max_csz, x, y, status, s))) }
+  }
   return hipGetLastError();
+}
+template <int L>
+static void launch_chunk_project(const GenStructure& G, const double* values, const double* ete_inv, double* t_rows, int update_t, double* x_e,
+                                 const int* status, hipStream_t s) {
+  const dim3 grid(blocks_for(int64_t(G.nelim) * L));
+  if (G.max_csz_e <= 4) hipLaunchKernelGGL((gen_chunk_project_kernel<L, 4>), grid, dim3(kB), 0, s, G, values, ete_inv, t_rows, update_t, x_e, status);
+  else hipLaunchKernelGGL((gen_chunk_project_kernel<L, 10>), grid, dim3(kB), 0, s, G, values, ete_inv, t_rows, update_t, x_e, status);
+}
+hipError_t LaunchGenChunkProject(const GenStructure& G, const double* values, const double* ete_inv, double* t_rows, int update_t,
+                                 double* x_e, const int* status, hipStream_t s) {
+  if (G.nelim <= 0) return hipSuccess;
+  if (G.lanes_chunk == 0 || !G.chunk_start || G.max_csz_e > 10) return hipErrorNotSupported;
+  GEN_DISPATCH_L(G.lanes_chunk, (launch_chunk_project<L>(G, values, ete_inv, t_rows, update_t, x_e, status, s)))
+  return hipGetLastError();
+}
+template <int L>
+static void launch_block_diagonal_grouped(const GenStructure& G, const double* values, int part, int j0, int nb, const int64_t* off, int first,
+                                          int max_c, const double* D, double* blocks, hipStream_t s) {
+  const dim3 grid(blocks_for(int64_t(nb) * L));
+  if (max_c <= 4) hipLaunchKernelGGL((gen_block_diagonal_grouped_kernel<L, 4>), grid, dim3(kB), 0, s, G, values, part, j0, nb, off, first, D, blocks);
+  else hipLaunchKernelGGL((gen_block_diagonal_grouped_kernel<L, 10>), grid, dim3(kB), 0, s, G, values, part, j0, nb, off, first, D, blocks);
 }
 hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* values, double* x, hipStream_t s) {
   if (G.num_cols > 0) hipLaunchKernelGGL(gen_squared_column_norm_kernel, dim3(blocks_for(G.num_cols)), dim3(kB), 0, s, G, values, x);
@@ -569,12 +864,35 @@ hipError_t LaunchAddBlockDiagonalSquares(const GenStructure& G, int first_block,
 // the structure; solver.hip passes it.
 hipError_t LaunchGenBlockDiagonal(const GenStructure& G, const double* values, int part, const double* D, double* blocks,
                                    int64_t total, hipStream_t s) {
-  if (total > 0) hipLaunchKernelGGL(gen_block_diagonal_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, part, D, blocks);
+  if (total <= 0) return hipSuccess;
+  const int max_c = part == kE ? G.max_csz_e : (part == kF ? G.max_csz_f : G.max_csz);
+  if (G.lanes_all == 0 || max_c > 10) {   // no hints, or blocks wider than the grouped kernel's register triangle: one thread per entry
+    hipLaunchKernelGGL(gen_block_diagonal_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, part, D, blocks);
+    return hipGetLastError();
+  }
+  const int64_t* off = part == kAll ? G.diag_off_all : (part == kE ? G.diag_off_e : G.diag_off_f);
+  const int first = part == kF ? G.nelim : 0;
+  if (part != kF && G.nelim > 0) { GEN_DISPATCH_L(G.lanes_e, (launch_block_diagonal_grouped<L>(G, values, part, 0, G.nelim, off, first, G.max_csz_e, D, blocks, s))) }
+  if (part != kE && G.ncb > G.nelim) {
+    if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_block_diagonal_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, off, first, G.max_csz_f, D, blocks, s))) }
+    else { GEN_DISPATCH_L(G.lanes_all, (launch_block_diagonal_grouped<L>(G, values, part, 0, G.ncb, off, first, G.max_csz, D, blocks, s))) }
+  }
   return hipGetLastError();
+}
+template <int L>
+static void launch_schur_jacobi_grouped(const GenStructure& G, const double* values, const double* ete_inv, const double* D, int add_f_diag,
+                                        double* blocks, hipStream_t s) {
+  const int nf = G.ncb - G.nelim;
+  hipLaunchKernelGGL((gen_schur_jacobi_grouped_kernel<L, 4, 10>), dim3(blocks_for(int64_t(nf) * L)), dim3(kB), 0, s, G, values, ete_inv, D, add_f_diag, blocks);
 }
 hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                  int add_f_diag, double* blocks, int64_t total, hipStream_t s) {
-  if (total > 0) hipLaunchKernelGGL(gen_schur_jacobi_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, ete_inv, D, add_f_diag, blocks);
+  if (total <= 0) return hipSuccess;
+  if (G.lanes_f == 0 || G.max_csz_e > 4 || G.max_csz_f > 10) {
+    hipLaunchKernelGGL(gen_schur_jacobi_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, ete_inv, D, add_f_diag, blocks);
+    return hipGetLastError();
+  }
+  GEN_DISPATCH_L(G.lanes_f, (launch_schur_jacobi_grouped<L>(G, values, ete_inv, D, add_f_diag, blocks, s)))
   return hipGetLastError();
 }
 

@@ -526,12 +526,18 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status, do
   hipStream_t st = s->stream;
   HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
   HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kF, x, s->tmp_rows, status, st));
-  HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
-  HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kE, s->tmp_rows, s->tmp_e, status, st));
-  HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
-  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, status, st));
-  HIP_TRY(s, LaunchAxpby(-1.0, s->tmp_e2, 0.0, s->tmp_e2, s->tmp_e2, h.num_cols_e, st));
-  HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kE, s->tmp_e2, s->tmp_rows, status, st));
+  // t -= E (E^T E)^-1 E^T t, chunk by chunk in one launch; block sizes beyond the grouped kernel's: the reference's three passes
+  const hipError_t pe = LaunchGenChunkProject(s->G, v, s->etei, s->tmp_rows, 1, nullptr, status, st);
+  if (pe == hipErrorNotSupported) {
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kE, s->tmp_rows, s->tmp_e, status, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, status, st));
+    HIP_TRY(s, LaunchAxpby(-1.0, s->tmp_e2, 0.0, s->tmp_e2, s->tmp_e2, h.num_cols_e, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kE, s->tmp_e2, s->tmp_rows, status, st));
+  } else {
+    HIP_TRY(s, pe);
+  }
   const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
   if (s->world <= 1) {
     HIP_TRY(s, LaunchSquareScale(D_f, x, y, h.num_cols_f, status, st));
@@ -612,13 +618,19 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
   HIP_TRY(s, LaunchGenInvertBlocks(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->d_fail_flag, st));
   if (!s->have_b) return 0;
   // rhs = F^T (b - E (E^T E)^-1 E^T b)           UpdateRhs
-  HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
-  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->b, s->tmp_e, nullptr, st));
-  HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
-  HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, nullptr, st));
-  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
-  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kE, s->tmp_e2, s->tmp_rows, nullptr, st));
-  HIP_TRY(s, LaunchAxpby(1.0, s->b, -1.0, s->tmp_rows, s->tmp_rows, h.num_rows, st));
+  HIP_TRY(s, hipMemcpyAsync(s->tmp_rows, s->b, sizeof(double) * h.num_rows, hipMemcpyDeviceToDevice, st));
+  const hipError_t pe = LaunchGenChunkProject(s->G, s->values, s->etei, s->tmp_rows, 1, nullptr, nullptr, st);
+  if (pe == hipErrorNotSupported) {
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->b, s->tmp_e, nullptr, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_e2, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, s->tmp_e2, nullptr, st));
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kE, s->tmp_e2, s->tmp_rows, nullptr, st));
+    HIP_TRY(s, LaunchAxpby(1.0, s->b, -1.0, s->tmp_rows, s->tmp_rows, h.num_rows, st));
+  } else {
+    HIP_TRY(s, pe);
+  }
   HIP_TRY(s, hipMemsetAsync(s->rhs_f, 0, sizeof(double) * std::max(1, h.num_cols_f), st));
   HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kF, s->tmp_rows, s->rhs_f, nullptr, st));
   TRY(allreduce(s, s->rhs_f, size_t(h.num_cols_f)));
@@ -656,10 +668,15 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
     HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
     if (h.num_cols_f > 0) HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kF, z, s->tmp_rows, nullptr, st));
     HIP_TRY(s, LaunchAxpby(1.0, s->b, -1.0, s->tmp_rows, s->tmp_rows, h.num_rows, st));
-    HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
-    HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->tmp_rows, s->tmp_e, nullptr, st));
     HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols, st));
-    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, x, nullptr, st));
+    const hipError_t pe = LaunchGenChunkProject(s->G, s->values, s->etei, s->tmp_rows, 0, x, nullptr, st);   // x_e = (E^T E)^-1 E^T t, chunk by chunk
+    if (pe == hipErrorNotSupported) {
+      HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
+      HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kE, s->tmp_rows, s->tmp_e, nullptr, st));
+      HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.nelim, s->G.diag_off_e, s->etei, s->tmp_e, x, nullptr, st));
+    } else {
+      HIP_TRY(s, pe);
+    }
   }
   if (h.num_cols_f > 0)
     HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, z, sizeof(double) * h.num_cols_f, hipMemcpyDeviceToDevice, st));
@@ -1764,8 +1781,28 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   UP32(csz, h.csz); UP32(cpos, h.cpos); UP32(tptr, h.tptr); UP32(trow, h.trow); UP32(tcell, h.tcell);
   UP32(row_block_of, h.row_block_of); UP32(col_block_of, h.col_block_of); UP32(row_e_block, h.row_e_block);
   UP64(diag_off_all, h.diag_off_all); UP64(diag_off_e, h.diag_off_e); UP64(diag_off_f, h.diag_off_f);
+  if (h.chunks_contiguous && h.nelim > 0) { UP32(chunk_start, h.chunk_start); UP32(chunk_size, h.chunk_size); }
 #undef UP32
 #undef UP64
+  {
+    // hints for the grouped generic kernels (kernels_generic.hip): block sizes per part, lanes per group from the average cell count.
+    // CERES_HIP_GENERIC_GROUPED=0 keeps the thread-per-scalar kernels (A/B measurements, tests of the old kernels).
+    const char* e = getenv("CERES_HIP_GENERIC_GROUPED");
+    if (!(e && atoi(e) == 0)) {
+      auto lanes_for = [](double avg) { int L = 4; while (L < 64 && L < avg) L *= 2; return L; };
+      int64_t cells_e = 0, cells_f = 0;
+      for (int j = 0; j < h.ncb; ++j) {
+        (j < h.nelim ? G.max_csz_e : G.max_csz_f) = std::max(j < h.nelim ? G.max_csz_e : G.max_csz_f, h.csz[j]);
+        (j < h.nelim ? cells_e : cells_f) += h.tptr[j + 1] - h.tptr[j];
+      }
+      G.max_csz = std::max(G.max_csz_e, G.max_csz_f);
+      for (int i = 0; i < h.nrb; ++i) G.max_rsz = std::max(G.max_rsz, h.rsz[i]);
+      G.lanes_e = lanes_for(h.nelim > 0 ? double(cells_e) / h.nelim : 0.0);
+      G.lanes_f = lanes_for(h.ncb > h.nelim ? double(cells_f) / (h.ncb - h.nelim) : 0.0);
+      G.lanes_all = lanes_for(h.ncb > 0 ? double(cells_e + cells_f) / h.ncb : 0.0);
+      G.lanes_chunk = (h.chunks_contiguous && h.nelim > 0) ? lanes_for(double(h.num_row_blocks_e) / h.nelim) : 0;
+    }
+  }
 
   // ---- inputs, temporaries, CG state ----
   TRY(dev_alloc(s, &s->own_values, size_t(h.values_extent)));
