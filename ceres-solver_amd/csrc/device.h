@@ -208,6 +208,18 @@ const BalOps* GetBalOps(int nf, int ns);   // nullptr: not compiled (common.h: B
 hipError_t AllowMaxLds(const void* kernel);
 
 // ---- generic kernels (kernels_generic.hip) --------------------------------
+// Work ITEMS of the grouped generic kernels over heavy column blocks (the cameras of a BAL-like problem): at most kGenItem consecutive
+// cells of ONE block's transpose list, never cutting the cells a block has inside one chunk apart.  A wave per item leaves the item's
+// partial result in `scratch` ([item][kGenItemValues]); a second kernel adds a block's items in list order (deterministic).  Without
+// them one wave walks a popular camera's thousands of cells alone and the kernel lasts as long as that chain (1.3 ms on the Ladybug shape).
+constexpr int kGenItem = 128;
+constexpr int kGenItemValues = 55;   // a 10 x 10 upper triangle
+struct GenItems {
+  int count = 0, first_block = 0, nblocks = 0;
+  const int32_t *block = nullptr, *t0 = nullptr, *t1 = nullptr;   // per item
+  const int32_t* block_ptr = nullptr;                             // per block of the range: its items [block_ptr[q], block_ptr[q + 1])
+  double* scratch = nullptr;
+};
 struct GenStructure {
   int nrb = 0, ncb = 0, nelim = 0, nrbe = 0, num_rows = 0, num_cols = 0, nce = 0, ncf = 0;
   const int32_t *rsz = nullptr, *rpos = nullptr, *rptr = nullptr, *ccol = nullptr, *cval = nullptr;
@@ -221,6 +233,7 @@ struct GenStructure {
   // chosen from the average number of cells per block (power of two, 4 .. 64); 0 = use the thread-per-scalar kernels
   int max_csz_e = 0, max_csz_f = 0, max_csz = 0, max_rsz = 0;
   int lanes_e = 0, lanes_f = 0, lanes_all = 0, lanes_chunk = 0;
+  GenItems items;   // over the F blocks (all blocks without an elimination order); count == 0: none
 };
 enum GenPart { kAll = 0, kE = 1, kF = 2 };
 

@@ -750,6 +750,171 @@ hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, i
   if (G.num_rows > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, part, x, y, status);
   return hipGetLastError();
 }
+// ---- itemized forms: one wave per ITEM (device.h: GenItems), partial results to scratch, a second kernel adds a block's items up ----
+template <int MAXC>
+__global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructure G, const double* __restrict__ v, int part, const double* __restrict__ x,
+                                                                     const int* status) {
+  if (status && *status != 0) return;
+  const int item = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
+  if (item >= G.items.count) return;
+  const int lane = threadIdx.x & 63;
+  const int j = G.items.block[item];
+  const int cs = G.csz[j];
+  double s[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) s[c] = 0.0;
+  for (int t = G.items.t0[item] + lane; t < G.items.t1[item]; t += 64) {
+    const int i = G.trow[t], k = G.tcell[t];
+    if (!cell_in_part(G, i, k, part)) continue;
+    const double* a = v + G.cval[k];
+    const double* xx = x + G.rpos[i];
+    const int rs = G.rsz[i];
+    for (int r = 0; r < rs; ++r) {
+      const double xr = xx[r];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+    }
+  }
+  double* out = G.items.scratch + int64_t(item) * kGenItemValues;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const double t = group_sum<64>(s[c]);
+    if (lane == c) out[c] = t;
+  }
+}
+// y[cpos(j) - ybase + c] += the items' partial sums, in list order; one thread per (block, column)
+__global__ __launch_bounds__(kB) void gen_left_multiply_combine_kernel(GenStructure G, int ybase, double* __restrict__ y, const int* status) {
+  if (status && *status != 0) return;
+  const int idx = blockIdx.x * kB + threadIdx.x;
+  const int q = idx / kMaxGenericBlock, c = idx % kMaxGenericBlock;
+  if (q >= G.items.nblocks) return;
+  const int j = G.items.first_block + q;
+  if (c >= G.csz[j]) return;
+  double s = 0.0;
+  for (int it = G.items.block_ptr[q]; it < G.items.block_ptr[q + 1]; ++it) s += G.items.scratch[int64_t(it) * kGenItemValues + c];
+  y[G.cpos[j] - ybase + c] += s;
+}
+
+// Per item: the packed upper triangle (10 x 10 layout) of sum A^T A over the item's cells (schur == 0), or of the item's share of the
+// Schur complement's diagonal block (schur != 0: see gen_schur_jacobi_grouped_kernel; an item never cuts a chunk's run of cells).
+template <int MAXE, int MAXC>
+__global__ __launch_bounds__(kB) void gen_block_items_kernel(GenStructure G, const double* __restrict__ v, int part, int schur,
+                                                             const double* __restrict__ ete_inv) {
+  constexpr int NT = MAXC * (MAXC + 1) / 2;
+  static_assert(NT <= kGenItemValues, "scratch row");
+  const int item = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
+  if (item >= G.items.count) return;
+  const int lane = threadIdx.x & 63;
+  const int j = G.items.block[item];
+  const int n = G.csz[j];
+  double acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = 0.0;
+  const int t0 = G.items.t0[item], t1 = G.items.t1[item];
+  for (int t = t0 + lane; t < t1; t += 64) {
+    const int i = G.trow[t];
+    if (!schur) {
+      const int k = G.tcell[t];
+      if (!cell_in_part(G, i, k, part)) continue;
+      const double* m = v + G.cval[k];
+      const int rs = G.rsz[i];
+      for (int r = 0; r < rs; ++r) {
+        double row[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) row[c] = c < n ? m[r * n + c] : 0.0;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+          for (int b = a; b < MAXC; ++b) acc[idx++] += row[a] * row[b];
+      }
+      continue;
+    }
+    const int e = G.row_e_block[i];
+    if (e >= 0 && t > t0 && G.row_e_block[G.trow[t - 1]] == e) continue;   // not the first cell of j in its chunk
+    const int es = e >= 0 ? G.csz[e] : 0;
+    double g[MAXE][MAXC];
+#pragma unroll
+    for (int p = 0; p < MAXE; ++p)
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) g[p][c] = 0.0;
+    for (int tt = t; tt < t1; ++tt) {   // the run of j's cells in this chunk (an E-free row: itself alone)
+      const int ii = G.trow[tt];
+      if (tt > t && (e < 0 || G.row_e_block[ii] != e)) break;
+      const double* f = v + G.cval[G.tcell[tt]];
+      const double* E = e >= 0 ? v + G.cval[G.rptr[ii]] : nullptr;
+      const int rs = G.rsz[ii];
+      for (int r = 0; r < rs; ++r) {
+        double row[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) row[c] = c < n ? f[r * n + c] : 0.0;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+          for (int b = a; b < MAXC; ++b) acc[idx++] += row[a] * row[b];
+        if (e >= 0) {
+#pragma unroll
+          for (int p = 0; p < MAXE; ++p) {
+            const double ep = p < es ? E[r * es + p] : 0.0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) g[p][c] += ep * row[c];
+          }
+        }
+      }
+    }
+    if (e >= 0) {
+      const double* inv = ete_inv + G.diag_off_e[e];
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < MAXC; ++a) {
+        double wa[MAXE];   // column a of (E^T E)^-1 G ... by symmetry of the inverse: row a of G^T (E^T E)^-1
+#pragma unroll
+        for (int p = 0; p < MAXE; ++p) {
+          double x = 0.0;
+#pragma unroll
+          for (int q = 0; q < MAXE; ++q) if (p < es && q < es) x += inv[q * es + p] * g[q][a];
+          wa[p] = x;
+        }
+#pragma unroll
+        for (int b = a; b < MAXC; ++b) {
+          double sub = 0.0;
+#pragma unroll
+          for (int p = 0; p < MAXE; ++p) sub += wa[p] * g[p][b];
+          acc[idx++] -= sub;
+        }
+      }
+    }
+  }
+  double* out = G.items.scratch + int64_t(item) * kGenItemValues;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const double t = group_sum<64>(acc[i]);
+    if (lane == (i & 63)) out[i] = t;
+  }
+}
+// blocks(j) = the items' partial triangles added in list order (+ D^2), mirrored; one thread per (block, entry of the MAXC triangle)
+template <int MAXC>
+__global__ __launch_bounds__(kB) void gen_block_items_combine_kernel(GenStructure G, const int64_t* __restrict__ off, int first, const double* __restrict__ D,
+                                                                     double* __restrict__ blocks) {
+  constexpr int NT = MAXC * (MAXC + 1) / 2;
+  const int idx = blockIdx.x * kB + threadIdx.x;
+  const int q = idx / NT, e = idx % NT;
+  if (q >= G.items.nblocks) return;
+  const int j = G.items.first_block + q;
+  const int n = G.csz[j];
+  int a = 0, rem = e;   // entry e of the MAXC triangle -> (a, b)
+  while (rem >= MAXC - a) { rem -= MAXC - a; ++a; }
+  const int b = a + rem;
+  if (a >= n || b >= n) return;
+  double s = 0.0;
+  for (int it = G.items.block_ptr[q]; it < G.items.block_ptr[q + 1]; ++it) s += G.items.scratch[int64_t(it) * kGenItemValues + e];
+  if (D && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+  double* o = blocks + (off[j - first] - off[0]);
+  o[a * n + b] = s;
+  o[b * n + a] = s;
+}
+
 // L lanes per group: dispatch of a grouped kernel over the compiled group widths
 #define GEN_DISPATCH_L(L_, CALL)            \
   switch (L_) {                             \
@@ -779,7 +944,13 @@ hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, in
   const int ybase = part == kF ? G.nce : 0;
   if (part != kF && G.nelim > 0) { GEN_DISPATCH_L(G.lanes_e, (launch_left_grouped<L>(G, values, part, 0, G.nelim, ybase, G.max_csz_e, x, y, status, s))) }
   if (part != kE && G.ncb > G.nelim) {
-    if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_left_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, ybase, G.max_csz_f, x, y, status, s))) }
+    if (G.items.count > 0 && G.items.first_block == G.nelim) {   // heavy blocks: a wave per item, then the items of a block in order
+      const dim3 grid((G.items.count + kB / 64 - 1) / (kB / 64));
+      if (G.max_csz_f <= 4 && G.nelim > 0) hipLaunchKernelGGL((gen_left_multiply_items_kernel<4>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      else if ((G.nelim > 0 ? G.max_csz_f : G.max_csz) <= 10) hipLaunchKernelGGL((gen_left_multiply_items_kernel<10>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      else hipLaunchKernelGGL((gen_left_multiply_items_kernel<kMaxGenericBlock>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      hipLaunchKernelGGL(gen_left_multiply_combine_kernel, dim3(blocks_for(int64_t(G.items.nblocks) * kMaxGenericBlock)), dim3(kB), 0, s, G, ybase, y, status);
+    } else if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_left_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, ybase, G.max_csz_f, x, y, status, s))) }
     else { GEN_DISPATCH_L(G.lanes_all, (launch_left_grouped<L>(G, values, part, 0, G.ncb, ybase, G.max_csz, x, y, status, s))) }
   }
   return hipGetLastError();
@@ -874,7 +1045,10 @@ hipError_t LaunchGenBlockDiagonal(const GenStructure& G, const double* values, i
   const int first = part == kF ? G.nelim : 0;
   if (part != kF && G.nelim > 0) { GEN_DISPATCH_L(G.lanes_e, (launch_block_diagonal_grouped<L>(G, values, part, 0, G.nelim, off, first, G.max_csz_e, D, blocks, s))) }
   if (part != kE && G.ncb > G.nelim) {
-    if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_block_diagonal_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, off, first, G.max_csz_f, D, blocks, s))) }
+    if (G.items.count > 0 && G.items.first_block == G.nelim) {
+      hipLaunchKernelGGL((gen_block_items_kernel<4, 10>), dim3((G.items.count + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, values, part, 0, nullptr);
+      hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3(blocks_for(int64_t(G.items.nblocks) * 55)), dim3(kB), 0, s, G, off, first, D, blocks);
+    } else if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_block_diagonal_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, off, first, G.max_csz_f, D, blocks, s))) }
     else { GEN_DISPATCH_L(G.lanes_all, (launch_block_diagonal_grouped<L>(G, values, part, 0, G.ncb, off, first, G.max_csz, D, blocks, s))) }
   }
   return hipGetLastError();
@@ -890,6 +1064,12 @@ hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, con
   if (total <= 0) return hipSuccess;
   if (G.lanes_f == 0 || G.max_csz_e > 4 || G.max_csz_f > 10) {
     hipLaunchKernelGGL(gen_schur_jacobi_kernel, dim3(blocks_for(total)), dim3(kB), 0, s, G, values, ete_inv, D, add_f_diag, blocks);
+    return hipGetLastError();
+  }
+  if (G.items.count > 0 && G.items.first_block == G.nelim) {
+    hipLaunchKernelGGL((gen_block_items_kernel<4, 10>), dim3((G.items.count + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, values, int(kF), 1, ete_inv);
+    hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3(blocks_for(int64_t(G.items.nblocks) * 55)), dim3(kB), 0, s, G, G.diag_off_f, G.nelim,
+                       add_f_diag ? D : nullptr, blocks);
     return hipGetLastError();
   }
   GEN_DISPATCH_L(G.lanes_f, (launch_schur_jacobi_grouped<L>(G, values, ete_inv, D, add_f_diag, blocks, s)))

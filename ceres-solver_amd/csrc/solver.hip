@@ -1801,6 +1801,36 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       G.lanes_f = lanes_for(h.ncb > h.nelim ? double(cells_f) / (h.ncb - h.nelim) : 0.0);
       G.lanes_all = lanes_for(h.ncb > 0 ? double(cells_e + cells_f) / h.ncb : 0.0);
       G.lanes_chunk = (h.chunks_contiguous && h.nelim > 0) ? lanes_for(double(h.num_row_blocks_e) / h.nelim) : 0;
+      // heavy column blocks (the F blocks; every block without an elimination order): ITEMS of <= kGenItem cells (device.h)
+      const int j0 = h.nelim, nb = h.ncb - h.nelim;
+      int max_cells = 0;
+      for (int j = j0; j < h.ncb; ++j) max_cells = std::max(max_cells, h.tptr[j + 1] - h.tptr[j]);
+      if (nb > 0 && ((h.nelim > 0 ? G.lanes_f : G.lanes_all) == 64 || max_cells > 8 * kGenItem)) {
+        std::vector<int32_t> ib, i0, i1, bp(nb + 1, 0);
+        for (int q = 0; q < nb; ++q) {
+          const int j = j0 + q;
+          bp[q] = int32_t(ib.size());
+          int t = h.tptr[j];
+          const int te = h.tptr[j + 1];
+          do {   // (a block without cells still gets one empty item: its block is written, D^2 joins the diagonal)
+            int cut = std::min(te, t + kGenItem);
+            // the cells a block has inside ONE chunk stay together (the Schur complement's diagonal block couples them)
+            while (cut < te && cut > t && h.row_e_block[h.trow[cut]] >= 0 && h.row_e_block[h.trow[cut]] == h.row_e_block[h.trow[cut - 1]]) ++cut;
+            ib.push_back(j); i0.push_back(t); i1.push_back(cut);
+            t = cut;
+          } while (t < te);
+        }
+        bp[nb] = int32_t(ib.size());
+        int32_t* q32 = nullptr;
+        TRY(dev_upload(s, &q32, ib)); G.items.block = q32;
+        TRY(dev_upload(s, &q32, i0)); G.items.t0 = q32;
+        TRY(dev_upload(s, &q32, i1)); G.items.t1 = q32;
+        TRY(dev_upload(s, &q32, bp)); G.items.block_ptr = q32;
+        G.items.count = int(ib.size()); G.items.first_block = j0; G.items.nblocks = nb;
+        double* sc = nullptr;
+        TRY(dev_alloc(s, &sc, size_t(ib.size()) * kGenItemValues));
+        G.items.scratch = sc;
+      }
     }
   }
 
@@ -1974,6 +2004,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       const int r0 = P.rem_row0, nr = P.n_rem_rows, k0 = h.rptr[r0];
       GenStructure& R = s->GR;
       R = s->G;
+      R.items = GenItems();   // (G's items and group widths describe G's transpose lists, not the remainder's)
+      R.lanes_e = R.lanes_f = R.lanes_all = R.lanes_chunk = 0;
       R.nrb = nr; R.nrbe = 0;
       s->rem_b0 = h.rpos[r0];
       s->rem_rows = h.num_rows - h.rpos[r0];
