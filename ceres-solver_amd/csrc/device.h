@@ -225,6 +225,9 @@ struct GenStructure {
   const int32_t *rsz = nullptr, *rpos = nullptr, *rptr = nullptr, *ccol = nullptr, *cval = nullptr;
   const int32_t *csz = nullptr, *cpos = nullptr;
   const int32_t *tptr = nullptr, *trow = nullptr, *tcell = nullptr;
+  // per transpose entry, what the itemized kernels would otherwise chase through three more arrays: the cell's value offset, its row
+  // block's first scalar row, and the row block's height | (1 << 8 if the cell is the E cell of its row)
+  const int32_t *tval = nullptr, *trpos = nullptr, *tinfo = nullptr;
   const int32_t *row_block_of = nullptr, *col_block_of = nullptr, *row_e_block = nullptr;
   const int64_t *diag_off_all = nullptr, *diag_off_e = nullptr, *diag_off_f = nullptr;
   // chunk = the (contiguous) rows of one E block: SchurEliminator's unit of work (I/schur_eliminator_impl.h:87-181)

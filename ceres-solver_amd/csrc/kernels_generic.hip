@@ -751,7 +751,10 @@ hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, i
   return hipGetLastError();
 }
 // ---- itemized forms: one wave per ITEM (device.h: GenItems), partial results to scratch, a second kernel adds a block's items up ----
-template <int MAXC>
+// is transpose entry t (info word) in `part`?
+__device__ __forceinline__ bool info_in_part(int info, int part) { return part == kAll || ((info >> 8) & 1) == (part == kE ? 1 : 0); }
+
+template <int MAXC, int MAXR>
 __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructure G, const double* __restrict__ v, int part, const double* __restrict__ x,
                                                                      const int* status) {
   if (status && *status != 0) return;
@@ -763,16 +766,32 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructur
   double s[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) s[c] = 0.0;
-  for (int t = G.items.t0[item] + lane; t < G.items.t1[item]; t += 64) {
-    const int i = G.trow[t], k = G.tcell[t];
-    if (!cell_in_part(G, i, k, part)) continue;
-    const double* a = v + G.cval[k];
-    const double* xx = x + G.rpos[i];
-    const int rs = G.rsz[i];
-    for (int r = 0; r < rs; ++r) {
-      const double xr = xx[r];
+  const int t1 = G.items.t1[item];
+  // two cells per lane and round: their loads are independent and all in flight together (rows up to MAXR high: fully unrolled, predicated)
+  for (int t = G.items.t0[item] + lane; t < t1; t += 128) {
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+    for (int h = 0; h < 2; ++h) {
+      const int tt = t + 64 * h;
+      const bool on = tt < t1;
+      const int ts = on ? tt : t;
+      const int info = G.tinfo[ts];
+      const int rs = (on && info_in_part(info, part)) ? (info & 0xff) : 0;
+      const double* a = v + G.tval[ts];
+      const double* xx = x + G.trpos[ts];
+      if constexpr (MAXR <= 4) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+          const double xr = r < rs ? xx[r] : 0.0;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) if (c < cs && r < rs) s[c] += a[r * cs + c] * xr;
+        }
+      } else {
+        for (int r = 0; r < rs; ++r) {
+          const double xr = xx[r];
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+        }
+      }
     }
   }
   double* out = G.items.scratch + int64_t(item) * kGenItemValues;
@@ -782,17 +801,28 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructur
     if (lane == c) out[c] = t;
   }
 }
-// y[cpos(j) - ybase + c] += the items' partial sums, in list order; one thread per (block, column)
+// y[cpos(j) - ybase + c] += the items' partial sums: a wave per block, lane l adds the items l, l + 64, ... (fixed order), the lanes'
+// sums combine by butterfly; lane c stores column c
 __global__ __launch_bounds__(kB) void gen_left_multiply_combine_kernel(GenStructure G, int ybase, double* __restrict__ y, const int* status) {
   if (status && *status != 0) return;
-  const int idx = blockIdx.x * kB + threadIdx.x;
-  const int q = idx / kMaxGenericBlock, c = idx % kMaxGenericBlock;
+  const int q = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
   if (q >= G.items.nblocks) return;
+  const int lane = threadIdx.x & 63;
   const int j = G.items.first_block + q;
-  if (c >= G.csz[j]) return;
-  double s = 0.0;
-  for (int it = G.items.block_ptr[q]; it < G.items.block_ptr[q + 1]; ++it) s += G.items.scratch[int64_t(it) * kGenItemValues + c];
-  y[G.cpos[j] - ybase + c] += s;
+  const int cs = G.csz[j];
+  double s[kMaxGenericBlock];
+#pragma unroll
+  for (int c = 0; c < kMaxGenericBlock; ++c) s[c] = 0.0;
+  for (int it = G.items.block_ptr[q] + lane; it < G.items.block_ptr[q + 1]; it += 64) {
+    const double* p = G.items.scratch + int64_t(it) * kGenItemValues;
+#pragma unroll
+    for (int c = 0; c < kMaxGenericBlock; ++c) if (c < cs) s[c] += p[c];
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxGenericBlock; ++c) {
+    const double t = group_sum<64>(s[c]);
+    if (lane == c && c < cs) y[G.cpos[j] - ybase + c] += t;
+  }
 }
 
 // Per item: the packed upper triangle (10 x 10 layout) of sum A^T A over the item's cells (schur == 0), or of the item's share of the
@@ -812,12 +842,12 @@ __global__ __launch_bounds__(kB) void gen_block_items_kernel(GenStructure G, con
   for (int i = 0; i < NT; ++i) acc[i] = 0.0;
   const int t0 = G.items.t0[item], t1 = G.items.t1[item];
   for (int t = t0 + lane; t < t1; t += 64) {
-    const int i = G.trow[t];
+    const int i = schur ? G.trow[t] : 0;
     if (!schur) {
-      const int k = G.tcell[t];
-      if (!cell_in_part(G, i, k, part)) continue;
-      const double* m = v + G.cval[k];
-      const int rs = G.rsz[i];
+      const int info = G.tinfo[t];
+      if (!info_in_part(info, part)) continue;
+      const double* m = v + G.tval[t];
+      const int rs = info & 0xff;
       for (int r = 0; r < rs; ++r) {
         double row[MAXC];
 #pragma unroll
@@ -893,26 +923,39 @@ __global__ __launch_bounds__(kB) void gen_block_items_kernel(GenStructure G, con
     if (lane == (i & 63)) out[i] = t;
   }
 }
-// blocks(j) = the items' partial triangles added in list order (+ D^2), mirrored; one thread per (block, entry of the MAXC triangle)
+// blocks(j) = the items' partial triangles (+ D^2), mirrored: a wave per block, lane l adds the items l, l + 64, ... entry by entry,
+// the lanes' sums combine by butterfly (a fixed tree: deterministic)
 template <int MAXC>
 __global__ __launch_bounds__(kB) void gen_block_items_combine_kernel(GenStructure G, const int64_t* __restrict__ off, int first, const double* __restrict__ D,
                                                                      double* __restrict__ blocks) {
   constexpr int NT = MAXC * (MAXC + 1) / 2;
-  const int idx = blockIdx.x * kB + threadIdx.x;
-  const int q = idx / NT, e = idx % NT;
+  const int q = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
   if (q >= G.items.nblocks) return;
+  const int lane = threadIdx.x & 63;
   const int j = G.items.first_block + q;
   const int n = G.csz[j];
-  int a = 0, rem = e;   // entry e of the MAXC triangle -> (a, b)
-  while (rem >= MAXC - a) { rem -= MAXC - a; ++a; }
-  const int b = a + rem;
-  if (a >= n || b >= n) return;
-  double s = 0.0;
-  for (int it = G.items.block_ptr[q]; it < G.items.block_ptr[q + 1]; ++it) s += G.items.scratch[int64_t(it) * kGenItemValues + e];
-  if (D && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+  double acc[NT];
+#pragma unroll
+  for (int e = 0; e < NT; ++e) acc[e] = 0.0;
+  for (int it = G.items.block_ptr[q] + lane; it < G.items.block_ptr[q + 1]; it += 64) {
+    const double* p = G.items.scratch + int64_t(it) * kGenItemValues;
+#pragma unroll
+    for (int e = 0; e < NT; ++e) acc[e] += p[e];
+  }
   double* o = blocks + (off[j - first] - off[0]);
-  o[a * n + b] = s;
-  o[b * n + a] = s;
+  int e = 0;
+#pragma unroll
+  for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+    for (int b = a; b < MAXC; ++b) {
+      double s = group_sum<64>(acc[e]);
+      if (a < n && b < n && lane == (e & 63)) {
+        if (D && a == b) { const double d = D[G.cpos[j] + a]; s += d * d; }
+        o[a * n + b] = s;
+        o[b * n + a] = s;
+      }
+      ++e;
+    }
 }
 
 // L lanes per group: dispatch of a grouped kernel over the compiled group widths
@@ -946,10 +989,12 @@ hipError_t LaunchGenLeftMultiply(const GenStructure& G, const double* values, in
   if (part != kE && G.ncb > G.nelim) {
     if (G.items.count > 0 && G.items.first_block == G.nelim) {   // heavy blocks: a wave per item, then the items of a block in order
       const dim3 grid((G.items.count + kB / 64 - 1) / (kB / 64));
-      if (G.max_csz_f <= 4 && G.nelim > 0) hipLaunchKernelGGL((gen_left_multiply_items_kernel<4>), grid, dim3(kB), 0, s, G, values, part, x, status);
-      else if ((G.nelim > 0 ? G.max_csz_f : G.max_csz) <= 10) hipLaunchKernelGGL((gen_left_multiply_items_kernel<10>), grid, dim3(kB), 0, s, G, values, part, x, status);
-      else hipLaunchKernelGGL((gen_left_multiply_items_kernel<kMaxGenericBlock>), grid, dim3(kB), 0, s, G, values, part, x, status);
-      hipLaunchKernelGGL(gen_left_multiply_combine_kernel, dim3(blocks_for(int64_t(G.items.nblocks) * kMaxGenericBlock)), dim3(kB), 0, s, G, ybase, y, status);
+      const int mc = G.nelim > 0 ? G.max_csz_f : G.max_csz;
+      if (mc <= 4 && G.max_rsz <= 4) hipLaunchKernelGGL((gen_left_multiply_items_kernel<4, 4>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      else if (mc <= 10 && G.max_rsz <= 2) hipLaunchKernelGGL((gen_left_multiply_items_kernel<10, 2>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      else if (mc <= 10) hipLaunchKernelGGL((gen_left_multiply_items_kernel<10, kMaxGenericBlock>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      else hipLaunchKernelGGL((gen_left_multiply_items_kernel<kMaxGenericBlock, kMaxGenericBlock>), grid, dim3(kB), 0, s, G, values, part, x, status);
+      hipLaunchKernelGGL(gen_left_multiply_combine_kernel, dim3((G.items.nblocks + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, ybase, y, status);
     } else if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_left_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, ybase, G.max_csz_f, x, y, status, s))) }
     else { GEN_DISPATCH_L(G.lanes_all, (launch_left_grouped<L>(G, values, part, 0, G.ncb, ybase, G.max_csz, x, y, status, s))) }
   }
@@ -1047,7 +1092,7 @@ hipError_t LaunchGenBlockDiagonal(const GenStructure& G, const double* values, i
   if (part != kE && G.ncb > G.nelim) {
     if (G.items.count > 0 && G.items.first_block == G.nelim) {
       hipLaunchKernelGGL((gen_block_items_kernel<4, 10>), dim3((G.items.count + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, values, part, 0, nullptr);
-      hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3(blocks_for(int64_t(G.items.nblocks) * 55)), dim3(kB), 0, s, G, off, first, D, blocks);
+      hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3((G.items.nblocks + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, off, first, D, blocks);
     } else if (G.nelim > 0) { GEN_DISPATCH_L(G.lanes_f, (launch_block_diagonal_grouped<L>(G, values, part, G.nelim, G.ncb - G.nelim, off, first, G.max_csz_f, D, blocks, s))) }
     else { GEN_DISPATCH_L(G.lanes_all, (launch_block_diagonal_grouped<L>(G, values, part, 0, G.ncb, off, first, G.max_csz, D, blocks, s))) }
   }
@@ -1068,7 +1113,7 @@ hipError_t LaunchGenSchurJacobi(const GenStructure& G, const double* values, con
   }
   if (G.items.count > 0 && G.items.first_block == G.nelim) {
     hipLaunchKernelGGL((gen_block_items_kernel<4, 10>), dim3((G.items.count + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, values, int(kF), 1, ete_inv);
-    hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3(blocks_for(int64_t(G.items.nblocks) * 55)), dim3(kB), 0, s, G, G.diag_off_f, G.nelim,
+    hipLaunchKernelGGL((gen_block_items_combine_kernel<10>), dim3((G.items.nblocks + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, G, G.diag_off_f, G.nelim,
                        add_f_diag ? D : nullptr, blocks);
     return hipGetLastError();
   }

@@ -1782,6 +1782,15 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   UP32(row_block_of, h.row_block_of); UP32(col_block_of, h.col_block_of); UP32(row_e_block, h.row_e_block);
   UP64(diag_off_all, h.diag_off_all); UP64(diag_off_e, h.diag_off_e); UP64(diag_off_f, h.diag_off_f);
   if (h.chunks_contiguous && h.nelim > 0) { UP32(chunk_start, h.chunk_start); UP32(chunk_size, h.chunk_size); }
+  {
+    std::vector<int32_t> tval(h.ncells), trpos(h.ncells), tinfo(h.ncells);
+    for (int t = 0; t < h.ncells; ++t) {
+      const int i = h.trow[t], k = h.tcell[t];
+      tval[t] = h.cval[k]; trpos[t] = h.rpos[i];
+      tinfo[t] = h.rsz[i] | ((i < h.num_row_blocks_e && k == h.rptr[i]) ? 256 : 0);
+    }
+    UP32(tval, tval); UP32(trpos, trpos); UP32(tinfo, tinfo);
+  }
 #undef UP32
 #undef UP64
   {
