@@ -262,6 +262,13 @@ hipError_t LaunchGenInvertBlocks(const GenStructure& G, int first_block, int nbl
 // (the caller then runs the separate passes).
 hipError_t LaunchGenChunkProject(const GenStructure& G, const double* values, const double* ete_inv, double* t_rows, int update_t,
                                  double* x_e, const int* status, hipStream_t stream);
+// z_rows (rows of the chunks) = F x_f - E (E^T E)^-1 E^T F x_f in one launch (the row-space half of S x); hipErrorNotSupported beyond the
+// compiled block sizes.  Rows WITHOUT an E block are not touched: LaunchGenRightMultiplyFrom(first_row = their first scalar row).
+hipError_t LaunchGenChunkSx(const GenStructure& G, const double* values, const double* ete_inv, const double* x_f, double* z_rows,
+                            const int* status, hipStream_t stream);
+// LaunchGenRightMultiply over the scalar rows [first_row, num_rows)
+hipError_t LaunchGenRightMultiplyFrom(const GenStructure& G, const double* values, int part, int first_row, const double* x, double* y,
+                                      const int* status, hipStream_t stream);
 // y += blockdiag x over column blocks [first_block, first_block+nblocks); vectors start at that block.
 hipError_t LaunchGenBlockDiagonalApply(const GenStructure& G, int first_block, int nblocks, const int64_t* diag_off,
                                        const double* blocks, const double* x, double* y, const int* status,

@@ -38,9 +38,9 @@ __device__ __forceinline__ bool cell_in_part(const GenStructure& G, int i, int k
 
 __global__ __launch_bounds__(kB) void gen_right_multiply_kernel(GenStructure G, const double* __restrict__ v, int part,
                                                                 const double* __restrict__ x, double* __restrict__ y,
-                                                                const int* status) {
+                                                                const int* status, int first_row) {
   if (status && *status != 0) return;
-  const int row = blockIdx.x * kB + threadIdx.x;
+  const int row = first_row + blockIdx.x * kB + threadIdx.x;
   if (row >= G.num_rows) return;
   const int i = G.row_block_of[row];
   const int r = row - G.rpos[i];
@@ -469,6 +469,104 @@ __global__ __launch_bounds__(kB) void gen_chunk_project_kernel(GenStructure G, c
   }
 }
 
+// The row-space half of S x in ONE launch, a group per chunk: z_r = t_r - E_r (E^T E)^-1 sum_r' E_r'^T t_r' with t_r = sum over the
+// row's F cells of F x_f — what RightMultiplyF, LeftMultiplyE, the block-diagonal solve and RightMultiplyE do in
+// ImplicitSchurComplement::RightMultiplyAndAccumulate (I/implicit_schur_complement.cc:106-144); z goes to `z_rows`, F^T z follows
+// (LaunchGenLeftMultiply).  Rows up to MAXR high, E up to MAXE wide, F cells up to MAXC wide: every load of a cell is issued
+// unconditionally (clamped), see gen_left_multiply_items_kernel.  A lane whose chunk has more than L rows recomputes t in the second sweep.
+template <int L, int MAXR, int MAXE, int MAXC>
+__global__ __launch_bounds__(kB) void gen_chunk_sx_kernel(GenStructure G, const double* __restrict__ v, const double* __restrict__ ete_inv,
+                                                          const double* __restrict__ x_f, double* __restrict__ z_rows, const int* status) {
+  if (status && *status != 0) return;
+  const int64_t grp = (int64_t(blockIdx.x) * kB + threadIdx.x) / L;
+  const int gl = threadIdx.x & (L - 1);
+  if (grp >= G.nelim) return;
+  const int e = int(grp);
+  const int es = G.csz[e];
+  const int i0 = G.chunk_start[e], i1 = i0 + G.chunk_size[e];
+  auto f_times_x = [&](int i, int rs, double (&t)[MAXR]) {
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) t[r] = 0.0;
+    for (int k = G.rptr[i] + 1; k < G.rptr[i + 1]; ++k) {
+      const int j = G.ccol[k];
+      const int cs = G.csz[j];
+      const double* a = v + G.cval[k];
+      const double* xx = x_f + (G.cpos[j] - G.nce);
+      const int last = rs * cs - 1;
+      double av[MAXR][MAXC], xv[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) xv[c] = xx[c < cs ? c : 0];
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { const int q = r * cs + c; av[r][c] = a[q < last ? q : last]; }
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) t[r] += (c < cs && r < rs) ? av[r][c] * xv[c] : 0.0;
+    }
+  };
+  auto load_e = [&](int i, int rs, double (&E)[MAXR][MAXE]) {
+    const double* m = v + G.cval[G.rptr[i]];
+    const int last = rs * es - 1;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+      for (int p = 0; p < MAXE; ++p) { const int q = r * es + p; const double val = m[q < last ? q : last]; E[r][p] = (r < rs && p < es) ? val : 0.0; }
+  };
+  double u[MAXE], t_first[MAXR], E_first[MAXR][MAXE];
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) u[p] = 0.0;
+  for (int i = i0 + gl; i < i1; i += L) {
+    const int rs = G.rsz[i];
+    double t[MAXR], E[MAXR][MAXE];
+    f_times_x(i, rs, t);
+    load_e(i, rs, E);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+      for (int p = 0; p < MAXE; ++p) u[p] += E[r][p] * t[r];
+    if (i == i0 + gl) {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) { t_first[r] = t[r];
+#pragma unroll
+        for (int p = 0; p < MAXE; ++p) E_first[r][p] = E[r][p]; }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) u[p] = group_sum<L>(u[p]);
+  const double* inv = ete_inv + G.diag_off_e[e];
+  double w[MAXE];
+#pragma unroll
+  for (int p = 0; p < MAXE; ++p) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) if (p < es && q < es) a += inv[p * es + q] * u[q];
+    w[p] = a;
+  }
+  for (int i = i0 + gl; i < i1; i += L) {
+    const int rs = G.rsz[i];
+    double t[MAXR], E[MAXR][MAXE];
+    if (i == i0 + gl) {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) { t[r] = t_first[r];
+#pragma unroll
+        for (int p = 0; p < MAXE; ++p) E[r][p] = E_first[r][p]; }
+    } else {
+      f_times_x(i, rs, t);
+      load_e(i, rs, E);
+    }
+    double* zz = z_rows + G.rpos[i];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      double a = t[r];
+#pragma unroll
+      for (int p = 0; p < MAXE; ++p) a -= E[r][p] * w[p];
+      if (r < rs) zz[r] = a;
+    }
+  }
+}
+
 // blocks(j) = sum over the cells of column block j (in `part`) of A^T A (+ D^2), j in [j0, j0 + nb); off = the offsets of the store
 // the blocks live in, indexed by j - first (first = the store's first block)
 template <int L, int MAXC>
@@ -747,7 +845,7 @@ hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode,
 
 hipError_t LaunchGenRightMultiply(const GenStructure& G, const double* values, int part, const double* x, double* y,
                                   const int* status, hipStream_t s) {
-  if (G.num_rows > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, part, x, y, status);
+  if (G.num_rows > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, part, x, y, status, 0);
   return hipGetLastError();
 }
 // ---- itemized forms: one wave per ITEM (device.h: GenItems), partial results to scratch, a second kernel adds a block's items up ----
@@ -779,12 +877,21 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructur
       const double* a = v + G.tval[ts];
       const double* xx = x + G.trpos[ts];
       if constexpr (MAXR <= 4) {
+        // every load of the cell is issued unconditionally, back to back (addresses clamped into the cell; what lies outside is
+        // selected away afterwards): loads under a predicate are separated by waits, and a 144-byte cell read by eighteen loads that
+        // are far apart in time is fetched from the L2 eighteen times — 64 lanes x 3 lines x the waves of a CU do not fit its L1
+        const int last = rs > 0 ? rs * cs - 1 : 0;
+        double av[MAXR][MAXC], xv[MAXR];
 #pragma unroll
         for (int r = 0; r < MAXR; ++r) {
-          const double xr = r < rs ? xx[r] : 0.0;
+          xv[r] = xx[r < rs ? r : 0];
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) if (c < cs && r < rs) s[c] += a[r * cs + c] * xr;
+          for (int c = 0; c < MAXC; ++c) { const int e = r * cs + c; av[r][c] = a[e < last ? e : last]; }
         }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) s[c] += (c < cs && r < rs) ? av[r][c] * xv[r] : 0.0;
       } else {
         for (int r = 0; r < rs; ++r) {
           const double xr = xx[r];
@@ -848,6 +955,20 @@ __global__ __launch_bounds__(kB) void gen_block_items_kernel(GenStructure G, con
       if (!info_in_part(info, part)) continue;
       const double* m = v + G.tval[t];
       const int rs = info & 0xff;
+      if (rs <= 2) {   // (the common case) both rows' loads issued together, unconditionally: see gen_left_multiply_items_kernel
+        const int last = rs * n - 1;
+        double row0[MAXC], row1[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { row0[c] = m[c < last ? c : last]; row1[c] = m[n + c < last ? n + c : last]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { row0[c] = c < n ? row0[c] : 0.0; row1[c] = (c < n && rs > 1) ? row1[c] : 0.0; }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a)
+#pragma unroll
+          for (int b = a; b < MAXC; ++b) acc[idx++] += row0[a] * row0[b] + row1[a] * row1[b];
+        continue;
+      }
       for (int r = 0; r < rs; ++r) {
         double row[MAXC];
 #pragma unroll
@@ -1012,6 +1133,26 @@ hipError_t LaunchGenChunkProject(const GenStructure& G, const double* values, co
   if (G.nelim <= 0) return hipSuccess;
   if (G.lanes_chunk == 0 || !G.chunk_start || G.max_csz_e > 10) return hipErrorNotSupported;
   GEN_DISPATCH_L(G.lanes_chunk, (launch_chunk_project<L>(G, values, ete_inv, t_rows, update_t, x_e, status, s)))
+  return hipGetLastError();
+}
+template <int L>
+static void launch_chunk_sx(const GenStructure& G, const double* values, const double* ete_inv, const double* x_f, double* z_rows, const int* status,
+                            hipStream_t s) {
+  const dim3 grid(blocks_for(int64_t(G.nelim) * L));
+  if (G.max_rsz <= 2) hipLaunchKernelGGL((gen_chunk_sx_kernel<L, 2, 4, 10>), grid, dim3(kB), 0, s, G, values, ete_inv, x_f, z_rows, status);
+  else hipLaunchKernelGGL((gen_chunk_sx_kernel<L, 4, 4, 10>), grid, dim3(kB), 0, s, G, values, ete_inv, x_f, z_rows, status);
+}
+hipError_t LaunchGenChunkSx(const GenStructure& G, const double* values, const double* ete_inv, const double* x_f, double* z_rows,
+                            const int* status, hipStream_t s) {
+  if (G.nelim <= 0) return hipSuccess;
+  if (G.lanes_chunk == 0 || !G.chunk_start || G.max_csz_e > 4 || G.max_csz_f > 10 || G.max_rsz > 4) return hipErrorNotSupported;
+  GEN_DISPATCH_L(G.lanes_chunk, (launch_chunk_sx<L>(G, values, ete_inv, x_f, z_rows, status, s)))
+  return hipGetLastError();
+}
+hipError_t LaunchGenRightMultiplyFrom(const GenStructure& G, const double* values, int part, int first_row, const double* x, double* y,
+                                      const int* status, hipStream_t s) {
+  const int n = G.num_rows - first_row;
+  if (n > 0) hipLaunchKernelGGL(gen_right_multiply_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, G, values, part, x, y, status, first_row);
   return hipGetLastError();
 }
 template <int L>

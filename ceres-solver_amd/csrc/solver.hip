@@ -524,10 +524,23 @@ int op_sx(ceres_hip_solver* s, const double* x, double* y, const int* status, do
   }
   const double* v = s->values;
   hipStream_t st = s->stream;
-  HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
-  HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kF, x, s->tmp_rows, status, st));
-  // t -= E (E^T E)^-1 E^T t, chunk by chunk in one launch; block sizes beyond the grouped kernel's: the reference's three passes
-  const hipError_t pe = LaunchGenChunkProject(s->G, v, s->etei, s->tmp_rows, 1, nullptr, status, st);
+  // the row-space half in one launch where the block sizes allow: z = F x - E (E^T E)^-1 E^T F x, a group of lanes per chunk
+  const int first_free_row = h.num_row_blocks_e < h.nrb ? h.rpos[h.num_row_blocks_e] : h.num_rows;   // rows without an E block: z = F x
+  const hipError_t fe = LaunchGenChunkSx(s->G, v, s->etei, x, s->tmp_rows, status, st);
+  hipError_t pe = hipSuccess;
+  if (fe == hipSuccess) {
+    if (first_free_row < h.num_rows) {
+      HIP_TRY(s, hipMemsetAsync(s->tmp_rows + first_free_row, 0, sizeof(double) * (h.num_rows - first_free_row), st));
+      HIP_TRY(s, LaunchGenRightMultiplyFrom(s->G, v, kF, first_free_row, x, s->tmp_rows, status, st));
+    }
+  } else if (fe != hipErrorNotSupported) {
+    HIP_TRY(s, fe);
+  } else {
+    HIP_TRY(s, hipMemsetAsync(s->tmp_rows, 0, sizeof(double) * h.num_rows, st));
+    HIP_TRY(s, LaunchGenRightMultiply(s->G, v, kF, x, s->tmp_rows, status, st));
+    // t -= E (E^T E)^-1 E^T t, chunk by chunk in one launch; block sizes beyond the grouped kernel's: the reference's three passes
+    pe = LaunchGenChunkProject(s->G, v, s->etei, s->tmp_rows, 1, nullptr, status, st);
+  }
   if (pe == hipErrorNotSupported) {
     HIP_TRY(s, hipMemsetAsync(s->tmp_e, 0, sizeof(double) * std::max(1, h.num_cols_e), st));
     HIP_TRY(s, LaunchGenLeftMultiply(s->G, v, kE, s->tmp_rows, s->tmp_e, status, st));
