@@ -138,6 +138,7 @@ def parse():
                     help="default venice1778 run at N=1: also run `--workload synthetic10M` (BASELINE.json configs[4]) in a child process and put a "
                          "condensed result under extra.synthetic10M (0: skip)")
     ap.add_argument("--extra-real-graph", type=int, default=1, help="default line: S.x / JtJx on the replicated libmv visibility graph (extra.real_graph)")
+    ap.add_argument("--extra-other-shapes", type=int, default=1, help="default line: camera widths other than 9, the libmv structure and the generic kernels on the Ladybug shape (extra.other_shapes)")
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=0, help="many-camera workloads: also time the fp32-tile storage mode (extra.fp32_tiles)")
     ap.add_argument("--oracle-check", type=int, default=0,
@@ -199,12 +200,13 @@ def step_min_bytes(solver_kind, n_obs, n_points, n_cameras, cg_iterations, s=8):
     return setup + precond + cg_iterations * (algorithmic_bytes("jtjx", n_obs, n_points, n_cameras, s) + cg_vectors)
 
 
-def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta=0.1):
+def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta=0.1, radius=None):
     tv, tb, tD, tx = ptrs
+    radius = RADIUS if radius is None else radius
 
     def one():
         if step_kind == "lm_step":  # the diagonal is recomputed every step, as after an accepted step
-            s, mcc, finite = solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), RADIUS, eta)
+            s, mcc, finite = solver.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), radius, eta)
             assert finite and mcc > 0, (s, mcc)
             return s
         return solver.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), eta, -1.0)
@@ -494,6 +496,25 @@ def main():
                 del vals_s, res_s
                 pt_cols = torch.from_numpy(bs.col_block_pos[prob.point_of_row].astype(np.int64)).to(dev)
                 cam_cols = torch.from_numpy(bs.col_block_pos[prob.camera_of_row].astype(np.int64)).to(dev)
+                txs = torch.empty_like(tx)
+                # A step in which the hot kernel DOMINATES: the same scene WITHOUT Jacobi scaling (Solver::Options::
+                # jacobi_scaling = false) — focal lengths ~1e3 next to angles make the reduced system badly conditioned, CG needs tens of
+                # iterations, and the step's time is S.x, not set-up.  Same entry point, same solver instance.
+                conditioned = {"what": f"ceres_hip_lm_compute_step_device on the UNSCALED Snavely Jacobian of the {args.workload}-shaped synthetic scene "
+                                       "(jacobi_scaling off): a badly conditioned reduced system, tens of CG iterations per step"}
+                for label, rad_c, eta_c in (("radius_1e4_eta_0.1", 1e4, 0.1), ("radius_1e4_eta_0.01", 1e4, 0.01), ("radius_1e8_eta_0.01", 1e8, 0.01)):
+                    try:
+                        es, its, last_c = timed_steps(solver, (tvs, tbs, None, txs), 5, 1, sync, "lm_step", eta_c, rad_c)
+                        tms = solver.last_timing()
+                        k_it = int(its[-1])
+                        mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
+                        conditioned[label] = {"ms_per_step": round(1e3 * es / 5, 4), "cg_iterations": k_it, "cg_ms": round(tms.cg_ms, 4),
+                                              "cg_share_of_step": round(tms.cg_ms / max(tms.total_ms, 1e-9), 3), "ms_per_cg_iteration": round(tms.cg_ms / max(k_it, 1), 4),
+                                              "termination": hs.TERMINATION_NAMES[last_c.termination_type],
+                                              "step_roofline_frac": round(mb / (es / 5) / 1e9 / HBM_PEAK_GBS, 4)}
+                    except AssertionError as ex:   # (a step the model does not decrease: reported, not fatal)
+                        conditioned[label] = {"error": repr(ex)[:200]}
+                extra["conditioned_step"] = conditioned
                 E, F = tvs[: 6 * n_obs].view(n_obs, 2, 3), tvs[6 * n_obs:].view(n_obs, 2, 9)
                 cn = torch.zeros(bs.num_cols, dtype=torch.float64, device=dev)
                 for c in range(3):
@@ -506,7 +527,6 @@ def main():
                 for c in range(9):
                     F[:, :, c] *= scale[cam_cols + c][:, None]
                 del pt_cols, cam_cols, cn, scale
-                txs = torch.empty_like(tx)
                 scene_step = {"what": f"ceres_hip_lm_compute_step_device on the Jacobi-scaled Snavely Jacobian of the {args.workload}-shaped synthetic scene "
                                       "(values and residuals from the device evaluator at the start point), inputs resident in HBM"}
                 for eta_s in (0.1, 0.01):
@@ -594,6 +614,51 @@ def main():
             extra["real_graph"] = rg
         except Exception as ex:  # the default line must not depend on it
             extra["real_graph"] = {"error": repr(ex)[:300]}
+
+    # ---- the fused path beyond <2,3,9> and the generic path, on the default line ----
+    if world == 1 and args.extra_other_shapes and args.workload == "venice1778" and not storage:
+        try:
+            lb_c, lb_p, lb_o = pkg.problems.BAL_SHAPES["ladybug1723"]
+            shapes = {"what": "S.x / JtJx (HIP events) and one LM step against the oracle for structures other than <2,3,9>, Ladybug-1723 block counts "
+                              "unless stated: bytes per application counted like SURVEY.md §8(d) with the slot's own size", "cases": []}
+            oracle_s = None if args.no_cpu_baseline else entry.load_oracle()
+            if oracle_s is not None:
+                oracle_s.set_num_threads(min(os.cpu_count() or 1, 16))
+            cases = [("<2,3,10> quaternion cameras (bundle_adjuster --use_quaternions)", dict(camera_width=10), False),
+                     ("<2,3,6>", dict(camera_width=6), False),
+                     ("<2,3,9> on the GENERIC kernels (force_generic_path)", dict(camera_width=9), True),
+                     ("libmv structure <2, 8 | 6, 3>: shared intrinsics + 6-wide pose + point, first camera constant", dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)), False)]
+            for label, kw, force_generic in cases:
+                sp = pkg.problems.synthetic_structured(lb_c, lb_p, lb_o, seed=38401, skew=args.skew, **kw)
+                nf_, ns_ = kw["camera_width"], sum(kw.get("shared_widths", ()))
+                slot_b = (6 + 2 * nf_ + 2 * ns_) * 8 + 8
+                n_fs = int(sp.bs.col_block_size[sp.num_eliminate_blocks:].sum())
+                case = {"structure": label, "bytes_per_observation": slot_b}
+                for sv, kd, typ, pre in (("iterative_schur", "sx", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI), ("cgnr", "jtjx", hs.CGNR, hs.JACOBI)):
+                    so_ = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
+                                                                    elimination_groups=[sp.num_eliminate_blocks], device=local_rank, force_generic_path=force_generic))
+                    so_.set_structure(sp.bs)
+                    case["kernel_path"] = "fused" if so_.info().kernel_path == hs.PATH_BAL else "generic"
+                    so_.load(sp.values, sp.b, sp.D)
+                    ms_ = min(so_.time_op(hs.TIMED_SX if kd == "sx" else hs.TIMED_JTJX, 20) for _ in range(3))
+                    nb_ = lb_o * slot_b + (lb_p * 72 + n_fs * 32 if kd == "sx" else (3 * lb_p + n_fs) * 32)
+                    case[kd] = {"ms": round(ms_, 5), "frac": round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    if sv == "iterative_schur":
+                        step_, summ_, mcc_ = so_.lm_compute_step(sp.values, sp.b, RADIUS, args.eta)
+                        case["lm_step"] = {"cg_iterations": summ_.num_iterations, "ms_device": round(so_.last_timing().total_ms - so_.last_timing().upload_ms - so_.last_timing().download_ms, 4)}
+                        if oracle_s is not None:
+                            mo_s = oracle_s.Matrix(sp.bs, sp.num_eliminate_blocks)
+                            Ds = np.sqrt(np.clip(oracle_s.Matrix(sp.bs, 0).squared_column_norm(sp.values), 1e-6, 1e32) / RADIUS)
+                            k_ = int(summ_.num_iterations)
+                            xo_s, so_s = mo_s.iterative_schur_solve(sp.values, sp.b, Ds, preconditioner=2, min_it=k_, max_it=k_, q_tol=-1.0, r_tol=-1.0)
+                            case["lm_step"]["step_rel_diff_vs_oracle_iterate_of_the_same_index"] = float(np.linalg.norm(step_ + xo_s) / np.linalg.norm(xo_s))
+                    so_.close()
+                shapes["cases"].append(case)
+            if oracle_s is not None:
+                oracle_s.set_num_threads(1)
+            extra["other_shapes"] = shapes
+        except Exception as ex:  # the default line must not depend on it
+            extra["other_shapes"] = {"error": repr(ex)[:400]}
 
     # ---- DENSE_SCHUR's factorisation on the matrix pipe (the one real contraction of the path: SURVEY §8 f2) ----
     if world == 1 and args.extra_dense_cholesky and args.workload == "venice1778" and not storage:
@@ -763,8 +828,9 @@ def main():
                                      "what": "minimum HBM bytes of every pass of the step (J in the layout each pass wants; re-layout not counted) / ms_per_step"}
         if roofline_other is not None:
             line["roofline_jtjx" if args.solver == "iterative_schur" else "roofline_sx"] = roofline_other
-        if cpu:  # a reported ratio, not a quality measure (the baseline is a port on 16 threads): kept inside cpu_baseline
-            cpu["gpu_over_cpu"] = round(value / cpu["value"], 2)
+        # what a Ceres process with a CPU evaluator gets through the drop-in boundary (PCIe H2D of J and f every accepted step): next to
+        # `value`, which is the device-resident rate
+        line["value_host_boundary"] = None if host_boundary is None else host_boundary["steps_per_s"]
         print(json.dumps(line), flush=True)
     solver.close()
     if dist is not None:
