@@ -134,6 +134,9 @@ def parse():
     ap.add_argument("--scene-step-steps", type=int, default=10,
                     help="also time this many LM steps at eta = 0.1 and 0.01 on the Jacobi-scaled Jacobian of the synthetic SCENE the device "
                          "evaluator produces (scene_step; N=1, needs --minimizer-iterations > 0; 0: skip)")
+    ap.add_argument("--conditioned-steps", type=int, default=5,
+                    help="also time this many LM steps at eta = 1e-2 / 1e-3 / 1e-4 on a SEQUENCE-like scene (banded camera graph: tens of CG "
+                         "iterations per step; conditioned_step; N=1, needs --minimizer-iterations > 0; 0: skip)")
     ap.add_argument("--extra-synthetic10m", type=int, default=1,
                     help="default venice1778 run at N=1: also run `--workload synthetic10M` (BASELINE.json configs[4]) in a child process and put a "
                          "condensed result under extra.synthetic10M (0: skip)")
@@ -497,24 +500,6 @@ def main():
                 pt_cols = torch.from_numpy(bs.col_block_pos[prob.point_of_row].astype(np.int64)).to(dev)
                 cam_cols = torch.from_numpy(bs.col_block_pos[prob.camera_of_row].astype(np.int64)).to(dev)
                 txs = torch.empty_like(tx)
-                # A step in which the hot kernel DOMINATES: the same scene WITHOUT Jacobi scaling (Solver::Options::
-                # jacobi_scaling = false) — focal lengths ~1e3 next to angles make the reduced system badly conditioned, CG needs tens of
-                # iterations, and the step's time is S.x, not set-up.  Same entry point, same solver instance.
-                conditioned = {"what": f"ceres_hip_lm_compute_step_device on the UNSCALED Snavely Jacobian of the {args.workload}-shaped synthetic scene "
-                                       "(jacobi_scaling off): a badly conditioned reduced system, tens of CG iterations per step"}
-                for label, rad_c, eta_c in (("radius_1e4_eta_0.1", 1e4, 0.1), ("radius_1e4_eta_0.01", 1e4, 0.01), ("radius_1e8_eta_0.01", 1e8, 0.01)):
-                    try:
-                        es, its, last_c = timed_steps(solver, (tvs, tbs, None, txs), 5, 1, sync, "lm_step", eta_c, rad_c)
-                        tms = solver.last_timing()
-                        k_it = int(its[-1])
-                        mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
-                        conditioned[label] = {"ms_per_step": round(1e3 * es / 5, 4), "cg_iterations": k_it, "cg_ms": round(tms.cg_ms, 4),
-                                              "cg_share_of_step": round(tms.cg_ms / max(tms.total_ms, 1e-9), 3), "ms_per_cg_iteration": round(tms.cg_ms / max(k_it, 1), 4),
-                                              "termination": hs.TERMINATION_NAMES[last_c.termination_type],
-                                              "step_roofline_frac": round(mb / (es / 5) / 1e9 / HBM_PEAK_GBS, 4)}
-                    except AssertionError as ex:   # (a step the model does not decrease: reported, not fatal)
-                        conditioned[label] = {"error": repr(ex)[:200]}
-                extra["conditioned_step"] = conditioned
                 E, F = tvs[: 6 * n_obs].view(n_obs, 2, 3), tvs[6 * n_obs:].view(n_obs, 2, 9)
                 cn = torch.zeros(bs.num_cols, dtype=torch.float64, device=dev)
                 for c in range(3):
@@ -540,6 +525,42 @@ def main():
                         "step_roofline_frac": round(mb / (es / args.scene_step_steps) / 1e9 / HBM_PEAK_GBS, 4)}
                 del tvs, tbs, txs
             bp.close()
+            # ---- a step in which the hot kernel DOMINATES: the same camera model on a SEQUENCE — every point seen by
+            # a run of consecutive cameras (problems.banded_bal) — whose reduced system is as badly conditioned as video-like scenes are:
+            # tens of CG iterations at eta = 1e-3 / 1e-4, where the randomly connected scene above stops after 2-7.  (Jacobi scaling does
+            # not change the count: with the LM diagonal the scaled system is the unscaled one under a diagonal congruence, and
+            # SCHUR_JACOBI-preconditioned CG is invariant under it.)
+            if args.conditioned_steps > 0:
+                try:
+                    nc2, np2, cam2, pt2, obs2, par2 = pkg.problems.bal_scene(args.workload, seed=38401, visibility="banded")
+                    bp2 = hs.BalProblem(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
+                                                               device=local_rank), nc2, np2, cam2, pt2, obs2)
+                    x02 = bp2.state_from_bal(par2)
+                    _, res2, _, vals2 = bp2.evaluate(x02, residuals=True, jacobian=True)
+                    bp2.close()
+                    pb2 = pkg.problems.banded_bal(args.workload, seed=38401, with_values=False)
+                    tv2, tb2 = torch.from_numpy(vals2).to(dev), torch.from_numpy(res2).to(dev)
+                    del vals2, res2
+                    s2c = make_solver(hs, pb2.bs, pb2.num_eliminate_blocks, args.solver, local_rank, None, 0)
+                    tx2c = torch.empty(pb2.bs.num_cols, dtype=torch.float64, device=dev)
+                    conditioned = {"what": f"ceres_hip_lm_compute_step_device on the Snavely Jacobian of a {args.workload}-shaped synthetic SEQUENCE (every point seen by "
+                                           "consecutive cameras: a banded camera graph; problems.banded_bal), values and residuals from the device evaluator, "
+                                           "inputs resident in HBM, radius 1e4"}
+                    for eta_c in (1e-2, 1e-3, 1e-4):
+                        es, its, last_c = timed_steps(s2c, (tv2, tb2, None, tx2c), args.conditioned_steps, 1, sync, "lm_step", eta_c)
+                        tms = s2c.last_timing()
+                        k_it = int(its[-1])
+                        mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
+                        conditioned[f"eta_{eta_c:g}"] = {
+                            "ms_per_step": round(1e3 * es / args.conditioned_steps, 4), "cg_iterations": k_it, "cg_ms": round(tms.cg_ms, 4),
+                            "cg_share_of_step": round(tms.cg_ms / max(tms.total_ms, 1e-9), 3), "ms_per_cg_iteration": round(tms.cg_ms / max(k_it, 1), 4),
+                            "termination": hs.TERMINATION_NAMES[last_c.termination_type],
+                            "step_roofline_frac": round(mb / (es / args.conditioned_steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                    s2c.close()
+                    del tv2, tb2, tx2c
+                    extra["conditioned_step"] = conditioned
+                except Exception as ex:  # the default line must not depend on it
+                    extra["conditioned_step"] = {"error": repr(ex)[:400]}
     extra["solve_phases_ms"] = {k: round(getattr(timing, k), 4) for k in
                                 ("pack_ms", "setup_ms", "preconditioner_ms", "cg_ms", "back_substitute_ms", "total_ms")}
     extra["operator_launches_enqueued_last_step"] = int(timing.operator_applications)

@@ -381,6 +381,7 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 
 // y[cpos(j) - ybase + c] += sum over the cells of column block j (in `part`) of sum_r A[r][c] x[rpos(i) + r],  j in [j0, j0 + nb)
+// (x == nullptr: the squared column norms instead, y[col] += sum of A[r][c]^2 — BlockSparseMatrix::SquaredColumnNorm)
 template <int L, int MAXC>
 __global__ __launch_bounds__(kB) void gen_left_multiply_grouped_kernel(GenStructure G, const double* __restrict__ v, int part, int j0, int nb,
                                                                        int ybase, const double* __restrict__ x, double* __restrict__ y,
@@ -398,12 +399,11 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_grouped_kernel(GenStruct
     const int i = G.trow[t], k = G.tcell[t];
     if (!cell_in_part(G, i, k, part)) continue;
     const double* a = v + G.cval[k];
-    const double* xx = x + G.rpos[i];
     const int rs = G.rsz[i];
     for (int r = 0; r < rs; ++r) {
-      const double xr = xx[r];
+      const double xr = x ? x[G.rpos[i] + r] : 0.0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+      for (int c = 0; c < MAXC; ++c) if (c < cs) { const double av = a[r * cs + c]; s[c] += av * (x ? xr : av); }
     }
   }
   double* out = y + G.cpos[j] - ybase;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructur
       const int info = G.tinfo[ts];
       const int rs = (on && info_in_part(info, part)) ? (info & 0xff) : 0;
       const double* a = v + G.tval[ts];
-      const double* xx = x + G.trpos[ts];
+      const double* xx = x ? x + G.trpos[ts] : a;   // (x == nullptr: the squared column norms; xx is then a valid address that is not used)
       if constexpr (MAXR <= 4) {
         // every load of the cell is issued unconditionally, back to back (addresses clamped into the cell; what lies outside is
         // selected away afterwards): loads under a predicate are separated by waits, and a 144-byte cell read by eighteen loads that
@@ -891,12 +891,12 @@ __global__ __launch_bounds__(kB) void gen_left_multiply_items_kernel(GenStructur
 #pragma unroll
         for (int r = 0; r < MAXR; ++r)
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) s[c] += (c < cs && r < rs) ? av[r][c] * xv[r] : 0.0;
+          for (int c = 0; c < MAXC; ++c) s[c] += (c < cs && r < rs) ? av[r][c] * (x ? xv[r] : av[r][c]) : 0.0;
       } else {
         for (int r = 0; r < rs; ++r) {
           const double xr = xx[r];
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) if (c < cs) s[c] += a[r * cs + c] * xr;
+          for (int c = 0; c < MAXC; ++c) if (c < cs) { const double av = a[r * cs + c]; s[c] += av * (x ? xr : av); }
         }
       }
     }
@@ -1163,8 +1163,14 @@ static void launch_block_diagonal_grouped(const GenStructure& G, const double* v
   else hipLaunchKernelGGL((gen_block_diagonal_grouped_kernel<L, 10>), grid, dim3(kB), 0, s, G, values, part, j0, nb, off, first, D, blocks);
 }
 hipError_t LaunchGenSquaredColumnNorm(const GenStructure& G, const double* values, double* x, hipStream_t s) {
-  if (G.num_cols > 0) hipLaunchKernelGGL(gen_squared_column_norm_kernel, dim3(blocks_for(G.num_cols)), dim3(kB), 0, s, G, values, x);
-  return hipGetLastError();
+  if (G.num_cols <= 0) return hipSuccess;
+  if (G.lanes_all == 0) {
+    hipLaunchKernelGGL(gen_squared_column_norm_kernel, dim3(blocks_for(G.num_cols)), dim3(kB), 0, s, G, values, x);
+    return hipGetLastError();
+  }
+  // the grouped / itemized left-multiply kernels with the values in place of the vector (x == nullptr): x[col] = sum of A[r][col]^2
+  if (hipError_t e = hipMemsetAsync(x, 0, sizeof(double) * size_t(G.num_cols), s); e != hipSuccess) return e;
+  return LaunchGenLeftMultiply(G, values, kAll, nullptr, x, nullptr, s);
 }
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t s) {
   if (G.num_rows > 0) hipLaunchKernelGGL(gen_scale_columns_kernel, dim3(blocks_for(G.num_rows)), dim3(kB), 0, s, G, values, scale);

@@ -716,14 +716,37 @@ def scene_values(prob: LinearProblem, n_cams: int, n_points: int, seed=38401, pi
     return prob
 
 
+def banded_bal(shape="dubrovnik16", seed=38401, num_cameras=None, num_points=None, num_observations=None, with_values=True) -> LinearProblem:
+    """BAL-shaped <2,3,9> problem whose visibility is a SEQUENCE: every point is seen by a run of consecutive cameras (a track through
+    consecutive frames of a turntable / video sequence; the camera ids wrap around), the same track-length distribution as
+    synthetic_bal.  The camera graph is then a band (a ring of width ~ the track length) instead of an expander, and the reduced
+    system is as badly conditioned as sequences are: SCHUR_JACOBI-preconditioned CG on the Snavely Jacobian of such a scene needs 11
+    iterations at eta = 1e-3 and ~40 at 1e-4, where the randomly connected scene needs 4 and 7."""
+    n_cams, n_points, n_obs = BAL_SHAPES[shape] if shape else (num_cameras, num_points, num_observations)
+    if num_cameras is not None:
+        n_cams, n_points, n_obs = num_cameras, num_points, num_observations
+    rng = np.random.default_rng(seed)
+    k = _track_lengths(rng, n_cams, n_points, n_obs)
+    point_of_obs = np.repeat(np.arange(n_points, dtype=np.int64), k)
+    start = rng.integers(0, n_cams, size=n_points)
+    first = np.concatenate([[0], np.cumsum(k)[:-1]])
+    offset = np.arange(int(k.sum()), dtype=np.int64) - np.repeat(first, k)
+    cam_of_obs = (np.repeat(start, k) + offset) % n_cams
+    order = np.lexsort((cam_of_obs, point_of_obs))
+    return _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs[order], "schur", with_values)
+
+
 def bal_scene(shape="dubrovnik16", seed=38401, skew=0.0, num_cameras=None, num_points=None, num_observations=None,
-              pixel_noise=0.5, param_noise=0.02, chunk=400_000):
+              pixel_noise=0.5, param_noise=0.02, chunk=400_000, visibility="random"):
     """A synthetic bundle-adjustment problem in BAL form (examples/bal_problem.cc:75-135) with the
     observation graph of `synthetic_bal`: returns (num_cameras, num_points, camera_index, point_index,
     observations (n,2), parameters) — parameters in BAL file order (9 per camera, then 3 per point),
     perturbed away from the scene that generated the observations."""
-    prob = synthetic_bal(shape, layout="schur", seed=seed, skew=skew, num_cameras=num_cameras, num_points=num_points,
-                         num_observations=num_observations, with_values=False)
+    if visibility == "banded":   # a sequence: see banded_bal
+        prob = banded_bal(shape, seed=seed, num_cameras=num_cameras, num_points=num_points, num_observations=num_observations, with_values=False)
+    else:
+        prob = synthetic_bal(shape, layout="schur", seed=seed, skew=skew, num_cameras=num_cameras, num_points=num_points,
+                             num_observations=num_observations, with_values=False)
     n_points = int(prob.num_eliminate_blocks)
     n_cams = int(prob.bs.num_col_blocks - n_points)
     pt = np.asarray(prob.point_of_row, dtype=np.int64)

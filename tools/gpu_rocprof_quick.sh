@@ -7,7 +7,7 @@ export CERES_HIP_PROBLEM_CACHE=/tmp/ceres_problem_cache
 cd /tmp && export TMPDIR=/tmp
 for SOLVER in iterative_schur cgnr; do
   rm -rf /tmp/prof_$SOLVER
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SOLVER -o $SOLVER -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --both-solvers 0 --minimizer-iterations 0 --host-boundary-steps 0 --scene-step-steps 0 --extra-synthetic10m 0 --extra-real-graph 0 --extra-other-shapes 0 --extra-dense-cholesky 0 --solver $SOLVER > $OUT/rocprof_bench_${SOLVER}_$TAG.json 2> $OUT/rocprof_${SOLVER}_$TAG.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$SOLVER -o $SOLVER -- python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --both-solvers 0 --minimizer-iterations 0 --host-boundary-steps 0 --scene-step-steps 0 --conditioned-steps 0 --extra-synthetic10m 0 --extra-real-graph 0 --extra-other-shapes 0 --extra-dense-cholesky 0 --solver $SOLVER > $OUT/rocprof_bench_${SOLVER}_$TAG.json 2> $OUT/rocprof_${SOLVER}_$TAG.err
   F=$(find /tmp/prof_$SOLVER -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $OUT/kernel_stats_${SOLVER}_venice_$TAG.csv && head -8 $F | cut -c1-160
   python -c "
