@@ -21,6 +21,46 @@ __global__ __launch_bounds__(256) void mfma_kernel(double* out, int iters, doubl
   for (int i = 0; i < ACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (s == 1.2345e-300) out[0] = s;
 }
+// v_mfma_f64_4x4x4_4b_f64: four 4 x 4 x 4 blocks per instruction (512 flop), one double of accumulator per lane
+template <int ACC>
+__global__ __launch_bounds__(256) void mfma4_kernel(double* out, int iters, double a0, double b0) {
+  double acc[ACC];
+#pragma unroll
+  for (int i = 0; i < ACC; ++i) acc[i] = 0.0;
+  double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < ACC; ++i) s += acc[i];
+  if (s == 1.2345e-300) out[0] = s;
+}
+// both pipes at once: 8 MFMA chains and 16 FMA chains interleaved in one wave (does the matrix pipe run beside the vector pipe?)
+__global__ __launch_bounds__(256) void mixed_kernel(double* out, int iters, double a0, double b0) {
+  v4f64 acc[8];
+  double f[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) f[i] = i;
+  const double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+      f[2 * i] = fma(a, f[2 * i], b);
+      f[2 * i + 1] = fma(a, f[2 * i + 1], b);
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += f[i];
+  if (s == 1.2345e-300) out[0] = s;
+}
 __global__ __launch_bounds__(256) void fma_kernel(double* out, int iters, double a0, double b0) {   // the vector pipe, for comparison
   double acc[16];
 #pragma unroll
@@ -62,6 +102,15 @@ int run(const char* name, K kernel, int waves_per_simd, int per_iter_flops_per_w
 int main() {
   double* d_out = nullptr;
   CK(hipMalloc(&d_out, 64));
+  // round 4: more chains, more waves, the 4x4x4 form, both pipes at once; "nominal cycles per wave-iteration" / chains
+  // = issue interval of one instruction on one SIMD
+  for (int w = 1; w <= 8; w *= 2) {
+    if (run("mfma_f64_16x16x4 x32 chains", mfma_kernel<32>, w, 32 * 2048, d_out)) return 1;
+    if (run("mfma_f64_4x4x4_4b x16 chains", mfma4_kernel<16>, w, 16 * 512, d_out)) return 1;
+    if (run("mfma_f64_4x4x4_4b x64 chains", mfma4_kernel<64>, w, 64 * 512, d_out)) return 1;
+    if (run("8 mfma16 + 16 v_fma per iter", mixed_kernel, w, 8 * 2048 + 16 * 64 * 2, d_out)) return 1;
+    if (run("v_fma_f64 x16 chains", fma_kernel, w, 16 * 64 * 2, d_out)) return 1;
+  }
   for (int w = 1; w <= 2; ++w) {
     if (run("mfma_f64_16x16x4 x16 chains", mfma_kernel<16>, w, 16 * 2048, d_out)) return 1;
     if (run("mfma_f64_16x16x4 x4 chains", mfma_kernel<4>, w, 4 * 2048, d_out)) return 1;
