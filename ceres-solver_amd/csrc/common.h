@@ -37,6 +37,7 @@ constexpr int kMaxPointsPerTile = 42;  // 3 * 42 = 126 <= 128 point-space scalar
 // The per-slot index word of the tiles: camera id in the low kSlotCamBits bits, LDS accumulator row above them (kSlotSpill = none)
 constexpr int kSlotCamBits = 20;
 constexpr int kSlotSpill = 0xFFF;
+constexpr int kSlotNoCamera = (1 << kSlotCamBits) - 1;   // camera field of a valid slot WITHOUT a camera cell when the accumulators are not all in LDS
 
 // ---------------------------------------------------------------------------
 // Host-side analysis (plan.cc).  Pure C++, unit-testable without a GPU through

@@ -106,7 +106,8 @@ struct BalArgs {
   int have_b = 0;
   // camera accumulation
   double* partials = nullptr;    // [grid][n_acc]   (LDS mode)
-  double* zbuf = nullptr;        // [rows][9]      (cameras do not fit in LDS: the ring of spilled / flushed F^T z rows, second pass by camera)
+  double* zbuf = nullptr;        // [rows][nf]     (cameras do not fit in LDS: the ring of spilled / flushed F^T z rows, second pass by camera)
+  double* strip_sums = nullptr;  // accumulators outside LDS, shapes with a strip: the strip's ns entries of the global sums (zeroed per application)
   int n_acc = 0;                 // nf * n_cameras + ns: the camera-space accumulator entries (the strip's behind the cameras')
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel

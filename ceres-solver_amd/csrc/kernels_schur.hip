@@ -392,11 +392,30 @@ __global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict
   double ra[16], rb[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) { ra[j] = ga[j][0]; rb[j] = gb[j][0]; }
+  // The wave's 64 x 64 outputs as 16 x 4 accumulators of v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction,
+  // one double per lane): acc[p][c] of lane (q = lane & 3, blk = (lane >> 2) & 3, h = lane >> 4) is C[4 p + h][16 c + 4 blk + q].
+  // Operand layout of the instruction (tools/probes/mfma4_layout_probe.hip, profiles/r04n_*): A(block, row, k) sits in lane
+  // row + 4 block + 16 k, B(block, k, col) in col + 4 block + 16 k, D(block, row, col) in col + 4 block + 16 row — so the B operand of
+  // column group c is "row lane & 15 of the strip's 16-row group c, column 4 ks + (lane >> 4)", exactly the 16x16x4 form's operand, and
+  // the A operand of row strip p is row 4 p + (lane & 3), the same for the four blocks (an LDS broadcast).  WHY: on gfx950 the
+  // 16x16x4 f64 instruction issues every 143 cycles per SIMD (35 TFLOP/s on the chip), the 4x4x4_4b form every 16.7 (77 TFLOP/s):
+  // tools/probes/mfma_f64_probe.hip, profiles/r04m_mfma_f64_probe.txt.  CERES_HIP_AB_SYRK_16X16=1 builds the round-3 form (A/B).
+#ifndef CERES_HIP_AB_SYRK_16X16
+#define CERES_HIP_AB_SYRK_16X16 0
+#endif
+#if CERES_HIP_AB_SYRK_16X16
   v4f64 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+#else
+  double acc4[16][4];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc4[p][c] = 0.0;
+#endif
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     sh[(srow + 8 * j) * kSyrkPitch + scol] = ra[j];
@@ -414,8 +433,9 @@ __global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict
       for (int j = 0; j < 16; ++j) { ra[j] = ga[j][kSyrkChunk * (ch + 1)]; rb[j] = gb[j][kSyrkChunk * (ch + 1)]; }
     }
     if (active) {
-      const double* pa = cur + (64 * (wv >> 1) + li) * kSyrkPitch + lq;
       const double* pb = cur + kSyrkOperand + (64 * (wv & 1) + li) * kSyrkPitch + lq;
+#if CERES_HIP_AB_SYRK_16X16
+      const double* pa = cur + (64 * (wv >> 1) + li) * kSyrkPitch + lq;
 #pragma unroll
       for (int ks = 0; ks < kSyrkChunk / 4; ++ks) {
         double av[4], bv[4];
@@ -426,6 +446,21 @@ __global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
       }
+#else
+      const double* pa4 = cur + (64 * (wv >> 1) + (lane & 3)) * kSyrkPitch + lq;
+#pragma unroll
+      for (int ks = 0; ks < kSyrkChunk / 4; ++ks) {
+        double ap[16], bv[4];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) ap[p] = pa4[4 * p * kSyrkPitch + 4 * ks];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = pb[16 * t * kSyrkPitch + 4 * ks];
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc4[p][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[p], bv[c], acc4[p][c], 0, 0, 0);
+      }
+#endif
     }
     if (more) {
 #pragma unroll
@@ -453,7 +488,11 @@ __global__ __launch_bounds__(256) void dense_syrk_mfma_kernel(double* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + 16 * a + lq + 4 * r, j = j0 + 16 * b + li;
+#if CERES_HIP_AB_SYRK_16X16
         if (i < n && j <= i) A[int64_t(i) * n + j] = c[b][r] - acc[a][b][r];
+#else
+        if (i < n && j <= i) A[int64_t(i) * n + j] = c[b][r] - acc4[4 * a + r][b];   // row 16 a + 4 r + lq = 4 p + h with p = 4 a + r
+#endif
       }
   }
 }

@@ -271,8 +271,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // Cameras whose 9-double accumulators do not fit in LDS (decided here: the point order below depends on it).
   // (1 KiB of the 160 stays free for the kernels' static LDS: workgroup reductions, the exchange area of the long points' rounds)
   P.cameras_in_lds = (size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double) <= kLdsBytesPerCu - 1024;
-  // the shared strip's sums and rows without a camera cell live with the LDS accumulators only
-  if (!P.cameras_in_lds && (P.ns > 0 || P.n_cam_cells != n_conf)) return no("shared blocks / rows without a camera cell with more cameras than LDS holds");
+  if (!P.cameras_in_lds && P.n_cameras >= kSlotNoCamera) return no("more cameras than the slot word holds");
   int64_t chunk_mib = 0;  // CERES_HIP_Z_CHUNK_MIB=<n>: bound the F^T z ring to n MiB (memory-constrained runs)
   if (const char* e = getenv("CERES_HIP_Z_CHUNK_MIB")) chunk_mib = atoll(e);
   if (!P.cameras_in_lds && P.n_cameras >= (1 << kSlotCamBits)) return no("more cameras than the slot word holds");
@@ -311,7 +310,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (hybrid) {
     const int G = hyb.groups, K = hyb.rows;
     std::vector<int64_t> deg(P.n_cameras, 0);
-    for (int i = 0; i < n_conf; ++i) ++deg[row_cam[i]];   // (every row has a camera cell here: checked above)
+    for (int i = 0; i < n_conf; ++i) if (row_cam[i] >= 0) ++deg[row_cam[i]];
     // most rows the popular cameras may take: the windows must still cover the others, (G - 1) stride + K_w >= n_cold with stride <= K_w
     const int max_hot = K - std::min(K, std::max(1, (P.n_cameras - K + (G - 2)) / (G - 1)));
     std::vector<int32_t> by_deg(P.n_cameras);
@@ -344,6 +343,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       if ((since_scan++ & 1023) == 0) least = int(std::min_element(load.begin(), load.end()) - load.begin());
       touched.clear();
       for (int q = row_start[p]; q < row_start[p + 1]; ++q) {
+        if (row_cam[order[q]] < 0) continue;   // a row without a camera cell votes for nobody
         const int r = cold_rank[row_cam[order[q]]];
         if (r < 0) continue;
         int g0, g1;
@@ -695,6 +695,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     int64_t n_local = 0;
     for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
       const int c = P.slot_cam[s];
+      if (c == -2) P.slot_word[s] = int32_t(uint32_t(kSlotNoCamera) | (uint32_t(kSlotSpill) << kSlotCamBits));   // valid, no camera cell: neither summed nor spilled
       if (c < 0) continue;
       int row = kSlotSpill;
       if (hybrid) {

@@ -474,6 +474,7 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     const BalPlan& P = s->plan;
     if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->chunk_grid; }
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
+    if (P.ns > 0) A.strip_sums = s->d_global_acc + size_t(P.nf) * P.n_cameras;
     const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
     for (int k = 0; k < n_chunks; ++k) {
       A.tile_begin = P.zc_tile_ptr[k];
@@ -700,7 +701,20 @@ int op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
 // H^T H (JACOBI) or H^T H - sum over points G^T (E^T E)^-1 G, G = sum over the point's rows of E^T H (SCHUR_JACOBI: the rows of a point
 // all hold the shared cell, so the block is not a sum of per-observation terms like a camera's), from one tile pass (kBalShBlocks);
 // + D^2, inverted in place like every other block.
-int shared_preconditioner_blocks(ceres_hip_solver* s, bool schur, double* out, bool invert) {
+// with_D / invert: a sharded run calls once for this rank's raw sums (the caller all-reduces the block store, adds D^2 to every F block)
+// and then invert_shared_blocks; one rank does it all in one call
+int invert_shared_blocks(ceres_hip_solver* s, double* out) {
+  const BalPlan& P = s->plan;
+  const HostStructure& h = s->hs;
+  if (s->path != CERES_HIP_PATH_BAL || P.ns == 0) return 0;
+  for (size_t q = 0; q < P.sh_block.size(); ++q) {   // (the generic kernel addresses blocks relative to the first of its range)
+    const int j = P.sh_block[q];
+    const int64_t off = is_schur(s) ? h.diag_off_f[j - h.nelim] : h.diag_off_all[j];
+    HIP_TRY(s, LaunchGenInvertBlocks(s->G, j, 1, is_schur(s) ? s->G.diag_off_f + (j - h.nelim) : s->G.diag_off_all + j, out + off, s->d_fail_flag, s->stream));
+  }
+  return 0;
+}
+int shared_preconditioner_blocks(ceres_hip_solver* s, bool schur, double* out, bool invert, bool with_D = true) {
   const BalPlan& P = s->plan;
   if (s->path != CERES_HIP_PATH_BAL || P.ns == 0) return 0;
   const HostStructure& h = s->hs;
@@ -717,13 +731,9 @@ int shared_preconditioner_blocks(ceres_hip_solver* s, bool schur, double* out, b
     sb.off[q] = P.sh_off[q]; sb.width[q] = h.csz[j]; sb.pos[q] = h.cpos[j] - h.num_cols_e;
     sb.out[q] = is_schur(s) ? h.diag_off_f[j - h.nelim] : h.diag_off_all[j];
   }
-  const double* D_f = s->D ? s->D + h.num_cols_e : nullptr;
+  const double* D_f = (with_D && s->D) ? s->D + h.num_cols_e : nullptr;
   HIP_TRY(s, s->ops->strip_finish(s->d_strip_parts, s->fused_grid, sb, D_f, out, st));
-  if (invert)
-    for (int q = 0; q < sb.count; ++q) {   // (the generic kernel addresses blocks relative to the first of its range)
-      const int j = P.sh_block[q];
-      HIP_TRY(s, LaunchGenInvertBlocks(s->G, j, 1, is_schur(s) ? s->G.diag_off_f + (j - h.nelim) : s->G.diag_off_all + j, out + sb.out[q], s->d_fail_flag, st));
-    }
+  if (invert) TRY(invert_shared_blocks(s, out));
   return 0;
 }
 
@@ -759,6 +769,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
         HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f,
                                          s->plan.cameras_contiguous ? nullptr : s->d_cam_pos, s->plan.cam_base, cam_f_offsets(s), out,
                                          (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
+        if (s->world > 1) TRY(shared_preconditioner_blocks(s, schur, out, false, false));   // this rank's raw sums join the all-reduce of the block store
         if (s->world > 1) {
           const size_t n9c = size_t(s->plan.nf) * s->plan.n_cameras;
           if (s->rhs_reduce_pending && out == s->precond && s->merged_layout) {
@@ -773,7 +784,8 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
           if (D_f && !fuse) HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, nf, s->G.diag_off_f, s->D, out, st));
         }
         if (invert) HIP_TRY(s, s->ops->invert(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, schur) : LmFuse(), CamGather(), st));
-        TRY(shared_preconditioner_blocks(s, schur, out, invert));
+        if (s->world > 1) { if (invert) TRY(invert_shared_blocks(s, out)); }
+        else TRY(shared_preconditioner_blocks(s, schur, out, invert));
       }
     } else {
       if (type == CERES_HIP_SCHUR_JACOBI) {
@@ -869,6 +881,7 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   // behind the point blocks in the Schur-ordered layout a sharded run requires)
   HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->plan.cam_base, s->d_cam_diag_off, blocks, nullptr,
                                    s->plan.n_cameras, st, rem_extra_blocks(s)));
+  TRY(shared_preconditioner_blocks(s, false, blocks, false, false));   // this rank's raw H^T H joins the all-reduce
   const int64_t first = h.diag_off_all[h.nelim];
   if (merge) {
     TRY(allreduce(s, blocks + first, size_t(len - first) + size_t(h.num_cols_f)));
@@ -879,6 +892,7 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   if (s->D && !s->lm_fuse_active)  // fused LM diagonal: bal_invert9_kernel forms D_f from the reduced diagonal and adds it
     HIP_TRY(s, LaunchAddBlockDiagonalSquares(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_all + h.nelim, s->D, blocks + first, st));
   HIP_TRY(s, s->ops->invert(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), CamGather(), st));
+  TRY(invert_shared_blocks(s, blocks));
   return 0;
 }
 
@@ -1762,8 +1776,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
   }
   s->ops = s->plan.eligible ? GetBalOps(s->plan.nf, s->plan.ns) : nullptr;
-  if (s->plan.eligible && (!s->ops || (s->opt.jacobian_storage == 1 && !s->ops->has_f32) || (s->world > 1 && s->plan.ns > 0))) {
-    // (fp32 tiles exist for the 9-wide shape only; a sharded run with a shared strip has not been built)
+  if (s->plan.eligible && (!s->ops || (s->opt.jacobian_storage == 1 && !s->ops->has_f32))) {
+    // (fp32 tiles exist for the 9-wide shape only)
     s->plan.eligible = false;
     s->plan.why_not = !s->ops ? "no kernels for this shape" : "option not available for this shape";
   }

@@ -32,7 +32,9 @@ def run_rank(rank, world, conn, device, scenario):
             os.environ["CERES_HIP_CG_FUSED"] = kw.get("cg_fused", "1")  # read when a solver is created
             os.environ["CERES_HIP_P2P_TIMEOUT"] = str(kw.get("p2p_timeout", 20))
             kind = kw["kind"]
-            if kind == "bal":
+            if kind == "bal" and kw.get("structured"):   # camera widths other than 9, shared blocks, locked cameras (problems.synthetic_structured)
+                prob = pkg.problems.synthetic_structured(kw["nc"], kw["np"], kw["no"], seed=kw["seed"], skew=kw.get("skew", 0.5), **kw["structured"])
+            elif kind == "bal":
                 prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),
                                                   num_cameras=kw["nc"], num_points=kw["np"], num_observations=kw["no"])
                 if kw.get("camera_rows", 0):  # rows without a point cell: partition.py hands them to the last rank

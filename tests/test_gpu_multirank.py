@@ -61,11 +61,15 @@ def assemble(partition_mod, recs, num_cols, key):
     return x
 
 
-def make_bal_case(hip, oracle, problems, nc, npts, nobs):
+def make_bal_case(hip, oracle, problems, nc, npts, nobs, structured=None, solvers=None):
     """A problem of the sharded BAL tests and everything the oracle says about it (computed once for all world sizes)."""
     kw = dict(kind="bal", seed=31, nc=nc, np=npts, no=nobs, skew=0.5,
-              solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)])
-    p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=nc, num_points=npts, num_observations=nobs)
+              solvers=solvers or [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)])
+    if structured:
+        kw["structured"] = structured
+        p = problems.synthetic_structured(nc, npts, nobs, seed=31, skew=0.5, **structured)
+    else:
+        p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=nc, num_points=npts, num_observations=nobs)
     m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
     m0 = oracle.Matrix(p.bs, 0)
     ref = {}
@@ -93,6 +97,26 @@ def many_camera_case(hip, oracle, problems):
     # 2600 cameras: more than LDS holds — every rank builds a hybrid plan for its shard (popular cameras + windows, the rest spilled),
     # CGNR runs on internally numbered points, and the step's merged all-reduce is 99 x 2600 doubles = 126 chunks of the one-shot kernel
     return make_bal_case(hip, oracle, problems, 2600, 20000, 90000)
+
+
+@pytest.fixture(scope="module")
+def quaternion_case(hip, oracle, problems):
+    # <2,3,10> cameras (bundle_adjuster --use_quaternions): both solvers sharded on the fused path of that shape
+    return make_bal_case(hip, oracle, problems, 37, 6000, 26000, structured=dict(camera_width=10))
+
+
+@pytest.fixture(scope="module")
+def libmv_like_case(hip, oracle, problems):
+    # shared intrinsics + 6-wide poses + a constant camera, sharded by point: the shared block's preconditioner block and the strip's sums
+    # are all-reduced with the cameras' (ITERATIVE_SCHUR; sharded CGNR needs points-then-cameras columns, which a shared block breaks)
+    return make_bal_case(hip, oracle, problems, 37, 6000, 26000, structured=dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,), shared_first=False),
+                         solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)])
+
+
+@pytest.mark.parametrize("world", (2, 4))
+def test_sharded_other_shapes_against_the_oracle(hip, quaternion_case, libmv_like_case, world):
+    check_sharded_case(hip, quaternion_case, world)
+    check_sharded_case(hip, libmv_like_case, world)
 
 
 @pytest.mark.parametrize("world", WORLDS)

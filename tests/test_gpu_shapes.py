@@ -109,6 +109,29 @@ def test_narrow_cameras_beyond_lds(hip, oracle, problems):
     assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
 
 
+def test_strip_and_locked_cameras_beyond_lds(hip, oracle, problems):
+    """More cameras than LDS rows TOGETHER with a shared block and rows without a camera cell: the strip's sums go through the global
+    accumulator (one atomic per wave and scalar), a slot without a camera cell is neither summed nor spilled."""
+    p = problems.synthetic_structured(30000, 60000, 200000, camera_width=6, shared_widths=(8,), locked_cameras=(0, 7, 29999), seed=10, skew=0.4)
+    errs = check_schur_operators(hip, oracle, p, False, hip.PATH_BAL)
+    raw = errs.pop("schur_jacobi_raw")
+    assert raw <= 1e-11, raw
+    assert_errs(errs)
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+    # the libmv structure on the replicated real visibility: 8 800 cameras x 6 + the intrinsics, every point a long one (rounds, hybrid groups)
+    q = problems.libmv_structured(2, 20)
+    s = make_solver(hip, q, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    info = s.info()
+    assert info.kernel_path == hip.PATH_BAL and info.camera_accum_in_lds == 0
+    m = oracle.Matrix(q.bs, q.num_eliminate_blocks)
+    x, summ = s.solve(q.values, q.b, hip.PerSolveOptions(D=q.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(x, summ, lambda lo, hi, qq, r: m.iterative_schur_solve(q.values, q.b, q.D, preconditioner=2, min_it=lo, max_it=hi, q_tol=qq, r_tol=r), 0.1, hip.SUCCESS)
+    s.close()
+    errs = check_schur_operators(hip, oracle, q, False, hip.PATH_BAL)
+    errs.pop("schur_jacobi_raw")
+    assert_errs(errs, 1e-11)
+
+
 def test_unsupported_widths_fall_back_to_the_generic_path(hip, oracle, problems):
     p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)
     assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_GENERIC))
