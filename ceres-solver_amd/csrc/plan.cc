@@ -643,13 +643,14 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     std::vector<int32_t> row_slot(n_conf, -1);
     P.mo_index.assign(size_t(P.n_tiles) * kTile, 0);
     for (int64_t s = 0; s < P.n_tiles * kTile; ++s) {
-      if (P.slot_cam[s] < 0) { P.mo_index[s] = int32_t(s % n_conf); continue; }
-      P.mo_index[s] = P.slot_row[s];
+      if (P.slot_cam[s] == -1) { P.mo_index[s] = int32_t(s % n_conf); continue; }   // padding: any record (never written: the slot is not valid)
+      P.mo_index[s] = P.slot_row[s];   // (also a valid slot without a camera cell: its own row's record, which no camera list refers to)
       row_slot[P.slot_row[s]] = int32_t(s);
     }
     std::vector<int32_t> cur(P.cam_ptr.begin(), P.cam_ptr.end() - 1);
     for (int i = 0; i < n_conf; ++i) {
       const int64_t s = row_slot[i];
+      if (P.slot_cam[s] < 0) continue;   // a row without a camera cell is in no camera's list
       const int q = cur[P.slot_cam[s]]++;
       P.cam_fpos[q] = P.slot_fpos[s];
       P.cam_slot[q] = i;

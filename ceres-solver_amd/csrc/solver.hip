@@ -771,7 +771,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
                                          (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
         if (s->world > 1) TRY(shared_preconditioner_blocks(s, schur, out, false, false));   // this rank's raw sums join the all-reduce of the block store
         if (s->world > 1) {
-          const size_t n9c = size_t(s->plan.nf) * s->plan.n_cameras;
+          const size_t n9c = size_t(h.num_cols_f);   // rhs / column norms: every camera-side scalar (the cameras' and a shared strip's)
           if (s->rhs_reduce_pending && out == s->precond && s->merged_layout) {
             // ONE collective for the step's camera-space sums: [blocks | rhs | column norms] are contiguous (set_structure)
             TRY(allreduce(s, out, size_t(len) + n9c + ((fuse && schur) ? n9c : 0)));

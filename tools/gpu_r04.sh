@@ -22,7 +22,7 @@ d = json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-
       done; done ;;
     pytest_files)   # FILES="tests/test_a.py tests/test_b.py"
       echo "===== $STAGE ($(date +%T))"
-      timeout 2400 python -m pytest $FILES -m gpu -q --timeout 900 2>&1 | tail -60 | tee $OUT/pytest_files_$TAG.log | tail -30 ;;
+      timeout 2400 python -m pytest $FILES -m gpu -q --timeout 900 2>&1 | tail -300 | tee $OUT/pytest_files_$TAG.log | tail -30 ;;
     *) bash tools/gpu_r03.sh $TAG $STAGE ;;
   esac
 done
