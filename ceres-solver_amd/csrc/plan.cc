@@ -326,9 +326,20 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     for (int r = 0; r < K_h; ++r) hot_row[by_deg[r]] = r;
     for (int c = 0; c < P.n_cameras; ++c) if (hot_row[c] < 0) cold_rank[c] = n_cold++;
     const int last_start = std::max(0, n_cold - K_w);
-    const int stride = (last_start + (G - 2)) / (G - 1);
+    // Window starts.  stride = the smallest step with which G windows reach the last cold camera; where that would put a camera
+    // into more than 16 windows (a few thousand cameras: stride of a handful, K_w / stride windows around every camera) the step is
+    // raised to K_w / 16 and the G workgroups SHARE the fewer distinct windows, in contiguous blocks: the vote below is per distinct
+    // window (at most 17 hold a camera), the point then goes to the lightest workgroup of the window it chose.
+    int stride = (last_start + (G - 2)) / (G - 1);
+    if (stride == 0 || K_w / stride > 16) stride = std::max(1, K_w / 16);
+    const int W = std::min<int64_t>(G, last_start == 0 ? 1 : (last_start + stride - 1) / stride + 1);   // distinct windows
     win_start.resize(G);
-    for (int g = 0; g < G; ++g) win_start[g] = int(std::min<int64_t>(int64_t(g) * stride, last_start));
+    std::vector<int32_t> win_of(G), win_grp(W + 1, G);   // group -> window; window -> its first group
+    for (int g = G - 1; g >= 0; --g) {
+      win_of[g] = int(int64_t(g) * W / G);
+      win_grp[win_of[g]] = g;
+      win_start[g] = int(std::min<int64_t>(int64_t(win_of[g]) * stride, last_start));
+    }
     // points -> groups
     grp_points.assign(G, {});
     // load in tile slots: a point of more than 64 observations owns whole tiles
@@ -338,7 +349,12 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     for (int p = 0; p < P.n_points; ++p) total_slots += slots_of(p);
     const int64_t cap = (total_slots * 103 / 100 + G - 1) / G + kTile;
     int least = 0, since_scan = 0;
-    std::vector<int32_t> votes(G, 0), touched;
+    std::vector<int32_t> votes(W, 0), touched;
+    auto lightest_of = [&](int w) {   // the least loaded workgroup of window w
+      int b = win_grp[w];
+      for (int g = b + 1; g < win_grp[w + 1]; ++g) if (load[g] < load[b]) b = g;
+      return b;
+    };
     for (int p = 0; p < P.n_points; ++p) {
       if ((since_scan++ & 1023) == 0) least = int(std::min_element(load.begin(), load.end()) - load.begin());
       touched.clear();
@@ -348,13 +364,15 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
         if (r < 0) continue;
         int g0, g1;
         groups_of(r, &g0, &g1);
-        for (int g = g0; g <= g1; ++g) if (votes[g]++ == 0) touched.push_back(g);
+        if (g0 > g1) continue;
+        for (int w = win_of[g0]; w <= win_of[g1]; ++w) if (votes[w]++ == 0) touched.push_back(w);
       }
-      int best = -1;
-      for (int g : touched) {   // most of the point's cameras, then the lighter load
-        if (load[g] < cap && (best < 0 || votes[g] > votes[best] || (votes[g] == votes[best] && load[g] < load[best]))) best = g;
+      int best = -1, best_votes = 0;
+      for (int w : touched) {   // most of the point's cameras, then the lighter load
+        const int g = lightest_of(w);
+        if (load[g] < cap && (best < 0 || votes[w] > best_votes || (votes[w] == best_votes && load[g] < load[best]))) { best = g; best_votes = votes[w]; }
       }
-      for (int g : touched) votes[g] = 0;
+      for (int w : touched) votes[w] = 0;
       if (best < 0) {
         if (load[least] >= cap) least = int(std::min_element(load.begin(), load.end()) - load.begin());
         best = least;

@@ -501,6 +501,10 @@ def simulate_camera_accumulation(pl, n_cameras, groups, rng):
     (dict(num_cameras=3000, num_points=3000, num_observations=30000), 16, 512, 0.3),       # 10 per point
     (dict(num_cameras=2400, num_points=900, num_observations=90000), 8, 320, 0.1),          # long points (100 per point) own their tiles
     (dict(num_cameras=40000, num_points=30000, num_observations=60000), 4, 64, 0.0),        # more cameras than groups x rows: some are in no window
+    # the device's own 256 workgroups x 2176 rows on a few thousand cameras: far fewer useful window positions than workgroups, the
+    # workgroups SHARE windows (the vote is per distinct window, then the lightest workgroup of it)
+    (dict(num_cameras=4500, num_points=60000, num_observations=240000), 256, 2176, 0.6),
+    (dict(num_cameras=2300, num_points=30000, num_observations=120000), 256, 2176, 0.9),     # one window position: every workgroup has it
 ])
 def test_hybrid_camera_accumulation_plan(problems, kw, groups, rows, min_local):
     """More cameras than LDS rows (csrc/plan.cc): popular cameras in every workgroup's LDS, the others in ONE workgroup's window, each
