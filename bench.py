@@ -834,7 +834,9 @@ def main():
                        "parallelism": (f"points sharded over {world} rank(s), camera-space sums by " +
                                        ("the one-shot peer-to-peer all-reduce (hipIpc / xGMI)" if solver.p2p_ok else "RCCL all-reduce") +
                                        (" — ONE-GPU VALIDATION MODE, timings meaningless" if one_gpu else ""))
-                       if world > 1 else "1 GPU", "inputs_resident_in_hbm": True, "step_finite": step_ok,
+                       if world > 1 else "1 GPU",
+                       "collectives_per_step": int(solver.info().collectives_last_step) if world > 1 and args.step == "lm_step" else 0,
+                       "inputs_resident_in_hbm": True, "step_finite": step_ok,
                        "jacobian_storage": "fp32 tiles, fp64 arithmetic (accuracy mode, not parity)" if storage else "fp64",
                        "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",
                        "camera_accumulators_in_lds": bool(info.camera_accum_in_lds)},

@@ -186,6 +186,7 @@ struct ceres_hip_solver {
   P2pPeers p2p_peers{};
   void* p2p_opened[kP2pMaxWorld] = {};
   unsigned long long p2p_epoch = 0;
+  int collectives = 0;   // all-reduces issued since the last LM step began (info.collectives_last_step)
   int* d_comm_error = nullptr;      // raised by a p2p all-reduce whose peer never arrived: device view of h_comm_error
   int* h_comm_error = nullptr;      // mapped pinned host memory
   int* d_comm_error_seen = nullptr; // device memory: set with it, so that later all-reduces do not wait the timeout again
@@ -252,6 +253,7 @@ void free_all(ceres_hip_solver* s) {
 // go to RCCL when a communicator exists.
 int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
   if (s->world <= 1 || n == 0) return 0;
+  ++s->collectives;
   if (s->p2p && (int64_t(n) <= s->p2p_cap || !s->comm)) {
     for (size_t off = 0; off < n; off += size_t(s->p2p_cap)) {
       const int64_t len = int64_t(std::min<size_t>(size_t(s->p2p_cap), n - off));
@@ -2106,6 +2108,7 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
   info->world_size = s->world; info->rank = s->rank;
   info->p2p_enabled = s->p2p ? 1 : 0;
   info->p2p_fine_grained = s->p2p_fine_grained ? 1 : 0;
+  info->collectives_last_step = s->collectives;
   if (s->path == CERES_HIP_PATH_BAL) {
     info->camera_accum_hybrid = s->plan.hybrid ? 1 : 0;
     info->hybrid_popular_rows = s->plan.hybrid ? s->plan.hyb_hot : 0;
@@ -2401,6 +2404,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   const HostStructure& h = s->hs;
   hipStream_t st = s->stream;
   memset(res, 0, sizeof(*res));
+  s->collectives = 0;
   if (!(o->radius > 0) || !(o->min_diagonal > 0) || o->min_diagonal > o->max_diagonal)
     return fail(s, CERES_HIP_E_INVALID, "bad LM options");
   // A fresh diagonal is diag(J^T J), which the set-up kernels of the <2,3,9> path have in hand anyway

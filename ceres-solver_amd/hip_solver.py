@@ -66,7 +66,7 @@ class CInfo(ctypes.Structure):
                 ("num_tiles", c_int64), ("device_bytes", c_int64), ("camera_accum_in_lds", c_int32),
                 ("world_size", c_int32), ("rank", c_int32), ("p2p_enabled", c_int32), ("p2p_fine_grained", c_int32),
                 ("camera_accum_hybrid", c_int32), ("hybrid_popular_rows", c_int32), ("num_observations_in_lds", c_int64),
-                ("points_renumbered", c_int32), ("cg_iteration_in_operator", c_int32)]
+                ("points_renumbered", c_int32), ("cg_iteration_in_operator", c_int32), ("collectives_last_step", c_int32)]
 
 
 class CTiming(ctypes.Structure):

@@ -170,6 +170,7 @@ typedef struct ceres_hip_info {
   int64_t num_observations_in_lds;    /* observations summed in LDS by the tile pass (the others are spilled to the ring)          */
   int32_t points_renumbered;          /* 1: the tiles hold the points in an internal order (fuller tiles, hybrid groups)           */
   int32_t cg_iteration_in_operator; /* 1: camera space of at most 512 scalars — the S.x pass finishes the CG iteration itself (one launch) */
+  int32_t collectives_last_step;    /* sharded instances: all-reduces this rank issued since its last ceres_hip_lm_compute_step began      */
 } ceres_hip_info;
 
 typedef struct ceres_hip_solver ceres_hip_solver; /* opaque */

@@ -82,6 +82,7 @@ def run_rank(rank, world, conn, device, scenario):
                 # (3) the whole LM step on the device (f1), incl. the all-reduced {finite flag, model cost}
                 step, summ, mcc = s.lm_compute_step(v, b, 1e4, 0.1)
                 rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
+                rec["collectives"] = int(s.info().collectives_last_step)
                 # (4) operators that sum over ranks
                 if solver_type == hs.ITERATIVE_SCHUR:
                     s.load(v, b, D)

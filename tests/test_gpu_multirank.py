@@ -161,6 +161,11 @@ def check_sharded_case(hip, case, world):
         assert_lm_style_step(-step, S, ref[(solver_type, "solve")], 0.1, hip.SUCCESS)
         Jx = m0.right_multiply(p.values, step)   # the model cost change belongs to the step the ranks produced, whatever its index
         assert abs(recs[0]["lm_step"][3] - (-(Jx @ (p.b + Jx / 2)))) <= 1e-9 * abs(recs[0]["lm_step"][3])
+        # collectives of that step (info.collectives_last_step): the merged per-step sum, the operator's camera vector per CG iteration
+        # (CGNR: + the scalars' all-reduce), {finite flag, model cost}; the same on every rank
+        its, per_it = recs[0]["lm_step"][2], (1 if solver_type == hip.ITERATIVE_SCHUR else 2)
+        assert all(rec["collectives"] == recs[0]["collectives"] for rec in recs)
+        assert per_it * its + 2 <= recs[0]["collectives"] <= per_it * (its + 1) + 6, (recs[0]["collectives"], its)
         if solver_type == hip.ITERATIVE_SCHUR:
             for rec in recs:
                 assert rel(rec["rhs"], ref["rhs"]) <= 1e-12 and rel(rec["sx"], ref["sx"]) <= 1e-12 and rel(rec["precond"], ref["precond"]) <= 1e-11
