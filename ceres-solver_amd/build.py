@@ -14,7 +14,7 @@ OUT = os.path.join(CSRC, "libceres_hip.so")
 BAL_SHAPES = [(3, 0), (4, 0), (6, 0), (8, 0), (9, 0), (10, 0), (6, 4), (6, 8), (9, 4), (9, 8)]
 SOURCES = (["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal_common.hip"] + [f"kernels_bal_shape_f{nf}_s{ns}.hip" for nf, ns in BAL_SHAPES] +
            ["kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"])
-HEADERS = ["common.h", "device.h", "bal_frontend.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
+HEADERS = ["common.h", "device.h", "snavely.h", "bal_frontend.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
 HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")
 HOST_DRIVER = os.path.join(HERE, "host", "host_driver")
 

@@ -141,6 +141,11 @@ struct CamItems {
   const int32_t *cam = nullptr, *begin = nullptr, *end = nullptr;
   int count = 0;
   int64_t observations = 0;   // of all items together (the launcher picks the kernel by the mean item length)
+  // <2,3,9> with the device evaluator (bal_frontend.inc): the pass EVALUATES its F cells instead of reading them — the records the
+  // tile-order evaluator left ([state | scale] per camera / point), and the point and pixel of every entry of the camera-major list
+  const double *ev_cam_pack = nullptr, *ev_pt_pack = nullptr;
+  const int32_t* ev_pt = nullptr;
+  const double2* ev_obs = nullptr;
 };
 struct CamGather {
   const double* parts = nullptr;          // nullptr: the blocks are already assembled in memory
@@ -490,6 +495,24 @@ struct BalEvalArgs {
   double* partials = nullptr;         // cost partial per workgroup (<= 2048)
 };
 hipError_t LaunchBalEvaluate(const BalEvalArgs& A, bool jacobian, int* nparts, hipStream_t stream);
+// The same in TILE order for the <2,3,9> fused path: the Jacobian lands in the solver's tiles (J_out, b_out: BalArgs' layout), the F
+// cells also at slot_fpos of e.values (nullptr: not), the residuals in e.residuals; e.values' E cells are NOT written.
+struct BalEvalTilesArgs {
+  BalEvalArgs e;
+  int64_t n_tiles = 0;
+  const int32_t* slot_bpos = nullptr;   // 2 x row of the slot, -1: padding
+  const int32_t* slot_fpos = nullptr;   // where the row's F cell starts in e.values
+  const int32_t* slot_cam = nullptr;    // the slot's camera / point (state order) / observed pixel: e.row_* in slot order
+  const int32_t* slot_pt = nullptr;
+  const double2* slot_obs = nullptr;
+  double* pt_pack = nullptr;            // scratch: [state 3 | scale 3] per point, [state 9 | scale 9] per camera (filled by the launch)
+  double* cam_pack = nullptr;
+  int debug_flags = 0;                  // timing experiments only (ceres_hip_debug_bal_evaluate_tiles_timing): 1 no F copy, 2 no tile J, 4 no b / residuals, 16 plain (not non-temporal) F copy
+  double2* J_out = nullptr;
+  int64_t tile_pitch = 0;               // double2 elements from one tile to the next
+  double2* b_out = nullptr;
+};
+hipError_t LaunchBalEvaluateTiles(const BalEvalTilesArgs& T, int64_t n_points, int64_t n_cameras, int* nparts, hipStream_t stream);
 // delta = step .* scale, cand = x + delta; partials[0..g) = |x|^2, [g..2g) = |delta|^2 partial sums
 hipError_t LaunchBalCandidate(const double* x, const double* step, const double* scale, double* delta, double* cand, int64_t n,
                               double* partials, int* nparts, hipStream_t stream);

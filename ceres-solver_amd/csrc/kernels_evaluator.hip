@@ -11,7 +11,10 @@
 // HBM-bound by its 208 B/observation of output; the arithmetic (~400 flop) is register resident.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device.h"
+#include "snavely.h"
 
 namespace chip {
 
@@ -26,92 +29,6 @@ __device__ __forceinline__ double wave_max_e(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
   return v;
-}
-
-// Residual (and, JAC, the Jacobian) of one observation.  cam = [angle-axis(3) t(3) f k1 k2].
-// jc = d res / d cam (2x9 row-major), jp = d res / d point (2x3 row-major).
-template <bool JAC>
-__device__ __forceinline__ void snavely(const double (&cam)[9], const double (&X)[3], double ox, double oy,
-                                        double (&res)[2], double (&jc)[18], double (&jp)[6]) {
-  const double a0 = cam[0], a1 = cam[1], a2 = cam[2];
-  const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
-  double P[3];
-  double R[9];      // d P / d X
-  double dPa[9];    // d P / d angle-axis, column j = derivative w.r.t. a_j, stored [row * 3 + j]
-  if (theta2 != 0.0) {
-    // Rodrigues: P = X cos + (w x X) sin + w (w.X)(1 - cos), w = a / theta   (include/ceres/rotation.h:864-905)
-    const double theta = sqrt(theta2);
-    const double c = cos(theta), s = sin(theta), inv = 1.0 / theta;
-    const double w[3] = {a0 * inv, a1 * inv, a2 * inv};
-    const double wxX[3] = {w[1] * X[2] - w[2] * X[1], w[2] * X[0] - w[0] * X[2], w[0] * X[1] - w[1] * X[0]};
-    const double wdX = w[0] * X[0] + w[1] * X[1] + w[2] * X[2];
-    const double omc = 1.0 - c;
-    const double tmp = wdX * omc;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) P[i] = X[i] * c + wxX[i] * s + w[i] * tmp;
-    if constexpr (JAC) {
-      // R = c I + s [w]x + (1 - c) w w^T
-      R[0] = c + omc * w[0] * w[0];         R[1] = -s * w[2] + omc * w[0] * w[1];  R[2] = s * w[1] + omc * w[0] * w[2];
-      R[3] = s * w[2] + omc * w[1] * w[0];  R[4] = c + omc * w[1] * w[1];          R[5] = -s * w[0] + omc * w[1] * w[2];
-      R[6] = -s * w[1] + omc * w[2] * w[0]; R[7] = s * w[0] + omc * w[2] * w[1];   R[8] = c + omc * w[2] * w[2];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        // d theta / d a_j = w_j ;  d w / d a_j = (e_j - w w_j) / theta
-        const double wj = w[j];
-        double dw[3] = {-w[0] * wj * inv, -w[1] * wj * inv, -w[2] * wj * inv};
-        dw[j] += inv;
-        const double dwxX[3] = {dw[1] * X[2] - dw[2] * X[1], dw[2] * X[0] - dw[0] * X[2], dw[0] * X[1] - dw[1] * X[0]};
-        const double dwdX = dw[0] * X[0] + dw[1] * X[1] + dw[2] * X[2];
-        const double dtmp = dwdX * omc + wdX * s * wj;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          dPa[i * 3 + j] = -X[i] * s * wj + dwxX[i] * s + wxX[i] * c * wj + dw[i] * tmp + w[i] * dtmp;
-      }
-    }
-  } else {
-    // first-order Taylor branch: P = X + a x X
-    P[0] = X[0] + (a1 * X[2] - a2 * X[1]);
-    P[1] = X[1] + (a2 * X[0] - a0 * X[2]);
-    P[2] = X[2] + (a0 * X[1] - a1 * X[0]);
-    if constexpr (JAC) {
-      R[0] = 1.0; R[1] = -a2; R[2] = a1;
-      R[3] = a2;  R[4] = 1.0; R[5] = -a0;
-      R[6] = -a1; R[7] = a0;  R[8] = 1.0;
-      // d (a x X) / d a_j = e_j x X
-      dPa[0] = 0.0;   dPa[1] = X[2];  dPa[2] = -X[1];
-      dPa[3] = -X[2]; dPa[4] = 0.0;   dPa[5] = X[0];
-      dPa[6] = X[1];  dPa[7] = -X[0]; dPa[8] = 0.0;
-    }
-  }
-  const double p0 = P[0] + cam[3], p1 = P[1] + cam[4], p2 = P[2] + cam[5];
-  const double iz = 1.0 / p2;
-  const double xp = -p0 * iz, yp = -p1 * iz;
-  const double f = cam[6], k1 = cam[7], k2 = cam[8];
-  const double r2 = xp * xp + yp * yp;
-  const double dist = 1.0 + r2 * (k1 + k2 * r2);
-  res[0] = f * dist * xp - ox;
-  res[1] = f * dist * yp - oy;
-  if constexpr (JAC) {
-    const double g = k1 + 2.0 * k2 * r2;  // d dist / d r2
-    // A = d res / d (xp, yp)
-    const double A00 = f * (dist + 2.0 * g * xp * xp), A01 = f * 2.0 * g * xp * yp;
-    const double A10 = A01, A11 = f * (dist + 2.0 * g * yp * yp);
-    // d (xp, yp) / d p = [-1/z 0 x/z^2 ; 0 -1/z y/z^2] = [-iz 0 -xp iz ; 0 -iz -yp iz]
-    const double J00 = -A00 * iz, J01 = -A01 * iz, J02 = -(A00 * xp + A01 * yp) * iz;
-    const double J10 = -A10 * iz, J11 = -A11 * iz, J12 = -(A10 * xp + A11 * yp) * iz;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      jp[j] = J00 * R[j] + J01 * R[3 + j] + J02 * R[6 + j];
-      jp[3 + j] = J10 * R[j] + J11 * R[3 + j] + J12 * R[6 + j];
-      jc[j] = J00 * dPa[j] + J01 * dPa[3 + j] + J02 * dPa[6 + j];
-      jc[9 + j] = J10 * dPa[j] + J11 * dPa[3 + j] + J12 * dPa[6 + j];
-    }
-    jc[3] = J00; jc[4] = J01; jc[5] = J02;
-    jc[12] = J10; jc[13] = J11; jc[14] = J12;
-    jc[6] = dist * xp;          jc[15] = dist * yp;
-    jc[7] = f * r2 * xp;        jc[16] = f * r2 * yp;
-    jc[8] = f * r2 * r2 * xp;   jc[17] = f * r2 * r2 * yp;
-  }
 }
 
 template <bool JAC>
@@ -150,6 +67,144 @@ __global__ __launch_bounds__(kVecBlock) void bal_evaluate_kernel(BalEvalArgs A) 
   }
   cost = wave_sum_e(cost);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cost;
+  __syncthreads();
+  if (threadIdx.x == 0) A.partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// The same evaluation in TILE order (round 4): one wavefront per tile of 64 observation slots, the Jacobian goes straight
+// into the layout the solver's passes read — J[tile][12][64] double2 (E pairs 0-2, F pairs 3-11), b[tile][64] double2, zeros in
+// the padding slots — with 1 KiB-contiguous stores per wave instruction, so the step has no re-layout pass and no caller-layout
+// E cells at all.  The F cells ALSO go to the caller layout (the camera-major preconditioner pass reads 144-byte cells there, where a
+// cell is contiguous): the wave's 64 cells are staged in LDS and written 16 bytes per lane in cell order, so that a wave
+// instruction covers whole cells of consecutive rows (a point's rows are consecutive: runs of a few hundred bytes) instead of 64
+// separate 16-byte pieces 144 bytes apart — the pattern that holds bal_evaluate_kernel<true> at 2.5 TB/s.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(double2* p, double x, double y) {
+  const double2 v = make_double2(x, y);
+  v4i raw;
+  __builtin_memcpy(&raw, &v, 16);
+  __builtin_nontemporal_store(raw, reinterpret_cast<v4i*>(p));
+}
+
+// {state, scale} of every parameter block as ONE 16-byte-aligned record — [3 + 3] doubles per point, [9 + 9] per camera — so that a lane
+// of the tile-order evaluator fetches its camera with 9 and its point with 3 16-byte loads instead of 18 + 6 8-byte ones: lanes of a
+// tile see 64 different cameras, every load instruction costs the texture path one line per lane, and the instruction count is what
+// that kernel's time follows (bal_evaluate_kernel<false>: 12 such gathers per observation, 87 us on the Venice shape = 64 lines x 12 per
+// 64 observations at one line per clock and CU).
+__global__ __launch_bounds__(kVecBlock) void bal_pack_state_kernel(const double* state, const double* scale, int64_t n_points, int64_t n_cameras,
+                                                                   double* pt_pack, double* cam_pack) {
+  const int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x;
+  if (i < n_points) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { pt_pack[6 * i + j] = state[3 * i + j]; pt_pack[6 * i + 3 + j] = scale ? scale[3 * i + j] : 1.0; }
+  } else if (i < n_points + n_cameras) {
+    const int64_t c = i - n_points, o = 3 * n_points + 9 * c;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { cam_pack[18 * c + j] = state[o + j]; cam_pack[18 * c + 9 + j] = scale ? scale[o + j] : 1.0; }
+  }
+}
+
+// Software pipeline, two stages deep: a tile's index words are loaded two iterations ahead, its parameter records one iteration ahead,
+// and nothing a wave waits for is ever queued BEHIND a store — the vector memory counter retires in order, so a load issued after tile
+// N's 23 store instructions cannot be consumed before every one of them is acknowledged (the first version did exactly that: its
+// time was compute + tile stores + F copy + residuals, 135 + 190 + 230 + 40 us on the Venice shape, nothing overlapped;
+// profiles/r04w_eval_tiles_store_groups.jsonl).  The loads are unconditional (clamped tile index, padding slots read record 0): the
+// wait counts stay static.
+struct TileIdx { int bp, fp, cam, pt; double2 obs; };
+struct TileRec { double2 c[9]; double2 p[3]; };
+__device__ __forceinline__ void issue_tile_idx(const BalEvalTilesArgs& T, int64_t tile, int lane, TileIdx& x) {
+  const int64_t sl = tile * 64 + lane;
+  x.bp = T.slot_bpos[sl]; x.fp = T.slot_fpos[sl]; x.cam = T.slot_cam[sl]; x.pt = T.slot_pt[sl]; x.obs = T.slot_obs[sl];
+}
+__device__ __forceinline__ void issue_tile_rec(const BalEvalTilesArgs& T, const TileIdx& x, TileRec& r) {
+  const double2* cp = reinterpret_cast<const double2*>(T.cam_pack + 18 * int64_t(x.cam));
+  const double2* pp = reinterpret_cast<const double2*>(T.pt_pack + 6 * int64_t(x.pt));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.c[i] = cp[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.p[i] = pp[i];
+}
+
+template <int DBG, bool F_COPY>   // DBG: BalEvalTilesArgs::debug_flags, compile-time (a run-time flag's branches cost the static wait counts)
+__global__ __launch_bounds__(kVecBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void bal_evaluate_tiles_kernel(BalEvalTilesArgs T) {
+  static_assert(kVecBlock == 256, "four waves per workgroup");
+  __shared__ double sh[4];
+  __shared__ double2 cells[4][64 * 9];   // a wave's 64 F cells, cell-major (9 pairs each)
+  const BalEvalArgs& A = T.e;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t stride = int64_t(gridDim.x) * 4, last = T.n_tiles - 1;
+  double cost = 0.0;
+  int64_t tile = int64_t(blockIdx.x) * 4 + wave;
+  TileIdx ix, ix1;
+  TileRec rec;
+  if (tile < T.n_tiles) {
+    issue_tile_idx(T, tile, lane, ix);
+    issue_tile_idx(T, tile + stride < last ? tile + stride : last, lane, ix1);
+    issue_tile_rec(T, ix, rec);
+    // everything of the prologue has arrived before the loop is entered: the loop header then inherits the back edge's state (23 stores
+    // in flight, no load) and not the prologue's — the compiler merges the two to the smaller count, which made every iteration wait
+    // for ten of the previous tile's stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  }
+  for (; tile < T.n_tiles; tile += stride) {
+    TileRec rec1;
+    TileIdx ix2;
+    issue_tile_rec(T, ix1, rec1);                                                           // tile + stride: its index words arrived an iteration ago
+    issue_tile_idx(T, tile + 2 * stride < last ? tile + 2 * stride : last, lane, ix2);
+    const int64_t sl = tile * 64 + lane;
+    const int bp = ix.bp;                      // 2 x row, -1: padding
+    const int fp = bp >= 0 ? ix.fp : -1;
+    double res[2] = {0.0, 0.0}, jc[18], jp[6];
+    {
+      const double cam9[9] = {rec.c[0].x, rec.c[0].y, rec.c[1].x, rec.c[1].y, rec.c[2].x, rec.c[2].y, rec.c[3].x, rec.c[3].y, rec.c[4].x};
+      const double X3[3] = {rec.p[0].x, rec.p[0].y, rec.p[1].x};
+      snavely<true>(cam9, X3, ix.obs.x, ix.obs.y, res, jc, jp);
+      const double sc[9] = {rec.c[4].y, rec.c[5].x, rec.c[5].y, rec.c[6].x, rec.c[6].y, rec.c[7].x, rec.c[7].y, rec.c[8].x, rec.c[8].y};
+#pragma unroll
+      for (int j = 0; j < 9; ++j) { jc[j] *= sc[j]; jc[9 + j] *= sc[j]; }
+      jp[0] *= rec.p[1].y; jp[3] *= rec.p[1].y; jp[1] *= rec.p[2].x; jp[4] *= rec.p[2].x; jp[2] *= rec.p[2].y; jp[5] *= rec.p[2].y;
+    }
+    if (bp < 0) {   // padding: zeros in the tiles (the record it evaluated is somebody's, the values are dropped)
+      res[0] = res[1] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 18; ++j) jc[j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) jp[j] = 0.0;
+    }
+    cost += 0.5 * (res[0] * res[0] + res[1] * res[1]);
+    // (padding lanes store their zeros into their own slot of the b tile — which holds zeros — instead of skipping the store: a store
+    // under a lane predicate may be branched over, and the compiler then counts on fewer stores in flight, so that its wait for the
+    // NEXT tile's index words would cover ten of this tile's stores.  Not one shared dummy line: non-temporal stores of thousands of
+    // waves to the same kilobyte serialise — 1.07 ms instead of 0.5.)
+    if constexpr (!(DBG & 4)) *(bp >= 0 ? reinterpret_cast<double2*>(A.residuals) + (bp >> 1) : T.b_out + sl) = make_double2(res[0], res[1]);
+    double2* o = T.J_out + tile * T.tile_pitch + lane;
+    if constexpr (!(DBG & 2)) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) nt_store(o + j * 64, jp[2 * j], jp[2 * j + 1]);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) nt_store(o + (3 + j) * 64, jc[2 * j], jc[2 * j + 1]);
+    }
+    if constexpr (!(DBG & 4)) nt_store(T.b_out + sl, res[0], res[1]);
+    if constexpr (F_COPY && !(DBG & 1)) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) cells[wave][lane * 9 + j] = make_double2(jc[2 * j], jc[2 * j + 1]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int q = k * 64 + lane, slot = q / 9, piece = q - 9 * slot;
+        const int f = __shfl(fp, slot, 64);
+        const double2 v = cells[wave][q];
+        // (non-temporal: the camera-major pass reads these 720 MB three kernels later; 609 -> 485 us in the unpipelined kernel)
+        double2* const dst = f >= 0 ? reinterpret_cast<double2*>(A.values + f) + piece : T.b_out + (tile * 64 + slot);
+        if constexpr ((DBG & 16) != 0) *dst = v;
+        else nt_store(dst, v.x, v.y);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    ix = ix1; ix1 = ix2; rec = rec1;
+  }
+  cost = wave_sum_e(cost);
+  if (lane == 0) sh[wave] = cost;
   __syncthreads();
   if (threadIdx.x == 0) A.partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
@@ -208,6 +263,25 @@ hipError_t LaunchBalEvaluate(const BalEvalArgs& A, bool jacobian, int* nparts, h
   *nparts = grid;
   if (jacobian) hipLaunchKernelGGL(bal_evaluate_kernel<true>, dim3(grid), dim3(kVecBlock), 0, stream, A);
   else hipLaunchKernelGGL(bal_evaluate_kernel<false>, dim3(grid), dim3(kVecBlock), 0, stream, A);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBalEvaluateTiles(const BalEvalTilesArgs& T, int64_t n_points, int64_t n_cameras, int* nparts, hipStream_t stream) {
+  hipLaunchKernelGGL(bal_pack_state_kernel, dim3(unsigned((n_points + n_cameras + kVecBlock - 1) / kVecBlock)), dim3(kVecBlock), 0, stream,
+                     T.e.state, T.e.scale, n_points, n_cameras, T.pt_pack, T.cam_pack);
+  const int64_t g = (T.n_tiles + 3) / 4;
+  const int grid = int(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+  *nparts = grid;
+#define EVAL_TILES_CASE(D) case D: hipLaunchKernelGGL((bal_evaluate_tiles_kernel<D, true>), dim3(grid), dim3(kVecBlock), 0, stream, T); break;
+  if (!T.e.values) {
+    hipLaunchKernelGGL((bal_evaluate_tiles_kernel<0, false>), dim3(grid), dim3(kVecBlock), 0, stream, T);
+  } else {
+    switch (T.debug_flags) {
+      EVAL_TILES_CASE(0) EVAL_TILES_CASE(1) EVAL_TILES_CASE(2) EVAL_TILES_CASE(3) EVAL_TILES_CASE(4) EVAL_TILES_CASE(7) EVAL_TILES_CASE(16)
+      default: return hipErrorInvalidValue;
+    }
+  }
+#undef EVAL_TILES_CASE
   return hipGetLastError();
 }
 

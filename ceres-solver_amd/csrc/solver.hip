@@ -52,6 +52,7 @@ struct ceres_hip_solver {
   int num_cus = 256;
   bool have_structure = false, loaded = false, have_b = false, have_D = false;
   bool packed = false;  // <2,3,9> path: tiles hold the currently loaded values
+  bool tiles_only = false;  // the loaded Jacobian exists ONLY as tiles (the device evaluator wrote them: bal_frontend.inc); `values` is not readable
   int path = CERES_HIP_PATH_GENERIC;
   HostStructure hs;
   BalPlan plan;
@@ -264,6 +265,13 @@ int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
   }
   if (!s->comm) return fail(s, CERES_HIP_E_COMM, "world_size > 1 but no communicator is connected");
   NCCL_TRY(s, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, s->comm, s->stream));
+  return 0;
+}
+
+// Kernels that read the caller-layout value array (the generic operators, also where the fused path borrows them) cannot serve a
+// Jacobian that exists only as tiles.
+int require_caller_values(ceres_hip_solver* s, const char* what) {
+  if (s->tiles_only) return fail(s, CERES_HIP_E_UNSUPPORTED, "%s reads the caller-layout values, which the device evaluator did not write (tiles only)", what);
   return 0;
 }
 
@@ -825,6 +833,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
     TRY(shared_preconditioner_blocks(s, false, out, true));
     return 0;
   }
+  TRY(require_caller_values(s, "the uninverted JACOBI blocks"));
   HIP_TRY(s, LaunchGenBlockDiagonal(s->G, s->values, kAll, s->world > 1 ? nullptr : s->D, out, len, st));
   if (s->world > 1) {
     // shared (camera) blocks follow the local (point) blocks in the sharded layout
@@ -977,6 +986,7 @@ int op_squared_column_norm(ceres_hip_solver* s, double* out) {
     PackGuard g = use_gather_if_unpacked(s, A);
     return g.commit(bal_scatter(s, kBalColNorm, A, nullptr, out + h.num_cols_e, false, nullptr));
   }
+  TRY(require_caller_values(s, "SquaredColumnNorm with the cameras' sums outside LDS"));
   HIP_TRY(s, LaunchGenSquaredColumnNorm(s->G, s->values, out, s->stream));
   if (s->world > 1) TRY(allreduce(s, out + h.num_cols_e, size_t(h.num_cols_f)));
   return 0;
@@ -1258,6 +1268,7 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->precond_valid = false;
   s->ftf_inv_valid = false;
   s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
+  s->tiles_only = false;
   s->rem_blocks_valid = false;
   s->D_int_valid = false;
   s->loaded = true;
@@ -2614,6 +2625,7 @@ int down(ceres_hip_solver* s, double* host, const double* dev, size_t n) {
 
 int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y) {
   TRY(require_loaded(s));
+  TRY(require_caller_values(s, "ceres_hip_op_right_multiply"));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   const HostStructure& h = s->hs;
   double *dx = s->scratch_vec, *dy = s->scratch_vec + h.num_cols;
@@ -2625,6 +2637,7 @@ int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y)
 
 int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) {
   TRY(require_loaded(s));
+  TRY(require_caller_values(s, "ceres_hip_op_left_multiply"));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   const HostStructure& h = s->hs;
   double *dy = s->scratch_vec, *dx = s->scratch_vec + h.num_cols;
@@ -2640,6 +2653,7 @@ int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) 
 namespace {
 int pmv_product(ceres_hip_solver* s, int part, bool left, const double* x, double* y) {
   TRY(require_loaded(s));
+  TRY(require_caller_values(s, "a PartitionedMatrixView product"));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   const HostStructure& h = s->hs;
   const size_t ncols = size_t(part == kE ? h.num_cols_e : h.num_cols_f);
@@ -2657,6 +2671,7 @@ int pmv_product(ceres_hip_solver* s, int part, bool left, const double* x, doubl
 }
 int pmv_block_diagonal(ceres_hip_solver* s, int part, double* blocks, int64_t capacity) {
   TRY(require_loaded(s));
+  TRY(require_caller_values(s, "a PartitionedMatrixView product"));
   HIP_TRY(s, hipSetDevice(s->opt.device));
   const HostStructure& h = s->hs;
   const int64_t len = part == kE ? h.diag_off_e.back() : h.diag_off_f.back();

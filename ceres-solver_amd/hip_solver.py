@@ -186,6 +186,7 @@ ABI += [
     ("ceres_hip_bal_destroy", None, [c_void_p]),
     ("ceres_hip_bal_last_error", c_char_p, [c_void_p]),
     ("ceres_hip_bal_linear_solver", c_void_p, [c_void_p]),
+    ("ceres_hip_debug_bal_evaluate_tiles_timing", c_int32, [c_void_p, _DP, c_int32, c_int32, _DP]),
     ("ceres_hip_bal_sizes", c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     ("ceres_hip_bal_get_row_order", c_int32, [c_void_p, POINTER(c_int32)]),
     ("ceres_hip_bal_evaluate", c_int32, [c_void_p, _DP, _DP, _DP, _DP, _DP]),
@@ -806,6 +807,29 @@ class BalProblem:
             self.close()
         except Exception:
             pass
+
+    def solver_info(self) -> CInfo:
+        """ceres_hip_get_info of the linear solver inside (which kernels its structure runs on, the tile plan)."""
+        i = CInfo()
+        self._check(self._lib.ceres_hip_get_info(self._lib.ceres_hip_bal_linear_solver(self._h), byref(i)))
+        return i
+
+    def preconditioner_blocks(self, not_inverted=False):
+        """The block-diagonal preconditioner of the LAST linear solve inside minimize (camera blocks; CGNR: point blocks first)."""
+        n = 81 * self.num_cameras + (9 * self.num_points if self.options.type == CGNR else 0)
+        out = np.full(n, np.nan)
+        inner = self._lib.ceres_hip_bal_linear_solver(self._h)
+        rc = self._lib.ceres_hip_get_preconditioner_blocks(inner, int(not_inverted), _p(out), n)
+        if rc != 0:
+            raise HipError(f"ceres_hip error {rc}: {self._lib.ceres_hip_last_error(inner).decode()}")
+        return out
+
+    def evaluate_tiles_timing(self, state, flags=0, iters=20) -> float:
+        """Average microseconds of the tile-order evaluator's launch (experiments: flags switch groups of its stores off)."""
+        x = _f64(state, self.num_parameters)
+        out = np.zeros(1)
+        self._check(self._lib.ceres_hip_debug_bal_evaluate_tiles_timing(self._h, _p(x), int(flags), int(iters), _p(out)))
+        return float(out[0])
 
     def row_order(self):
         out = np.empty(self.num_observations, dtype=np.int32)

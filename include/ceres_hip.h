@@ -457,6 +457,10 @@ typedef struct ceres_hip_minimizer_summary {
 /* TrustRegionMinimizer::Minimize with LEVENBERG_MARQUARDT, monotonic steps.  state: host, in/out. */
 int ceres_hip_bal_minimize(ceres_hip_bal* p, const ceres_hip_minimizer_options* options, double* state,
                            ceres_hip_minimizer_summary* summary);
+/* Timing probe of the evaluator that writes the solver's tiles (what ceres_hip_bal_minimize runs per Jacobian evaluation on the
+ * fused <2,3,9> path): average microseconds of `iters` back-to-back launches at `state`; flags != 0 switch groups of its stores
+ * off (experiments; the handle's Jacobian is unusable afterwards until the next evaluation).                                  */
+int ceres_hip_debug_bal_evaluate_tiles_timing(ceres_hip_bal* p, const double* state, int32_t flags, int32_t iters, double* avg_us);
 
 /* ---- timing for the roofline numbers --------------------------------------
  * Runs `iters` back-to-back launches of one operator on the solver's stream

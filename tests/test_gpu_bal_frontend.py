@@ -100,6 +100,53 @@ def test_minimize_follows_the_oracle_trust_region_loop(hip, oracle, solver_type,
     gp.close()
 
 
+@pytest.mark.parametrize("solver_type,pre,shape", [(5, 2, (12, 800, 3600)), (6, 1, (12, 800, 3600)), (5, 2, (2600, 1500, 9000)), (5, 2, (100, 30, 2400))])
+def test_evaluator_writing_the_tiles_is_the_two_pass_form(hip, oracle, monkeypatch, solver_type, pre, shape):
+    """Round 4: inside ceres_hip_bal_minimize the evaluator writes the solver's tiles itself (bal_evaluate_tiles_kernel: tile order, no
+    caller-layout E cells, no re-layout pass).  CERES_HIP_EVAL_TILES=0 is the earlier form — caller-layout values, gathered into the
+    tiles by the gradient's pass: the same numbers in the same tiles, so the two loops must agree far below the inexact-Newton
+    tolerance the oracle comparison has to allow.  Shapes: plain, more cameras than LDS rows (hybrid plan), points of more than
+    64 observations (whole tiles, rounds)."""
+    nc, npts, nobs = shape
+    op, gp, bs, nelim = make_pair(hip, oracle, nc, npts, nobs, seed=5, solver_type=solver_type, pre=pre)
+    assert gp.solver_info().kernel_path == hip.PATH_BAL
+    x0 = op.state()
+    runs = {}
+    # "1" (the default): tiles from the evaluator, and the camera-major preconditioner pass evaluates its F cells too — no caller-layout
+    # Jacobian exists; "2": tiles from the evaluator + a caller-layout copy of the F cells for that pass; "0": the two-pass form
+    blocks = {}
+    for form in ("1", "2", "0"):
+        monkeypatch.setenv("CERES_HIP_EVAL_TILES", form)
+        gp.minimize(x0, max_num_iterations=0)                        # evaluates at x0, solves nothing
+        if solver_type == hip.ITERATIVE_SCHUR:
+            blocks[form] = gp.preconditioner_blocks(not_inverted=True)   # camera-major pass over that Jacobian, as this form runs it
+        elif form != "0":   # CGNR's uninverted blocks come from a generic kernel over the caller layout: refused, not served from stale memory
+            with pytest.raises(hip.HipError, match="tiles only"):
+                gp.preconditioner_blocks(not_inverted=True)
+        runs[form] = gp.minimize(x0, max_num_iterations=6)
+    xb, Sb = runs["0"]
+    # the three forms evaluate the same formula in three kernels (other fused multiply-adds: the last bit of a cell may differ): the
+    # preconditioner blocks agree to rounding, and what inexact solves (eta = 0.1) on top of them return agrees as far as the oracle
+    # comparison's own tolerance — in practice far closer (1e-11 where the cameras are well determined)
+    if blocks:
+        print("blocks:", rel(blocks["1"], blocks["0"]), rel(blocks["2"], blocks["0"]))
+        assert rel(blocks["2"], blocks["0"]) <= 1e-13 and rel(blocks["1"], blocks["0"]) <= 1e-13
+    for form, cost_tol, x_tol in (("1", 1e-9, 1e-7), ("2", 1e-9, 1e-7)):
+        xa, Sa = runs[form]
+        assert Sa.num_iterations_logged == Sb.num_iterations_logged and Sa.num_iterations_logged >= 4
+        for i in range(Sa.num_iterations_logged):
+            a, b = Sa.iterations[i], Sb.iterations[i]
+            assert (a.step_is_successful, a.step_is_valid, a.linear_solver_iterations) == (b.step_is_successful, b.step_is_valid, b.linear_solver_iterations), (form, i)
+            assert abs(a.cost - b.cost) <= cost_tol * abs(a.cost) and abs(a.gradient_max_norm - b.gradient_max_norm) <= 100 * cost_tol * abs(a.gradient_max_norm), (form, i)
+        assert rel(xa, xb) <= x_tol, form
+        print("form", form, "cost diff", max(abs(Sa.iterations[i].cost - Sb.iterations[i].cost) / Sb.iterations[i].cost for i in range(Sa.num_iterations_logged)), "x", rel(xa, xb))
+    # an evaluation through the API afterwards (caller-layout values, E cells included) still gives the whole Jacobian
+    cost_o, res_o, vals_o = op.evaluate(xb)
+    cost, res, grad, vals = gp.evaluate(xb, residuals=True, gradient=True, jacobian=True)
+    assert rel(vals, vals_o) <= 1e-12 and rel(res, res_o) <= 1e-11   # (residuals near a minimum: differences of nearly equal pixels)
+    gp.close()
+
+
 def test_minimize_with_rejected_steps_and_without_jacobi_scaling(hip, oracle):
     # a huge initial radius makes the first steps overshoot: exercises the rejection path (reuse_diagonal,
     # radius /= decrease_factor) on both sides
