@@ -93,14 +93,22 @@ __device__ __forceinline__ void nt_store(double2* p, double x, double y) {
 // 64 observations at one line per clock and CU).
 __global__ __launch_bounds__(kVecBlock) void bal_pack_state_kernel(const double* state, const double* scale, int64_t n_points, int64_t n_cameras,
                                                                    double* pt_pack, double* cam_pack) {
-  const int64_t i = int64_t(blockIdx.x) * kVecBlock + threadIdx.x;
-  if (i < n_points) {
+  // one thread per 16-byte PAIR of the output (3 per point, 9 per camera): coalesced stores, reads of neighbouring words
+  const int64_t e = int64_t(blockIdx.x) * kVecBlock + threadIdx.x, n_pt_pairs = 3 * n_points;
+  if (e < n_pt_pairs) {
+    const int64_t i = e / 3;
+    const int k = int(e - 3 * i);   // pairs of [x0 x1 x2 s0 s1 s2]
+    double v[2];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { pt_pack[6 * i + j] = state[3 * i + j]; pt_pack[6 * i + 3 + j] = scale ? scale[3 * i + j] : 1.0; }
-  } else if (i < n_points + n_cameras) {
-    const int64_t c = i - n_points, o = 3 * n_points + 9 * c;
+    for (int h = 0; h < 2; ++h) { const int j = 2 * k + h; v[h] = j < 3 ? state[3 * i + j] : (scale ? scale[3 * i + j - 3] : 1.0); }
+    reinterpret_cast<double2*>(pt_pack)[e] = make_double2(v[0], v[1]);
+  } else if (e < n_pt_pairs + 9 * n_cameras) {
+    const int64_t q = e - n_pt_pairs, c = q / 9, o = 3 * n_points + 9 * c;
+    const int k = int(q - 9 * c);   // pairs of [state 9 | scale 9]
+    double v[2];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { cam_pack[18 * c + j] = state[o + j]; cam_pack[18 * c + 9 + j] = scale ? scale[o + j] : 1.0; }
+    for (int h = 0; h < 2; ++h) { const int j = 2 * k + h; v[h] = j < 9 ? state[o + j] : (scale ? scale[o + j - 9] : 1.0); }
+    reinterpret_cast<double2*>(cam_pack)[q] = make_double2(v[0], v[1]);
   }
 }
 
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(kVecBlock) void bal_pack_state_kernel(const double*
 // and nothing a wave waits for is ever queued BEHIND a store — the vector memory counter retires in order, so a load issued after tile
 // N's 23 store instructions cannot be consumed before every one of them is acknowledged (the first version did exactly that: its
 // time was compute + tile stores + F copy + residuals, 135 + 190 + 230 + 40 us on the Venice shape, nothing overlapped;
-// profiles/r04w_eval_tiles_store_groups.jsonl).  The loads are unconditional (clamped tile index, padding slots read record 0): the
+// profiles/r04w_eval_tiles_store_groups_unpipelined.jsonl).  The loads are unconditional (clamped tile index, padding slots read record 0): the
 // wait counts stay static.
 struct TileIdx { int bp, fp, cam, pt; double2 obs; };
 struct TileRec { double2 c[9]; double2 p[3]; };
@@ -267,7 +275,7 @@ hipError_t LaunchBalEvaluate(const BalEvalArgs& A, bool jacobian, int* nparts, h
 }
 
 hipError_t LaunchBalEvaluateTiles(const BalEvalTilesArgs& T, int64_t n_points, int64_t n_cameras, int* nparts, hipStream_t stream) {
-  hipLaunchKernelGGL(bal_pack_state_kernel, dim3(unsigned((n_points + n_cameras + kVecBlock - 1) / kVecBlock)), dim3(kVecBlock), 0, stream,
+  hipLaunchKernelGGL(bal_pack_state_kernel, dim3(unsigned((3 * n_points + 9 * n_cameras + kVecBlock - 1) / kVecBlock)), dim3(kVecBlock), 0, stream,
                      T.e.state, T.e.scale, n_points, n_cameras, T.pt_pack, T.cam_pack);
   const int64_t g = (T.n_tiles + 3) / 4;
   const int grid = int(g < 1 ? 1 : (g > 2048 ? 2048 : g));
