@@ -106,7 +106,7 @@ struct BalPlan {
   std::vector<int32_t> slot_epos, slot_fpos, slot_bpos;  // value / residual offsets, -1 = padding
   std::vector<int32_t> slot_cam, slot_pt;                // ids, -1 = padding
   std::vector<int32_t> slot_row;                         // row block of the slot, -1 = padding
-  std::vector<int32_t> mo_index;                         // hybrid plans: where a slot's M_o record lives (its row: plan.cc); empty: at the slot
+  std::vector<int32_t> mo_index;                         // where a slot's M_o record lives: its place in the camera-major list (hybrid plans: its row); empty: at the slot
   // first | last<<8 | valid<<16 | tailA<<17 | hasA<<23 | tailB<<24 | hasB<<30   (tails: see plan.cc)
   std::vector<uint32_t> slot_seg;
   // per tile: 0 normal (tile_aux = longest track | #points<<8), 1 / 3 head of a long point (tile_aux = #tiles; 3: the streaming
@@ -122,7 +122,7 @@ struct BalPlan {
   // camera-major lists
   std::vector<int32_t> cam_ptr;    // n_cameras+1
   std::vector<int32_t> cam_fpos;   // F value offset of each observation, camera-major
-  std::vector<int32_t> cam_slot;   // M_o record of each observation, camera-major (its slot; hybrid plans: its row, see mo_index)
+  std::vector<int32_t> cam_slot;   // M_o record of each observation, camera-major (see mo_index: the identity, or the row in hybrid plans)
   // work items of the camera-block kernel: (camera, [begin,end) in the camera-major list)
   std::vector<int32_t> item_cam, item_begin, item_end;
   std::vector<int32_t> cam_item_ptr;  // n_cameras+1: items [cam_item_ptr[c], cam_item_ptr[c+1]) belong to camera c
