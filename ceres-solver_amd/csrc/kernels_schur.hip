@@ -359,6 +359,61 @@ __global__ __launch_bounds__(256) void dense_trsm_mfma_kernel(double* __restrict
   }
 }
 
+// The same substitution with L_kk (and the parked inverses of its diagonal sub-blocks) staged in LDS once per workgroup (round 4): in the
+// kernel above every one of a strip's 144 MFMAs takes its A operand from memory — 144 dependent-looking 8-byte gathers with a row
+// pitch of n doubles per wavefront, and 50 us per panel at n = 8190 although the MFMA chain itself is 2 us long; the panel chain
+// (potrf -> trsm -> potrf -> trsm) is what the whole factorisation waits for (the bulk updates run beside it: LaunchDenseCholesky).
+// Here a workgroup copies the 128 x 128 block (coalesced rows, 132 KB of LDS) and its wavefronts take strips in turn.
+__global__ __launch_bounds__(256) void dense_trsm_lds_kernel(double* __restrict__ A, int n, int k0) {
+  extern __shared__ double Ls[];   // [kPanel][kPanelPitch]: lower triangle = L_kk, the parked 16 x 16 inverses above the diagonal
+  constexpr int kS = kPanel / kSub;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  {
+    const double* Lb = A + int64_t(k0) * n + k0;
+    const int c = tid & 127;
+    for (int rb = tid >> 7; rb < kPanel; rb += 32) {   // thread = column, two rows per sweep, 16 loads in flight
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = Lb[int64_t(rb + 2 * t) * n + c];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Ls[(rb + 2 * t) * kPanelPitch + c] = v[t];
+    }
+  }
+  __syncthreads();
+  const int n_strips = (n - k0 - kPanel + kSub - 1) / kSub;
+  for (int strip = blockIdx.x * 4 + (tid >> 6); strip < n_strips; strip += gridDim.x * 4) {
+    const int i0 = k0 + kPanel + kSub * strip;
+    const bool live = i0 + li < n;
+    double* arow = A + int64_t(min(i0 + li, n - 1)) * n + k0;
+    v4f64 X[kS], R[kS];
+#pragma unroll
+    for (int s = 0; s < kS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[s][r] = arow[kSub * s + lq + 4 * r];
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+      v4f64 acc = R[s];
+#pragma unroll
+      for (int sp = 0; sp < s; ++sp) {
+        const double* lp = Ls + (kSub * s + li) * kPanelPitch + kSub * sp + lq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[4 * kk], X[sp][kk], acc, 0, 0, 0);
+      }
+      const double* ip = Ls + (kSub * linv_block_row(s) + li) * kPanelPitch + kSub * linv_block_col(s) + lq;
+      v4f64 t = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ip[4 * kk], acc[kk], t, 0, 0, 0);
+      X[s] = t;
+    }
+    if (live) {
+#pragma unroll
+      for (int s = 0; s < kS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) arow[kSub * s + lq + 4 * r] = X[s][r];
+    }
+  }
+}
+
 // Trailing update of the LOWER triangle: A[i, j] -= sum_p X[i, p] X[j, p], X = A[:, k0 : k0 + kPanel], i >= j >= k0 + kPanel.
 // Workgroup = 128 x 128 outputs, wavefront = 64 x 64 = 4 x 4 MFMA tiles (16 accumulators in AGPRs).  The two 128-row operand strips
 // go through LDS 32 panel columns at a time — coalesced loads into registers while the previous chunk multiplies, two LDS buffers,
@@ -603,7 +658,8 @@ hipError_t LaunchDenseCholesky(double* A, int n, int* fail_flag, hipStream_t s) 
     const unsigned long long bit = 1ull << (dev & 63);
     std::lock_guard<std::mutex> lock(lds_mu);
     if (!(lds_done & bit)) {
-      const void* kernels[2] = {reinterpret_cast<const void*>(dense_potrf_panel_kernel), reinterpret_cast<const void*>(dense_syrk_mfma_kernel)};
+      const void* kernels[3] = {reinterpret_cast<const void*>(dense_potrf_panel_kernel), reinterpret_cast<const void*>(dense_syrk_mfma_kernel),
+                                reinterpret_cast<const void*>(dense_trsm_lds_kernel)};
       for (const void* k : kernels) {
         hipFuncAttributes fa;
         if (hipError_t e = hipFuncGetAttributes(&fa, k); e != hipSuccess) return e;
@@ -626,7 +682,11 @@ hipError_t LaunchDenseCholesky(double* A, int n, int* fail_flag, hipStream_t s) 
     const size_t lds = size_t((kw + kSub - 1) / kSub * kSub) * kPanelPitch * sizeof(double);
     hipLaunchKernelGGL(dense_potrf_panel_kernel, dim3(1), dim3(256), lds, s, A, n, k0, kw, fail_flag);
     const int rest = n - k0 - kw;
-    if (rest > 0) hipLaunchKernelGGL(dense_trsm_mfma_kernel, dim3((rest + 63) / 64), dim3(256), 0, s, A, n, k0);   // (rest > 0: a full panel)
+    if (rest > 0) {   // (rest > 0: a full panel)
+      static const bool from_memory = [] { const char* e = getenv("CERES_HIP_AB_TRSM_GLOBAL"); return e && atoi(e) != 0; }();   // (A/B: the round-3 kernel)
+      if (from_memory) hipLaunchKernelGGL(dense_trsm_mfma_kernel, dim3((rest + 63) / 64), dim3(256), 0, s, A, n, k0);
+      else hipLaunchKernelGGL(dense_trsm_lds_kernel, dim3(std::min((rest + 63) / 64, 256)), dim3(256), size_t(kPanel) * kPanelPitch * sizeof(double), s, A, n, k0);
+    }
     return rest;
   };
   for (int k0 = 0; k0 < n; k0 += 2 * kPanel) {
