@@ -647,11 +647,11 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   P.cam_fpos.resize(P.n_obs);
   P.cam_slot.resize(P.n_obs);
   if (!hybrid) {
-    // The M_o records live in CAMERA-major order (round 4): kInit scatters its 32-byte records — free there, the pass is bound by its
-    // gathers and tile stores (0.475 ms either way on the Venice shape) — and the camera-major pass reads them back to back instead
-    // of a 128-byte line per record: 0.332 -> 0.278 ms, 2.3x -> 1.7x its algorithmic bytes (profiles/r04zf_mo_camera_major_ab.txt).
-    // CERES_HIP_MO_CAMERA_MAJOR=0: records at their slots, as before.
-    bool mo_cm = true;
+    // CERES_HIP_MO_CAMERA_MAJOR=1 (experiment, round 4): the M_o records in CAMERA-major order — kInit scatters its 32-byte records,
+    // the camera-major pass reads them back to back instead of a 128-byte line per record.  Measured on the Venice shape
+    // (profiles/r04zi_mo_camera_major_ab.txt): the pass 0.332 -> 0.278 ms, kInit 0.471 -> 0.526 ms — the scattered stores cost what
+    // the coalesced reads save; off.
+    bool mo_cm = false;
     if (const char* e = getenv("CERES_HIP_MO_CAMERA_MAJOR")) mo_cm = atoi(e) != 0;
     if (mo_cm) P.mo_index.assign(size_t(P.n_tiles) * kTile, 0);
     int64_t extra = P.n_obs;   // records of valid slots without a camera cell: behind the lists (nobody reads them)

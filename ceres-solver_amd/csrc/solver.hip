@@ -77,7 +77,7 @@ struct ceres_hip_solver {
   bool cam_items_few = false;   // no camera has more than a handful of items: bal_invert9_kernel gathers seven cameras per wavefront
   int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr, *d_seq_ptr = nullptr, *d_round_flag = nullptr;  // long points: where they begin, their rounds (plan.cc)
   uint32_t* d_round_word = nullptr;
-  int32_t* d_mo_index = nullptr;                               // hybrid plans: M_o record of each slot
+  int32_t* d_mo_index = nullptr;                               // M_o record of each slot (camera-major; hybrid plans: the slot's row)
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
@@ -2021,10 +2021,10 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->d_partials, s->lds_mode ? size_t(s->fused_grid) * n9 : 1));
     TRY(dev_alloc(s, &s->d_global_acc, n9));
     TRY(dev_alloc(s, &s->d_zbuf, s->lds_mode ? size_t(1) : size_t(P.z_ring_rows) * P.nf));  // ring of ONE chunk's F^T z rows
+    if (!P.mo_index.empty()) TRY(dev_upload(s, &s->d_mo_index, P.mo_index));   // where kInit puts a slot's M_o record (plan.cc)
     if (!s->lds_mode) {
       TRY(dev_upload(s, &s->d_tile_zbase, P.tile_zbase));
       if (P.hybrid) TRY(dev_upload(s, &s->d_grp_tile_ptr, P.grp_tile_ptr));
-      if (!P.mo_index.empty()) TRY(dev_upload(s, &s->d_mo_index, P.mo_index));
       int32_t *uc = nullptr, *ub = nullptr, *ue = nullptr, *us = nullptr, *zs = nullptr;
       TRY(dev_upload(s, &uc, P.zu_cam)); TRY(dev_upload(s, &ub, P.zu_begin)); TRY(dev_upload(s, &ue, P.zu_end));
       TRY(dev_upload(s, &us, P.zu_shared)); TRY(dev_upload(s, &zs, P.zc_slot));
