@@ -76,6 +76,21 @@ def test_lm_compute_step_matches_reference(hip, oracle, problems, kind, solver_t
     s.close()
 
 
+def test_camera_major_mo_records_experiment(hip, oracle, problems, monkeypatch):
+    """CERES_HIP_MO_CAMERA_MAJOR=1 (design/11 §11.8: measured, net zero, off by default): kInit scatters the 2 x 2 M_o records into
+    camera-major order and the SCHUR_JACOBI pass reads them back to back.  Same step, same preconditioner blocks as the oracle's."""
+    monkeypatch.setenv("CERES_HIP_MO_CAMERA_MAJOR", "1")
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+    assert s.info().kernel_path == hip.PATH_BAL
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, 1e4, 0.1)
+    ref_step, ref_summ, ref_mcc, ref_D, diag = reference_step(oracle, hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, 1e4, 0.1)
+    check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, ref_D, step, summ, mcc, 0.1)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    assert rel(s.preconditioner_blocks(not_inverted=True), m.schur_jacobi(p.values, ref_D)[1]) <= 1e-11
+    s.close()
+
+
 @pytest.mark.parametrize("kind,solver_type,pre", [("bal_schur", 5, 2), ("bal_cgnr", 6, 1), ("general", 5, 2), ("bal_many_cameras", 5, 2)])
 def test_retry_after_rejection_keeps_the_resident_jacobian(hip, oracle, problems, kind, solver_type, pre):
     """ceres_hip_lm_options::values_unchanged: after a rejected step the minimizer calls ComputeStep on the SAME Jacobian with a smaller
