@@ -100,7 +100,8 @@ def test_minimize_follows_the_oracle_trust_region_loop(hip, oracle, solver_type,
     gp.close()
 
 
-@pytest.mark.parametrize("solver_type,pre,shape", [(5, 2, (12, 800, 3600)), (6, 1, (12, 800, 3600)), (5, 2, (2600, 1500, 9000)), (5, 2, (100, 30, 2400))])
+@pytest.mark.parametrize("solver_type,pre,shape", [(5, 2, (12, 800, 3600)), (6, 1, (12, 800, 3600)), (5, 2, (2600, 1500, 9000)), (5, 2, (100, 30, 2400)),
+                                                   (5, 0, (2600, 1500, 9000))])   # (the last: the combination that keeps the two-pass form, bal_writes_tiles)
 def test_evaluator_writing_the_tiles_is_the_two_pass_form(hip, oracle, monkeypatch, solver_type, pre, shape):
     """Round 4: inside ceres_hip_bal_minimize the evaluator writes the solver's tiles itself (bal_evaluate_tiles_kernel: tile order, no
     caller-layout E cells, no re-layout pass).  CERES_HIP_EVAL_TILES=0 is the earlier form — caller-layout values, gathered into the
