@@ -693,10 +693,11 @@ def main():
             tf = n_dc ** 3 / 3.0 / ms_dc / 1e9
             extra["dense_schur_cholesky"] = {
                 "what": "DenseCholesky::FactorAndSolve of a random SPD matrix the size of a 910-camera reduced system (blocked, 128-wide panels, "
-                        "trailing update on v_mfma_f64_16x16x4_f64; csrc/kernels_schur.hip)", "n": n_dc, "factor_ms": round(ms_dc, 3),
+                        "trailing update on v_mfma_f64_4x4x4_4b_f64 beside the potrf / trsm panel chain, which is what the factorisation waits "
+                        "for; csrc/kernels_schur.hip, design/11_round4.md 11.6)", "n": n_dc, "factor_ms": round(ms_dc, 3),
                 "TFLOPs": round(tf, 2), "peak_TFLOPs_datasheet_fp64_matrix": 78.6, "frac_of_datasheet_peak": round(tf / 78.6, 4),
-                "mfma_f64_sustained_TFLOPs_probe": 35.6, "frac_of_probe": round(tf / 35.6, 4),
-                "probe": "tools/probes/mfma_f64_probe.hip, profiles/r03j_mfma_f64_probe.txt: 16 independent accumulator chains per wave, no memory traffic",
+                "mfma_f64_sustained_TFLOPs_probe": 77.0, "frac_of_probe": round(tf / 77.0, 4),
+                "probe": "tools/probes/mfma_f64_probe.hip, profiles/r04m_mfma_f64_probe.txt: v_mfma_f64_4x4x4_4b_f64 75-77.8 TFLOP/s (the 16x16x4 form: 35)",
                 "failed": bool(failed_dc), "rel_err_of_solve": float(np.linalg.norm(xs - xt) / np.linalg.norm(xt))}
             del Bm, Am
         except Exception as ex:
