@@ -334,6 +334,7 @@ def main():
 
     # ---- timed region: K LM linear solves, inputs resident in HBM -------------------
     elapsed, iters, last = timed_steps(solver, (tv, tb, tD, tx), args.steps, args.warmup, sync, args.step, args.eta)
+    collectives_last_step = int(solver.info().collectives_last_step)   # (of the last timed step: read before any other leg runs a solve)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -836,7 +837,7 @@ def main():
                                        ("the one-shot peer-to-peer all-reduce (hipIpc / xGMI)" if solver.p2p_ok else "RCCL all-reduce") +
                                        (" — ONE-GPU VALIDATION MODE, timings meaningless" if one_gpu else ""))
                        if world > 1 else "1 GPU",
-                       "collectives_per_step": int(solver.info().collectives_last_step) if world > 1 and args.step == "lm_step" else 0,
+                       "collectives_per_step": collectives_last_step if world > 1 and args.step == "lm_step" else 0,
                        "inputs_resident_in_hbm": True, "step_finite": step_ok,
                        "jacobian_storage": "fp32 tiles, fp64 arithmetic (accuracy mode, not parity)" if storage else "fp64",
                        "kernel_path": "fused<2,3,9>" if info.kernel_path == hs.PATH_BAL else "generic",
