@@ -112,10 +112,11 @@ def test_evaluator_writing_the_tiles_is_the_two_pass_form(hip, oracle, monkeypat
     assert gp.solver_info().kernel_path == hip.PATH_BAL
     x0 = op.state()
     runs = {}
-    # "1" (the default): tiles from the evaluator, and the camera-major preconditioner pass evaluates its F cells too — no caller-layout
-    # Jacobian exists; "2": tiles from the evaluator + a caller-layout copy of the F cells for that pass; "0": the two-pass form
+    # "1" (the default): tiles from the evaluator; the camera-major preconditioner pass evaluates its F cells too where its items are long
+    # (no caller-layout Jacobian exists then) and reads a caller-layout copy of them otherwise; "3" / "2": always the first / the second;
+    # "0": the two-pass form
     blocks = {}
-    for form in ("1", "2", "0"):
+    for form in ("1", "2", "3", "0"):
         monkeypatch.setenv("CERES_HIP_EVAL_TILES", form)
         gp.minimize(x0, max_num_iterations=0)                        # evaluates at x0, solves nothing
         if solver_type == hip.ITERATIVE_SCHUR:
@@ -129,10 +130,10 @@ def test_evaluator_writing_the_tiles_is_the_two_pass_form(hip, oracle, monkeypat
     # preconditioner blocks agree to rounding, and what inexact solves (eta = 0.1) on top of them return agrees as far as the oracle
     # comparison's own tolerance — in practice far closer (1e-11 where the cameras are well determined)
     if blocks:
-        print("blocks:", rel(blocks["1"], blocks["0"]), rel(blocks["2"], blocks["0"]))
-        assert rel(blocks["2"], blocks["0"]) <= 1e-13 and rel(blocks["1"], blocks["0"]) <= 1e-13
+        print("blocks:", rel(blocks["1"], blocks["0"]), rel(blocks["2"], blocks["0"]), rel(blocks["3"], blocks["0"]))
+        assert rel(blocks["2"], blocks["0"]) <= 1e-13 and rel(blocks["1"], blocks["0"]) <= 1e-13 and rel(blocks["3"], blocks["0"]) <= 1e-13
     loose = False
-    for form, cost_tol, x_tol in (("1", 1e-5 if loose else 1e-9, 1e-3 if loose else 1e-7), ("2", 1e-5 if loose else 1e-9, 1e-3 if loose else 1e-7)):
+    for form, cost_tol, x_tol in ((f, 1e-5 if loose else 1e-9, 1e-3 if loose else 1e-7) for f in ("1", "2", "3")):
         xa, Sa = runs[form]
         assert Sa.num_iterations_logged == Sb.num_iterations_logged and Sa.num_iterations_logged >= 4
         for i in range(Sa.num_iterations_logged):
