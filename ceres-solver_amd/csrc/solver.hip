@@ -1269,6 +1269,8 @@ int load_device(ceres_hip_solver* s, const double* dv, const double* db, const d
   s->ftf_inv_valid = false;
   s->packed = false;  // the tiles are (re)built by the first kernel that walks J, or by ensure_packed()
   s->tiles_only = false;
+  // (values from anybody but the device evaluator: the camera-major pass reads its cells again — bal_frontend.inc sets these after its load)
+  s->cam_items.ev_cam_pack = nullptr; s->cam_items.ev_pt_pack = nullptr; s->cam_items.ev_pt = nullptr; s->cam_items.ev_obs = nullptr;
   s->rem_blocks_valid = false;
   s->D_int_valid = false;
   s->loaded = true;
