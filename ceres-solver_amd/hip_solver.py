@@ -87,6 +87,8 @@ class CLmResult(ctypes.Structure):
 
 # every symbol include/ceres_hip.h declares: (name, restype, argtypes)
 _DP = POINTER(c_double)
+ABI_VERSION = 2   # CERES_HIP_ABI_VERSION of include/ceres_hip.h this binding mirrors (struct layouts below)
+
 ABI = [
     ("ceres_hip_abi_version", c_int32, []),
     ("ceres_hip_device_count", c_int32, []),
@@ -218,8 +220,8 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.ceres_hip_abi_version() != 1:
-            raise RuntimeError("ABI version mismatch")
+        if lib.ceres_hip_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI version mismatch: the library says {lib.ceres_hip_abi_version()}, this binding is written for {ABI_VERSION}")
         _lib = lib
     return _lib
 

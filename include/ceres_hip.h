@@ -52,7 +52,8 @@
 extern "C" {
 #endif
 
-#define CERES_HIP_ABI_VERSION 1
+/* 2 (round 4): ceres_hip_info grew by collectives_last_step (128 -> 136 bytes); ceres_hip_lm_options.reserved became values_unchanged */
+#define CERES_HIP_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define CERES_HIP_OK 0

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, (set(declared) ^ set(bound))
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ceres_hip_abi_version() == 1
+    assert lib.ceres_hip_abi_version() == hs.ABI_VERSION == 2
 
 
 def test_enums_match_reference_values():
@@ -64,3 +64,35 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".cc", ".hip")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "libceres_oracle" not in src and "ceres_oracle.h" not in src and "oracle_" not in src, f
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Every struct the ctypes binding mirrors has the size AND the field offsets the C compiler gives include/ceres_hip.h (a grown
+    struct behind an unchanged ABI version is how a stale binding corrupts memory: ceres_hip_info grew in round 4, version 2)."""
+    import ctypes
+    import shutil
+    import subprocess
+    hs = pkg.hip_solver
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"ceres_hip_options": hs.COptions, "ceres_hip_summary": hs.CSummary, "ceres_hip_info": hs.CInfo, "ceres_hip_solve_timing": hs.CTiming,
+             "ceres_hip_lm_options": hs.CLmOptions, "ceres_hip_lm_result": hs.CLmResult, "ceres_hip_minimizer_options": hs.CMinimizerOptions,
+             "ceres_hip_iteration_summary": hs.CIterationSummary, "ceres_hip_minimizer_summary": hs.CMinimizerSummary}
+    lines = ['#include "ceres_hip.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().splitlines()
+    assert len(out) == len(pairs)
+    for line, (cname, cls) in zip(out, pairs.items()):
+        got = line.split()
+        assert got[0] == cname
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(v) for v in got[1:]] == want, cname
