@@ -77,7 +77,8 @@ def test_struct_layouts_match_the_header(tmp_path):
         pytest.skip("no C compiler")
     pairs = {"ceres_hip_options": hs.COptions, "ceres_hip_summary": hs.CSummary, "ceres_hip_info": hs.CInfo, "ceres_hip_solve_timing": hs.CTiming,
              "ceres_hip_lm_options": hs.CLmOptions, "ceres_hip_lm_result": hs.CLmResult, "ceres_hip_minimizer_options": hs.CMinimizerOptions,
-             "ceres_hip_iteration_summary": hs.CIterationSummary, "ceres_hip_minimizer_summary": hs.CMinimizerSummary}
+             "ceres_hip_iteration_summary": hs.CIterationSummary, "ceres_hip_minimizer_summary": hs.CMinimizerSummary,
+             "ceres_hip_block_structure": pkg.block_structure.CBlockStructure}
     lines = ['#include "ceres_hip.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {"]
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
