@@ -11,7 +11,9 @@ from conftest import ROOT
 
 LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r02x_bench_*.json")) +
                [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03zb_bench_default_iterative_schur.json", "r03zm_bench_default_iterative_schur.json",
-                                                          "r03zq_bench_default_iterative_schur.json", "r03p_bench_cgnr.json")])
+                                                          "r03zq_bench_default_iterative_schur.json", "r03p_bench_cgnr.json",
+                                                          "r04a_bench_default_iterative_schur.json", "r04l_bench_default_iterative_schur.json",
+                                                          "r04_final_bench_default_iterative_schur.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -38,7 +40,7 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "under_rocprof" not in path and "fp32" not in path and not two_ranks:   # profiled / fp32-storage / validation runs skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
-    if os.path.basename(path).startswith(("r02", "r03")):   # since round 2: what the traffic figure is, and the probe for real Ceres
+    if os.path.basename(path).startswith(("r02", "r03", "r04")):   # since round 2: what the traffic figure is, and the probe for real Ceres
         assert r["traffic"] is None or "profiles/" in r["traffic_source"]
         if cpu:
             assert "tools/probe.sh" in cpu["sample"]
@@ -96,3 +98,22 @@ def test_end_of_round3_line_has_the_long_points_in_rounds():
     assert rg[1]["hybrid"] == 1 and rg[1]["sx"]["frac"] >= 0.35 and rg[1]["jtjx"]["frac"] >= 0.30
     assert d["roofline"]["frac"] >= 0.70 and d["extra"]["cgnr"]["jtjx_frac_hbm"] >= 0.60
     assert d["extra"]["synthetic10M"]["sx"]["frac"] >= 0.40
+
+
+def test_round4_default_line_fields():
+    """Round 4: the host-boundary rate next to `value`, the retry after a rejected step, the conditioned workload in which CG dominates,
+    the structures beyond <2,3,9>, the full-size oracle check of configs[4], and a trust-region iteration under 4.1 ms."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_final_bench_default_iterative_schur.json")).read())
+    assert "gpu_over_cpu" not in d and d["value_host_boundary"] == pytest.approx(d["host_boundary"]["steps_per_s"], rel=1e-6)
+    retry = d["host_boundary"]["retry_after_rejection"]
+    assert retry["ms_per_step"] < 0.15 * d["host_boundary"]["ms_per_step"] and retry["device_pointer_retry_ms_per_step"] < d["ms_per_step"]
+    cond = d["extra"]["conditioned_step"]["eta_0.0001"]
+    assert cond["cg_iterations"] >= 15 and cond["cg_share_of_step"] > 0.8
+    assert d["extra"]["synthetic10M"]["step_rel_diff_vs_oracle"] < 1e-9
+    cases = d["extra"]["other_shapes"]["cases"]
+    assert len(cases) >= 4 and all(c["lm_step"]["step_rel_diff_vs_oracle_iterate_of_the_same_index"] < 1e-9 for c in cases)
+    assert sum(c["kernel_path"] == "fused" for c in cases) >= 3
+    assert d["scene_trust_region"]["ms_per_lm_iteration"] < 4.1
+    assert d["config"]["collectives_per_step"] == 0   # one rank
+    two = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r04_final_bench_self_launched_2ranks_ladybug_iterative_schur.json")) if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 4 and two["oracle_check"]["step_rel_diff_vs_oracle"] < 1e-9
