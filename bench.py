@@ -649,21 +649,24 @@ def main():
             cases = [("<2,3,10> quaternion cameras (bundle_adjuster --use_quaternions)", dict(camera_width=10), False),
                      ("<2,3,6>", dict(camera_width=6), False),
                      ("<2,3,9> on the GENERIC kernels (force_generic_path)", dict(camera_width=9), True),
-                     ("libmv structure <2, 8 | 6, 3>: shared intrinsics + 6-wide pose + point, first camera constant", dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)), False)]
+                     ("libmv structure <2, 8 | 6, 3>: shared intrinsics + 6-wide pose + point, first camera constant", dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)), False),
+                     ("<2,4,9> homogeneous points (the reference's (2,4,9) specialisation; round 5: point blocks 2 and 4 wide on the fused path)", dict(camera_width=9, point_width=4), False)]
             for label, kw, force_generic in cases:
                 sp = pkg.problems.synthetic_structured(lb_c, lb_p, lb_o, seed=38401, skew=args.skew, **kw)
-                nf_, ns_ = kw["camera_width"], sum(kw.get("shared_widths", ()))
-                slot_b = (6 + 2 * nf_ + 2 * ns_) * 8 + 8
+                nf_, ns_, pw_ = kw["camera_width"], sum(kw.get("shared_widths", ())), kw.get("point_width", 3)
+                slot_b = (2 * pw_ + 2 * nf_ + 2 * ns_) * 8 + 8
                 n_fs = int(sp.bs.col_block_size[sp.num_eliminate_blocks:].sum())
                 case = {"structure": label, "bytes_per_observation": slot_b}
                 for sv, kd, typ, pre in (("iterative_schur", "sx", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI), ("cgnr", "jtjx", hs.CGNR, hs.JACOBI)):
+                    if pw_ != 3 and sv == "cgnr":
+                        continue   # (point blocks that are not 3 wide: the Schur solvers run fused, CGNR on the generic kernels)
                     so_ = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
                                                                     elimination_groups=[sp.num_eliminate_blocks], device=local_rank, force_generic_path=force_generic))
                     so_.set_structure(sp.bs)
                     case["kernel_path"] = "fused" if so_.info().kernel_path == hs.PATH_BAL else "generic"
                     so_.load(sp.values, sp.b, sp.D)
                     ms_ = min(so_.time_op(hs.TIMED_SX if kd == "sx" else hs.TIMED_JTJX, 20) for _ in range(3))
-                    nb_ = lb_o * slot_b + (lb_p * 72 + n_fs * 32 if kd == "sx" else (3 * lb_p + n_fs) * 32)
+                    nb_ = lb_o * slot_b + (lb_p * pw_ * pw_ * 8 + n_fs * 32 if kd == "sx" else (pw_ * lb_p + n_fs) * 32)
                     case[kd] = {"ms": round(ms_, 5), "frac": round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     if sv == "iterative_schur":
                         step_, summ_, mcc_ = so_.lm_compute_step(sp.values, sp.b, RADIUS, args.eta)

@@ -76,7 +76,12 @@ struct HostStructure {
 // of 4 / 8 scalars next to the 6- and 9-wide cameras.
 constexpr int kMaxSharedScalars = 8;   // strip width limit (BalArgs::sh_pos)
 constexpr int kMaxSharedCellsPerRow = 2;
-inline bool BalShapeCompiled(int nf, int ns) {
+// Point blocks: 3 wide, and — round 5 — the other E widths the reference specialises with a 2-high row
+// (generate_template_specializations.py:55-75): (2,2,2) (2,2,3) (2,2,4) and (2,4,3) (2,4,4) (2,4,6) (2,4,8) (2,4,9), no strip.
+inline bool BalShapeCompiled(int ne, int nf, int ns) {
+  if (ne == 2) return ns == 0 && (nf == 2 || nf == 3 || nf == 4);
+  if (ne == 4) return ns == 0 && (nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9);
+  if (ne != 3) return false;
   if (ns == 0) return nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9 || nf == 10;
   return (nf == 6 || nf == 9) && (ns == 4 || ns == 8);
 }
@@ -86,6 +91,7 @@ struct BalPlan {
   bool eligible = false;
   std::string why_not;         // reason the fused path was not selected
   int n_points = 0, n_cameras = 0;
+  int ne = 3;                  // width of the point blocks (2, 3 or 4: BalShapeCompiled)
   int nf = 9;                  // width of the camera blocks
   int ns_used = 0, ns = 0;     // shared strip: scalars in use, compiled strip width (BalStripWidthFor)
   std::vector<int32_t> sh_block;   // shared column blocks, in strip order

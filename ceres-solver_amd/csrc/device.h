@@ -79,7 +79,7 @@ struct BalArgs {
   const uint32_t* round_word = nullptr;
   int64_t z_flush_row0 = 0;
   int pq_accumulate = 0;       // kJtJx chunked: pq_out[workgroup] += instead of = (later chunks of one application)
-  const int32_t* pt_pos = nullptr;   // nullptr => 3*p
+  const int32_t* pt_pos = nullptr;   // nullptr => ne*p (ne: the shape's point width)
   const int32_t* cam_pos = nullptr;  // nullptr => cam_base + nf*c   (relative to the F base pointer)
   int cam_base = 0;
   int sh_pos[kMaxSharedScalars] = {};   // the strip's scalars in the F-space vectors (shapes with a shared strip)
@@ -97,10 +97,10 @@ struct BalArgs {
   double lm_radius = 0.0, lm_min = 0.0, lm_max = 0.0;
   double* lm_diag_e = nullptr;  // clamped diag(J^T J), point part (indexed like x_e)
   double* lm_D_e = nullptr;     // D, point part
-  // per-point 3x3 inverses, packed symmetric 6 doubles / point
+  // per-point ne x ne inverses, packed upper triangle at a pitch of BalOps::etei_pitch doubles (3-wide points: 6 doubles / point)
   double* etei = nullptr;
-  double* point_blocks = nullptr;         // dense 3x3 output (CGNR JACOBI) or nullptr
-  const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => 9*p
+  double* point_blocks = nullptr;         // dense ne x ne output (CGNR JACOBI) or nullptr
+  const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => ne*ne*p
   double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 m01 (kInit)
   const int32_t* mo_index = nullptr;      // record of each slot in Mo (nullptr: the slot itself; hybrid plans: the slot's row)
   int have_b = 0;
@@ -182,7 +182,7 @@ struct StripBlocks {
 // The fused kernels are compiled once per SHAPE (camera width nf, shared strip ns: common.h, kernels_bal.inc — one translation unit
 // per shape); this is one shape's launchers.
 struct BalOps {
-  int nf, ns, pairs, tile_pitch, cam_part, has_f32, has_cg_tail;   // tile_pitch: double2 elements per tile; cam_part: doubles per item of the camera-major pass
+  int ne, nf, ns, pairs, tile_pitch, cam_part, etei_pitch, has_f32, has_cg_tail;   // tile_pitch: double2 elements per tile; cam_part: doubles per item of the camera-major pass; etei_pitch: doubles per point in the store of packed (E^T E)^-1
   hipError_t (*fused)(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
   // whether fused(kBalSx, A, lds, ..) runs the pipelined kernel — the one that can finish a CG iteration (A.tail)
   bool (*sx_runs_pipelined)(const BalArgs& A);
@@ -209,7 +209,7 @@ struct BalOps {
   // cut into the shared blocks' dense diagonal blocks (+ D^2) in the F-block store
   hipError_t (*strip_finish)(const double* parts, int nparts, const StripBlocks& sb, const double* D_f, double* blocks, hipStream_t stream);
 };
-const BalOps* GetBalOps(int nf, int ns);   // nullptr: not compiled (common.h: BalShapeCompiled)
+const BalOps* GetBalOps(int ne, int nf, int ns);   // nullptr: not compiled (common.h: BalShapeCompiled)
 // the dynamic-LDS ceiling of a kernel, raised once per (kernel, device)
 hipError_t AllowMaxLds(const void* kernel);
 
@@ -364,7 +364,8 @@ hipError_t LaunchPermutePoints(const double* in, double* out, const int32_t* pt_
 hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_t stream);
 // values(cell)[r][c] *= scale[col]: BlockSparseMatrix::ScaleColumns (I/block_sparse_matrix.cc:403-450)
 hipError_t LaunchGenScaleColumns(const GenStructure& G, double* values, const double* scale, hipStream_t stream);
-hipError_t LaunchExpandSym3(const double* packed6, double* dense9, const int64_t* pt_diag_off, int n_points, hipStream_t stream);
+// dense[off[p] ..] (ne x ne) = the symmetric matrix whose packed upper triangle sits at packed[p * pitch ..]
+hipError_t LaunchExpandSym(const double* packed, int ne, int pitch, double* dense, const int64_t* pt_diag_off, int n_points, hipStream_t stream);
 // out[off[p] + k] = in[9 p + k], k < 9 (in and out must not overlap)
 hipError_t LaunchScatterBlocks9(const double* in, double* out, const int64_t* off, int n_points, hipStream_t stream);
 

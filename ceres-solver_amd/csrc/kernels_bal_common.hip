@@ -51,9 +51,35 @@ const BalOps* BalOps_bal_f6_s4();
 const BalOps* BalOps_bal_f6_s8();
 const BalOps* BalOps_bal_f9_s4();
 const BalOps* BalOps_bal_f9_s8();
+const BalOps* BalOps_bal_e2_f2_s0();
+const BalOps* BalOps_bal_e2_f3_s0();
+const BalOps* BalOps_bal_e2_f4_s0();
+const BalOps* BalOps_bal_e4_f3_s0();
+const BalOps* BalOps_bal_e4_f4_s0();
+const BalOps* BalOps_bal_e4_f6_s0();
+const BalOps* BalOps_bal_e4_f8_s0();
+const BalOps* BalOps_bal_e4_f9_s0();
 
-const BalOps* GetBalOps(int nf, int ns) {
-  if (!BalShapeCompiled(nf, ns)) return nullptr;
+const BalOps* GetBalOps(int ne, int nf, int ns) {
+  if (!BalShapeCompiled(ne, nf, ns)) return nullptr;
+  if (ne == 2) {
+    switch (nf) {
+      case 2: return BalOps_bal_e2_f2_s0();
+      case 3: return BalOps_bal_e2_f3_s0();
+      case 4: return BalOps_bal_e2_f4_s0();
+    }
+    return nullptr;
+  }
+  if (ne == 4) {
+    switch (nf) {
+      case 3: return BalOps_bal_e4_f3_s0();
+      case 4: return BalOps_bal_e4_f4_s0();
+      case 6: return BalOps_bal_e4_f6_s0();
+      case 8: return BalOps_bal_e4_f8_s0();
+      case 9: return BalOps_bal_e4_f9_s0();
+    }
+    return nullptr;
+  }
   switch (nf * 100 + ns) {
     case 300: return BalOps_bal_f3_s0();
     case 400: return BalOps_bal_f4_s0();

@@ -114,12 +114,17 @@ __global__ __launch_bounds__(kVecBlock) void dot_final_kernel(const double* part
   v = block_sum(v, sh);
   if (threadIdx.x == 0) out[0] = v;
 }
-__global__ void expand_sym3_kernel(const double* p6, double* d9, const int64_t* off, int n) {
+// the packed upper triangle of a point's ne x ne block (row by row, `pitch` doubles per point) -> the dense block
+__global__ void expand_sym_kernel(const double* packed, int ne, int pitch, double* dense, const int64_t* off, int n) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const double* a = p6 + int64_t(p) * 6;
-  double* o = d9 + (off ? off[p] : int64_t(9) * p);
-  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[1]; o[4] = a[3]; o[5] = a[4]; o[6] = a[2]; o[7] = a[4]; o[8] = a[5];
+  const double* a = packed + int64_t(p) * pitch;
+  double* o = dense + (off ? off[p] : int64_t(ne) * ne * p);
+  for (int i = 0; i < ne; ++i)
+    for (int j = 0; j < ne; ++j) {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      o[ne * i + j] = a[lo * (2 * ne + 1 - lo) / 2 + (hi - lo)];
+    }
 }
 
 // out[off[p] + k] = in[9 p + k]: the dense 3x3 point blocks of a CGNR solve (internal point order) into the caller's block order
@@ -710,8 +715,8 @@ hipError_t LaunchNegateAndCheck(double* x, int64_t n, int* nonfinite, hipStream_
   if (n > 0) hipLaunchKernelGGL(negate_and_check_kernel, dim3(vec_grid(n)), dim3(kVecBlock), 0, s, x, n, nonfinite);
   return hipGetLastError();
 }
-hipError_t LaunchExpandSym3(const double* p6, double* d9, const int64_t* off, int n, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(expand_sym3_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p6, d9, off, n);
+hipError_t LaunchExpandSym(const double* packed, int ne, int pitch, double* dense, const int64_t* off, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(expand_sym_kernel, dim3((n + 255) / 256), dim3(256), 0, s, packed, ne, pitch, dense, off, n);
   return hipGetLastError();
 }
 

@@ -136,9 +136,13 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (h.nrb == 0) return no("empty matrix");
   // Classify column blocks: POINTS (the eliminated blocks; without an elimination order: the 3-wide ones), and among the others the
   // CAMERAS (at most one cell per row, all of one width nf) and a few SHARED blocks (common.h: the strip).
+  // The eliminated blocks are all of ONE width: 3, or — with an elimination order — 2 or 4 (common.h: BalShapeCompiled; the reference's
+  // (2,2,*) and (2,4,*) specialisations).
+  P.ne = h.nelim > 0 ? h.csz[0] : 3;
+  if (P.ne < 2 || P.ne > 4) return no("eliminated blocks that are not 2, 3 or 4 wide");
   auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
   for (int j = 0; j < h.ncb; ++j)
-    if (is_point(j) && h.csz[j] != 3) return no("an eliminated block is not 3 wide");
+    if (is_point(j) && h.csz[j] != P.ne) return no("eliminated blocks of different widths");
 
   // Remainder: the longest run of TRAILING rows that touch camera blocks only (no point cell; possibly no cell at all).  A conforming
   // row has a point cell, so the split is unambiguous.  Everything in front of it must conform.
@@ -195,8 +199,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   for (int c = 0; c < P.n_cameras; ++c)
     if (h.csz[P.cam_block[c]] != P.nf) return no("camera blocks of different widths");
   P.ns = BalStripWidthFor(P.ns_used);
-  if (P.ns < 0 || !BalShapeCompiled(P.nf, P.ns)) return no("no fused kernels are compiled for this camera width / shared strip");
-  if (P.n_rem_rows > 0 && !(P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
+  if (P.ns < 0 || !BalShapeCompiled(P.ne, P.nf, P.ns)) return no("no fused kernels are compiled for this point width / camera width / shared strip");
+  if (P.n_rem_rows > 0 && !(P.ne == 3 && P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
   for (size_t q = 0; q < P.sh_block.size(); ++q)
     for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
 
@@ -262,7 +266,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
 
   // the caller's column layout: points-then-cameras, back to back?
   P.caller_contiguous = true;
-  for (int p = 0; p < P.n_points && P.caller_contiguous; ++p) P.caller_contiguous = h.cpos[P.pt_block[p]] == 3 * p;
+  for (int p = 0; p < P.n_points && P.caller_contiguous; ++p) P.caller_contiguous = h.cpos[P.pt_block[p]] == P.ne * p;
   for (int c = 0; c < P.n_cameras && P.caller_contiguous; ++c) P.caller_contiguous = h.cpos[P.cam_block[c]] - h.num_cols_e == P.nf * c;
   if (P.ns > 0) P.caller_contiguous = false;   // (a shared block sits somewhere among the camera-side columns)
   const bool reorder_points = reorder_mode == kReorderAlways || (reorder_mode == kReorderIfContiguous && P.caller_contiguous);
@@ -451,7 +455,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   P.points_contiguous = P.cameras_contiguous = true;
   for (int p = 0; p < P.n_points; ++p) {
     P.pt_pos[p] = h.cpos[P.pt_block[p]];
-    if (P.pt_pos[p] != 3 * p) P.points_contiguous = false;
+    if (P.pt_pos[p] != P.ne * p) P.points_contiguous = false;
   }
   for (int c = 0; c < P.n_cameras; ++c) {
     P.cam_pos[c] = h.cpos[P.cam_block[c]] - h.num_cols_e;

@@ -1372,7 +1372,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       if (s->dense_from_blocks) {
         const double* ei = s->etei;
         if (s->path == CERES_HIP_PATH_BAL) {  // packed 6-per-point inverses (internal point order) -> the dense E-block store
-          HIP_TRY(s, LaunchExpandSym3(s->etei, s->etei_dense, s->d_pt_eoff, s->plan.n_points, st));
+          HIP_TRY(s, LaunchExpandSym(s->etei, s->ops->ne, s->ops->etei_pitch, s->etei_dense, s->d_pt_eoff, s->plan.n_points, st));
           ei = s->etei_dense;
         }
         HIP_TRY(s, LaunchSchurSparseEliminate(s->G, s->schur_pairs, s->values, ei, s->D, s->d_Sblk, st));
@@ -1790,11 +1790,17 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     // Schur solvers: no CG vector lives in point space; CGNR: only where its CG vectors can be the caller's with the points renumbered
     BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
   }
-  s->ops = s->plan.eligible ? GetBalOps(s->plan.nf, s->plan.ns) : nullptr;
+  s->ops = s->plan.eligible ? GetBalOps(s->plan.ne, s->plan.nf, s->plan.ns) : nullptr;
   if (s->plan.eligible && (!s->ops || (s->opt.jacobian_storage == 1 && !s->ops->has_f32))) {
     // (fp32 tiles exist for the 9-wide shape only)
     s->plan.eligible = false;
     s->plan.why_not = !s->ops ? "no kernels for this shape" : "option not available for this shape";
+  }
+  if (s->plan.eligible && s->plan.ne != 3 && (!is_schur(s) || s->world > 1)) {
+    // point blocks of 2 or 4 scalars: the Schur solvers' tile passes on one device (CGNR's vector kernels and the sharded runs'
+    // bookkeeping hold points as 3-vectors)
+    s->plan.eligible = false;
+    s->plan.why_not = "point blocks that are not 3 wide: the fused path takes the Schur solvers on one device";
   }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
@@ -2013,7 +2019,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * s->ops->tile_pitch));
     TRY(dev_alloc(s, &s->d_bt, n_slots));
     TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
-    TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * 6));
+    TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * s->ops->etei_pitch));
     const size_t n9 = size_t(P.nf) * P.n_cameras + size_t(P.ns);   // accumulator entries: the cameras' scalars, then the strip
     s->lds_mode = P.cameras_in_lds;
     s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
@@ -2740,7 +2746,7 @@ int ceres_hip_get_ete_inverse(ceres_hip_solver* s, double* blocks, int64_t capac
   if (s->path == CERES_HIP_PATH_BAL) {
     double* tmp = nullptr;
     HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * len));
-    hipError_t e = LaunchExpandSym3(s->etei, tmp, s->d_pt_eoff, s->plan.n_points, s->stream);  // internal point order -> the caller's E blocks
+    hipError_t e = LaunchExpandSym(s->etei, s->ops->ne, s->ops->etei_pitch, tmp, s->d_pt_eoff, s->plan.n_points, s->stream);  // internal point order -> the caller's E blocks
     int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "expand failed");
     (void)hipFree(tmp);
     return rc;

@@ -396,7 +396,7 @@ def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_
 
 
 def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
-                   shared_of_obs=None, layout="schur", seed=38401, with_values=True) -> LinearProblem:
+                   shared_of_obs=None, layout="schur", seed=38401, with_values=True, point_width=3) -> LinearProblem:
     """Bundle-adjustment Jacobian of the structures the reference's examples produce beyond <2,3,9>: rows are 2 high and hold one point
     cell (2 x 3), the observing camera's cell (2 x camera_width; none if the camera is in `locked_cameras`: SetParameterBlockConstant,
     examples/libmv_bundle_adjuster.cc:725-728) and a cell on every SHARED block (`shared_widths`: libmv's camera intrinsics, <2, 8, 6, 3>,
@@ -404,7 +404,10 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
     Rows grouped by point (observations must come sorted by point).  layout "schur": column blocks = points, then the camera-side blocks in
     program order (shared blocks first, like libmv's intrinsics, or last), values E|F-split, the F cells of a row back to back in column
     order (internal/ceres/block_jacobian_writer.cc:68-167); "cgnr": the same column order, values row-sequential, no elimination.
-    camera_width 10 = bundle_adjuster --use_quaternions (examples/snavely_reprojection_error.h:164)."""
+    camera_width 10 = bundle_adjuster --use_quaternions (examples/snavely_reprojection_error.h:164).  point_width: the width of the point
+    (E) blocks — 3, or 2 / 4 for the reference's (2,2,*) / (2,4,*) specialisations (generate_template_specializations.py:55-75; 4 =
+    homogeneous points)."""
+    pw = int(point_width)
     rng = np.random.default_rng(seed)
     n_obs = int(point_of_obs.shape[0])
     nsb = len(shared_widths)
@@ -414,7 +417,7 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
     f_sizes = ([int(w) for w in shared_widths] if shared_first else []) + [int(camera_width)] * n_cams + ([] if shared_first else [int(w) for w in shared_widths])
     sh0 = 0 if shared_first else n_cams          # F index of the first shared block
     cam0 = nsb if shared_first else 0            # F index of camera 0
-    col_sizes = np.concatenate([np.full(n_points, 3, np.int64), np.asarray(f_sizes, np.int64)]).astype(np.int32)
+    col_sizes = np.concatenate([np.full(n_points, pw, np.int64), np.asarray(f_sizes, np.int64)]).astype(np.int32)
     col_pos = np.concatenate([[0], np.cumsum(col_sizes.astype(np.int64))[:-1]])
     has_cam = ~locked[cam_of_obs]
     sh_mask = np.ones((n_obs, nsb), dtype=bool) if shared_of_obs is None else np.asarray(shared_of_obs, dtype=bool)
@@ -425,7 +428,7 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
     cell_col = np.empty(n_cells, dtype=np.int64)
     cell_w = np.empty(n_cells, dtype=np.int64)
     cur = ptr[:-1].copy()
-    cell_col[cur] = point_of_obs; cell_w[cur] = 3; cur += 1
+    cell_col[cur] = point_of_obs; cell_w[cur] = pw; cur += 1
 
     def put_shared():
         for q in range(nsb):
@@ -444,9 +447,9 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
     is_e[ptr[:-1]] = True
     cell_pos = np.empty(n_cells, dtype=np.int64)
     if layout == "schur":
-        cell_pos[is_e] = 6 * np.arange(n_obs)
+        cell_pos[is_e] = 2 * pw * np.arange(n_obs)
         f_len = cell_len[~is_e]
-        cell_pos[~is_e] = 6 * n_obs + np.concatenate([[0], np.cumsum(f_len)[:-1]])
+        cell_pos[~is_e] = 2 * pw * n_obs + np.concatenate([[0], np.cumsum(f_len)[:-1]])
         nelim = n_points
     elif layout == "cgnr":
         cell_pos[:] = np.concatenate([[0], np.cumsum(cell_len)[:-1]])
@@ -473,7 +476,7 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
 
 
 def synthetic_structured(num_cameras, num_points, num_observations, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
-                         layout="schur", seed=38401, skew=0.0, with_values=True) -> LinearProblem:
+                         layout="schur", seed=38401, skew=0.0, with_values=True, point_width=3) -> LinearProblem:
     """structured_bal on the random visibility of synthetic_bal (every point seen by >= 2 distinct cameras)."""
     rng = np.random.default_rng(seed)
     k = _track_lengths(rng, num_cameras, num_points, num_observations)
@@ -485,7 +488,7 @@ def synthetic_structured(num_cameras, num_points, num_observations, camera_width
     cam_of_obs = _distinct_cameras(rng, num_cameras, point_of_obs, weights)
     order = np.lexsort((cam_of_obs, point_of_obs))
     return structured_bal(num_cameras, num_points, point_of_obs, cam_of_obs[order], camera_width, shared_widths, shared_first, locked_cameras,
-                          None, layout, seed + 1, with_values)
+                          None, layout, seed + 1, with_values, point_width)
 
 
 def libmv_structured(problem=2, copies=1, intrinsics_width=8, lock_first_camera=True, layout="schur", seed=38401, with_values=True) -> LinearProblem:

@@ -135,3 +135,92 @@ def test_strip_and_locked_cameras_beyond_lds(hip, oracle, problems):
 def test_unsupported_widths_fall_back_to_the_generic_path(hip, oracle, problems):
     p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)
     assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_GENERIC))
+
+
+# ---- point blocks that are not 3 wide (round 5): the reference's (2,2,*) and (2,4,*) specialisations
+# (internal/ceres/generate_template_specializations.py:55-75) on the fused path — every (E, F) pair of that list
+POINT_SHAPES = {f"e{ne}_f{nf}": dict(point_width=ne, camera_width=nf) for ne, nf in ((2, 2), (2, 3), (2, 4), (4, 3), (4, 4), (4, 6), (4, 8), (4, 9))}
+
+
+@pytest.mark.parametrize("name", list(POINT_SHAPES))
+def test_operators_with_point_blocks_of_2_and_4(hip, oracle, problems, name):
+    """ImplicitSchurComplement / SchurEliminator / PartitionedMatrixView operators of the Schur solvers on the fused kernels at 1e-12;
+    DetectStructure reports the reference's static triple.  CGNR (no Schur solver): the generic kernels."""
+    kw = POINT_SHAPES[name]
+    p = problems.synthetic_structured(40, 2500, 11000, seed=5, skew=0.5, **kw)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    info = s.info()
+    assert (info.row_block_size, info.e_block_size, info.f_block_size) == (2, kw["point_width"], kw["camera_width"])
+    s.close()
+    # CGNR knows no elimination order: "points" are whatever is 3 wide.  (2,4,3): the 3-wide cameras take the points' role and the 4-wide
+    # points the cameras' — a <2,3,4> plan, fused; everything else here has no such reading and runs on the generic kernels.
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL if name == "e4_f3" else hip.PATH_GENERIC))
+
+
+@pytest.mark.parametrize("name", ["e4_f9", "e4_f6", "e2_f3", "e2_f2", "e4_f3"])
+@pytest.mark.parametrize("pre", [2, 1])
+def test_schur_solver_with_point_blocks_of_2_and_4(hip, oracle, problems, name, pre):
+    """ITERATIVE_SCHUR (SCHUR_JACOBI / JACOBI) on rungs (2) and (4) of the parity ladder, the device LM step and its retry."""
+    p = problems.synthetic_structured(40, 2500, 11000, seed=6, skew=0.5, **POINT_SHAPES[name])
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    fn = m.iterative_schur_solve
+    for k in (1, 7, 25):
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, min_it=k, max_it=k)
+        assert s.info().kernel_path == hip.PATH_BAL
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=0.0))
+        s.close()
+        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=k, max_it=k, q_tol=-1.0, r_tol=0.0)
+        assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
+        assert rel(x, xo) <= 1e-9, (k, rel(x, xo))
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, max_it=500)
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(x, summ, lambda lo, hi, q, r: fn(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r), 0.1, hip.SUCCESS)
+    radius = 1e4
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)
+    diag = np.clip(oracle.Matrix(p.bs, 0).squared_column_norm(p.values), 1e-6, 1e32)
+    assert rel(s.lm_diagonal(), np.sqrt(diag / radius)) <= 1e-13
+    check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+    step, summ, mcc = s.lm_compute_step(None, None, radius / 2, 0.1, reuse_diagonal=True, values_unchanged=True)
+    check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, pre, np.sqrt(diag / (radius / 2)), step, summ, mcc, 0.1)
+    s.close()
+
+
+def test_homogeneous_points_with_long_tracks_and_many_cameras(hip, oracle, problems):
+    """(2,4,9) where the plain tile walk is not enough: points of more than 64 observations (whole tiles, rounds) on the libmv visibility
+    graph, and more cameras than LDS rows (hybrid plan, spilled rows)."""
+    n_c, n_p, cam_of, pt_of = problems.libmv_visibility(2)
+    order = np.lexsort((cam_of, pt_of))
+    p = problems.structured_bal(n_c, n_p, pt_of[order], cam_of[order], 9, point_width=4, seed=3)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+    # (tracks of at least THREE observations: two rows of a 4-wide point make its E square, E^T E + D^2 is then inverted at a condition
+    # number of 1e4 .. 1e6 and M_o = I - E (E^T E + D^2)^-1 E^T is a difference of nearly equal numbers — the blocks of a camera that sees
+    # only such points agree with the oracle to 3e-10 instead of 1e-12; a point needs three views to be determined up to scale anyway)
+    rng = np.random.default_rng(8)
+    k = 3 + np.minimum(rng.geometric(0.75, size=60000) - 1, 20)
+    pt_of = np.repeat(np.arange(60000, dtype=np.int64), k)
+    w = np.arange(1, 30001, dtype=np.float64) ** -0.4
+    cam_of = problems._distinct_cameras(rng, 30000, pt_of, w / w.sum())
+    order = np.lexsort((cam_of, pt_of))
+    q = problems.structured_bal(30000, 60000, pt_of[order], cam_of[order], 6, point_width=4, seed=9)
+    errs = check_schur_operators(hip, oracle, q, False, hip.PATH_BAL)
+    raw = errs.pop("schur_jacobi_raw")
+    assert_errs(errs)
+    assert raw <= 1e-11, raw
+    s = make_solver(hip, q, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    assert s.info().camera_accum_in_lds == 0
+    s.close()
+
+
+def test_dense_schur_with_homogeneous_points(hip, oracle, problems):
+    """DENSE_SCHUR on a (2,4,6) problem: the fused set-up pass's packed 4 x 4 inverses, expanded into the eliminator's dense E-block
+    store, feed SchurEliminator::Eliminate; the solve is the damped least-squares solution."""
+    p = problems.synthetic_structured(24, 900, 4000, camera_width=6, point_width=4, seed=12, skew=0.3)
+    A = p.bs.to_dense(p.values)
+    ref = np.linalg.lstsq(np.vstack([A, np.diag(p.D)]), np.concatenate([p.b, np.zeros(p.num_cols)]), rcond=None)[0]
+    s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.DENSE_SCHUR, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=1))
+    s.set_structure(p.bs)
+    assert s.info().kernel_path == hip.PATH_BAL
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
+    s.close()
+    assert summ.termination_type == hip.SUCCESS and rel(x, ref) <= 1e-9, (summ, rel(x, ref))

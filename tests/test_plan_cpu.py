@@ -275,10 +275,11 @@ def test_plan_rejections(problems):
 
 
 @pytest.mark.parametrize("kw", [dict(camera_width=10), dict(camera_width=6), dict(camera_width=3), dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
-                                dict(camera_width=9, shared_widths=(5, 3), shared_first=False)])
+                                dict(camera_width=9, shared_widths=(5, 3), shared_first=False),
+                                dict(point_width=4, camera_width=9), dict(point_width=4, camera_width=3, locked_cameras=(2,)), dict(point_width=2, camera_width=4)])
 def test_plan_of_other_shapes(problems, kw):
-    """Camera widths other than 9, shared blocks and rows without a camera cell (common.h: shapes): the tiles still hold every row once,
-    grouped by point; a row without a camera cell is a valid slot whose camera is -2."""
+    """Camera widths other than 9, shared blocks, rows without a camera cell, point blocks 2 and 4 wide (common.h: shapes): the tiles still
+    hold every row once, grouped by point; a row without a camera cell is a valid slot whose camera is -2."""
     hs = pkg.hip_solver
     p = problems.synthetic_structured(25, 700, 3300, seed=11, with_values=False, **kw)
     r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
