@@ -14,8 +14,11 @@ OUT = os.path.join(CSRC, "libceres_hip.so")
 BAL_SHAPES = [(3, 0), (4, 0), (6, 0), (8, 0), (9, 0), (10, 0), (6, 4), (6, 8), (9, 4), (9, 8)]
 # point blocks other than 3 wide (round 5): (ne, nf), no strip
 BAL_SHAPES_E = [(2, 2), (2, 3), (2, 4), (4, 3), (4, 4), (4, 6), (4, 8), (4, 9)]
+# row blocks other than 2 high (round 5): (nr, ne, nf), no strip — the reference's (3,3,3), (4,4,2), (4,4,3), (4,4,4)
+BAL_SHAPES_R = [(3, 3, 3), (4, 4, 2), (4, 4, 3), (4, 4, 4)]
 SOURCES = (["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal_common.hip"] + [f"kernels_bal_shape_f{nf}_s{ns}.hip" for nf, ns in BAL_SHAPES] +
            [f"kernels_bal_shape_e{ne}_f{nf}_s0.hip" for ne, nf in BAL_SHAPES_E] +
+           [f"kernels_bal_shape_r{nr}_e{ne}_f{nf}_s0.hip" for nr, ne, nf in BAL_SHAPES_R] +
            ["kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"])
 HEADERS = ["common.h", "device.h", "snavely.h", "bal_frontend.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
 HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")

@@ -78,7 +78,11 @@ constexpr int kMaxSharedScalars = 8;   // strip width limit (BalArgs::sh_pos)
 constexpr int kMaxSharedCellsPerRow = 2;
 // Point blocks: 3 wide, and — round 5 — the other E widths the reference specialises with a 2-high row
 // (generate_template_specializations.py:55-75): (2,2,2) (2,2,3) (2,2,4) and (2,4,3) (2,4,4) (2,4,6) (2,4,8) (2,4,9), no strip.
-inline bool BalShapeCompiled(int ne, int nf, int ns) {
+// Row blocks: 2 high, and — round 5 — the reference's remaining static specialisations (3,3,3), (4,4,2), (4,4,3), (4,4,4), no strip.
+inline bool BalShapeCompiled(int nr, int ne, int nf, int ns) {
+  if (nr == 3) return ne == 3 && nf == 3 && ns == 0;
+  if (nr == 4) return ne == 4 && ns == 0 && (nf == 2 || nf == 3 || nf == 4);
+  if (nr != 2) return false;
   if (ne == 2) return ns == 0 && (nf == 2 || nf == 3 || nf == 4);
   if (ne == 4) return ns == 0 && (nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9);
   if (ne != 3) return false;
@@ -91,6 +95,7 @@ struct BalPlan {
   bool eligible = false;
   std::string why_not;         // reason the fused path was not selected
   int n_points = 0, n_cameras = 0;
+  int nr = 2;                  // height of the row blocks (2, 3 or 4: BalShapeCompiled)
   int ne = 3;                  // width of the point blocks (2, 3 or 4: BalShapeCompiled)
   int nf = 9;                  // width of the camera blocks
   int ns_used = 0, ns = 0;     // shared strip: scalars in use, compiled strip width (BalStripWidthFor)

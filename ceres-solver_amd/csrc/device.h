@@ -42,7 +42,7 @@ struct BalArgs {
   // packed problem
   const double2* J = nullptr;   // [n_tiles][3 + nf + ns][64]
   const float4* Jf = nullptr;   // [n_tiles][6][64]  fp32 storage mode (then J is unused)
-  const double2* b = nullptr;   // [n_tiles][64]
+  const double2* b = nullptr;   // [n_tiles][b_pairs][64]: the slot's nr residuals (2-high rows: one double2 per slot)
   // fused re-layout: when src_values != nullptr the kernel gathers from the caller's layout and
   // writes the tiles (J_out, b_out) as it goes (first pass of a step)
   const double* src_values = nullptr;
@@ -101,7 +101,7 @@ struct BalArgs {
   double* etei = nullptr;
   double* point_blocks = nullptr;         // dense ne x ne output (CGNR JACOBI) or nullptr
   const int64_t* pt_diag_off = nullptr;   // offsets into point_blocks; nullptr => ne*ne*p
-  double* Mo = nullptr;                   // [n_slots][4] symmetric 2x2 per observation: m00 m01 m11 m01 (kInit)
+  double* Mo = nullptr;                   // [n_slots][mo_pitch] symmetric nr x nr per observation, packed upper triangle (2-high rows: m00 m01 m11 m01) (kInit)
   const int32_t* mo_index = nullptr;      // record of each slot in Mo (nullptr: the slot itself; hybrid plans: the slot's row)
   int have_b = 0;
   // camera accumulation
@@ -182,7 +182,9 @@ struct StripBlocks {
 // The fused kernels are compiled once per SHAPE (camera width nf, shared strip ns: common.h, kernels_bal.inc — one translation unit
 // per shape); this is one shape's launchers.
 struct BalOps {
-  int ne, nf, ns, pairs, tile_pitch, cam_part, etei_pitch, has_f32, has_cg_tail;   // tile_pitch: double2 elements per tile; cam_part: doubles per item of the camera-major pass; etei_pitch: doubles per point in the store of packed (E^T E)^-1
+  // tile_pitch: double2 elements per tile; cam_part: doubles per item of the camera-major pass; etei_pitch: doubles per point in the store
+  // of packed (E^T E)^-1; b_pairs: double2 per slot of the residual tiles; mo_pitch: doubles per M_o record
+  int nr, ne, nf, ns, pairs, tile_pitch, cam_part, etei_pitch, b_pairs, mo_pitch, has_f32, has_cg_tail;
   hipError_t (*fused)(int mode, const BalArgs& A, bool lds, int grid, hipStream_t stream);
   // whether fused(kBalSx, A, lds, ..) runs the pipelined kernel — the one that can finish a CG iteration (A.tail)
   bool (*sx_runs_pipelined)(const BalArgs& A);
@@ -209,7 +211,7 @@ struct BalOps {
   // cut into the shared blocks' dense diagonal blocks (+ D^2) in the F-block store
   hipError_t (*strip_finish)(const double* parts, int nparts, const StripBlocks& sb, const double* D_f, double* blocks, hipStream_t stream);
 };
-const BalOps* GetBalOps(int ne, int nf, int ns);   // nullptr: not compiled (common.h: BalShapeCompiled)
+const BalOps* GetBalOps(int nr, int ne, int nf, int ns);   // nullptr: not compiled (common.h: BalShapeCompiled)
 // the dynamic-LDS ceiling of a kernel, raised once per (kernel, device)
 hipError_t AllowMaxLds(const void* kernel);
 

@@ -59,9 +59,22 @@ const BalOps* BalOps_bal_e4_f4_s0();
 const BalOps* BalOps_bal_e4_f6_s0();
 const BalOps* BalOps_bal_e4_f8_s0();
 const BalOps* BalOps_bal_e4_f9_s0();
+const BalOps* BalOps_bal_r3_e3_f3_s0();
+const BalOps* BalOps_bal_r4_e4_f2_s0();
+const BalOps* BalOps_bal_r4_e4_f3_s0();
+const BalOps* BalOps_bal_r4_e4_f4_s0();
 
-const BalOps* GetBalOps(int ne, int nf, int ns) {
-  if (!BalShapeCompiled(ne, nf, ns)) return nullptr;
+const BalOps* GetBalOps(int nr, int ne, int nf, int ns) {
+  if (!BalShapeCompiled(nr, ne, nf, ns)) return nullptr;
+  if (nr == 3) return BalOps_bal_r3_e3_f3_s0();
+  if (nr == 4) {
+    switch (nf) {
+      case 2: return BalOps_bal_r4_e4_f2_s0();
+      case 3: return BalOps_bal_r4_e4_f3_s0();
+      case 4: return BalOps_bal_r4_e4_f4_s0();
+    }
+    return nullptr;
+  }
   if (ne == 2) {
     switch (nf) {
       case 2: return BalOps_bal_e2_f2_s0();

@@ -1,0 +1,8 @@
+// The fused kernels for row blocks 4 high, point blocks 4 wide and camera blocks 4 wide, no shared strip: the reference's (4,4,4)
+// specialisation (internal/ceres/generate_template_specializations.py:55-75; common.h: shapes; kernels_bal.inc: the kernels).
+#define CERES_HIP_NR 4
+#define CERES_HIP_NE 4
+#define CERES_HIP_NF 4
+#define CERES_HIP_NS 0
+#define CERES_HIP_SHAPE bal_r4_e4_f4_s0
+#include "kernels_bal.inc"

@@ -138,6 +138,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // CAMERAS (at most one cell per row, all of one width nf) and a few SHARED blocks (common.h: the strip).
   // The eliminated blocks are all of ONE width: 3, or — with an elimination order — 2 or 4 (common.h: BalShapeCompiled; the reference's
   // (2,2,*) and (2,4,*) specialisations).
+  P.nr = h.rsz[0];   // every conforming row is this high (checked below): 2, or 3 / 4 for the reference's (3,3,3) and (4,4,*)
+  if (P.nr < 2 || P.nr > 4) return no("row blocks that are not 2, 3 or 4 high");
   P.ne = h.nelim > 0 ? h.csz[0] : 3;
   if (P.ne < 2 || P.ne > 4) return no("eliminated blocks that are not 2, 3 or 4 wide");
   auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
@@ -199,8 +201,8 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   for (int c = 0; c < P.n_cameras; ++c)
     if (h.csz[P.cam_block[c]] != P.nf) return no("camera blocks of different widths");
   P.ns = BalStripWidthFor(P.ns_used);
-  if (P.ns < 0 || !BalShapeCompiled(P.ne, P.nf, P.ns)) return no("no fused kernels are compiled for this point width / camera width / shared strip");
-  if (P.n_rem_rows > 0 && !(P.ne == 3 && P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
+  if (P.ns < 0 || !BalShapeCompiled(P.nr, P.ne, P.nf, P.ns)) return no("no fused kernels are compiled for this row height / point width / camera width / shared strip");
+  if (P.n_rem_rows > 0 && !(P.nr == 2 && P.ne == 3 && P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
   for (size_t q = 0; q < P.sh_block.size(); ++q)
     for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
 
@@ -210,7 +212,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (P.ns > 0)
     for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { row_hpos[q].assign(n_conf, -1); row_hdesc[q].assign(n_conf, 0); }
   for (int i = 0; i < n_conf; ++i) {
-    if (h.rsz[i] != 2) return no("row block that is not 2 high");
+    if (h.rsz[i] != P.nr) return no(P.nr == 2 ? "row block that is not 2 high" : "row blocks of different heights");
     int n_pt = 0, n_cam = 0, n_sh = 0;
     for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
       const int j = h.ccol[k];

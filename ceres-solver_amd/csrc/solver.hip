@@ -1790,17 +1790,17 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     // Schur solvers: no CG vector lives in point space; CGNR: only where its CG vectors can be the caller's with the points renumbered
     BuildBalPlan(h, (e && atoi(e) == 0) ? kReorderNever : (is_schur(s) ? kReorderAlways : kReorderIfContiguous), hyb, &s->plan);
   }
-  s->ops = s->plan.eligible ? GetBalOps(s->plan.ne, s->plan.nf, s->plan.ns) : nullptr;
+  s->ops = s->plan.eligible ? GetBalOps(s->plan.nr, s->plan.ne, s->plan.nf, s->plan.ns) : nullptr;
   if (s->plan.eligible && (!s->ops || (s->opt.jacobian_storage == 1 && !s->ops->has_f32))) {
     // (fp32 tiles exist for the 9-wide shape only)
     s->plan.eligible = false;
     s->plan.why_not = !s->ops ? "no kernels for this shape" : "option not available for this shape";
   }
-  if (s->plan.eligible && s->plan.ne != 3 && (!is_schur(s) || s->world > 1)) {
-    // point blocks of 2 or 4 scalars: the Schur solvers' tile passes on one device (CGNR's vector kernels and the sharded runs'
-    // bookkeeping hold points as 3-vectors)
+  if (s->plan.eligible && (s->plan.ne != 3 || s->plan.nr != 2) && (!is_schur(s) || s->world > 1)) {
+    // point blocks of 2 or 4 scalars, rows of 3 or 4 residuals: the Schur solvers' tile passes on one device (CGNR's vector kernels and
+    // the sharded runs' bookkeeping hold points as 3-vectors and rows as pairs)
     s->plan.eligible = false;
-    s->plan.why_not = "point blocks that are not 3 wide: the fused path takes the Schur solvers on one device";
+    s->plan.why_not = "point blocks that are not 3 wide or rows that are not 2 high: the fused path takes the Schur solvers on one device";
   }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
@@ -2017,8 +2017,8 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     const size_t n_slots = size_t(P.n_tiles) * kTile;
     if (s->opt.jacobian_storage == 1) TRY(dev_alloc(s, &s->d_Jf, n_slots * 6));   // (has_f32 shapes only: checked above)
     else TRY(dev_alloc(s, &s->d_J, size_t(P.n_tiles) * s->ops->tile_pitch));
-    TRY(dev_alloc(s, &s->d_bt, n_slots));
-    TRY(dev_alloc(s, &s->d_Mo, 4 * n_slots));
+    TRY(dev_alloc(s, &s->d_bt, n_slots * s->ops->b_pairs));
+    TRY(dev_alloc(s, &s->d_Mo, size_t(s->ops->mo_pitch) * n_slots));
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * s->ops->etei_pitch));
     const size_t n9 = size_t(P.nf) * P.n_cameras + size_t(P.ns);   // accumulator entries: the cameras' scalars, then the strip
     s->lds_mode = P.cameras_in_lds;

@@ -396,7 +396,7 @@ def _assemble_bal(rng, n_cams, n_points, point_of_obs, cam_of_obs, layout, with_
 
 
 def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
-                   shared_of_obs=None, layout="schur", seed=38401, with_values=True, point_width=3) -> LinearProblem:
+                   shared_of_obs=None, layout="schur", seed=38401, with_values=True, point_width=3, row_height=2) -> LinearProblem:
     """Bundle-adjustment Jacobian of the structures the reference's examples produce beyond <2,3,9>: rows are 2 high and hold one point
     cell (2 x 3), the observing camera's cell (2 x camera_width; none if the camera is in `locked_cameras`: SetParameterBlockConstant,
     examples/libmv_bundle_adjuster.cc:725-728) and a cell on every SHARED block (`shared_widths`: libmv's camera intrinsics, <2, 8, 6, 3>,
@@ -406,8 +406,8 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
     order (internal/ceres/block_jacobian_writer.cc:68-167); "cgnr": the same column order, values row-sequential, no elimination.
     camera_width 10 = bundle_adjuster --use_quaternions (examples/snavely_reprojection_error.h:164).  point_width: the width of the point
     (E) blocks — 3, or 2 / 4 for the reference's (2,2,*) / (2,4,*) specialisations (generate_template_specializations.py:55-75; 4 =
-    homogeneous points)."""
-    pw = int(point_width)
+    homogeneous points); row_height: residuals per observation — 2, or 3 / 4 for (3,3,3) and (4,4,*)."""
+    pw, rh = int(point_width), int(row_height)
     rng = np.random.default_rng(seed)
     n_obs = int(point_of_obs.shape[0])
     nsb = len(shared_widths)
@@ -442,14 +442,14 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
         put_shared(); put_cameras()
     else:
         put_cameras(); put_shared()
-    cell_len = 2 * cell_w
+    cell_len = rh * cell_w
     is_e = np.zeros(n_cells, dtype=bool)
     is_e[ptr[:-1]] = True
     cell_pos = np.empty(n_cells, dtype=np.int64)
     if layout == "schur":
-        cell_pos[is_e] = 2 * pw * np.arange(n_obs)
+        cell_pos[is_e] = rh * pw * np.arange(n_obs)
         f_len = cell_len[~is_e]
-        cell_pos[~is_e] = 2 * pw * n_obs + np.concatenate([[0], np.cumsum(f_len)[:-1]])
+        cell_pos[~is_e] = rh * pw * n_obs + np.concatenate([[0], np.cumsum(f_len)[:-1]])
         nelim = n_points
     elif layout == "cgnr":
         cell_pos[:] = np.concatenate([[0], np.cumsum(cell_len)[:-1]])
@@ -458,16 +458,16 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
         raise ValueError(layout)
     nnz = int(cell_len.sum())
     r = np.arange(n_obs, dtype=np.int64)
-    bs = BlockStructure(np.full(n_obs, 2, np.int32), 2 * r, col_sizes, col_pos, ptr, cell_col, cell_pos)
+    bs = BlockStructure(np.full(n_obs, rh, np.int32), rh * r, col_sizes, col_pos, ptr, cell_col, cell_pos)
     cam_block = np.where(has_cam, n_points + cam0 + cam_of_obs, -1)
     if not with_values:
         return LinearProblem(bs, np.zeros(0), np.zeros(0), None, nelim, {}, cam_block, point_of_obs.copy())
     values = rng.standard_normal(nnz)
-    b = rng.standard_normal(2 * n_obs)
+    b = rng.standard_normal(rh * n_obs)
     diag = np.zeros(bs.num_cols)
     for w in np.unique(cell_w):   # column square sums, cells of one width at a time
         idx = np.flatnonzero(cell_w == w)
-        v = values[(cell_pos[idx][:, None] + np.arange(2 * w)[None, :])].reshape(-1, 2, w)
+        v = values[(cell_pos[idx][:, None] + np.arange(rh * w)[None, :])].reshape(-1, rh, w)
         sq = (v * v).sum(axis=1)
         for c in range(int(w)):
             diag += np.bincount(col_pos[cell_col[idx]] + c, weights=sq[:, c], minlength=bs.num_cols)
@@ -476,7 +476,7 @@ def structured_bal(n_cams, n_points, point_of_obs, cam_of_obs, camera_width=9, s
 
 
 def synthetic_structured(num_cameras, num_points, num_observations, camera_width=9, shared_widths=(), shared_first=True, locked_cameras=(),
-                         layout="schur", seed=38401, skew=0.0, with_values=True, point_width=3) -> LinearProblem:
+                         layout="schur", seed=38401, skew=0.0, with_values=True, point_width=3, row_height=2) -> LinearProblem:
     """structured_bal on the random visibility of synthetic_bal (every point seen by >= 2 distinct cameras)."""
     rng = np.random.default_rng(seed)
     k = _track_lengths(rng, num_cameras, num_points, num_observations)
@@ -488,7 +488,7 @@ def synthetic_structured(num_cameras, num_points, num_observations, camera_width
     cam_of_obs = _distinct_cameras(rng, num_cameras, point_of_obs, weights)
     order = np.lexsort((cam_of_obs, point_of_obs))
     return structured_bal(num_cameras, num_points, point_of_obs, cam_of_obs[order], camera_width, shared_widths, shared_first, locked_cameras,
-                          None, layout, seed + 1, with_values, point_width)
+                          None, layout, seed + 1, with_values, point_width, row_height)
 
 
 def libmv_structured(problem=2, copies=1, intrinsics_width=8, lock_first_camera=True, layout="schur", seed=38401, with_values=True) -> LinearProblem:

@@ -224,3 +224,72 @@ def test_dense_schur_with_homogeneous_points(hip, oracle, problems):
     x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
     s.close()
     assert summ.termination_type == hip.SUCCESS and rel(x, ref) <= 1e-9, (summ, rel(x, ref))
+
+
+# ---- row blocks that are not 2 high (round 5): the reference's remaining static specialisations (3,3,3), (4,4,2), (4,4,3), (4,4,4)
+ROW_SHAPES = {f"r{nr}_e{ne}_f{nf}": dict(row_height=nr, point_width=ne, camera_width=nf) for nr, ne, nf in ((3, 3, 3), (4, 4, 2), (4, 4, 3), (4, 4, 4))}
+
+
+@pytest.mark.parametrize("name", list(ROW_SHAPES))
+def test_operators_with_rows_of_3_and_4_residuals(hip, oracle, problems, name):
+    kw = ROW_SHAPES[name]
+    p = problems.synthetic_structured(40, 2500, 11000, seed=5, skew=0.5, **kw)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    info = s.info()
+    assert (info.row_block_size, info.e_block_size, info.f_block_size) == (kw["row_height"], kw["point_width"], kw["camera_width"])
+    s.close()
+    # a row with a locked camera, tracks of more than 64 observations (whole tiles, rounds)
+    n_c, n_p, cam_of, pt_of = problems.libmv_visibility(2)
+    order = np.lexsort((cam_of, pt_of))
+    q = problems.structured_bal(n_c, n_p, pt_of[order], cam_of[order], kw["camera_width"], locked_cameras=(0,), point_width=kw["point_width"],
+                                row_height=kw["row_height"], seed=3)
+    assert_errs(check_schur_operators(hip, oracle, q, False, hip.PATH_BAL))
+
+
+@pytest.mark.parametrize("name", list(ROW_SHAPES))
+@pytest.mark.parametrize("pre", [2, 1])
+def test_schur_solver_with_rows_of_3_and_4_residuals(hip, oracle, problems, name, pre):
+    p = problems.synthetic_structured(40, 2500, 11000, seed=6, skew=0.5, **ROW_SHAPES[name])
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    fn = m.iterative_schur_solve
+    for k in (1, 7, 25):
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, min_it=k, max_it=k)
+        assert s.info().kernel_path == hip.PATH_BAL
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=0.0))
+        s.close()
+        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=k, max_it=k, q_tol=-1.0, r_tol=0.0)
+        assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
+        assert rel(x, xo) <= 1e-9, (k, rel(x, xo))
+    s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, max_it=500)
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(x, summ, lambda lo, hi, q, r: fn(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r), 0.1, hip.SUCCESS)
+    radius = 1e4
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)
+    diag = np.clip(oracle.Matrix(p.bs, 0).squared_column_norm(p.values), 1e-6, 1e32)
+    assert rel(s.lm_diagonal(), np.sqrt(diag / radius)) <= 1e-13
+    check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+    step, summ, mcc = s.lm_compute_step(None, None, radius / 2, 0.1, reuse_diagonal=True, values_unchanged=True)
+    check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, pre, np.sqrt(diag / (radius / 2)), step, summ, mcc, 0.1)
+    s.close()
+
+
+def test_rows_of_4_residuals_with_many_cameras_and_dense_schur(hip, oracle, problems):
+    """(4,4,3): more cameras than LDS rows (hybrid plan, spilled rows) and DENSE_SCHUR on the fused set-up passes."""
+    q = problems.synthetic_structured(60000, 60000, 200000, camera_width=3, point_width=4, row_height=4, seed=8, skew=0.4)
+    errs = check_schur_operators(hip, oracle, q, False, hip.PATH_BAL)
+    raw = errs.pop("schur_jacobi_raw")
+    assert_errs(errs)
+    assert raw <= 1e-11, raw
+    s = make_solver(hip, q, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)
+    assert s.info().camera_accum_in_lds == 0
+    s.close()
+    p = problems.synthetic_structured(24, 900, 4000, camera_width=4, point_width=4, row_height=4, seed=12, skew=0.3)
+    A = p.bs.to_dense(p.values)
+    ref = np.linalg.lstsq(np.vstack([A, np.diag(p.D)]), np.concatenate([p.b, np.zeros(p.num_cols)]), rcond=None)[0]
+    s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.DENSE_SCHUR, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=1))
+    s.set_structure(p.bs)
+    assert s.info().kernel_path == hip.PATH_BAL
+    x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
+    s.close()
+    assert summ.termination_type == hip.SUCCESS and rel(x, ref) <= 1e-9, (summ, rel(x, ref))

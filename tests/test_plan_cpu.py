@@ -276,9 +276,10 @@ def test_plan_rejections(problems):
 
 @pytest.mark.parametrize("kw", [dict(camera_width=10), dict(camera_width=6), dict(camera_width=3), dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
                                 dict(camera_width=9, shared_widths=(5, 3), shared_first=False),
-                                dict(point_width=4, camera_width=9), dict(point_width=4, camera_width=3, locked_cameras=(2,)), dict(point_width=2, camera_width=4)])
+                                dict(point_width=4, camera_width=9), dict(point_width=4, camera_width=3, locked_cameras=(2,)), dict(point_width=2, camera_width=4),
+                                dict(row_height=3, point_width=3, camera_width=3), dict(row_height=4, point_width=4, camera_width=2, locked_cameras=(1,))])
 def test_plan_of_other_shapes(problems, kw):
-    """Camera widths other than 9, shared blocks, rows without a camera cell, point blocks 2 and 4 wide (common.h: shapes): the tiles still
+    """Camera widths other than 9, shared blocks, rows without a camera cell, point blocks 2 and 4 wide, rows 3 and 4 high (common.h: shapes): the tiles still
     hold every row once, grouped by point; a row without a camera cell is a valid slot whose camera is -2."""
     hs = pkg.hip_solver
     p = problems.synthetic_structured(25, 700, 3300, seed=11, with_values=False, **kw)
