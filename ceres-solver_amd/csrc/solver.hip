@@ -1796,11 +1796,11 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     s->plan.eligible = false;
     s->plan.why_not = !s->ops ? "no kernels for this shape" : "option not available for this shape";
   }
-  if (s->plan.eligible && (s->plan.ne != 3 || s->plan.nr != 2) && (!is_schur(s) || s->world > 1)) {
-    // point blocks of 2 or 4 scalars, rows of 3 or 4 residuals: the Schur solvers' tile passes on one device (CGNR's vector kernels and
-    // the sharded runs' bookkeeping hold points as 3-vectors and rows as pairs)
+  if (s->plan.eligible && (s->plan.ne != 3 || s->plan.nr != 2) && !is_schur(s)) {
+    // point blocks of 2 or 4 scalars, rows of 3 or 4 residuals: the Schur solvers' tile passes, one device or sharded (CGNR sees no
+    // elimination order — its "points" are whatever is 3 wide — and its vector kernels hold points as 3-vectors)
     s->plan.eligible = false;
-    s->plan.why_not = "point blocks that are not 3 wide or rows that are not 2 high: the fused path takes the Schur solvers on one device";
+    s->plan.why_not = "point blocks that are not 3 wide or rows that are not 2 high: the fused path takes the Schur solvers";
   }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;

@@ -113,6 +113,26 @@ def libmv_like_case(hip, oracle, problems):
                          solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)])
 
 
+@pytest.fixture(scope="module")
+def homogeneous_points_case(hip, oracle, problems):
+    # (2,4,9): 4-wide point blocks (round 5), ITERATIVE_SCHUR sharded by point on the fused path of that shape
+    return make_bal_case(hip, oracle, problems, 37, 6000, 26000, structured=dict(camera_width=9, point_width=4), solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)])
+
+
+@pytest.fixture(scope="module")
+def three_residual_rows_case(hip, oracle, problems):
+    # (3,3,3): rows of three residuals (round 5)
+    return make_bal_case(hip, oracle, problems, 37, 6000, 26000, structured=dict(camera_width=3, point_width=3, row_height=3), solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)])
+
+
+def test_sharded_homogeneous_points_against_the_oracle(hip, homogeneous_points_case):
+    check_sharded_case(hip, homogeneous_points_case, 2)
+
+
+def test_sharded_rows_of_three_residuals_against_the_oracle(hip, three_residual_rows_case):
+    check_sharded_case(hip, three_residual_rows_case, 3)
+
+
 @pytest.mark.parametrize("world", (2, 4))
 def test_sharded_quaternion_cameras_against_the_oracle(hip, quaternion_case, world):
     check_sharded_case(hip, quaternion_case, world)
