@@ -650,15 +650,16 @@ def main():
                      ("<2,3,6>", dict(camera_width=6), False),
                      ("<2,3,9> on the GENERIC kernels (force_generic_path)", dict(camera_width=9), True),
                      ("libmv structure <2, 8 | 6, 3>: shared intrinsics + 6-wide pose + point, first camera constant", dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)), False),
-                     ("<2,4,9> homogeneous points (the reference's (2,4,9) specialisation; round 5: point blocks 2 and 4 wide on the fused path)", dict(camera_width=9, point_width=4), False)]
+                     ("<2,4,9> homogeneous points (the reference's (2,4,9) specialisation; round 5: point blocks 2 and 4 wide on the fused path)", dict(camera_width=9, point_width=4), False),
+                     ("<3,3,3> rows of three residuals (the reference's (3,3,3) specialisation; round 5: rows 3 and 4 high on the fused path)", dict(camera_width=3, point_width=3, row_height=3), False)]
             for label, kw, force_generic in cases:
                 sp = pkg.problems.synthetic_structured(lb_c, lb_p, lb_o, seed=38401, skew=args.skew, **kw)
-                nf_, ns_, pw_ = kw["camera_width"], sum(kw.get("shared_widths", ())), kw.get("point_width", 3)
-                slot_b = (2 * pw_ + 2 * nf_ + 2 * ns_) * 8 + 8
+                nf_, ns_, pw_, rh_ = kw["camera_width"], sum(kw.get("shared_widths", ())), kw.get("point_width", 3), kw.get("row_height", 2)
+                slot_b = rh_ * (pw_ + nf_ + ns_) * 8 + 8
                 n_fs = int(sp.bs.col_block_size[sp.num_eliminate_blocks:].sum())
                 case = {"structure": label, "bytes_per_observation": slot_b}
                 for sv, kd, typ, pre in (("iterative_schur", "sx", hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI), ("cgnr", "jtjx", hs.CGNR, hs.JACOBI)):
-                    if pw_ != 3 and sv == "cgnr":
+                    if (pw_ != 3 or rh_ != 2) and sv == "cgnr":
                         continue   # (point blocks that are not 3 wide: the Schur solvers run fused, CGNR on the generic kernels)
                     so_ = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
                                                                     elimination_groups=[sp.num_eliminate_blocks], device=local_rank, force_generic_path=force_generic))

@@ -83,7 +83,9 @@ extern "C" {
 
 /* Which device code path set_structure selected (ceres_hip_info.kernel_path). */
 #define CERES_HIP_PATH_GENERIC 0 /* any block sizes, multi-pass kernels          */
-#define CERES_HIP_PATH_BAL 1     /* static <2,3,9>, fused single-pass kernels    */
+#define CERES_HIP_PATH_BAL 1     /* fused single-pass kernels: bundle-adjustment structures — one point cell (2, 3 or 4 wide), at most one
+                                  * camera cell and a few shared blocks per row, rows 2, 3 or 4 high; every static specialisation of
+                                  * internal/ceres/generate_template_specializations.py:55-75 (csrc/common.h: BalShapeCompiled) */
 
 /* ---- flattened CompressedRowBlockStructure (I/block_structure.h:52-182) ---
  * cols[j] = {col_block_size[j], col_block_pos[j]}
