@@ -298,12 +298,12 @@ hipError_t LaunchGenExtractDiagBlocks(const GenStructure& G, const double* S, co
 hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, const double* ete_inv, const double* D,
                                double* lhs, hipStream_t stream);
 
-// ---- remainder rows of the fused <2,3,9> path: rows without a point cell, R = their own GenStructure (kernels_generic.hip) ----
-hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, double* out, hipStream_t stream);
-// y_f[pos(c) ..] += F_R^T t over the remainder rows' cells on the 9-wide camera blocks (one wavefront per camera)
-hipError_t LaunchRemLeftMultiply9(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras,
-                                  const double* t_rows, double* y_f, const int* status, hipStream_t stream);
-hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, double* y, hipStream_t stream);
+// ---- remainder rows of the fused path: rows without a point cell, R = their own GenStructure (kernels_generic.hip); nf = the camera width ----
+hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, int nf, double* out, hipStream_t stream);
+// y_f[pos(c) ..] += F_R^T t over the remainder rows' cells on the nf-wide camera blocks (one wavefront per camera)
+hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras, int nf,
+                                 const double* t_rows, double* y_f, const int* status, hipStream_t stream);
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, int nf, double* y, hipStream_t stream);
 hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t stream);
 
 // ---- explicit Schur complement solvers (kernels_schur.hip) ------------------

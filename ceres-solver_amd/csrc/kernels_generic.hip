@@ -709,103 +709,111 @@ __global__ __launch_bounds__(kB) void gen_schur_jacobi_grouped_kernel(GenStructu
 }
 
 
-// ---- remainder rows of the fused <2,3,9> path (rows without a point cell; R = their own GenStructure, compact row space) ----
-// out[81 c + 9 a + b] = sum over the remainder cells of camera c of (F^T F)(a, b): what SchurEliminator::NoEBlockRowsUpdate adds to
+// ---- remainder rows of the fused path (rows without a point cell; R = their own GenStructure, compact row space) ----
+// Templated on the camera width NF (the widths kernels_bal.inc is compiled for: 2, 3, 4, 6, 8, 9, 10; round 5 — the round-3 kernels
+// were 9-wide and plan.cc kept every other shape with such rows off the fused path).
+// out[NF NF c + NF a + b] = sum over the remainder cells of camera c of (F^T F)(a, b): what SchurEliminator::NoEBlockRowsUpdate adds to
 // the diagonal cell of S (I/schur_eliminator_impl.h:574-666) and UpdateBlockDiagonalFtF's second loop to blockdiag(F^T F)
-// (I/partitioned_matrix_view_impl.h:617-658).  One thread per entry through the transpose list of the camera's column block.
-// One WAVEFRONT per camera, one LANE per cell (64 cells per round): a lane forms its cell's F^T F — the 45 upper-triangle entries, every
+// (I/partitioned_matrix_view_impl.h:617-658).
+// One WAVEFRONT per camera, one LANE per cell (64 cells per round): a lane forms its cell's F^T F — the upper-triangle entries, every
 // load of a row in flight at once — and the wave adds the lanes' results up by shuffles.  (Thread per entry, as this kernel first was,
 // and then wave per camera with every lane walking all the cells, are one long chain of dependent loads: 131 / 140 us for 50 k prior rows
 // on 1778 cameras.)
-template <int RS>   // rows of a cell known at compile time (9: priors on whole cameras), or 0: read from the structure
-__device__ __forceinline__ void cell_ftf_upper(const double* __restrict__ m, int rs, double (&u)[45]) {
+template <int NF, int RS>   // RS: rows of a cell known at compile time (NF: priors on whole cameras), or 0: read from the structure
+__device__ __forceinline__ void cell_ftf_upper(const double* __restrict__ m, int rs, double (&u)[NF * (NF + 1) / 2]) {
   const int n = RS > 0 ? RS : rs;
 #pragma unroll
   for (int r = 0; r < (RS > 0 ? RS : 1); ++r) {
     for (int rr = r; rr < n; rr += (RS > 0 ? RS : 1)) {
-      double f[9];
+      double f[NF];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) f[k] = m[rr * 9 + k];
+      for (int k = 0; k < NF; ++k) f[k] = m[rr * NF + k];
       int idx = 0;
 #pragma unroll
-      for (int a = 0; a < 9; ++a)
+      for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b2 = a; b2 < 9; ++b2) u[idx++] += f[a] * f[b2];
+        for (int b2 = a; b2 < NF; ++b2) u[idx++] += f[a] * f[b2];
     }
   }
 }
+template <int NF>
 __global__ __launch_bounds__(kB) void rem_camera_blocks_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
                                                                int n_cameras, double* __restrict__ out) {
+  constexpr int NU = NF * (NF + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
   if (c >= n_cameras) return;
   const int j = cam_block[c];
-  double u[45];
+  double u[NU];
 #pragma unroll
-  for (int i = 0; i < 45; ++i) u[i] = 0.0;
+  for (int i = 0; i < NU; ++i) u[i] = 0.0;
   for (int t = R.tptr[j] + lane; t < R.tptr[j + 1]; t += 64) {
     const int rs = R.rsz[R.trow[t]];
     const double* m = v + R.cval[R.tcell[t]];
-    if (rs == 9) cell_ftf_upper<9>(m, rs, u);
-    else cell_ftf_upper<0>(m, rs, u);
+    if (rs == NF) cell_ftf_upper<NF, NF>(m, rs, u);
+    else cell_ftf_upper<NF, 0>(m, rs, u);
   }
-  double* o = out + 81 * int64_t(c);
+  double* o = out + int64_t(NF * NF) * c;
   int idx = 0;
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < NF; ++a)
 #pragma unroll
-    for (int b2 = a; b2 < 9; ++b2) {
+    for (int b2 = a; b2 < NF; ++b2) {
       double x = u[idx++];
 #pragma unroll
       for (int w = 32; w >= 1; w >>= 1) x += __shfl_xor(x, w, 64);
-      if (lane == 0) { o[9 * a + b2] = x; o[9 * b2 + a] = x; }
+      if (lane == 0) { o[NF * a + b2] = x; o[NF * b2 + a] = x; }
     }
 }
-// y_f[pos(c) + k] += sum over the remainder cells of camera c of sum_r F[r][k] t[row + r]: F_R^T t on the 9-wide camera blocks, one
-// WAVEFRONT per camera — lane = (cell slot 0..6, column k 0..8), seven cells per round, the seven partial sums of a column combined by
-// shuffles; a 9-row cell's loads are all issued before the first is used.  (gen_left_multiply_kernel's thread per output scalar walks a
-// camera's cells alone: 111 us per call on the same problem, three calls per solve: a Venice-shaped problem with 1 % prior rows ran 1.32x
-// the pure one.)
-__global__ __launch_bounds__(kB) void rem_left_multiply9_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
-                                                                const int32_t* __restrict__ cam_pos, int n_cameras, const double* __restrict__ t_rows,
-                                                                double* __restrict__ y_f, const int* __restrict__ status) {
+// y_f[pos(c) + k] += sum over the remainder cells of camera c of sum_r F[r][k] t[row + r]: F_R^T t on the NF-wide camera blocks, one
+// WAVEFRONT per camera — lane = (cell slot 0..CS-1, column k 0..NF-1) with CS = 64 / NF cells per round (9 wide: seven), the CS partial
+// sums of a column combined through a fixed shuffle tree (deterministic); a cell of NF rows (a prior on a whole camera) has all its loads
+// issued before the first is used.  (gen_left_multiply_kernel's thread per output scalar walks a camera's cells alone: 111 us per call on
+// a Venice-shaped problem with 1 % prior rows, three calls per solve: 1.32x the pure problem.)
+template <int NF>
+__global__ __launch_bounds__(kB) void rem_left_multiply_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
+                                                               const int32_t* __restrict__ cam_pos, int n_cameras, const double* __restrict__ t_rows,
+                                                               double* __restrict__ y_f, const int* __restrict__ status) {
   if (status && *status != 0) return;
+  constexpr int CS = 64 / NF;   // cell slots of a wavefront (lanes CS NF .. 63 idle)
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kB / 64) + (threadIdx.x >> 6);
   if (c >= n_cameras) return;
   const int j = cam_block[c];
-  const int cs = lane / 9, k = lane - 9 * cs;   // lane 63: cs = 7, idle
+  const int cs = lane / NF, k = lane - NF * cs;
   double acc = 0;
   const int t0 = R.tptr[j], t1 = R.tptr[j + 1];
-  for (int t = t0 + cs; t < t1 && cs < 7; t += 7) {
+  for (int t = t0 + cs; t < t1 && cs < CS; t += CS) {
     const int i = R.trow[t];
     const double* m = v + R.cval[R.tcell[t]] + k;
     const double* tr = t_rows + R.rpos[i];
     const int rs = R.rsz[i];
-    if (rs == 9) {
-      double a[9], x[9];
+    if (rs == NF) {
+      double a[NF], x[NF];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) { a[r] = m[r * 9]; x[r] = tr[r]; }
+      for (int r = 0; r < NF; ++r) { a[r] = m[r * NF]; x[r] = tr[r]; }
 #pragma unroll
-      for (int r = 0; r < 9; ++r) acc += a[r] * x[r];
+      for (int r = 0; r < NF; ++r) acc += a[r] * x[r];
     } else {
-      for (int r = 0; r < rs; ++r) acc += m[r * 9] * tr[r];
+      for (int r = 0; r < rs; ++r) acc += m[r * NF] * tr[r];
     }
   }
-  double u = __shfl_down(acc, 36, 64);
-  if (lane < 27) acc += u;
-  u = __shfl_down(acc, 18, 64);
-  if (lane < 18) acc += u;
-  u = __shfl_down(acc, 9, 64);
-  if (lane < 9) y_f[(cam_pos ? cam_pos[c] : 9 * c) + k] += acc + u;
+  // slot s (lanes [s NF, (s + 1) NF)) adds slot s + h for h = the powers of two below CS, largest first: slot 0 ends with every slot's sum
+  constexpr int H0 = CS > 16 ? 16 : (CS > 8 ? 8 : (CS > 4 ? 4 : (CS > 2 ? 2 : 1)));
+#pragma unroll
+  for (int h = H0; h >= 1; h >>= 1) {
+    const double u = __shfl_down(acc, h * NF, 64);
+    if (cs + h < CS && cs < h) acc += u;
+  }
+  if (lane < NF) y_f[(cam_pos ? cam_pos[c] : NF * c) + k] += acc;
 }
-// y[pos(c) + k] += blocks[81 c + 10 k]: the remainder's share of the camera columns' squared norms
-__global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int n_cameras,
+// y[pos(c) + k] += blocks[nf nf c + (nf + 1) k]: the remainder's share of the camera columns' squared norms
+__global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int n_cameras, int nf,
                                                           double* __restrict__ y) {
   const int i = blockIdx.x * kB + threadIdx.x;
-  if (i >= 9 * n_cameras) return;
-  const int c = i / 9, k = i % 9;
-  y[(cam_pos ? cam_pos[c] : 9 * c) + k] += blocks[81 * int64_t(c) + 10 * k];
+  if (i >= nf * n_cameras) return;
+  const int c = i / nf, k = i % nf;
+  y[(cam_pos ? cam_pos[c] : nf * c) + k] += blocks[int64_t(nf) * nf * c + (nf + 1) * k];
 }
 // One workgroup: *out = sum_r m_r (f_r - m_r / 2)   (mode 0: m = J x of the un-negated solution, the back-substitution kernel's
 // convention) or  -sum_r m_r (f_r + m_r / 2)  (mode 1: m = J step) — the remainder rows' share of the model cost change,
@@ -824,18 +832,33 @@ __global__ __launch_bounds__(kB) void rem_model_cost_kernel(const double* __rest
 
 }  // namespace
 
-hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, double* out, hipStream_t s) {
-  if (n_cameras > 0) hipLaunchKernelGGL(rem_camera_blocks_kernel, dim3((n_cameras + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, R, values, cam_block, n_cameras, out);
+// one instantiation per camera width kernels_bal.inc is compiled for (common.h: BalShapeCompiled)
+#define CERES_HIP_REM_WIDTHS(X) X(2) X(3) X(4) X(6) X(8) X(9) X(10)
+hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, int nf, double* out, hipStream_t s) {
+  if (n_cameras <= 0) return hipSuccess;
+  const dim3 grid((n_cameras + kB / 64 - 1) / (kB / 64));
+  switch (nf) {
+#define X(W) case W: hipLaunchKernelGGL(rem_camera_blocks_kernel<W>, grid, dim3(kB), 0, s, R, values, cam_block, n_cameras, out); break;
+    CERES_HIP_REM_WIDTHS(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
-hipError_t LaunchRemLeftMultiply9(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras,
-                                  const double* t_rows, double* y_f, const int* status, hipStream_t s) {
-  if (n_cameras > 0) hipLaunchKernelGGL(rem_left_multiply9_kernel, dim3((n_cameras + kB / 64 - 1) / (kB / 64)), dim3(kB), 0, s, R, values, cam_block, cam_pos,
-                                        n_cameras, t_rows, y_f, status);
+hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras, int nf,
+                                 const double* t_rows, double* y_f, const int* status, hipStream_t s) {
+  if (n_cameras <= 0) return hipSuccess;
+  const dim3 grid((n_cameras + kB / 64 - 1) / (kB / 64));
+  switch (nf) {
+#define X(W) case W: hipLaunchKernelGGL(rem_left_multiply_kernel<W>, grid, dim3(kB), 0, s, R, values, cam_block, cam_pos, n_cameras, t_rows, y_f, status); break;
+    CERES_HIP_REM_WIDTHS(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
-hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, double* y, hipStream_t s) {
-  if (n_cameras > 0) hipLaunchKernelGGL(rem_add_diag_kernel, dim3(blocks_for(9 * n_cameras)), dim3(kB), 0, s, blocks, cam_pos, n_cameras, y);
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, int nf, double* y, hipStream_t s) {
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_add_diag_kernel, dim3(blocks_for(int64_t(nf) * n_cameras)), dim3(kB), 0, s, blocks, cam_pos, n_cameras, nf, y);
   return hipGetLastError();
 }
 hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t s) {

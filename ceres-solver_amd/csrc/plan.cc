@@ -202,7 +202,9 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     if (h.csz[P.cam_block[c]] != P.nf) return no("camera blocks of different widths");
   P.ns = BalStripWidthFor(P.ns_used);
   if (P.ns < 0 || !BalShapeCompiled(P.nr, P.ne, P.nf, P.ns)) return no("no fused kernels are compiled for this row height / point width / camera width / shared strip");
-  if (P.n_rem_rows > 0 && !(P.nr == 2 && P.ne == 3 && P.nf == 9 && P.ns == 0)) return no("rows without a point cell next to cameras that are not 9 wide");   // (kernels_generic.hip: rem_*)
+  // (kernels_generic.hip: rem_* are templated on the camera width — any compiled shape; a remainder row's cell on a SHARED block would
+  // have to join the strip's sums, which those kernels do not form)
+  if (P.n_rem_rows > 0 && P.ns != 0) return no("rows without a point cell next to a shared strip");
   for (size_t q = 0; q < P.sh_block.size(); ++q)
     for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
 

@@ -421,7 +421,7 @@ bool has_remainder(const ceres_hip_solver* s) { return s->path == CERES_HIP_PATH
 // raw F^T F of the remainder rows, per camera (cached until the next load)
 int ensure_rem_blocks(ceres_hip_solver* s) {
   if (!has_remainder(s) || s->rem_blocks_valid) return 0;
-  HIP_TRY(s, LaunchRemCameraBlocks(s->GR, s->values, s->d_cam_block, s->plan.n_cameras, s->rem_blocks, s->stream));
+  HIP_TRY(s, LaunchRemCameraBlocks(s->GR, s->values, s->d_cam_block, s->plan.n_cameras, s->plan.nf, s->rem_blocks, s->stream));
   s->rem_blocks_valid = true;
   return 0;
 }
@@ -435,14 +435,14 @@ int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f,
     case kBalSx: case kBalJtJx:   // F_R^T (F_R x)
       HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
       HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, status, st));
-      HIP_TRY(s, LaunchRemLeftMultiply9(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->rem_tmp, y_f, status, st));
+      HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->plan.nf, s->rem_tmp, y_f, status, st));
       return 0;
     case kBalInit: case kBalJtb: case kBalCgnrInit:   // F_R^T b_R
-      if (s->have_b) HIP_TRY(s, LaunchRemLeftMultiply9(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->b + s->rem_b0, y_f, status, st));
+      if (s->have_b) HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->plan.nf, s->b + s->rem_b0, y_f, status, st));
       return 0;
     case kBalColNorm:   // diag(F_R^T F_R)
       TRY(ensure_rem_blocks(s));
-      HIP_TRY(s, LaunchRemAddDiag(s->rem_blocks, cam_pos, s->plan.n_cameras, y_f, st));
+      HIP_TRY(s, LaunchRemAddDiag(s->rem_blocks, cam_pos, s->plan.n_cameras, s->plan.nf, y_f, st));
       return 0;
     default: return 0;  // kSpseZ: F^T E (E^T E)^-1 E^T F has no share from rows without an E block
   }
@@ -2090,7 +2090,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       R.row_e_block = nullptr;
       TRY(dev_upload(s, &s->d_cam_block, P.cam_block));
       TRY(dev_alloc(s, &s->rem_tmp, size_t(s->rem_rows)));
-      TRY(dev_alloc(s, &s->rem_blocks, size_t(81) * P.n_cameras));   // (the remainder kernels are 9-wide: plan.cc admits such rows for that shape only)
+      TRY(dev_alloc(s, &s->rem_blocks, size_t(P.nf) * P.nf * P.n_cameras));   // raw F^T F of the remainder rows, one nf x nf block per camera
     }
     {
       const char* e = getenv("CERES_HIP_COOP");  // 0: per-lane strided point-space accesses in JtJx instead of the cooperative ones

@@ -506,15 +506,21 @@ def libmv_structured(problem=2, copies=1, intrinsics_width=8, lock_first_camera=
                           (0,) if lock_first_camera else (), None, layout, seed, with_values)
 
 
-def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair_fraction=0.0) -> LinearProblem:
+def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair_fraction=0.0, camera_width=9) -> LinearProblem:
     """Appends `num_rows` row blocks WITHOUT a point cell to a BAL-shaped problem (either layout): priors / regularisers on
-    cameras — one `row_size` x 9 cell on camera i mod n_cameras, or (a `pair_fraction` of the rows) two cells coupling two
-    cameras.  In the Schur ordering these are the rows behind num_row_blocks_e that SchurEliminator::NoEBlockRowsUpdate
+    cameras — one `row_size` x camera_width cell on camera i mod n_cameras, or (a `pair_fraction` of the rows) two cells coupling two
+    cameras.  The cameras are the column blocks behind the eliminated ones (Schur ordering), or, without an elimination order, the
+    blocks that are camera_width wide.  In the Schur ordering these are the rows behind num_row_blocks_e that SchurEliminator::NoEBlockRowsUpdate
     (internal/ceres/schur_eliminator_impl.h:574-666) and PartitionedMatrixView's second loops
     (internal/ceres/partitioned_matrix_view_impl.h:171-190) handle.  Values are appended behind the existing ones."""
     rng = np.random.default_rng(seed + 991)
     bs = prob.bs
-    cam_blocks = np.flatnonzero(bs.col_block_size == 9)
+    w = int(camera_width)
+    if prob.num_eliminate_blocks > 0:
+        cam_blocks = np.arange(prob.num_eliminate_blocks, bs.num_col_blocks)
+        cam_blocks = cam_blocks[bs.col_block_size[cam_blocks] == w]
+    else:
+        cam_blocks = np.flatnonzero(bs.col_block_size == w)
     n_cams = cam_blocks.shape[0]
     two = rng.random(num_rows) < pair_fraction
     c0 = cam_blocks[np.arange(num_rows) % n_cams]
@@ -530,7 +536,7 @@ def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair
         for c in cols:
             cell_cols.append(c)
             cell_pos.append(pos)
-            pos += row_size * 9
+            pos += row_size * w
     new_bs = BlockStructure(np.concatenate([bs.row_block_size, row_sizes]), np.concatenate([bs.row_block_pos, row_pos]),
                             bs.col_block_size, bs.col_block_pos,
                             np.concatenate([bs.row_cell_ptr.astype(np.int64), bs.row_cell_ptr[-1] + np.cumsum(ncell)]),
@@ -546,8 +552,8 @@ def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair
         diag = (D * D) * 1e4
         cp = bs.col_block_pos.astype(np.int64)
         for k, c in enumerate(cell_cols):
-            blk = extra[cell_pos[k] - extent0: cell_pos[k] - extent0 + row_size * 9].reshape(row_size, 9)
-            diag[cp[c]: cp[c] + 9] += (blk * blk).sum(0)
+            blk = extra[cell_pos[k] - extent0: cell_pos[k] - extent0 + row_size * w].reshape(row_size, w)
+            diag[cp[c]: cp[c] + w] += (blk * blk).sum(0)
         D = np.sqrt(np.clip(diag, 1e-6, 1e32) / 1e4)
     return LinearProblem(new_bs, values, b, D, prob.num_eliminate_blocks, {}, prob.camera_of_row, prob.point_of_row)
 

@@ -121,3 +121,43 @@ def test_lm_step_with_leftover_rows(hip, oracle, problems, solver, pre):
     D2 = D * np.sqrt(2.0)
     assert_lm_style_step(-step2, summ2, lambda lo, hi, q, r: fn(p.values, p.b, D2, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r), 0.1, hip.SUCCESS)
     s.close()
+
+
+# ---- round 5: leftover rows next to every compiled shape (the remainder kernels are templated on the camera width) ----
+OTHER_SHAPES = {
+    "f10_quaternion_cameras": dict(camera_width=10), "f6": dict(camera_width=6), "f3": dict(camera_width=3), "f4": dict(camera_width=4),
+    "f8": dict(camera_width=8), "e4_f9": dict(point_width=4, camera_width=9), "e2_f2": dict(point_width=2, camera_width=2),
+    "r3_e3_f3": dict(row_height=3, point_width=3, camera_width=3), "r4_e4_f4": dict(row_height=4, point_width=4, camera_width=4),
+}
+
+
+@pytest.mark.parametrize("name", list(OTHER_SHAPES))
+def test_leftover_rows_next_to_every_compiled_shape(hip, oracle, problems, name):
+    """Priors on cameras that are not 9 wide (e.g. on quaternion cameras, examples/snavely_reprojection_error.h:164): the tiles of the
+    shape's own kernels plus the remainder kernels of the camera's width — every Schur operator, both block preconditioners, the
+    LM-style solve and the LM step against the oracle on the WHOLE problem; CGNR where it can tell cameras from points."""
+    from test_gpu_operators import assert_errs, check_cgnr_operators, check_schur_operators
+    from test_gpu_lm_step import check_step
+    kw = OTHER_SHAPES[name]
+    w = kw["camera_width"]
+    base = problems.synthetic_structured(37, 3000, 13000, seed=21, skew=0.5, **kw)
+    # rows as high as the camera is wide (a prior on the whole block), 2 high, and pairs coupling two cameras
+    p = problems.add_camera_rows(base, 50, seed=3, row_size=w, pair_fraction=0.3, camera_width=w)
+    p = problems.add_camera_rows(p, 30, seed=4, row_size=2, pair_fraction=0.0, camera_width=w)
+    assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    for pre in (hip.SCHUR_JACOBI, hip.JACOBI):
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, pre, max_it=500)
+        assert s.info().kernel_path == hip.PATH_BAL
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+        assert_lm_style_step(x, summ, lambda lo, hi, q, r: m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r),
+                             0.1, hip.SUCCESS)
+        radius = 1e4
+        step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)
+        diag = np.clip(oracle.Matrix(p.bs, 0).squared_column_norm(p.values), 1e-6, 1e32)
+        assert rel(s.lm_diagonal(), np.sqrt(diag / radius)) <= 1e-13
+        check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+        s.close()
+    # CGNR knows no elimination order: points are whatever is 3 wide (tests/test_gpu_shapes.py) — fused where that reading exists
+    if kw.get("point_width", 3) == 3 and kw.get("row_height", 2) == 2 and w != 3:
+        assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))

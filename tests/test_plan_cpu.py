@@ -400,6 +400,19 @@ def test_trailing_rows_without_a_point_cell_are_a_remainder_not_a_rejection(prob
     assert with_rows["eligible"] and with_rows["n_tiles"] == base["n_tiles"]
     for k in ("slot_row", "slot_cam", "slot_pt", "tile_kind", "tile_aux"):
         assert np.array_equal(with_rows[k], base[k]), k
+    # round 5: the same next to every compiled shape without a shared strip (the remainder kernels are templated on the camera width) ...
+    if layout == "schur":
+        for kw in (dict(camera_width=10), dict(camera_width=6, point_width=4), dict(camera_width=3, point_width=3, row_height=3)):
+            o = problems.synthetic_structured(15, 700, 3300, seed=4, skew=0.3, **kw)
+            o_base = pkg.hip_solver.debug_plan(o.bs, o.num_eliminate_blocks)
+            o_rows = pkg.hip_solver.debug_plan(problems.add_camera_rows(o, 25, seed=2, row_size=5, pair_fraction=0.5, camera_width=kw["camera_width"]).bs,
+                                               o.num_eliminate_blocks)
+            assert o_base["eligible"] and o_rows["eligible"] and o_rows["n_tiles"] == o_base["n_tiles"], kw
+            assert np.array_equal(o_rows["slot_row"], o_base["slot_row"])
+        # ... but not next to a shared strip (a prior on the shared block would have to join the strip's sums)
+        o = problems.synthetic_structured(15, 700, 3300, seed=4, skew=0.3, camera_width=6, shared_widths=(8,))
+        assert pkg.hip_solver.debug_plan(o.bs, o.num_eliminate_blocks)["eligible"]
+        assert not pkg.hip_solver.debug_plan(problems.add_camera_rows(o, 25, seed=2, row_size=5, camera_width=6).bs, o.num_eliminate_blocks)["eligible"]
     # a row higher than the generic kernels take
     tall = problems.add_camera_rows(p, 3, seed=2, row_size=17)
     assert not pkg.hip_solver.debug_plan(tall.bs, nelim)["eligible"]
