@@ -156,11 +156,15 @@ struct BalPlan {
   int64_t z_flush_row0 = 0, n_local_obs = 0;  // n_local_obs: observations summed in LDS (the others are spilled)
   std::vector<int32_t> grp_tile_ptr;
   int max_track = 0, max_camera_degree = 0;
-  // REMAINDER: trailing row blocks [rem_row0, nrb) that are not "one point cell + one camera cell" but touch camera blocks only
+  // REMAINDER: the row blocks that are not "one point cell + camera-side cells" but touch camera blocks only
   // (rows without an E block: priors / regularisers on cameras, the rows SchurEliminator::NoEBlockRowsUpdate handles,
   // I/schur_eliminator_impl.h:574-666, and PartitionedMatrixView's second loops, I/partitioned_matrix_view_impl.h:171-190).  The fused
-  // tiles cover rows [0, rem_row0); the remainder's contributions are sums over its rows and are added by small generic kernels.
+  // tiles cover the other (conforming) rows; the remainder's contributions are sums over its rows and are added by small generic
+  // kernels.  rem_list: their row blocks, ascending.  With an elimination order they trail, [rem_row0, nrb); without one they may sit
+  // anywhere (rem_row0 = -1 unless they happen to trail).  slot_row / mo_index / cam_slot hold COMPACT ids of the conforming rows
+  // (= the row block itself when the remainder trails).
   int rem_row0 = 0, n_rem_rows = 0;
+  std::vector<int32_t> rem_list;
 };
 
 // Storage of an EXPLICIT Schur complement: what SparseSchurComplementSolver::InitStorage builds

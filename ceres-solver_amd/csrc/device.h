@@ -301,9 +301,11 @@ hipError_t LaunchGenSchurDense(const GenStructure& G, const double* values, cons
 // ---- remainder rows of the fused path: rows without a point cell, R = their own GenStructure (kernels_generic.hip); nf = the camera width ----
 hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, int nf, double* out, hipStream_t stream);
 // y_f[pos(c) ..] += F_R^T t over the remainder rows' cells on the nf-wide camera blocks (one wavefront per camera)
-hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras, int nf,
-                                 const double* t_rows, double* y_f, const int* status, hipStream_t stream);
-hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, int nf, double* y, hipStream_t stream);
+// (cam_pos: each camera's offset in the F-space vectors, or nullptr: back to back from cam_base)
+hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int cam_base, int n_cameras,
+                                 int nf, const double* t_rows, double* y_f, const int* status, hipStream_t stream);
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int cam_base, int n_cameras, int nf, double* y, hipStream_t stream);
+hipError_t LaunchGatherRows(const double* in, const int32_t* map, int n, double* out, hipStream_t stream);   // out[r] = in[map[r]]
 hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t stream);
 
 // ---- explicit Schur complement solvers (kernels_schur.hip) ------------------

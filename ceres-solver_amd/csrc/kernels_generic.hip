@@ -772,8 +772,8 @@ __global__ __launch_bounds__(kB) void rem_camera_blocks_kernel(GenStructure R, c
 // a Venice-shaped problem with 1 % prior rows, three calls per solve: 1.32x the pure problem.)
 template <int NF>
 __global__ __launch_bounds__(kB) void rem_left_multiply_kernel(GenStructure R, const double* __restrict__ v, const int32_t* __restrict__ cam_block,
-                                                               const int32_t* __restrict__ cam_pos, int n_cameras, const double* __restrict__ t_rows,
-                                                               double* __restrict__ y_f, const int* __restrict__ status) {
+                                                               const int32_t* __restrict__ cam_pos, int cam_base, int n_cameras,
+                                                               const double* __restrict__ t_rows, double* __restrict__ y_f, const int* __restrict__ status) {
   if (status && *status != 0) return;
   constexpr int CS = 64 / NF;   // cell slots of a wavefront (lanes CS NF .. 63 idle)
   const int lane = threadIdx.x & 63;
@@ -805,15 +805,20 @@ __global__ __launch_bounds__(kB) void rem_left_multiply_kernel(GenStructure R, c
     const double u = __shfl_down(acc, h * NF, 64);
     if (cs + h < CS && cs < h) acc += u;
   }
-  if (lane < NF) y_f[(cam_pos ? cam_pos[c] : NF * c) + k] += acc;
+  if (lane < NF) y_f[(cam_pos ? cam_pos[c] : cam_base + NF * c) + k] += acc;   // (cam_base: where camera 0 sits in the F-space vectors when they are back to back)
 }
 // y[pos(c) + k] += blocks[nf nf c + (nf + 1) k]: the remainder's share of the camera columns' squared norms
-__global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int n_cameras, int nf,
-                                                          double* __restrict__ y) {
+__global__ __launch_bounds__(kB) void rem_add_diag_kernel(const double* __restrict__ blocks, const int32_t* __restrict__ cam_pos, int cam_base, int n_cameras,
+                                                          int nf, double* __restrict__ y) {
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= nf * n_cameras) return;
   const int c = i / nf, k = i % nf;
-  y[(cam_pos ? cam_pos[c] : nf * c) + k] += blocks[int64_t(nf) * nf * c + (nf + 1) * k];
+  y[(cam_pos ? cam_pos[c] : cam_base + nf * c) + k] += blocks[int64_t(nf) * nf * c + (nf + 1) * k];
+}
+// out[r] = in[map[r]]: the remainder rows' residuals into their compact row space (rows anywhere among the observation rows)
+__global__ __launch_bounds__(kB) void gather_rows_kernel(const double* __restrict__ in, const int32_t* __restrict__ map, int n, double* __restrict__ out) {
+  const int r = blockIdx.x * kB + threadIdx.x;
+  if (r < n) out[r] = in[map[r]];
 }
 // One workgroup: *out = sum_r m_r (f_r - m_r / 2)   (mode 0: m = J x of the un-negated solution, the back-substitution kernel's
 // convention) or  -sum_r m_r (f_r + m_r / 2)  (mode 1: m = J step) — the remainder rows' share of the model cost change,
@@ -845,20 +850,24 @@ hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, co
   }
   return hipGetLastError();
 }
-hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int n_cameras, int nf,
-                                 const double* t_rows, double* y_f, const int* status, hipStream_t s) {
+hipError_t LaunchRemLeftMultiply(const GenStructure& R, const double* values, const int32_t* cam_block, const int32_t* cam_pos, int cam_base, int n_cameras,
+                                 int nf, const double* t_rows, double* y_f, const int* status, hipStream_t s) {
   if (n_cameras <= 0) return hipSuccess;
   const dim3 grid((n_cameras + kB / 64 - 1) / (kB / 64));
   switch (nf) {
-#define X(W) case W: hipLaunchKernelGGL(rem_left_multiply_kernel<W>, grid, dim3(kB), 0, s, R, values, cam_block, cam_pos, n_cameras, t_rows, y_f, status); break;
+#define X(W) case W: hipLaunchKernelGGL(rem_left_multiply_kernel<W>, grid, dim3(kB), 0, s, R, values, cam_block, cam_pos, cam_base, n_cameras, t_rows, y_f, status); break;
     CERES_HIP_REM_WIDTHS(X)
 #undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int n_cameras, int nf, double* y, hipStream_t s) {
-  if (n_cameras > 0) hipLaunchKernelGGL(rem_add_diag_kernel, dim3(blocks_for(int64_t(nf) * n_cameras)), dim3(kB), 0, s, blocks, cam_pos, n_cameras, nf, y);
+hipError_t LaunchRemAddDiag(const double* blocks, const int32_t* cam_pos, int cam_base, int n_cameras, int nf, double* y, hipStream_t s) {
+  if (n_cameras > 0) hipLaunchKernelGGL(rem_add_diag_kernel, dim3(blocks_for(int64_t(nf) * n_cameras)), dim3(kB), 0, s, blocks, cam_pos, cam_base, n_cameras, nf, y);
+  return hipGetLastError();
+}
+hipError_t LaunchGatherRows(const double* in, const int32_t* map, int n, double* out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(n)), dim3(kB), 0, s, in, map, n, out);
   return hipGetLastError();
 }
 hipError_t LaunchRemModelCost(const double* m, const double* f, int n, int mode, double* out, hipStream_t s) {

@@ -138,40 +138,48 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // CAMERAS (at most one cell per row, all of one width nf) and a few SHARED blocks (common.h: the strip).
   // The eliminated blocks are all of ONE width: 3, or — with an elimination order — 2 or 4 (common.h: BalShapeCompiled; the reference's
   // (2,2,*) and (2,4,*) specialisations).
-  P.nr = h.rsz[0];   // every conforming row is this high (checked below): 2, or 3 / 4 for the reference's (3,3,3) and (4,4,*)
-  if (P.nr < 2 || P.nr > 4) return no("row blocks that are not 2, 3 or 4 high");
   P.ne = h.nelim > 0 ? h.csz[0] : 3;
   if (P.ne < 2 || P.ne > 4) return no("eliminated blocks that are not 2, 3 or 4 wide");
   auto is_point = [&](int j) { return h.nelim > 0 ? j < h.nelim : h.csz[j] == 3; };
   for (int j = 0; j < h.ncb; ++j)
     if (is_point(j) && h.csz[j] != P.ne) return no("eliminated blocks of different widths");
 
-  // Remainder: the longest run of TRAILING rows that touch camera blocks only (no point cell; possibly no cell at all).  A conforming
-  // row has a point cell, so the split is unambiguous.  Everything in front of it must conform.
-  int n_conf = h.nrb;
-  while (n_conf > 0) {
-    const int i = n_conf - 1;
+  // Remainder: the rows that touch camera-side blocks only (no point cell; possibly no cell at all).  A conforming row has a point cell,
+  // so the split is unambiguous.  With an elimination order they must TRAIL (the reference's E rows come first: an E row behind an
+  // E-free row is not a structure its Schur solvers accept, I/partitioned_matrix_view_impl.h:124-136); without one (CGNR: rows in
+  // the order the residual blocks were added) they may sit ANYWHERE among the observation rows (round 5) — a prior added together with
+  // its camera, in front of that camera's observations.  `orig[q]` = the row block of conforming row q (compact ids from here on).
+  std::vector<int32_t> orig;
+  orig.reserve(h.nrb);
+  P.rem_list.clear();
+  for (int i = 0; i < h.nrb; ++i) {
     bool camera_only = true;
     for (int k = h.rptr[i]; k < h.rptr[i + 1] && camera_only; ++k) camera_only = !is_point(h.ccol[k]);
-    if (!camera_only) break;
+    if (!camera_only) { orig.push_back(i); continue; }
     if (h.rsz[i] > kMaxGenericBlock) return no("a row without a point cell is higher than the generic kernels take");
-    --n_conf;
+    P.rem_list.push_back(i);
   }
+  const int n_conf = int(orig.size());
   if (n_conf == 0) return no("no row with a point cell");
-  P.rem_row0 = n_conf;
-  P.n_rem_rows = h.nrb - n_conf;
+  P.nr = h.rsz[orig[0]];   // every conforming row is this high (checked below): 2, or 3 / 4 for the reference's (3,3,3) and (4,4,*)
+  if (P.nr < 2 || P.nr > 4) return no("row blocks that are not 2, 3 or 4 high");
+  const bool rem_trailing = P.rem_list.empty() || P.rem_list.front() == n_conf;
+  if (h.nelim > 0 && !rem_trailing) return no("a row without a point cell in front of rows with one (Schur ordering)");
+  P.rem_row0 = rem_trailing ? n_conf : -1;
+  P.n_rem_rows = int(P.rem_list.size());
 
   // Shared blocks: as long as some row holds more than one cell outside the points and the shared set, the most referenced block
   // among those rows' cells joins the shared set (libmv: the one intrinsics block every row references).
   std::vector<uint8_t> shared(h.ncb, 0);
   {
     std::vector<int32_t> refs(h.ncb, 0);
-    for (int i = 0; i < n_conf; ++i)
-      for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) ++refs[h.ccol[k]];
+    for (int q = 0; q < n_conf; ++q)
+      for (int k = h.rptr[orig[q]]; k < h.rptr[orig[q] + 1]; ++k) ++refs[h.ccol[k]];
     int n_shared_scalars = 0;
     for (int round = 0;; ++round) {
       int pick = -1;
-      for (int i = 0; i < n_conf; ++i) {
+      for (int q = 0; q < n_conf; ++q) {
+        const int i = orig[q];
         int others = 0;
         for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) others += !is_point(h.ccol[k]) && !shared[h.ccol[k]];
         if (others < 2) continue;
@@ -213,13 +221,14 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   std::vector<int32_t> row_hpos[kMaxSharedCellsPerRow], row_hdesc[kMaxSharedCellsPerRow];
   if (P.ns > 0)
     for (int q = 0; q < kMaxSharedCellsPerRow; ++q) { row_hpos[q].assign(n_conf, -1); row_hdesc[q].assign(n_conf, 0); }
-  for (int i = 0; i < n_conf; ++i) {
-    if (h.rsz[i] != P.nr) return no(P.nr == 2 ? "row block that is not 2 high" : "row blocks of different heights");
+  for (int i = 0; i < n_conf; ++i) {   // i: compact id of the conforming row, ro: its row block
+    const int ro = orig[i];
+    if (h.rsz[ro] != P.nr) return no(P.nr == 2 ? "row block that is not 2 high" : "row blocks of different heights");
     int n_pt = 0, n_cam = 0, n_sh = 0;
-    for (int k = h.rptr[i]; k < h.rptr[i + 1]; ++k) {
+    for (int k = h.rptr[ro]; k < h.rptr[ro + 1]; ++k) {
       const int j = h.ccol[k];
       if (is_point(j)) {
-        if (h.nelim > 0 && k != h.rptr[i]) return no("E cell is not the first cell of its row");
+        if (h.nelim > 0 && k != h.rptr[ro]) return no("E cell is not the first cell of its row");
         if (n_pt++) return no("row with two point cells");
         row_pt[i] = id_of[j]; row_epos[i] = h.cval[k];
       } else if (shared[j]) {
@@ -501,7 +510,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
         for (int l = 0; l < cnt; ++l) {
           const int i = order[idx++];
           const int64_t s = tile * kTile + l;
-          P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
+          P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[orig[i]];
           P.slot_cam[s] = row_cam[i] >= 0 ? row_cam[i] : -2; P.slot_pt[s] = p; P.slot_row[s] = i;   // -2: a valid slot without a camera cell
           put_shared(s, i);
           P.slot_seg[s] = 0u | (uint32_t(cnt - 1) << 8) | (1u << 16);
@@ -519,7 +528,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     for (int l = 0; l < k; ++l) {
       const int i = order[idx++];
       const int64_t s = tile * kTile + used + l;
-      P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[i];
+      P.slot_epos[s] = row_epos[i]; P.slot_fpos[s] = row_fpos[i]; P.slot_bpos[s] = h.rpos[orig[i]];
       P.slot_cam[s] = row_cam[i] >= 0 ? row_cam[i] : -2; P.slot_pt[s] = p; P.slot_row[s] = i;
       put_shared(s, i);
       P.slot_seg[s] = uint32_t(used) | (uint32_t(used + k - 1) << 8) | (1u << 16);

@@ -123,8 +123,9 @@ struct ceres_hip_solver {
   bool rhs_reduce_pending = false;  // rhs holds this rank's raw sums; the all-reduce is still owed
   double* cgnr_rhs_tail = nullptr;  // CGNR: 9 n_c doubles behind the camera blocks of `precond`
   GenStructure GR;
-  int rem_rows = 0, rem_b0 = 0;
-  double *rem_tmp = nullptr, *rem_blocks = nullptr;
+  int rem_rows = 0, rem_b0 = 0;   // rem_b0: where the remainder's residuals begin in b when its rows trail, -1: gathered through d_rem_row_map
+  double *rem_tmp = nullptr, *rem_blocks = nullptr, *rem_b = nullptr;
+  int32_t* d_rem_row_map = nullptr;  // scalar row of the remainder's compact row space -> scalar row of the whole problem (rows anywhere: CGNR)
   int32_t* d_cam_block = nullptr;
   bool rem_blocks_valid = false;
   int bal_flags = 0;
@@ -426,6 +427,14 @@ int ensure_rem_blocks(ceres_hip_solver* s) {
   return 0;
 }
 const double* rem_extra_blocks(ceres_hip_solver* s) { return has_remainder(s) ? s->rem_blocks : nullptr; }
+// the remainder rows' residuals in their compact row space: a window of b where those rows trail, gathered otherwise (a few thousand
+// scalars; gathered at each use so that every way b can arrive — host load, device pointers, the LM step — is covered)
+int rem_residuals(ceres_hip_solver* s, const double** out) {
+  if (s->rem_b0 >= 0) { *out = s->b + s->rem_b0; return 0; }
+  HIP_TRY(s, LaunchGatherRows(s->b, s->d_rem_row_map, s->rem_rows, s->rem_b, s->stream));
+  *out = s->rem_b;
+  return 0;
+}
 // y_f += what the remainder rows add to the camera part of a fused operator's output (before any all-reduce: the rows live on one rank)
 int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f, const int* status) {
   if (!has_remainder(s)) return 0;
@@ -435,14 +444,18 @@ int add_remainder(ceres_hip_solver* s, int mode, const double* x_f, double* y_f,
     case kBalSx: case kBalJtJx:   // F_R^T (F_R x)
       HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
       HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, status, st));
-      HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->plan.nf, s->rem_tmp, y_f, status, st));
+      HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.cam_base, s->plan.n_cameras, s->plan.nf, s->rem_tmp, y_f, status, st));
       return 0;
     case kBalInit: case kBalJtb: case kBalCgnrInit:   // F_R^T b_R
-      if (s->have_b) HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.n_cameras, s->plan.nf, s->b + s->rem_b0, y_f, status, st));
+      if (s->have_b) {
+        const double* b_rem = nullptr;
+        TRY(rem_residuals(s, &b_rem));
+        HIP_TRY(s, LaunchRemLeftMultiply(s->GR, s->values, s->d_cam_block, cam_pos, s->plan.cam_base, s->plan.n_cameras, s->plan.nf, b_rem, y_f, status, st));
+      }
       return 0;
     case kBalColNorm:   // diag(F_R^T F_R)
       TRY(ensure_rem_blocks(s));
-      HIP_TRY(s, LaunchRemAddDiag(s->rem_blocks, cam_pos, s->plan.n_cameras, s->plan.nf, y_f, st));
+      HIP_TRY(s, LaunchRemAddDiag(s->rem_blocks, cam_pos, s->plan.cam_base, s->plan.n_cameras, s->plan.nf, y_f, st));
       return 0;
     default: return 0;  // kSpseZ: F^T E (E^T E)^-1 E^T F has no share from rows without an E block
   }
@@ -452,7 +465,9 @@ int rem_model_cost(ceres_hip_solver* s, const double* x_f, int mode, double* out
   hipStream_t st = s->stream;
   HIP_TRY(s, hipMemsetAsync(s->rem_tmp, 0, sizeof(double) * s->rem_rows, st));
   HIP_TRY(s, LaunchGenRightMultiply(s->GR, s->values, kF, x_f, s->rem_tmp, nullptr, st));
-  HIP_TRY(s, LaunchRemModelCost(s->rem_tmp, s->b + s->rem_b0, s->rem_rows, mode, out, st));
+  const double* b_rem = nullptr;
+  TRY(rem_residuals(s, &b_rem));
+  HIP_TRY(s, LaunchRemModelCost(s->rem_tmp, b_rem, s->rem_rows, mode, out, st));
   return 0;
 }
 
@@ -2058,23 +2073,33 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     }
     if (P.n_rem_rows > 0) {
       // the remainder rows as a structure of their own: compact row space, cells and transpose lists rebased, columns shared with G
-      const int r0 = P.rem_row0, nr = P.n_rem_rows, k0 = h.rptr[r0];
+      // (P.rem_list: their row blocks, ascending — trailing, or anywhere among the observation rows when there is no elimination order)
+      const int nr = P.n_rem_rows;
       GenStructure& R = s->GR;
       R = s->G;
       R.items = GenItems();   // (G's items and group widths describe G's transpose lists, not the remainder's)
       R.lanes_e = R.lanes_f = R.lanes_all = R.lanes_chunk = 0;
       R.nrb = nr; R.nrbe = 0;
-      s->rem_b0 = h.rpos[r0];
-      s->rem_rows = h.num_rows - h.rpos[r0];
-      R.num_rows = s->rem_rows;
-      std::vector<int32_t> rsz(h.rsz.begin() + r0, h.rsz.end()), rpos(nr), rptr(nr + 1), ccol(h.ccol.begin() + k0, h.ccol.end()),
-          cval(h.cval.begin() + k0, h.cval.end()), rbo(s->rem_rows), tptr(h.ncb + 1, 0), trow, tcell;
-      for (int i = 0; i < nr; ++i) { rpos[i] = h.rpos[r0 + i] - s->rem_b0; std::fill_n(rbo.begin() + rpos[i], rsz[i], i); }
-      for (int i = 0; i <= nr; ++i) rptr[i] = h.rptr[r0 + i] - k0;
-      for (int j = 0; j < h.ncb; ++j) {  // the transpose lists are in row order: the remainder's entries are their tails
+      std::vector<int32_t> rsz(nr), rpos(nr), rptr(nr + 1, 0), ccol, cval, rbo, row_map, tptr(h.ncb + 1, 0), trow, tcell;
+      std::vector<int32_t> rem_of(h.nrb, -1), cell_of(h.rptr[h.nrb], -1);   // row block -> remainder row, cell -> remainder cell
+      int nscal = 0;
+      for (int i = 0; i < nr; ++i) {
+        const int ro = P.rem_list[i];
+        rem_of[ro] = i;
+        rsz[i] = h.rsz[ro];
+        rpos[i] = nscal;
+        for (int r = 0; r < h.rsz[ro]; ++r) { rbo.push_back(i); row_map.push_back(h.rpos[ro] + r); }
+        nscal += h.rsz[ro];
+        for (int k = h.rptr[ro]; k < h.rptr[ro + 1]; ++k) { cell_of[k] = int32_t(ccol.size()); ccol.push_back(h.ccol[k]); cval.push_back(h.cval[k]); }
+        rptr[i + 1] = int32_t(ccol.size());
+      }
+      s->rem_rows = nscal;
+      R.num_rows = nscal;
+      s->rem_b0 = P.rem_row0 >= 0 ? h.rpos[P.rem_row0] : -1;   // a window of b (the rows trail, back to back), or gathered
+      for (int j = 0; j < h.ncb; ++j) {  // the transpose lists are in row order: the remainder's entries keep theirs
         tptr[j] = int32_t(trow.size());
         for (int t = h.tptr[j]; t < h.tptr[j + 1]; ++t)
-          if (h.trow[t] >= r0) { trow.push_back(h.trow[t] - r0); tcell.push_back(h.tcell[t] - k0); }
+          if (rem_of[h.trow[t]] >= 0) { trow.push_back(rem_of[h.trow[t]]); tcell.push_back(cell_of[h.tcell[t]]); }
       }
       tptr[h.ncb] = int32_t(trow.size());
       int32_t* q = nullptr;
@@ -2090,6 +2115,10 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       R.row_e_block = nullptr;
       TRY(dev_upload(s, &s->d_cam_block, P.cam_block));
       TRY(dev_alloc(s, &s->rem_tmp, size_t(s->rem_rows)));
+      if (s->rem_b0 < 0) {
+        TRY(dev_upload(s, &s->d_rem_row_map, row_map));
+        TRY(dev_alloc(s, &s->rem_b, size_t(s->rem_rows)));
+      }
       TRY(dev_alloc(s, &s->rem_blocks, size_t(P.nf) * P.nf * P.n_cameras));   // raw F^T F of the remainder rows, one nf x nf block per camera
     }
     {

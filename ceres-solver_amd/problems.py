@@ -558,6 +558,29 @@ def add_camera_rows(prob: LinearProblem, num_rows: int, seed=0, row_size=9, pair
     return LinearProblem(new_bs, values, b, D, prob.num_eliminate_blocks, {}, prob.camera_of_row, prob.point_of_row)
 
 
+def permute_rows(prob: LinearProblem, order) -> LinearProblem:
+    """The same linear problem with its ROW BLOCKS in another order (`order[k]` = the old row block that becomes row block k): the
+    value array is untouched (cells keep their positions, which BlockSparseMatrix allows: cell.position is data), the residuals move
+    with their rows.  What a Program whose residual blocks were added in another order produces without an elimination ordering
+    (CGNR: internal/ceres/block_jacobian_writer.cc:198-263 lays rows out in residual-block order) — e.g. a prior added together with
+    its camera, in front of that camera's observations."""
+    bs = prob.bs
+    order = np.asarray(order, dtype=np.int64)
+    assert np.array_equal(np.sort(order), np.arange(bs.num_row_blocks))
+    ptr = bs.row_cell_ptr.astype(np.int64)
+    sizes = bs.row_block_size[order]
+    pos = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))[:-1]])
+    ncell = (ptr[1:] - ptr[:-1])[order]
+    new_ptr = np.concatenate([[0], np.cumsum(ncell)])
+    cell_idx = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in order]) if len(order) else np.zeros(0, np.int64)
+    new_bs = BlockStructure(sizes, pos, bs.col_block_size, bs.col_block_pos, new_ptr, bs.cell_col_block[cell_idx], bs.cell_value_pos[cell_idx])
+    b = None
+    if prob.b is not None and prob.b.shape[0]:
+        old_pos = bs.row_block_pos.astype(np.int64)
+        b = np.concatenate([prob.b[old_pos[r]: old_pos[r] + bs.row_block_size[r]] for r in order])
+    return LinearProblem(new_bs, prob.values, b if b is not None else prob.b, prob.D, prob.num_eliminate_blocks, {}, None, None)
+
+
 # --------------------------------------------------------------------------
 # Scene-based values: the first LM linear system of a synthetic bundle-adjustment problem
 # --------------------------------------------------------------------------

@@ -125,6 +125,7 @@ def test_lm_step_with_leftover_rows(hip, oracle, problems, solver, pre):
 
 # ---- round 5: leftover rows next to every compiled shape (the remainder kernels are templated on the camera width) ----
 OTHER_SHAPES = {
+    "f9": dict(camera_width=9),   # (the BAL shape too: CGNR WITHOUT elimination groups on Schur-ordered columns — cameras back to back behind the points)
     "f10_quaternion_cameras": dict(camera_width=10), "f6": dict(camera_width=6), "f3": dict(camera_width=3), "f4": dict(camera_width=4),
     "f8": dict(camera_width=8), "e4_f9": dict(point_width=4, camera_width=9), "e2_f2": dict(point_width=2, camera_width=2),
     "r3_e3_f3": dict(row_height=3, point_width=3, camera_width=3), "r4_e4_f4": dict(row_height=4, point_width=4, camera_width=4),
@@ -161,3 +162,39 @@ def test_leftover_rows_next_to_every_compiled_shape(hip, oracle, problems, name)
     # CGNR knows no elimination order: points are whatever is 3 wide (tests/test_gpu_shapes.py) — fused where that reading exists
     if kw.get("point_width", 3) == 3 and kw.get("row_height", 2) == 2 and w != 3:
         assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+
+
+@pytest.mark.parametrize("shape", ["f9", "f10_quaternion_cameras", "f6"])
+def test_cgnr_with_camera_rows_anywhere_among_the_observations(hip, oracle, problems, shape):
+    """Without an elimination order the Jacobian's rows come in the order the residual blocks were added
+    (internal/ceres/block_jacobian_writer.cc:198-263): priors on cameras may sit anywhere among the observations.  The tiles take the
+    observation rows, the remainder kernels the others (their residuals gathered into a compact row space) — every CGNR operator, the
+    converged solve, the LM-style solve and the LM step with its model cost against the oracle on the whole problem."""
+    from test_gpu_operators import assert_errs, check_cgnr_operators
+    from test_gpu_lm_step import check_step
+    w = {"f9": 9, "f10_quaternion_cameras": 10, "f6": 6}[shape]
+    base = problems.synthetic_structured(37, 3000, 13000, seed=31, skew=0.5, camera_width=w, layout="cgnr")
+    base = type(base)(base.bs, base.values, base.b, base.D, 0)
+    q = problems.add_camera_rows(base, 60, seed=5, row_size=w, pair_fraction=0.3, camera_width=w)
+    q = problems.add_camera_rows(q, 25, seed=6, row_size=3, camera_width=w)
+    rng = np.random.default_rng(17)
+    n_obs = base.bs.num_row_blocks
+    keys = np.concatenate([np.arange(n_obs, dtype=np.float64), rng.uniform(-1, n_obs, 85)])
+    p = problems.permute_rows(q, np.argsort(keys, kind="stable"))
+    assert p.bs.row_cell_ptr[1] - p.bs.row_cell_ptr[0] >= 1
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+    m0 = oracle.Matrix(p.bs, 0)
+    s = make_solver(hip, p, hip.CGNR, hip.JACOBI, max_it=400)
+    assert s.info().kernel_path == hip.PATH_BAL and s.info().num_observations == n_obs
+    xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=1e-12))
+    xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=400, q_tol=-1.0, r_tol=1e-12)
+    assert summ.termination_type == so.termination_type == hip.SUCCESS and rel(xs, xo) <= 1e-8
+    xs, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+    assert_lm_style_step(xs, summ, lambda lo, hi, qt, r: m0.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=lo, max_it=hi, q_tol=qt, r_tol=r),
+                         0.1, hip.SUCCESS)
+    radius = 3e3
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)
+    diag = np.clip(m0.squared_column_norm(p.values), 1e-6, 1e32)
+    assert rel(s.lm_diagonal(), np.sqrt(diag / radius)) <= 1e-12
+    check_step(oracle, hip, p, hip.CGNR, hip.JACOBI, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+    s.close()

@@ -428,7 +428,21 @@ def test_trailing_rows_without_a_point_cell_are_a_remainder_not_a_rejection(prob
                          np.concatenate([b.cell_col_block, cells0]), np.concatenate([b.cell_value_pos, b.cell_value_pos[ptr[0]:ptr[1]]]))
     assert bad.num_row_blocks == nrb + 1
     if layout == "cgnr":   # (in the Schur ordering an E row behind E-free rows is not a valid structure for a Schur solver at all)
-        assert not pkg.hip_solver.debug_plan(bad, nelim)["eligible"]
+        assert not pkg.hip_solver.debug_plan(bad, nelim)["eligible"]   # (that copied row observes a camera a second time)
+        # round 5: without an elimination order the rows without a point cell may sit ANYWHERE among the observation rows (a prior
+        # added together with its camera): the tiles still hold exactly the observation rows, in the same point-major arrangement
+        rng = np.random.default_rng(3)
+        n_obs = p.bs.num_row_blocks
+        keys = np.concatenate([np.arange(n_obs, dtype=np.float64), rng.uniform(-1, n_obs, 25)])   # the 25 camera rows go anywhere
+        mixed = problems.permute_rows(q, np.argsort(keys, kind="stable"))
+        got = pkg.hip_solver.debug_plan(mixed.bs, nelim)
+        assert got["eligible"] and got["n_tiles"] == base["n_tiles"]
+        for k in ("slot_row", "slot_cam", "slot_pt", "tile_kind", "tile_aux"):   # (slot_row: compact ids of the observation rows)
+            assert np.array_equal(got[k], base[k]), k
+    else:   # Schur ordering: the same rows in the middle are not a structure the reference's Schur solvers accept
+        order = np.arange(q.bs.num_row_blocks)
+        order[[5, -1]] = order[[-1, 5]]
+        assert not pkg.hip_solver.debug_plan(problems.permute_rows(q, order).bs, nelim)["eligible"]
 
 
 @pytest.mark.parametrize("shape,kw", [("ladybug1723", {}), (None, dict(num_cameras=300, num_points=250, num_observations=9000)),
