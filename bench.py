@@ -143,7 +143,8 @@ def parse():
     ap.add_argument("--extra-real-graph", type=int, default=1, help="default line: S.x / JtJx on the replicated libmv visibility graph (extra.real_graph)")
     ap.add_argument("--extra-other-shapes", type=int, default=1, help="default line: camera widths other than 9, the libmv structure and the generic kernels on the Ladybug shape (extra.other_shapes)")
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
-    ap.add_argument("--also-fp32", type=int, default=0, help="many-camera workloads: also time the fp32-tile storage mode (extra.fp32_tiles)")
+    ap.add_argument("--also-fp32", type=int, default=-1, help="also time the fp32-tile storage mode (extra.fp32_tiles; BASELINE.json configs[4] asks for a sweep over both "
+                                                               "precisions): -1 = on the default Venice line, 1 = on, 0 = off")
     ap.add_argument("--oracle-check", type=int, default=-1,
                     help="(-1 = on where one oracle step takes about a second: the workloads whose camera sums fit in LDS) compare the step of the LAST timed solve with ONE oracle step on the same FULL-SIZE inputs (16 threads; N > 1: the ranks' "
                          "shards of the step are gathered and assembled first) and report it as oracle_check.  Independent of --no-cpu-baseline: "
@@ -570,7 +571,7 @@ def main():
     extra["device_bytes"] = int(info.device_bytes)
 
     # ---- many-camera workloads: the fp32-tile storage mode next to fp64 (BASELINE.json configs[4]: "fp32 and fp64") ----
-    if world == 1 and many_cameras and args.also_fp32 and not storage:
+    if world == 1 and (args.also_fp32 > 0 or (args.also_fp32 < 0 and args.workload == "venice1778" and args.extra_synthetic10m)) and not storage and info.kernel_path == hs.PATH_BAL:
         s32 = make_solver(hs, bs, nelim_local, args.solver, local_rank, None, 1)
         tx32 = torch.empty_like(tx)
         n32 = max(3, args.steps // 2)
@@ -578,7 +579,8 @@ def main():
         s32.load_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr())
         ms32 = s32.time_op(hs.TIMED_JTJX if kind == "jtjx" else hs.TIMED_SX, args.kernel_iters)
         nb32 = algorithmic_bytes(kind, my_obs, my_points, n_cams, 4)
-        extra["fp32_tiles"] = {"what": "Jacobian tiles rounded to fp32, fp64 arithmetic: an accuracy mode, never parity",
+        extra["fp32_tiles"] = {"what": "Jacobian tiles rounded to fp32, fp64 arithmetic (BASELINE.json configs[4] asks for both precisions): an accuracy mode, never parity; "
+                                       "it runs on the unpipelined tile kernel (bal_fused_kernel), which is why half the bytes buy only 10-20 %",
                                "steps_per_s": round(n32 / e32, 3), "ms_per_step": round(1e3 * e32 / n32, 4), "cg_iterations": it32[-1],
                                f"{kind}_ms": round(ms32, 5), f"{kind}_frac_hbm_of_fp32_bytes": round(nb32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "step_rel_diff_vs_fp64": float((torch.linalg.norm(tx32 - tx) / torch.linalg.norm(tx)).item())}

@@ -141,6 +141,11 @@ struct BalPlan {
   // camera-major pass sums it.  Both can run CHUNK by chunk of tiles through a ring buffer (plan.cc: default one chunk).
   bool cameras_in_lds = true;
   std::vector<int32_t> slot_word;            // per slot, what the kernels read: camera | accumulator row << kSlotCamBits (plan.cc)
+  // Accumulators of ALL cameras in LDS (cameras_in_lds): the LDS left over holds a copy of x_f for the xhot_cam.size() most observed
+  // cameras (row r = camera xhot_cam[r]); their slots carry r + 1 in the (otherwise unused) row field of the word.  The streaming
+  // kernels read those cameras' part of x from LDS: the gathers of the popular cameras' 72 bytes were what S.x / JtJx lost against
+  // the bare tile stream (round 5: profiles/r05m_*).
+  std::vector<int32_t> xhot_cam;
   int64_t z_ring_rows = 0;                   // 72-byte rows of the largest chunk's ring (spilled slots + the hybrid flush rows)
   std::vector<int32_t> tile_zbase;           // per tile: ring row of its first spilled slot (chunk-relative)
   std::vector<int32_t> zc_tile_ptr;          // n_chunks+1 tile boundaries (never inside a long point)

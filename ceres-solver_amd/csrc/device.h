@@ -109,6 +109,10 @@ struct BalArgs {
   double* zbuf = nullptr;        // [rows][nf]     (cameras do not fit in LDS: the ring of spilled / flushed F^T z rows, second pass by camera)
   double* strip_sums = nullptr;  // accumulators outside LDS, shapes with a strip: the strip's ns entries of the global sums (zeroed per application)
   int n_acc = 0;                 // nf * n_cameras + ns: the camera-space accumulator entries (the strip's behind the cameras')
+  // LDS mode, streaming kernels: x_f of the n_xhot most observed cameras staged in LDS behind the accumulators (BalPlan::xhot_cam;
+  // the slot word's row field = row + 1)
+  const int32_t* xhot_cam = nullptr;
+  int n_xhot = 0;
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
   const double* copy_src = nullptr;

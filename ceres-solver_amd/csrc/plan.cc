@@ -725,6 +725,28 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   // spilled).  With the accumulators of ALL cameras in LDS the row is the camera id itself and the upper bits stay 0.
   P.slot_word.assign(P.slot_cam.begin(), P.slot_cam.end());
   for (auto& w : P.slot_word) if (w == -2) w = 0;   // no camera cell: the tiles hold zeros for F, any camera's row takes the zero sums
+  P.xhot_cam.clear();
+  if (P.cameras_in_lds) {
+    // x_f of the most observed cameras in what LDS the accumulators leave (1 KiB stays for the kernels' static arrays, as above)
+    static const bool enabled = [] { const char* e = getenv("CERES_HIP_XHOT"); return !e || atoi(e) != 0; }();
+    const size_t used = (size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double) + 1024;
+    int64_t n_hot = enabled && kLdsBytesPerCu > used ? int64_t((kLdsBytesPerCu - used) / (sizeof(double) * P.nf)) : 0;
+    n_hot = std::min<int64_t>({n_hot, int64_t(P.n_cameras), int64_t(kSlotSpill) - 2});   // (the word's row field: 12 bits, all ones = kSlotSpill)
+    if (n_hot > 0) {
+      std::vector<int64_t> deg(P.n_cameras, 0);
+      for (int64_t sl = 0; sl < P.n_tiles * kTile; ++sl) if (P.slot_cam[sl] >= 0) ++deg[P.slot_cam[sl]];
+      std::vector<int32_t> by_deg(P.n_cameras);
+      std::iota(by_deg.begin(), by_deg.end(), 0);
+      std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+      P.xhot_cam.assign(by_deg.begin(), by_deg.begin() + n_hot);
+      std::vector<int32_t> row_of(P.n_cameras, -1);
+      for (int r = 0; r < int(n_hot); ++r) row_of[P.xhot_cam[r]] = r;
+      for (int64_t sl = 0; sl < P.n_tiles * kTile; ++sl) {
+        const int c = P.slot_cam[sl];
+        if (c >= 0 && row_of[c] >= 0) P.slot_word[sl] = int32_t(uint32_t(c) | (uint32_t(row_of[c] + 1) << kSlotCamBits));
+      }
+    }
+  }
   if (!P.cameras_in_lds) {
     // Camera-major second pass.  The tile pass leaves the spilled rows of a tile back to back in a ring (tile_zbase = the tile's
     // first row; a slot's row = tile_zbase + its rank among the tile's spilled slots), the hybrid workgroups append their accumulator

@@ -112,6 +112,7 @@ struct ceres_hip_solver {
   double2 *d_J = nullptr, *d_bt = nullptr;
   float4* d_Jf = nullptr;  // fp32 tile storage (options.jacobian_storage == 1)
   double *d_Mo = nullptr, *d_partials = nullptr, *d_global_acc = nullptr;
+  int32_t* d_xhot_cam = nullptr;   // BalPlan::xhot_cam (LDS mode: the cameras whose part of x the streaming kernels keep in LDS)
   double* d_zbuf = nullptr;
   // Remainder rows of the fused path (BalPlan::rem_row0: trailing rows without a point cell): their own structure for the generic
   // kernels (compact row space), the residual offset of the first of them, a row-space temporary and their F^T F per camera
@@ -309,6 +310,9 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.mo_index = s->d_mo_index;
   A.n_acc = s->plan.nf * s->plan.n_cameras + s->plan.ns;
+  // (a workgroup stages its copy once per launch: that pays from about a hundred tiles per workgroup on — Ladybug-sized problems, 41
+  // tiles per workgroup, lose 3 us of a 42 us pass to it: profiles/r05n_*)
+  A.xhot_cam = s->d_xhot_cam; A.n_xhot = (s->d_xhot_cam && s->plan.n_tiles >= int64_t(100) * s->fused_grid) ? int(s->plan.xhot_cam.size()) : 0;
   A.cam_base = s->plan.cam_base;
   for (int j = 0; j < kMaxSharedScalars; ++j) A.sh_pos[j] = j < s->plan.ns_used ? s->plan.sh_pos[j] : -1;
   A.have_b = s->have_b ? 1 : 0;
@@ -1984,6 +1988,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       TRY(dev_upload(s, &s->d_cam_foff, cfo));
     }
     TRY(dev_upload(s, &s->d_slot_cam, P.slot_word));  // camera | accumulator row << kSlotCamBits
+    if (!P.xhot_cam.empty()) TRY(dev_upload(s, &s->d_xhot_cam, P.xhot_cam));
     TRY(dev_upload(s, &s->d_tile_pt0, P.tile_pt0));
     TRY(dev_upload(s, &s->d_slot_seg, P.slot_seg));
     TRY(dev_upload(s, &s->d_tile_kind, P.tile_kind));

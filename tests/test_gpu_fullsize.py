@@ -208,3 +208,15 @@ def test_venice_shape_cgnr_layout_properties_and_solve(hip, oracle, problems):
     model = 0.5 * step @ s.jtjx(step) - g @ step
     assert model < 0
     s.close()
+
+
+@pytest.mark.parametrize("n_cams,what", [(2250, "accumulators fill LDS: a handful of cameras' x beside them"), (1000, "every camera's x in LDS"),
+                                         (300, "few cameras, long camera lists")])
+def test_popular_cameras_x_in_lds_at_the_edges_of_the_budget(hip, oracle, problems, n_cams, what):
+    """Round 5: the streaming S.x / JtJx kernels keep x_f of the most observed cameras in the LDS the accumulators leave
+    (BalPlan::xhot_cam; from about a hundred tiles per workgroup on).  Venice (1778 cameras, 483 of them staged) is covered above; here the
+    extremes — 2250 cameras (162 000 of 162 816 bytes taken by the accumulators: eleven cameras staged), 1000 (all of them staged:
+    no slot gathers from memory) and 300 — on 1.8 M observations, both solvers' operators at 1e-12 and the LM-style solves."""
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=n_cams, num_points=420000, num_observations=1800000, seed=77, skew=0.7)
+    check_schur_side(hip, oracle, p, True, solve=(n_cams == 1000))
+    check_cgnr_side(hip, oracle, p, True, solve=(n_cams == 1000))

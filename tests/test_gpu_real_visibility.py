@@ -86,7 +86,7 @@ def test_every_track_length_against_the_oracle(hip, oracle, problems, cameras, e
 
 
 def test_every_track_length_with_fp32_tiles(hip, oracle, problems):
-    """The same mix of track lengths with the tiles rounded to fp32 (jacobian_storage = 1: the unpipelined kernels, whose long points
+    """The same mix of track lengths with the tiles rounded to fp32 (jacobian_storage = 1; round 5: the pipelined kernels take fp32 tiles too — CERES_HIP_F32_PIPELINE=0 for the unpipelined ones, whose long points
     run the rounds of `fused_long_rounds` — also for S.x and JtJx).  An accuracy mode: exact against the oracle on the fp32-rounded
     Jacobian, ~1e-7 against the fp64 one."""
     p = problems.bal_from_tracks(MIXED_TRACKS, 1100, seed=11)
