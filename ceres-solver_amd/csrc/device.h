@@ -113,6 +113,9 @@ struct BalArgs {
   // the slot word's row field = row + 1)
   const int32_t* xhot_cam = nullptr;
   int n_xhot = 0;
+  // kBackSub / kJx (no accumulators in LDS): the whole camera part of x staged in LDS, nf * n_cameras scalars (0: gathered from
+  // memory; the dispatcher clears it for every other mode)
+  int x_lds_scalars = 0;
   double* scalar_out = nullptr;  // kJx: one partial sum per workgroup
   // kBackSub: the reduced solution z is also the camera part of x (ImplicitSchurComplement::BackSubstitute copies it): done by the kernel
   const double* copy_src = nullptr;

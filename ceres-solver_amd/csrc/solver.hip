@@ -313,6 +313,7 @@ BalArgs bal_args(ceres_hip_solver* s) {
   // (a workgroup stages its copy once per launch: that pays from about a hundred tiles per workgroup on — Ladybug-sized problems, 41
   // tiles per workgroup, lose 3 us of a 42 us pass to it: profiles/r05n_*)
   A.xhot_cam = s->d_xhot_cam; A.n_xhot = (s->d_xhot_cam && s->plan.n_tiles >= int64_t(100) * s->fused_grid) ? int(s->plan.xhot_cam.size()) : 0;
+  A.x_lds_scalars = (s->lds_mode && s->plan.n_tiles >= int64_t(100) * s->fused_grid) ? s->plan.nf * s->plan.n_cameras : 0;
   A.cam_base = s->plan.cam_base;
   for (int j = 0; j < kMaxSharedScalars; ++j) A.sh_pos[j] = j < s->plan.ns_used ? s->plan.sh_pos[j] : -1;
   A.have_b = s->have_b ? 1 : 0;
