@@ -244,3 +244,38 @@ def test_fp32_tile_storage_is_accurate_not_exact(hip, oracle, problems):
         if summ.num_iterations == so.num_iterations:
             assert rel(xs, xo) <= 1e-5
         s.close()
+
+
+@pytest.mark.parametrize("n_cams,n_pts,n_obs,what", [(30000, 60000, 200000, "more cameras than LDS rows: hybrid plan, spilled rows"),
+                                                      (1500, 420000, 1800000, "popular cameras' x staged in LDS (a hundred tiles per workgroup)")])
+def test_fp32_tiles_through_the_pipelined_kernels(hip, oracle, problems, n_cams, n_pts, n_obs, what):
+    """Round 5: fp32 tiles run on the software-pipelined kernels too (CERES_HIP_F32_PIPELINE=0: the unpipelined ones).  Both regimes
+    of the camera sums, S.x and JtJx exact (1e-12) against the oracle on the fp32-ROUNDED Jacobian — the arithmetic is fp64 — and
+    within 5e-7 of the oracle on the fp64 one (an accuracy mode, never parity)."""
+    p = problems.synthetic_bal(None, num_cameras=n_cams, num_points=n_pts, num_observations=n_obs, seed=53, skew=0.5)
+    rounded = p.values.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(3)
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    for solver_type, pre in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)):
+        o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=200,
+                                    elimination_groups=[p.num_eliminate_blocks], jacobian_storage=1)
+        s = hip.HipLinearSolver(o)
+        s.set_structure(p.bs)
+        info = s.info()
+        assert info.kernel_path == hip.PATH_BAL and info.camera_accum_in_lds == int(n_cams <= 2000)
+        s.load(p.values, p.b, p.D)
+        if solver_type == hip.ITERATIVE_SCHUR:
+            s.schur_init()
+            x = rng.standard_normal(m.num_cols_f)
+            got = s.schur_sx(x)
+            for vals, tol in ((p.values, 5e-7), (rounded, 1e-12)):
+                isc = oracle.ImplicitSchurComplement(m)
+                isc.init(vals, p.D, p.b)
+                assert rel(got, isc.sx(x)) <= tol, (what, tol)
+        else:
+            x = rng.standard_normal(m.num_cols)
+            got = s.jtjx(x)
+            for vals, tol in ((p.values, 5e-7), (rounded, 1e-12)):
+                want = m.left_multiply(vals, m.right_multiply(vals, x)) + p.D ** 2 * x
+                assert rel(got, want) <= tol, (what, tol)
+        s.close()
