@@ -13,7 +13,8 @@ LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + 
                [os.path.join(ROOT, "profiles", f) for f in ("r03n_bench_default_iterative_schur.json", "r03zb_bench_default_iterative_schur.json", "r03zm_bench_default_iterative_schur.json",
                                                           "r03zq_bench_default_iterative_schur.json", "r03p_bench_cgnr.json",
                                                           "r04a_bench_default_iterative_schur.json", "r04l_bench_default_iterative_schur.json",
-                                                          "r04_final_bench_default_iterative_schur.json")])
+                                                          "r04_final_bench_default_iterative_schur.json", "r05_final_bench_default_iterative_schur.json",
+                                                          "r05_final_bench_under_rocprof_iterative_schur.json", "r05_final_bench_under_rocprof_cgnr.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -40,7 +41,7 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "under_rocprof" not in path and "fp32" not in path and not two_ranks:   # profiled / fp32-storage / validation runs skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
-    if os.path.basename(path).startswith(("r02", "r03", "r04")):   # since round 2: what the traffic figure is, and the probe for real Ceres
+    if os.path.basename(path).startswith(("r02", "r03", "r04", "r05")):   # since round 2: what the traffic figure is, and the probe for real Ceres
         assert r["traffic"] is None or "profiles/" in r["traffic_source"]
         if cpu:
             assert "tools/probe.sh" in cpu["sample"]
@@ -117,3 +118,29 @@ def test_round4_default_line_fields():
     assert d["config"]["collectives_per_step"] == 0   # one rank
     two = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r04_final_bench_self_launched_2ranks_ladybug_iterative_schur.json")) if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 4 and two["oracle_check"]["step_rel_diff_vs_oracle"] < 1e-9
+
+
+def test_round5_default_line_fields():
+    """Round 5: the timed step itself checked against the oracle at full size ON the headline line (and the CPU leg's figure, which compared
+    steps of different radii until round 4, agrees with it), the fp32-tile leg next to it, S.x at 0.74 of peak with its kernel at 0.79 under
+    rocprofv3 (the camera part of x for the popular cameras in LDS), CGNR's iteration under 0.30 ms, shapes of every row height / point width."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_final_bench_default_iterative_schur.json")).read())
+    oc = d["oracle_check"]
+    assert oc["observations"] == 5001946 and oc["step_rel_diff_vs_oracle"] < 1e-9 and oc["cg_iterations_gpu"] == oc["cg_iterations_oracle"]
+    assert d["cpu_baseline"]["step_rel_diff_vs_gpu"] < 1e-9
+    f32 = d["extra"]["fp32_tiles"]
+    assert 1e-8 < f32["step_rel_diff_vs_fp64"] < 1e-5 and f32["sx_frac_hbm_of_fp32_bytes"] > 0.55 and f32["steps_per_s"] > d["value"]
+    assert d["roofline"]["frac"] >= 0.73 and d["roofline_jtjx"]["frac"] >= 0.65 and d["value"] > 670
+    assert d["extra"]["back_substitute_ms"] <= 0.205
+    shapes = " ".join(c["structure"] for c in d["extra"]["other_shapes"]["cases"])
+    assert "<2,4,9>" in shapes and "<3,3,3>" in shapes and all(c["lm_step"]["step_rel_diff_vs_oracle_iterate_of_the_same_index"] < 1e-9 for c in d["extra"]["other_shapes"]["cases"])
+    # the rocprofv3 run of the same tree: S.x kernel + partial reduction = the line's launch time
+    import csv
+    rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_final_kernel_stats_iterative_schur_venice.csv")))}
+    sx = [float(r["AverageNs"]) for n, r in rows.items() if "bal_stream_kernel<0, true, true, false>" in n][0]
+    red = [float(r["AverageNs"]) for n, r in rows.items() if "bal_reduce_partials_kernel" in n][0]
+    under = json.loads(open(os.path.join(ROOT, "profiles", "r05_final_bench_under_rocprof_iterative_schur.json")).read())
+    assert (sx + red) * 1e-6 == pytest.approx(under["roofline"]["avg_launch_ms"], rel=0.03)
+    assert 1072463720 / (sx * 1e-9) / 8e12 >= 0.78        # the tile pass alone
+    cg = json.loads(open(os.path.join(ROOT, "profiles", "r05_final_long_cg_30_iterations_venice.jsonl")).read())
+    assert cg["cgnr_cg_ms"] / cg["cgnr_its"] < 0.30 and cg["schur_cg_ms"] / cg["schur_its"] < 0.205
