@@ -3051,6 +3051,23 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
 }
 
 // ---- debug exports: the host-side packing plan, testable without a GPU -------
+int ceres_hip_debug_staged_x_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int64_t counts[4], int32_t* staged_cam,
+                                  int32_t* slot_word, int64_t staged_capacity, int64_t slot_capacity) {
+  HostStructure h;
+  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
+  BalPlan P;
+  BuildBalPlan(h, num_eliminate_blocks > 0 ? kReorderIfContiguous : kReorderNever, HybridRequest(), &P);
+  if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
+  counts[0] = P.n_tiles; counts[1] = P.n_cameras; counts[2] = int64_t(P.xhot_cam.size());
+  counts[3] = int64_t((size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double));
+  if (staged_capacity >= int64_t(P.xhot_cam.size()) && staged_cam)
+    for (size_t r = 0; r < P.xhot_cam.size(); ++r) staged_cam[r] = P.xhot_cam[r];
+  const int64_t n_slots = P.n_tiles * kTile;
+  if (slot_capacity >= n_slots && slot_word)
+    for (int64_t i = 0; i < n_slots; ++i) slot_word[i] = P.slot_cam[i] < 0 ? -1 : P.slot_word[i];
+  return 0;
+}
+
 int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t* eligible,
                          int64_t* n_tiles, int32_t* slot_row_out, int32_t* slot_cam_out, int32_t* slot_pt_out,
                          uint32_t* slot_seg_out, int32_t* tile_kind_out, int32_t* tile_aux_out, int64_t slot_capacity,

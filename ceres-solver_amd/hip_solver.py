@@ -151,6 +151,7 @@ ABI = [
     ("ceres_hip_op_dense_cholesky_solve", c_int32, [c_void_p, c_int32, _DP, _DP, _DP, c_int32, POINTER(c_double), POINTER(c_int32)]),
     ("ceres_hip_debug_hybrid_plan", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, POINTER(c_int64)] + [POINTER(c_int32)] * 8 +
      [c_int64, c_int64, c_int64]),
+    ("ceres_hip_debug_staged_x_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32), c_int64, c_int64]),
     ("ceres_hip_debug_long_rounds", c_int32, [POINTER(CBlockStructure), c_int32, c_int32, c_int32, c_int32, POINTER(c_int64)] +
      [POINTER(c_int32)] * 7 + [POINTER(c_uint32), c_int64, c_int64, c_int64]),
 ]
@@ -695,6 +696,23 @@ def debug_plan(bs: BlockStructure, num_eliminate_blocks: int):
     return {"eligible": True, "n_tiles": nt, "slot_row": row, "slot_cam": cam, "slot_pt": pt, "seg_first": seg & 0xff,
             "seg_last": (seg >> 8) & 0xff, "valid": (seg >> 16) & 1, "tail_a": (seg >> 17) & 63, "has_a": (seg >> 23) & 1,
             "tail_b": (seg >> 24) & 63, "has_b": (seg >> 30) & 1, "tile_kind": kind, "tile_aux": aux}
+
+
+def debug_staged_x_plan(bs: BlockStructure, num_eliminate_blocks: int):
+    """Which cameras' part of x the streaming kernels keep in LDS beside the accumulators (csrc/plan.cc, BalPlan::xhot_cam; no device
+    needed).  Returns None for structures off the fused path."""
+    lib = load_library()
+    c = bs.as_ctypes()
+    counts = (c_int64 * 4)()
+    n32 = POINTER(c_int32)()
+    fn = lib.ceres_hip_debug_staged_x_plan
+    if fn(byref(c), c_int32(num_eliminate_blocks), counts, n32, n32, c_int64(0), c_int64(0)) != 0:
+        return None
+    nt, ncam, nst, acc_bytes = (int(v) for v in counts)
+    staged, word = np.zeros(max(nst, 1), np.int32), np.zeros(nt * 64, np.int32)
+    ip = lambda a: a.ctypes.data_as(POINTER(c_int32))
+    assert fn(byref(c), c_int32(num_eliminate_blocks), counts, ip(staged), ip(word), c_int64(nst), c_int64(nt * 64)) == 0
+    return {"n_tiles": nt, "n_cameras": ncam, "staged_cam": staged[:nst], "accumulator_bytes": acc_bytes, "slot_word": word}
 
 
 def debug_hybrid_plan(bs: BlockStructure, num_eliminate_blocks: int, groups: int, rows: int):

@@ -533,6 +533,14 @@ int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num
                                 int32_t* long_ptr, int32_t* round_ptr, int32_t* seq_ptr, int32_t* round_flag, uint32_t* round_word,
                                 int64_t tile_capacity, int64_t range_capacity, int64_t round_capacity);
 
+/* Debug: which cameras' part of x the streaming kernels keep in LDS beside the accumulators (csrc/plan.cc, BalPlan::xhot_cam; pure
+ * host code; the plan of a Schur solver when num_eliminate_blocks > 0).  counts[4] = {n_tiles, cameras, staged cameras, LDS bytes the
+ * accumulators take}; staged_cam[r] = the camera of LDS row r (most observed first); slot_word = camera | (row + 1) << 20 for a staged
+ * camera's slot, camera alone otherwise, -1 = padding slot.  counts[2] = 0 when the accumulators do not all fit in LDS (the hybrid plan's
+ * regime) or CERES_HIP_XHOT=0.  Call once with capacities 0 for the counts.  Returns CERES_HIP_E_UNSUPPORTED for structures off the fused path. */
+int ceres_hip_debug_staged_x_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int64_t counts[4], int32_t* staged_cam,
+                                  int32_t* slot_word, int64_t staged_capacity, int64_t slot_capacity);
+
 /* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
  * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */
 int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world);

@@ -585,3 +585,40 @@ def test_hybrid_plan_keeps_real_tracks_in_lds(problems):
     local = simulate_camera_accumulation(pl, n_c, 64, np.random.default_rng(2))
     print(f"summed in LDS: {local:.3f}")
     assert local > 0.9
+
+
+@pytest.mark.parametrize("n_cams,n_pts,n_obs", [(1778, 60000, 300000), (2250, 30000, 150000), (300, 20000, 90000), (16, 3000, 12000)])
+def test_staged_x_plan_fits_the_lds_and_takes_the_most_observed_cameras(problems, n_cams, n_pts, n_obs):
+    """Round 5 (csrc/plan.cc, BalPlan::xhot_cam): with every camera's accumulator row in LDS the bytes left (160 KiB minus 1 KiB for the
+    kernels' static arrays) hold the 9 scalars of x for as many cameras as fit, most observed first; their slots carry row + 1 above the
+    camera id of the index word, every other slot the camera id alone."""
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=n_cams, num_points=n_pts, num_observations=n_obs, seed=3, skew=0.6, with_values=False)
+    plan = pkg.hip_solver.debug_staged_x_plan(p.bs, p.num_eliminate_blocks)
+    assert plan is not None and plan["n_cameras"] == n_cams and plan["accumulator_bytes"] == 72 * n_cams
+    staged, word = plan["staged_cam"], plan["slot_word"]
+    want = min(n_cams, (160 * 1024 - 1024 - 72 * n_cams) // 72)
+    assert len(staged) == want and len(set(staged.tolist())) == want
+    assert 72 * n_cams + 72 * want + 1024 <= 160 * 1024
+    valid = word >= 0
+    cam = word[valid] & ((1 << 20) - 1)
+    row = (word[valid].astype(np.int64) >> 20) & 0xFFF
+    deg = np.bincount(cam, minlength=n_cams)
+    # the staged cameras are a top-`want` set by number of observations, listed in non-increasing order
+    assert (np.diff(deg[staged]) <= 0).all()
+    if want < n_cams:
+        rest = np.setdiff1d(np.arange(n_cams), staged)
+        assert deg[staged].min() >= deg[rest].max()
+    # slot words: row + 1 of the slot's camera, or nothing
+    row_of = np.full(n_cams, -1)
+    row_of[staged] = np.arange(want)
+    assert np.array_equal(row, row_of[cam] + 1)
+    assert row.max() < 0xFFF    # all ones is the hybrid plan's "spilled"
+
+
+def test_no_staged_x_where_the_accumulators_do_not_fit(problems):
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=3000, num_points=9000, num_observations=40000, seed=3, skew=0.4, with_values=False)
+    plan = pkg.hip_solver.debug_staged_x_plan(p.bs, p.num_eliminate_blocks)
+    w = plan["slot_word"].view(np.uint32)
+    real = w != 0xFFFFFFFF    # (padding slots)
+    assert plan is not None and len(plan["staged_cam"]) == 0 and plan["accumulator_bytes"] > 160 * 1024 - 1024
+    assert ((w[real] >> 20) == 0xFFF).all()    # no hybrid plan was asked for: every slot is marked "spilled", none carries a staged-x row
