@@ -293,3 +293,32 @@ def test_rows_of_4_residuals_with_many_cameras_and_dense_schur(hip, oracle, prob
     x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
     s.close()
     assert summ.termination_type == hip.SUCCESS and rel(x, ref) <= 1e-9, (summ, rel(x, ref))
+
+
+# ---- round 5: the LDS copies of x (the popular cameras' part in the streaming kernels, all of it in back-substitution / the model-cost
+# pass) switch on from about a hundred tiles per workgroup; the shape tests above are far smaller — here every kind of shape once at 1.8 M
+# observations, so that those paths run for camera widths other than 9, with a shared strip, and for the shapes whose S.x runs on
+# bal_fused_kernel (point blocks 4 wide, rows 4 high)
+BIG_SHAPES = {"f10_quaternion_cameras": dict(camera_width=10), "f6_s8_libmv_like": dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
+              "f3": dict(camera_width=3), "e4_f9": dict(point_width=4, camera_width=9), "r4_e4_f4": dict(row_height=4, point_width=4, camera_width=4)}
+
+
+@pytest.mark.parametrize("name", list(BIG_SHAPES))
+def test_shapes_at_a_size_where_x_is_read_from_lds(hip, oracle, problems, name):
+    import os
+    oracle.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        kw = BIG_SHAPES[name]
+        p = problems.synthetic_structured(900, 420000, 1800000, seed=41, skew=0.7, **kw)
+        assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_BAL))
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, max_it=500)
+        assert s.info().camera_accum_in_lds == 1
+        radius = 1e4
+        step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1)   # back-substitution + model cost inside the step
+        diag = np.clip(oracle.Matrix(p.bs, 0).squared_column_norm(p.values), 1e-6, 1e32)
+        check_step(oracle, hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+        s.close()
+        if name == "f10_quaternion_cameras":
+            assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL))
+    finally:
+        oracle.set_num_threads(1)
