@@ -194,3 +194,41 @@ def test_power_series_expansion_against_dense(oracle, problems, with_D):
                                                   use_spse_initialization=init, max_num_spse_iterations=5, spse_tolerance=0.1)
         assert s.termination_type == 0, s
         assert np.linalg.norm(xs - ref) <= 1e-8 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("shape", [dict(camera_width=9), dict(camera_width=10), dict(camera_width=6, point_width=4)])
+def test_generators_of_leftover_rows_against_dense(oracle, problems, shape):
+    """The problem generators the round-5 GPU tests lean on, pinned on the CPU: camera-only rows appended to a structured problem
+    (problems.add_camera_rows) and the rows of a problem in another order (problems.permute_rows) are what they claim — the dense
+    matrix of the result is the dense matrix of the parts, stacked / permuted — and the oracle's operators on them equal dense algebra.
+    (Size-independent property: J'J, J'b and D do not depend on the order of the rows.)"""
+    w = shape["camera_width"]
+    base = problems.synthetic_structured(7, 60, 260, seed=3, skew=0.4, layout="cgnr", **shape)
+    base = type(base)(base.bs, base.values, base.b, base.D, 0)
+    q = problems.add_camera_rows(base, 9, seed=5, row_size=w, pair_fraction=0.4, camera_width=w)
+    q = problems.add_camera_rows(q, 4, seed=6, row_size=2, camera_width=w)
+    A0, A1 = base.bs.to_dense(base.values), q.bs.to_dense(q.values)
+    n0 = base.bs.num_rows
+    assert A1.shape == (n0 + 9 * w + 8, A0.shape[1]) and np.array_equal(A1[:n0], A0)
+    extra = A1[n0:]
+    pw = shape.get("point_width", 3)
+    point_cols = np.concatenate([np.arange(p, p + s) for p, s in zip(base.bs.col_block_pos, base.bs.col_block_size) if s == pw and pw != w] or [np.zeros(0, int)]).astype(int)
+    assert not extra[:, point_cols].any() and np.abs(extra).sum() > 0             # camera-only rows
+    np.testing.assert_allclose(q.D ** 2 * 1e4, np.clip((A1 * A1).sum(0), 1e-6, 1e32), rtol=1e-12)   # D follows LM's formula on the whole matrix
+    rng = np.random.default_rng(1)
+    order = np.argsort(np.concatenate([np.arange(base.bs.num_row_blocks, dtype=float), rng.uniform(-1, base.bs.num_row_blocks, 13)]), kind="stable")
+    p = problems.permute_rows(q, order)
+    A2 = p.bs.to_dense(p.values)
+    # same rows, another order: the row blocks of A2 are those of A1 in `order`
+    pos1 = q.bs.row_block_pos.astype(int); sz1 = q.bs.row_block_size.astype(int)
+    rows = np.concatenate([np.arange(pos1[r], pos1[r] + sz1[r]) for r in order])
+    assert np.array_equal(A2, A1[rows]) and np.array_equal(p.b, q.b[rows])
+    m = oracle.Matrix(p.bs, 0)
+    x = rng.standard_normal(A2.shape[1])
+    tol = dict(rtol=0, atol=1e-12 * np.abs(A2).max() ** 2 * A2.shape[0])
+    np.testing.assert_allclose(m.left_multiply(p.values, m.right_multiply(p.values, x)), A1.T @ (A1 @ x), **tol)
+    np.testing.assert_allclose(m.left_multiply(p.values, p.b), A1.T @ q.b, **tol)
+    np.testing.assert_allclose(m.squared_column_norm(p.values), (A1 * A1).sum(0), **tol)
+    xs, so = m.cgnr_solve(p.values, p.b, p.D, preconditioner=1, min_it=0, max_it=500, q_tol=-1.0, r_tol=1e-13)
+    want = np.linalg.solve(A1.T @ A1 + np.diag(q.D ** 2), A1.T @ q.b)
+    assert so.termination_type == 0 and np.linalg.norm(xs - want) <= 1e-9 * np.linalg.norm(want)
