@@ -144,3 +144,13 @@ def test_round5_default_line_fields():
     assert 1072463720 / (sx * 1e-9) / 8e12 >= 0.78        # the tile pass alone
     cg = json.loads(open(os.path.join(ROOT, "profiles", "r05_final_long_cg_30_iterations_venice.jsonl")).read())
     assert cg["cgnr_cg_ms"] / cg["cgnr_its"] < 0.30 and cg["schur_cg_ms"] / cg["schur_its"] < 0.205
+
+
+@pytest.mark.parametrize("solver,collectives", [("iterative_schur", 4), ("cgnr", 7)])
+def test_round5_two_rank_lines_at_the_headline_size(solver, collectives):
+    """`python bench.py --gpus 2` typed without a launcher (two ranks sharing one GPU: validation mode) on the Venice shape — shards large
+    enough for the LDS copies of x to be on — the assembled step against the oracle at full size."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", f"r05w_bench_self_launched_2ranks_venice_{solver}.json")).read())
+    assert d["n_gpus"] == 2 and d["config"]["collectives_per_step"] == collectives
+    oc = d["oracle_check"]
+    assert oc["ranks"] == 2 and oc["observations"] == 5001946 and oc["step_rel_diff_vs_oracle"] < 1e-9 and oc["cg_iterations_gpu"] == oc["cg_iterations_oracle"]
