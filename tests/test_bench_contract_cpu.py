@@ -14,7 +14,8 @@ LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + 
                                                           "r03zq_bench_default_iterative_schur.json", "r03p_bench_cgnr.json",
                                                           "r04a_bench_default_iterative_schur.json", "r04l_bench_default_iterative_schur.json",
                                                           "r04_final_bench_default_iterative_schur.json", "r05_final_bench_default_iterative_schur.json",
-                                                          "r05_final_bench_under_rocprof_iterative_schur.json", "r05_final_bench_under_rocprof_cgnr.json")])
+                                                          "r05_final_bench_under_rocprof_iterative_schur.json", "r05_final_bench_under_rocprof_cgnr.json",
+                                                          "r05x_bench_default_iterative_schur_second_box.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
