@@ -65,6 +65,8 @@ def _self_launch():
         print(f"bench.py: {visible} GPU(s) visible for --gpus {n}: the ranks share device 0 (one-GPU validation mode, timings meaningless)",
               file=sys.stderr, flush=True)
         env["CERES_HIP_BENCH_ONE_GPU"] = "1"
+    if env.get("CERES_HIP_BENCH_ONE_GPU", "0") == "1":   # ranks that share a device: few workgroups in the kernels that wait for their peers
+        env.setdefault("CERES_HIP_P2P_SHARED_DEVICE", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -228,6 +230,50 @@ def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta
     return time.perf_counter() - t0, iters, s
 
 
+def phase_timing(solver, ptrs, step_kind="lm_step", eta=0.1, radius=None):
+    """Per-phase HIP-event timings of ONE more step, outside every timed region: the events idle the device for about 6 us each
+    (ceres_hip_set_phase_timing), so the timed steps run without them."""
+    solver.set_phase_timing(True)
+    try:
+        timed_steps(solver, ptrs, 1, 0, torch.cuda.synchronize, step_kind, eta, radius)
+        return solver.last_timing()
+    finally:
+        solver.set_phase_timing(False)
+
+
+def shard_ceiling(pkg, hs, prob, solver_kind, device, t1_ms, k_iters, eta, worlds=(2, 4, 8), steps=20, warmup=3, radius=None, dev=None):
+    """What ONE rank of an N-rank strong-scaling run costs, measured on one GPU: rank 0's shard of `prob`
+    (partition.shard_by_point) through ceres_hip_lm_compute_step_device with the SHARDED code path on — every all-reduce of the step
+    runs the peer-to-peer kernel against ghost peers (ceres_hip_debug_comm_ghost_peers: all pushes, flags, waits and sums, local
+    memory instead of xGMI) — and CG pinned to the iteration count of the whole problem's step (min = max = k_iters: the shard alone is
+    another linear system).  efficiency_ceiling = T_1 / (N T_shard): what a perfect interconnect would give; xGMI latency is NOT in it."""
+    from ceres_solver_amd import partition
+    nelim = prob.num_eliminate_blocks
+    out = {"what": "rank 0's shard of the problem alone on the device, sharded code path on (peer-to-peer all-reduce kernel against ghost "
+                   "peers: local memory, no xGMI hop), CG iterations pinned to the whole problem's; efficiency_ceiling = T_1 / (N T_shard)",
+           "t1_ms": round(t1_ms, 4), "cg_iterations": int(k_iters), "cases": []}
+    typ, pre = (hs.CGNR, hs.JACOBI) if solver_kind == "cgnr" else (hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)
+    for n in worlds:
+        sh = partition.shard_by_point(prob.bs, nelim, n, 0)
+        f = sh.bs.col_block_size[sh.num_eliminate_blocks:].astype(np.int64)
+        o = hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=int(k_iters), max_num_iterations=int(k_iters),
+                                   residual_reset_period=10, elimination_groups=[sh.num_eliminate_blocks], device=device)
+        sv = hs.HipLinearSolver(o, ghost_world=n, p2p_max_elements=int((f * f).sum() + 2 * f.sum() + 2))
+        sv.set_structure(sh.bs)
+        tvs, tbs = (torch.from_numpy(a).to(dev) for a in (sh.local_values(prob.values), sh.local_rows(prob.b)))
+        txs = torch.empty(sh.bs.num_cols, dtype=torch.float64, device=dev)
+        el, its, last = timed_steps(sv, (tvs, tbs, None, txs), steps, warmup, torch.cuda.synchronize, "lm_step", eta, radius)
+        ms = 1e3 * el / steps
+        tm = phase_timing(sv, (tvs, tbs, None, txs), "lm_step", eta, radius)
+        out["cases"].append({"ranks": n, "shard_observations": int(sh.bs.num_row_blocks), "ms_per_step": round(ms, 4),
+                             "efficiency_ceiling": round(t1_ms / (n * ms), 4), "collectives_per_step": int(sv.info().collectives_last_step),
+                             "cg_iterations": int(its[-1]), "cg_ms": round(tm.cg_ms, 4), "setup_ms": round(tm.setup_ms + tm.preconditioner_ms, 4),
+                             "back_substitute_ms": round(tm.back_substitute_ms, 4)})
+        sv.close()
+        del tvs, tbs, txs
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -246,6 +292,7 @@ def main():
     one_gpu = os.environ.get("CERES_HIP_BENCH_ONE_GPU", "0") == "1" and world > 1
     if one_gpu:
         local_rank = 0
+        os.environ.setdefault("CERES_HIP_P2P_SHARED_DEVICE", "1")   # (read when a solver is created)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -340,8 +387,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timing = solver.last_timing()
     step_ok = bool(torch.isfinite(tx).all().item())
+    timing = phase_timing(solver, (tv, tb, tD, tx), args.step, args.eta)   # (one more step of the same kind, untimed, with the phase events on)
 
     # ---- dominant kernel against the HBM roofline (HIP events on the solver's stream) ----
     kind = "jtjx" if args.solver == "cgnr" else "sx"
@@ -427,6 +474,7 @@ def main():
         hv = torch.from_numpy(prob.values).pin_memory()
         hb = torch.from_numpy(prob.b).pin_memory()
         nh = args.host_boundary_steps
+        solver.set_phase_timing(True)   # upload_ms / download_ms below come from the phase events (6 us each: nothing against the PCIe copies)
         solver.lm_compute_step(hv.numpy(), hb.numpy(), RADIUS, 0.1)
         per_step = []
         for _ in range(nh):
@@ -444,6 +492,7 @@ def main():
             solver.lm_compute_step(None, None, RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True, out=h_step.numpy())
             retry.append(time.perf_counter() - t0)
         tr_ = solver.last_timing()
+        solver.set_phase_timing(False)
         dev_retry_ms = None
         if nh > 1:   # the same retry with J and f resident (the device evaluator's case)
             tx_retry = torch.empty_like(tx)   # (its own step vector: tx keeps the step of the last TIMED solve for the parity figures below)
@@ -520,7 +569,7 @@ def main():
                                       "(values and residuals from the device evaluator at the start point), inputs resident in HBM"}
                 for eta_s in (0.1, 0.01):
                     es, its, _ = timed_steps(solver, (tvs, tbs, None, txs), args.scene_step_steps, 2, sync, "lm_step", eta_s)
-                    tms = solver.last_timing()
+                    tms = phase_timing(solver, (tvs, tbs, None, txs), "lm_step", eta_s)
                     k_it = int(its[-1])
                     mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
                     scene_step[f"eta_{eta_s}"] = {
@@ -552,7 +601,7 @@ def main():
                                            "inputs resident in HBM, radius 1e4"}
                     for eta_c in (1e-2, 1e-3, 1e-4):
                         es, its, last_c = timed_steps(s2c, (tv2, tb2, None, tx2c), args.conditioned_steps, 1, sync, "lm_step", eta_c)
-                        tms = s2c.last_timing()
+                        tms = phase_timing(s2c, (tv2, tb2, None, tx2c), "lm_step", eta_c)
                         k_it = int(its[-1])
                         mb = step_min_bytes(args.solver, n_obs, n_points, n_cams, k_it)
                         conditioned[f"eta_{eta_c:g}"] = {
@@ -674,6 +723,7 @@ def main():
                     nb_ = lb_o * slot_b + (lb_p * pw_ * pw_ * 8 + n_fs * 32 if kd == "sx" else (pw_ * lb_p + n_fs) * 32)
                     case[kd] = {"ms": round(ms_, 5), "frac": round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                     if sv == "iterative_schur":
+                        so_.set_phase_timing(True)
                         step_, summ_, mcc_ = so_.lm_compute_step(sp.values, sp.b, RADIUS, args.eta)
                         case["lm_step"] = {"cg_iterations": summ_.num_iterations, "ms_device": round(so_.last_timing().total_ms - so_.last_timing().upload_ms - so_.last_timing().download_ms, 4)}
                         if oracle_s is not None:

@@ -15,6 +15,28 @@ constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 constexpr int kVecBlock = 256;
 constexpr int kMaxVecGrid = 512;             // partial sums per inner product
 
+// ---- one-shot peer-to-peer exchange (p2p.h: the device side; kernels_cg.hip: the stand-alone all-reduce) ----
+constexpr int kP2pMaxWorld = 8;    // one node: 8 GPUs on the xGMI mesh
+constexpr int kP2pChunk = 512;     // slot capacity is rounded up to a multiple of this
+constexpr int kP2pFlagChunk = 8;   // arrival flags per (parity, rank): cap / 8 — a chunk of p2p_exchange_wave is at most one wavefront of slots,
+                                   // and may be as few as the 8 packed sums of a 2-wide camera block (bal_invert_exchange_kernel: a chunk per camera)
+constexpr int kP2pMaxGrid = 256;   // workgroups of one all-reduce (each takes every kP2pMaxGrid-th chunk): never the whole device spinning
+struct P2pPeers {
+  double* slots[kP2pMaxWorld];               // rank q's receive slots [2][world][cap], as mapped into THIS process
+  unsigned long long* flags[kP2pMaxWorld];   // rank q's arrival flags [2][world][chunks_cap]
+};
+struct P2pComm {   // what a kernel needs of the communicator (by value)
+  P2pPeers peers;
+  int rank = 0, world = 1;
+  unsigned long long epoch = 0;
+  long long cap = 0;          // doubles per slot
+  int chunks_cap = 0;         // flags per (parity, source rank)
+  int* error_flag = nullptr;  // mapped host memory
+  int* error_seen = nullptr;  // device memory
+  long long timeout_ticks = 0;
+  int fences = 0;             // 1: system-scope release / acquire fences around the flags as well (p2p.h)
+};
+
 // ---- fused <2,3,9> kernels (kernels_bal.hip) ------------------------------
 enum BalMode { kBalSx = 0, kBalJtJx = 1, kBalJtb = 2, kBalInit = 3, kBalEte = 4, kBalBackSub = 5, kBalCgnrInit = 6, kBalColNorm = 7, kBalJx = 8, kBalSpseZ = 9,
                kBalShBlocks = 10 /* the strip's own diagonal block sums, per workgroup into BalArgs::scalar_out (shapes with a shared strip) */ };
@@ -200,19 +222,29 @@ struct BalOps {
   hipError_t (*reduce_partials)(const double* partials, int nparts, int n_acc, const FMap& map, const double* D_f, const double* x_f,
                                 double* y_f, const int* status, double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in,
                                 int n_sum_in, double* sum_out);
+  // the same for a SHARDED instance with the sum over ranks inside (p2p.h; one launch instead of reduction, all-reduce kernel and
+  // add_f_diagonal): y_f = sum over ranks (sum over the workgroups' partials) + D_f^2 x_f over the n_fv F-space positions; *sum_out
+  // (position n_fv) likewise summed over ranks.  Cameras back to back in F space only (map.cam_pos == nullptr).
+  hipError_t (*reduce_exchange)(const double* partials, int nparts, int n_acc, int n_fv, const FMap& map, const double* D_f, const double* x_f,
+                                double* y_f, const int* status, double* pq_out, int* n_pq, hipStream_t stream, const double* sum_in,
+                                int n_sum_in, double* sum_out, const P2pComm& comm, int grid_cap);
   hipError_t (*stream_probe)(const double2* J, int64_t n_tiles, int grid, double* out, hipStream_t stream);
   hipError_t (*add_f_diagonal)(int n_acc, const FMap& map, const double* D_f, const double* x_f, double* y_f, const int* status,
                                double* pq_out, int* n_pq, hipStream_t stream);
   hipError_t (*pack)(const BalArgs& A, hipStream_t stream);   // A.src_values / src_b / slot_* / J_out (Jf_out) / b_out set
   hipError_t (*invert)(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm, const CamGather& gather,
                        hipStream_t stream);
+  // sharded: invert in gathering mode with the sum over ranks inside (p2p.h): slots kCamPart c + e, chunks ceil(kCamPart / 64) c + q
+  hipError_t (*invert_exchange)(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm, const CamGather& gather,
+                                const P2pComm& comm, int grid_cap, hipStream_t stream);
   // Per-camera blocks in two steps: every item (<= kCamChunk observations of one camera) leaves its upper-triangle sums + nf column
   // square sums in parts[item][cam_part]; the items of a camera (cam_item_ptr) are then added in list order either by camera_finish
   // (raw sums to memory, + D_f^2 if given) or by the load phase of invert (CamGather).
   hipError_t (*camera_items)(bool schur, const double* values, const CamItems& items, const int32_t* cam_fpos, const int32_t* cam_slot,
                              const double* Mo, double* parts, hipStream_t stream);
   hipError_t (*camera_finish)(const double* parts, const int32_t* cam_item_ptr, const double* D_f, const int32_t* cam_pos, int cam_base,
-                              const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream, const double* extra);
+                              const int64_t* cam_diag_off, double* blocks, double* camsq, int n_cameras, hipStream_t stream, const double* extra,
+                              bool few /* every camera has a handful of items at most: kPerWave cameras per wavefront */);
   hipError_t (*camera_chunk)(const ZUnits& units, const double* ring, double* acc, const int* status, hipStream_t stream);
   // shapes with a shared strip: the packed upper triangle of the strip's ns x ns matrix from the workgroups' partial sums (kBalShBlocks),
   // cut into the shared blocks' dense diagonal blocks (+ D^2) in the F-block store
@@ -479,19 +511,15 @@ hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipSt
 
 // out[0] = (*flag != 0), out[1] = sum of parts[0 .. n) (one workgroup, fixed order)
 hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t stream);
+// ... summed over ranks in the same launch (p2p.h)
+hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t stream);
 
 // ---- one-shot peer-to-peer all-reduce (kernels_cg.hip) ----
-constexpr int kP2pMaxWorld = 8;   // one node: 8 GPUs on the xGMI mesh
-constexpr int kP2pChunk = 2048;   // doubles per workgroup and round
-constexpr int kP2pMaxGrid = 256;  // workgroups of one all-reduce (each takes every kP2pMaxGrid-th chunk): never the whole device spinning
-struct P2pPeers {
-  double* slots[kP2pMaxWorld];               // rank q's receive slots [2][world][cap], as mapped into THIS process
-  unsigned long long* flags[kP2pMaxWorld];   // rank q's arrival flags [2][world][chunks_cap]
-};
-// out = sum over ranks of in (n <= cap; in may alias out).  `epoch` counts this communicator's all-reduces from 1.
-hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
-                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag /* mapped host memory */,
-                              int* error_seen /* device memory */, double timeout_seconds, hipStream_t stream);
+// out = sum over ranks of in (n <= cap; in may alias out); comm.epoch counts this communicator's exchanges from 1 (solver.hip: next_exchange).
+hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pComm& comm, int grid_cap, hipStream_t stream);
+
+// host_dst[0 .. n) = src[0 .. n), then *host_stamp = stamp (both in mapped host memory): the solver's read-back "mailbox"
+hipError_t LaunchMailbox(const double* src, int n, double* host_dst, unsigned long long* host_stamp, unsigned long long stamp, hipStream_t stream);
 
 // ---- f4: BAL evaluator (kernels_evaluator.hip) ----
 struct BalEvalArgs {

@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "device.h"
+#include "p2p.h"
 
 namespace chip {
 
@@ -812,6 +813,24 @@ __global__ __launch_bounds__(kVecBlock) void collect_scalars_kernel(const int* f
   if (threadIdx.x == 0) { out[0] = (*flag != 0) ? 1.0 : 0.0; out[1] = v; }
 }
 }  // namespace
+namespace {
+// The same with the sum over ranks inside (p2p.h): out = sum over ranks of {flag != 0, sum(parts)}.
+__global__ __launch_bounds__(kVecBlock) void collect_scalars_exchange_kernel(const int* flag, const double* parts, int n, double* out, P2pComm C) {
+  __shared__ double sh[4];
+  double v = 0;
+  for (int k = threadIdx.x; k < n; k += kVecBlock) v += parts[k];
+  v = block_sum(v, sh);
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const double mine = lane == 0 ? ((*flag != 0) ? 1.0 : 0.0) : v;
+  const double t = p2p_exchange_wave(C, 0, lane, lane < 2, mine);
+  if (lane < 2) out[lane] = t;
+}
+}  // namespace
+hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t s) {
+  hipLaunchKernelGGL(collect_scalars_exchange_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out, comm);
+  return hipGetLastError();
+}
 hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(collect_scalars_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out);
   return hipGetLastError();
@@ -819,102 +838,56 @@ hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, dou
 }  // namespace chip
 
 // ---- one-shot peer-to-peer all-reduce (the <= few-MB camera-space sums of a sharded solve) ----
-// RCCL's small-message all-reduce costs tens of microseconds; the vectors summed here (9 or 81 doubles per camera)
-// are latency-bound, and a step issues several.  Every rank owns one fine-grained buffer mapped by all peers
-// (hipIpc handles exchanged by the host once): receive slots [parity][source rank][capacity] and arrival
-// flags [parity][source rank][chunk].  One kernel, one workgroup per 2048-element chunk, no grid barrier:
-//   push   : the chunk of `in` is written into the slot [epoch & 1][my rank] of EVERY rank (its own included),
-//            system-scope release, then the chunk's flag at every rank is set to `epoch`;
-//   wait   : lane q of the workgroup spins (system-scope acquire loads, s_sleep, wall-clock timeout) on the flag
-//            that source rank q sets in MY buffer;
-//   reduce : out = sum over source ranks in rank order of MY slots — every rank adds the same numbers in the same
-//            order, so all ranks end with identical bits (ITERATIVE_SCHUR's replicated CG state relies on it).
-// Slots are double-buffered by epoch parity: a writer reaching epoch e + 2 has completed epoch e + 1, which needed
-// every peer's epoch e + 1 flag, which a peer sets only after its epoch e kernel (the reader of the slot) finished.
+// RCCL's small-message all-reduce costs tens of microseconds; the vectors summed here (9 or 81 doubles per camera) are latency-bound,
+// and a step issues several.  The protocol is p2p.h's (round 6): a chunk = 64 consecutive elements = one wavefront, slot index =
+// element index, flag index = chunk index — the SAME numbering the producers' own exchanges use for a vector (bal_reduce_exchange_kernel),
+// so a rank that has to take this stand-alone kernel for a sum (rows outside its tiles, a layout its fused kernels do not take) and a
+// rank that exchanges inside its reduction still meet in the same slots.  A wavefront takes K chunks per round trip (K = 8 for long
+// vectors: the step's merged sum is 99 doubles per camera), a workgroup four wavefronts, every kP2pMaxGrid-th group of them.
 namespace chip {
 namespace {
-__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n,
-                                                            P2pPeers P, int rank, int world, unsigned long long epoch,
-                                                            int64_t cap, int chunks_cap, int* error_flag, int* error_seen, long long timeout_ticks) {
-  __shared__ int timed_out;
-  // a communicator that has timed out once stays broken: later all-reduces poison their output at once instead of waiting the
-  // timeout again (error_seen: device memory, a cheap load; error_flag: mapped host memory for the host)
-  if (threadIdx.x == 0) timed_out = __hip_atomic_load(error_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const int parity = int(epoch & 1ull);
-  constexpr int kPer = kP2pChunk / 256;
-  const int n_chunks = int((n + kP2pChunk - 1) / kP2pChunk);
-  // A workgroup takes every gridDim.x-th chunk, in the same order on every rank (the grid is a function of n alone): a long vector
-  // — the step's merged sum is 99 doubles per camera — must not fill the GPU with spinning workgroups.  Ranks that SHARE a device
-  // (the one-GPU validation runs) would otherwise starve each other's kernels, whose data the spinners are waiting for.
-  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const int64_t lo = int64_t(c) * kP2pChunk;
-    if (timed_out) {   // an earlier chunk of this workgroup timed out
+template <int K>
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n, P2pComm C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t n_rounds = (n + 64 * K - 1) / (64 * K);
+  for (int64_t r = int64_t(blockIdx.x) * 4 + wv; r < n_rounds; r += int64_t(gridDim.x) * 4) {
+    const int64_t i0 = r * 64 * K;
+    double v[K];
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int64_t i = lo + threadIdx.x + 256 * k;
-        if (i < n) out[i] = __builtin_nan("");
-      }
-      continue;
-    }
-    double v[kPer];
+    for (int k = 0; k < K; ++k) { const int64_t i = i0 + 64 * k + lane; v[k] = i < n ? in[i] : 0.0; }
+    p2p_exchange_wave_multi<K>(C, int(r * K), i0, n, v);
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int64_t i = lo + threadIdx.x + 256 * k;
-      v[k] = i < n ? in[i] : 0.0;
-    }
-    for (int q = 0; q < world; ++q) {
-      double* dst = P.slots[q] + (int64_t(parity) * world + rank) * cap;
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int64_t i = lo + threadIdx.x + 256 * k;
-        if (i < n) dst[i] = v[k];
-      }
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (int(threadIdx.x) < world) {
-      const int q = threadIdx.x;
-      __hip_atomic_store(P.flags[q] + (int64_t(parity) * world + rank) * chunks_cap + c, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned long long* f = P.flags[rank] + (int64_t(parity) * world + q) * chunks_cap + c;
-      const long long t0 = wall_clock64();
-      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-        if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: do not hang the GPU
-          __hip_atomic_store(error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // mapped host memory: the host reads it after its next synchronisation
-          __hip_atomic_store(error_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          timed_out = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    __syncthreads();
-    __threadfence_system();
-    const double* mine = P.slots[rank] + int64_t(parity) * world * cap;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int64_t i = lo + threadIdx.x + 256 * k;
-      if (i < n) {
-        double s = 0.0;
-        for (int q = 0; q < world; ++q) s += mine[q * cap + i];
-        // an incomplete sum must not be consumed: NaN flows into the CG scalars, whose tests then end the solve (rho / alpha not finite), and
-        // the host reports CERES_HIP_E_COMM at its next poll
-        out[i] = timed_out ? __builtin_nan("") : s;
-      }
-    }
-    __syncthreads();   // `timed_out` is read above and may be written in the next round
+    for (int k = 0; k < K; ++k) { const int64_t i = i0 + 64 * k + lane; if (i < n) out[i] = v[k]; }
   }
 }
 }  // namespace
 
-hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pPeers& peers, int rank, int world,
-                              unsigned long long epoch, int64_t cap, int chunks_cap, int* error_flag, int* error_seen, double timeout_seconds,
-                              hipStream_t stream) {
+hipError_t LaunchP2pAllReduce(const double* in, double* out, int64_t n, const P2pComm& comm, int grid_cap, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  const int grid = int(std::min<int64_t>((n + kP2pChunk - 1) / kP2pChunk, kP2pMaxGrid));
-  const long long ticks = (long long)(timeout_seconds * 1e8);  // wall_clock64 counts at 100 MHz
-  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(grid), dim3(256), 0, stream, in, out, n, peers, rank, world, epoch, cap, chunks_cap,
-                     error_flag, error_seen, ticks);
+  const int cap = std::max(1, std::min(kP2pMaxGrid, grid_cap));
+  if (n > 64 * 1024) {
+    const int64_t rounds = (n + 64 * 8 - 1) / (64 * 8);
+    hipLaunchKernelGGL((p2p_allreduce_kernel<8>), dim3(int(std::min<int64_t>((rounds + 3) / 4, cap))), dim3(256), 0, stream, in, out, n, comm);
+  } else {
+    const int64_t rounds = (n + 63) / 64;
+    hipLaunchKernelGGL((p2p_allreduce_kernel<1>), dim3(int(std::min<int64_t>((rounds + 3) / 4, cap))), dim3(256), 0, stream, in, out, n, comm);
+  }
+  return hipGetLastError();
+}
+
+// Read-back without a copy command and without hipStreamSynchronize: the image goes to MAPPED host memory by plain stores, followed by a
+// stamp (system-scope release) the host spins on — see wait_mailbox, solver.hip.
+namespace {
+__global__ __launch_bounds__(256) void mailbox_kernel(const double* __restrict__ src, int n, double* __restrict__ host_dst,
+                                                      unsigned long long* host_stamp, unsigned long long stamp) {
+  for (int i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_stamp, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+hipError_t LaunchMailbox(const double* src, int n, double* host_dst, unsigned long long* host_stamp, unsigned long long stamp, hipStream_t stream) {
+  hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(256), 0, stream, src, n, host_dst, host_stamp, stamp);
   return hipGetLastError();
 }
 }  // namespace chip

@@ -30,8 +30,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// read-back image: 2 kMaxVecGrid partial sums, one double holding the two int flags, one spare, then the CG scalars
-constexpr int kScalarsOffset = 2 * kMaxVecGrid + 2;
+// read-back image: 2 kMaxVecGrid partial sums, one double holding the two int flags, one spare, two sums over ranks, then the CG scalars
+constexpr int kSumsOffset = 2 * kMaxVecGrid + 2;      // sharded speculative tail: {finite-step flag, model cost} summed over ranks
+constexpr int kScalarsOffset = 2 * kMaxVecGrid + 4;
 constexpr int kReadbackDoubles = kScalarsOffset + int((sizeof(CgScalars) + sizeof(double) - 1) / sizeof(double));
 
 struct Buf {  // device allocation owned by a solver
@@ -177,6 +178,15 @@ struct ceres_hip_solver {
   // status word brings the LM step's partial sums and flags along in the same copy (two copies per poll before: 4.7 us each)
   double* h_pinned = nullptr;
   CgScalars* h_scalars = nullptr;  // = h_pinned + kScalarsOffset
+  // The read-back "mailbox": h_pinned is MAPPED host memory; a one-workgroup kernel stores the image there and then a stamp, and the
+  // host spins on the stamp (wait_mailbox) — no copy command, no hipStreamSynchronize and its wake-up latency between the device
+  // finishing a step and the host knowing it.  CERES_HIP_MAILBOX=0: hipMemcpyAsync + hipStreamSynchronize as before (A/B).
+  double* d_h_pinned = nullptr;                 // device view of h_pinned
+  unsigned long long* h_stamp = nullptr;        // = h_pinned + kReadbackDoubles (host view), d_stamp its device view
+  unsigned long long* d_stamp = nullptr;
+  unsigned long long mailbox_seq = 0;
+  bool final_sync_skippable = [] { const char* e = getenv("CERES_HIP_FINAL_SYNC"); return e && atoi(e) == 0; }();   // (A/B: default keeps the synchronisation)
+  bool mailbox = [] { const char* e = getenv("CERES_HIP_MAILBOX"); return !e || atoi(e) != 0; }();
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
   // comm: RCCL communicator and / or the one-shot peer-to-peer all-reduce over hipIpc-mapped buffers
   ncclComm_t comm = nullptr;
@@ -194,8 +204,20 @@ struct ceres_hip_solver {
   int* h_comm_error = nullptr;      // mapped pinned host memory
   int* d_comm_error_seen = nullptr; // device memory: set with it, so that later all-reduces do not wait the timeout again
   double p2p_timeout_s = 10.0;
+  // Round 6: the sums over ranks happen INSIDE the kernels that produce them (p2p.h: the camera-space reduction of every tile pass, the
+  // per-camera blocks, the step's final scalars) instead of in all-reduce launches behind them.  CERES_HIP_P2P_FUSE=0: the stand-alone
+  // all-reduce everywhere (A/B).  CERES_HIP_P2P_SHARED_DEVICE=1: the ranks share ONE device (validation runs): kernels that wait for
+  // their peers are launched with few workgroups, so that all ranks' waiting workgroups fit on the device beside each other.
+  bool spec_agreed = false;           // sharded ITERATIVE_SCHUR: every rank can run the LM step's tail speculatively (agreed likewise)
+  bool cam_exchange_agreed = false;   // every rank's camera-major pass exchanges its blocks itself (agreed at the end of set_structure)
+  bool p2p_fences = [] { const char* e = getenv("CERES_HIP_P2P_FENCES"); return e && atoi(e) != 0; }();   // p2p.h: system-scope fences on top (A/B, fall-back)
+  bool p2p_fuse = [] { const char* e = getenv("CERES_HIP_P2P_FUSE"); return !e || atoi(e) != 0; }();
+  int p2p_grid_cap = [] { const char* e = getenv("CERES_HIP_P2P_SHARED_DEVICE"); return (e && atoi(e) != 0) ? 32 : (1 << 20); }();
   bool p2p_fine_grained = false;   // the receive buffer is a fine-grained allocation (false: the runtime could only export a coarse-grained one)
   ceres_hip_solve_timing timing{};
+  // per-phase HIP events of a solve (ceres_hip_get_last_timing): off unless asked for, see rec()
+  bool timing_enabled = [] { const char* e = getenv("CERES_HIP_TIMING"); return e && atoi(e) != 0; }();
+  std::chrono::steady_clock::time_point call_t0{};
 };
 
 namespace {
@@ -251,24 +273,53 @@ void free_all(ceres_hip_solver* s) {
   s->device_bytes = 0;
 }
 
+// The communicator as a kernel argument, for the NEXT epoch: one call per exchange, on every rank in the same order.
+P2pComm next_exchange(ceres_hip_solver* s) {
+  ++s->collectives;
+  P2pComm C;
+  C.peers = s->p2p_peers; C.rank = s->rank; C.world = s->world; C.epoch = ++s->p2p_epoch; C.cap = s->p2p_cap; C.chunks_cap = s->p2p_chunks_cap;
+  C.fences = s->p2p_fences ? 1 : 0;
+  C.error_flag = s->d_comm_error; C.error_seen = s->d_comm_error_seen; C.timeout_ticks = (long long)(s->p2p_timeout_s * 1e8);  // wall_clock64: 100 MHz
+  return C;
+}
 // Sum over ranks, in place, on the solver's stream.  Messages that fit the peer-to-peer slots (everything a solve
 // sums: 9 or 81 doubles per camera) go through the one-shot kernel; longer ones are cut into slot-sized pieces, or
 // go to RCCL when a communicator exists.
 int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
   if (s->world <= 1 || n == 0) return 0;
-  ++s->collectives;
   if (s->p2p && (int64_t(n) <= s->p2p_cap || !s->comm)) {
     for (size_t off = 0; off < n; off += size_t(s->p2p_cap)) {
       const int64_t len = int64_t(std::min<size_t>(size_t(s->p2p_cap), n - off));
-      HIP_TRY(s, LaunchP2pAllReduce(dev + off, dev + off, len, s->p2p_peers, s->rank, s->world, ++s->p2p_epoch, s->p2p_cap,
-                                    s->p2p_chunks_cap, s->d_comm_error, s->d_comm_error_seen, s->p2p_timeout_s, s->stream));
+      HIP_TRY(s, LaunchP2pAllReduce(dev + off, dev + off, len, next_exchange(s), s->p2p_grid_cap, s->stream));
     }
     return 0;
   }
+  ++s->collectives;
   if (!s->comm) return fail(s, CERES_HIP_E_COMM, "world_size > 1 but no communicator is connected");
   NCCL_TRY(s, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, s->comm, s->stream));
   return 0;
 }
+
+// Sharded instance on the fused path whose producers can exchange `slots` doubles in `chunks` wave-sized chunks themselves?
+bool exchange_in_producer(const ceres_hip_solver* s, int64_t slots, int64_t chunks) {
+  return s->world > 1 && s->p2p && s->p2p_fuse && s->path == CERES_HIP_PATH_BAL && slots <= s->p2p_cap && chunks <= s->p2p_chunks_cap;
+}
+// ... the camera-space reduction of a tile pass: a LOCAL choice — the kernel speaks the protocol of the stand-alone all-reduce of the
+// F-space vector, so a rank that cannot take it (rows outside its tiles join the raw sums first; cameras scattered over F space) meets
+// the others in the same slots
+bool reduction_exchanges(const ceres_hip_solver* s) {
+  if (s->path != CERES_HIP_PATH_BAL) return false;
+  const int64_t nfv = s->hs.num_cols_f;
+  return exchange_in_producer(s, nfv + 1, (nfv + 64) / 64) && s->plan.n_rem_rows == 0 && s->plan.cameras_contiguous;
+}
+// ... the camera-major pass (cam_part packed sums per camera): its exchange has a numbering of its own (a chunk per camera), so ALL
+// ranks must take it or none: camera_blocks_exchange_local is this rank's view, the ranks agree at the end of set_structure
+bool camera_blocks_exchange_local(const ceres_hip_solver* s) {
+  if (s->path != CERES_HIP_PATH_BAL || s->plan.ns != 0) return false;
+  const int64_t per = s->ops->cam_part;
+  return exchange_in_producer(s, per * s->plan.n_cameras, ((per + 63) / 64) * s->plan.n_cameras);
+}
+bool camera_blocks_exchange(const ceres_hip_solver* s) { return s->cam_exchange_agreed && s->p2p; }
 
 // Kernels that read the caller-layout value array (the generic operators, also where the fused path borrows them) cannot serve a
 // Jacobian that exists only as tiles.
@@ -494,15 +545,18 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
   // cg_pq_parts holds kMaxPqParts partial sums: the tile pass's (one per workgroup) + the reduction's (<= kMaxVecGrid).  A grid that
   // would not fit leaves p.q to the caller (run_cg then takes one pass over p and q) instead of writing past the buffer.
   if (pq && (s->lds_mode ? s->fused_grid : s->chunk_grid) + kMaxVecGrid > kMaxPqParts) { pq = nullptr; if (n_pq) *n_pq = 0; }
+  // sharded with the exchange inside the reduction: that kernel reads the tile pass's partials while its workgroups write the camera
+  // part's — the tile pass's go behind them (cg_pq_parts holds kMaxPqParts, checked above)
+  double* const pq_tiles = (pq && s->world > 1 && !defer_allreduce && reduction_exchanges(s)) ? pq + kMaxVecGrid : pq;
   if (s->lds_mode) {
-    if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->fused_grid; }
+    if (pq && mode == kBalJtJx) { A.pq_out = pq_tiles; n_first = s->fused_grid; }
     HIP_TRY(s, s->ops->fused(mode, A, true, s->fused_grid, s->stream));
   } else {
     // cameras do not fit in LDS: the tile pass sums what it can in LDS (hybrid plan) and leaves the other slots' F^T z, and at its
     // end its accumulator rows, in a ring; the camera-major pass adds the ring rows into the camera sums.  (Chunk by chunk when the
     // ring is bounded, CERES_HIP_Z_CHUNK_MIB.)
     const BalPlan& P = s->plan;
-    if (pq && mode == kBalJtJx) { A.pq_out = pq; n_first = s->chunk_grid; }
+    if (pq && mode == kBalJtJx) { A.pq_out = pq_tiles; n_first = s->chunk_grid; }
     HIP_TRY(s, hipMemsetAsync(s->d_global_acc, 0, size_t(n9) * sizeof(double), s->stream));
     if (P.ns > 0) A.strip_sums = s->d_global_acc + size_t(P.nf) * P.n_cameras;
     const int n_chunks = int(P.zc_tile_ptr.size()) - 1;
@@ -527,6 +581,14 @@ int bal_scatter(ceres_hip_solver* s, int mode, BalArgs& A, const double* x_f, do
     HIP_TRY(s, s->ops->add_f_diagonal(n9, map, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream));
   } else if (s->world <= 1) {
     HIP_TRY(s, s->ops->reduce_partials(parts, nparts, n9, map, D_f, x_f, y_f, status, pq ? pq + n_first : nullptr, &n_second, s->stream, nullptr, 0, nullptr));
+  } else if (!defer_allreduce && reduction_exchanges(s)) {
+    // the reduction sums over ranks itself (p2p.h), adds D_f^2 x_f and leaves the camera part of x . y: one launch
+    const bool pack = pq && pq_extra && n_first > 0;  // CGNR's p.q: the shard's share rides along as slot n9 of the exchange
+    HIP_TRY(s, s->ops->reduce_exchange(parts, nparts, n9, nfv, map, D_f, x_f, y_f, status, pq, &n_second, s->stream,
+                                       pack ? pq + kMaxVecGrid : nullptr, n_first, pack ? y_f + nfv : nullptr, next_exchange(s), s->p2p_grid_cap));
+    if (pack) *pq_extra = y_f + nfv;
+    else if (n_first > 0) { pq = nullptr; n_second = 0; }   // the shard's point part without the packing: no complete p.q from here
+    n_first = 0;   // (the tile pass's partials — behind the reduction's in pq, see below — are consumed: the camera part sits at pq[0 ..))
   } else {
     const bool pack = pq && pq_extra && n_first > 0;  // CGNR's p.q: the shard's share rides along as element n9 of the all-reduce
     HIP_TRY(s, s->ops->reduce_partials(parts, nparts, n9, map, nullptr, nullptr, y_f, status, nullptr, nullptr, s->stream,
@@ -784,7 +846,18 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       const bool fuse = s->lm_fuse_active && invert;
       HIP_TRY(s, s->ops->camera_items(schur, s->values, s->cam_items, s->d_cam_fpos, s->d_cam_slot, s->d_Mo, s->d_cam_parts, st));
       TRY(ensure_rem_blocks(s));  // rows without a point cell add their F^T F to the diagonal cells (NoEBlockRowsUpdate) and to the column norms
-      if (s->world <= 1 && invert) {
+      if (s->world > 1 && invert && camera_blocks_exchange(s) && !s->rhs_reduce_pending) {
+        // sharded: the inversion kernel adds up this rank's items, sums the packed blocks (and column norms) over ranks (p2p.h), adds
+        // D_f^2 — or forms the fused LM diagonal from the summed norms — and inverts: one launch, one exchange
+        CamGather g;
+        g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.want_sq = (fuse && schur) ? 1 : 0;
+        g.extra = rem_extra_blocks(s);
+        g.D_f = fuse ? nullptr : D_f;
+        g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
+        g.cam_base = s->plan.cam_base;
+        HIP_TRY(s, s->ops->invert_exchange(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g,
+                                           next_exchange(s), s->p2p_grid_cap, st));
+      } else if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
         CamGather g;
         g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.few = s->cam_items_few ? 1 : 0; g.want_sq = (fuse && schur) ? 1 : 0;
@@ -798,7 +871,7 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
         // raw sums in memory first (no diagonal when sharded: the ranks' sums are added up, then D_f^2 joins once)
         HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, (s->world > 1 || fuse) ? nullptr : D_f,
                                          s->plan.cameras_contiguous ? nullptr : s->d_cam_pos, s->plan.cam_base, cam_f_offsets(s), out,
-                                         (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s)));
+                                         (fuse && schur) ? s->d_camsq : nullptr, s->plan.n_cameras, st, rem_extra_blocks(s), s->cam_items_few));
         if (s->world > 1) TRY(shared_preconditioner_blocks(s, schur, out, false, false));   // this rank's raw sums join the all-reduce of the block store
         if (s->world > 1) {
           const size_t n9c = size_t(h.num_cols_f);   // rhs / column norms: every camera-side scalar (the cameras' and a shared strip's)
@@ -908,10 +981,20 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
     TRY(shared_preconditioner_blocks(s, false, blocks, true));
     return 0;
   }
+  if (!merge && camera_blocks_exchange(s)) {   // sharded, the sums over ranks inside the inversion kernel (see op_preconditioner)
+    CamGather g;
+    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.cam_pos = cam_pos;
+    g.cam_base = s->plan.cam_base;
+    g.extra = rem_extra_blocks(s);
+    g.D_f = s->lm_fuse_active ? nullptr : D_f;
+    HIP_TRY(s, s->ops->invert_exchange(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g,
+                                       next_exchange(s), s->p2p_grid_cap, st));
+    return 0;
+  }
   // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
   // behind the point blocks in the Schur-ordered layout a sharded run requires)
   HIP_TRY(s, s->ops->camera_finish(s->d_cam_parts, s->d_cam_item_ptr, nullptr, cam_pos, s->plan.cam_base, s->d_cam_diag_off, blocks, nullptr,
-                                   s->plan.n_cameras, st, rem_extra_blocks(s)));
+                                   s->plan.n_cameras, st, rem_extra_blocks(s), s->cam_items_few));
   TRY(shared_preconditioner_blocks(s, false, blocks, false, false));   // this rank's raw H^T H joins the all-reduce
   const int64_t first = h.diag_off_all[h.nelim];
   if (merge) {
@@ -1113,11 +1196,35 @@ int check_comm_error(ceres_hip_solver* s) {  // after a stream synchronisation
   return 0;
 }
 
-int poll_scalars(ceres_hip_solver* s) {
-  HIP_TRY(s, hipMemcpyAsync(s->h_pinned, s->scalar_partials, sizeof(double) * kReadbackDoubles, hipMemcpyDeviceToHost, s->stream));
+// Host side of the mailbox: spin on the stamp; every few thousand looks ask the runtime whether the stream has drained (a faulted
+// kernel never stamps).
+int wait_mailbox(ceres_hip_solver* s, unsigned long long seq) {
+  for (unsigned spin = 1;; ++spin) {
+    if (__atomic_load_n(s->h_stamp, __ATOMIC_ACQUIRE) == seq) break;
+    if ((spin & 4095u) == 0) {
+      const hipError_t q = hipStreamQuery(s->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(s->h_stamp, __ATOMIC_ACQUIRE) == seq) break;
+        return fail(s, CERES_HIP_E_HIP, "read-back kernel finished without stamping the mailbox");
+      }
+      if (q != hipErrorNotReady) return fail(s, CERES_HIP_E_HIP, "stream failed while waiting for a read-back: %s", hipGetErrorString(q));
+    }
+    __builtin_ia32_pause();
+  }
+  return check_comm_error(s);
+}
+// h_pinned[0 .. n) <- src[0 .. n) (device), and wait for it
+int read_back(ceres_hip_solver* s, const double* src, int n) {
+  if (s->mailbox && s->d_h_pinned) {
+    const unsigned long long seq = ++s->mailbox_seq;
+    HIP_TRY(s, LaunchMailbox(src, n, s->d_h_pinned, s->d_stamp, seq, s->stream));
+    return wait_mailbox(s, seq);
+  }
+  HIP_TRY(s, hipMemcpyAsync(s->h_pinned, src, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return check_comm_error(s);
 }
+int poll_scalars(ceres_hip_solver* s) { return read_back(s, s->scalar_partials, kReadbackDoubles); }
 
 int collapse_and_reduce(ceres_hip_solver* s, int first_slot, int count) {
   if (s->cg.grid_e == 0) return 0;
@@ -1323,6 +1430,16 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
+// Phase events (ceres_hip_get_last_timing): recorded only when the caller asked for them (ceres_hip_set_phase_timing / CERES_HIP_TIMING=1).
+// An event record between two kernels is a barrier packet with a completion signal: about 6 us of idle device each (rocprofv3
+// --kernel-trace, profiles/r06a_*), seven of them in an LM step — a tenth of what one rank of eight spends on a Venice-sized step.
+int rec(ceres_hip_solver* s, int i) {
+  if (i == 0) s->call_t0 = std::chrono::steady_clock::now();
+  if (!s->timing_enabled) return 0;
+  HIP_TRY(s, hipEventRecord(s->ev[i], s->stream));
+  return 0;
+}
+
 // The two LinearSolver::SolveImpl bodies.  x is a device pointer (num_cols).
 int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary);
 int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
@@ -1353,7 +1470,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), st));  // finite-step flag + factorization flag, adjacent
   s->fail_flag_clean = true;
   s->nonfinite_clean = true;
-  HIP_TRY(s, hipEventRecord(s->ev[2], st));
+  TRY(rec(s, 2));
   if (is_schur(s)) {
     // IterativeSchurComplementSolver::SolveImpl, I/iterative_schur_complement_solver.cc:64-157
     const int pre = s->opt.preconditioner_type;
@@ -1362,8 +1479,10 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     // (armed only where the code below REACHES that op_preconditioner call: the implicit iterative branch with F blocks — a direct or
     // explicit-S solve, or the no-F-blocks shortcut, would otherwise factor / iterate on this rank's raw rhs)
     const bool implicit_iterative = !is_dense_schur(s) && !s->sparse_S && !s->opt.use_explicit_schur_complement && h.ncb - h.nelim > 0;
+    // (round 6: not when the camera-major pass exchanges its blocks itself — a verdict all ranks share —: rhs is then summed over ranks by
+    // the first pass's own reduction, or by the stand-alone all-reduce on a rank whose reduction cannot: the same slots either way)
     s->merge_step_reduce = s->world > 1 && s->path == CERES_HIP_PATH_BAL && (pre == CERES_HIP_SCHUR_JACOBI || pre == CERES_HIP_JACOBI) &&
-                           !s->opt.use_spse_initialization && implicit_iterative;
+                           !s->opt.use_spse_initialization && implicit_iterative && !camera_blocks_exchange(s);
     const int rc_init = op_schur_init(s, pre == CERES_HIP_SCHUR_JACOBI);
     s->merge_step_reduce = false;
     TRY(rc_init);
@@ -1374,15 +1493,15 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       snprintf(summary->message, sizeof(summary->message), "E^T E + D^2 is not positive definite.");
       return 0;
     }
-    HIP_TRY(s, hipEventRecord(s->ev[3], st));
+    TRY(rec(s, 3));
     const int nf_blocks = h.ncb - h.nelim;
     if (nf_blocks == 0) {  // :88-95
       summary->termination_type = CERES_HIP_SUCCESS;
       summary->num_iterations = 0;
       TRY(op_back_substitute(s, nullptr, x));
-      HIP_TRY(s, hipEventRecord(s->ev[4], st));
-      HIP_TRY(s, hipEventRecord(s->ev[5], st));
-      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      TRY(rec(s, 4));
+      TRY(rec(s, 5));
+      TRY(rec(s, 6));
       return 0;
     }
     if (is_dense_schur(s)) {
@@ -1402,7 +1521,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         HIP_TRY(s, LaunchGenSchurDense(s->G, s->values, s->etei, (s->world > 1 && s->rank != 0) ? nullptr : s->D, s->d_S, st));
         if (s->world > 1) TRY(allreduce(s, s->d_S, size_t(nf * nf)));
       }
-      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      TRY(rec(s, 4));
       HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
       HIP_TRY(s, LaunchDenseCholesky(s->d_S, int(nf), s->d_fail_flag, st));
       TRY(check_factorization(s, &bad));
@@ -1414,11 +1533,11 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       }
       HIP_TRY(s, hipMemcpyAsync(s->cg.x, s->rhs_f, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
       HIP_TRY(s, LaunchDenseCholeskySolve(s->d_S, int(nf), s->cg.x, st));
-      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      TRY(rec(s, 5));
       summary->termination_type = CERES_HIP_SUCCESS;
       snprintf(summary->message, sizeof(summary->message), "Success.");
       TRY(op_back_substitute(s, s->cg.x, x));
-      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      TRY(rec(s, 6));
       return 0;
     }
     if (s->sparse_S) {
@@ -1438,7 +1557,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         return 0;
       }
       s->precond_valid = true;
-      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      TRY(rec(s, 4));
       CgSpec spec;
       spec.rhs = s->rhs_f;
       spec.n = nf;
@@ -1454,14 +1573,14 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       spec.diag_off = s->G.diag_off_f;
       spec.blocks = s->precond;
       TRY(run_cg(s, spec, q_tol, r_tol, summary));
-      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      TRY(rec(s, 5));
       if (summary->termination_type == CERES_HIP_SUCCESS) {
         TRY(op_back_substitute(s, s->cg.x, x));
       } else {  // x was zero-filled (:135), the reduced solution sits in its tail
         HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols_e, st));
         HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, s->cg.x, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
       }
-      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      TRY(rec(s, 6));
       return 0;
     }
     if (s->opt.use_explicit_schur_complement) {
@@ -1484,7 +1603,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         return 0;
       }
       s->precond_valid = true;
-      HIP_TRY(s, hipEventRecord(s->ev[4], st));
+      TRY(rec(s, 4));
       HIP_TRY(s, hipMemcpyAsync(s->cg_rhs, s->rhs_f, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
       CgSpec spec;
       spec.n = nf;
@@ -1500,14 +1619,14 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       spec.diag_off = s->G.diag_off_f;
       spec.blocks = s->precond;
       TRY(run_cg(s, spec, q_tol, r_tol, summary));
-      HIP_TRY(s, hipEventRecord(s->ev[5], st));
+      TRY(rec(s, 5));
       if (summary->termination_type == CERES_HIP_SUCCESS) {
         TRY(op_back_substitute(s, s->cg.x, x));
       } else {  // x was zero-filled (:135), the reduced solution sits in its tail
         HIP_TRY(s, hipMemsetAsync(x, 0, sizeof(double) * h.num_cols_e, st));
         HIP_TRY(s, hipMemcpyAsync(x + h.num_cols_e, s->cg.x, sizeof(double) * nf, hipMemcpyDeviceToDevice, st));
       }
-      HIP_TRY(s, hipEventRecord(s->ev[6], st));
+      TRY(rec(s, 6));
       return 0;
     }
     const bool spse_pre = pre == CERES_HIP_SCHUR_POWER_SERIES_EXPANSION;
@@ -1540,7 +1659,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
       TRY(allreduce(s, s->rhs_f, size_t(h.num_cols_f)));
       s->rhs_reduce_pending = false;
     }
-    HIP_TRY(s, hipEventRecord(s->ev[4], st));
+    TRY(rec(s, 4));
     CgSpec spec;
     spec.rhs = s->rhs_f;  // CG only reads it: no copy into cg_rhs
     spec.n = h.num_cols_f;
@@ -1590,22 +1709,27 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         const int rc = op_back_substitute(s, s->cg.x, x);
         s->gate_on_cg_status = false;
         if (rc) return rc;
+        // sharded: {finite-step flag, this rank's share of the model cost} summed over ranks into the read-back image, in the same tail
+        // (the exchange runs whether CG has ended or not — a handshake per epoch on every rank, p2p.h; its sums only mean something once it has)
+        if (s->world > 1)
+          HIP_TRY(s, LaunchCollectScalarsExchange(s->d_nonfinite, s->scalar_partials, s->backsub_cost_parts, s->scalar_partials + kSumsOffset,
+                                                  next_exchange(s), s->stream));
         s->spec_tail_done = true;   // (the poll that follows copies the partial sums and flags together with the CG scalars)
         return 0;
       };
     }
     TRY(run_cg(s, spec, q_tol, r_tol, summary));
-    HIP_TRY(s, hipEventRecord(s->ev[5], st));
+    TRY(rec(s, 5));
     if (summary->termination_type != CERES_HIP_FAILURE && summary->termination_type != CERES_HIP_FATAL_ERROR && !s->spec_tail_done)
       TRY(op_back_substitute(s, s->cg.x, x));
-    HIP_TRY(s, hipEventRecord(s->ev[6], st));
+    TRY(rec(s, 6));
     return 0;
   }
   // CgnrSolver::SolveImpl, I/cgnr_solver.cc:146-207
   const int pre = s->opt.preconditioner_type;
-  HIP_TRY(s, hipEventRecord(s->ev[3], st));
+  TRY(rec(s, 3));
   if (s->path == CERES_HIP_PATH_BAL) {
-    s->merge_step_reduce = s->world > 1;
+    s->merge_step_reduce = s->world > 1 && !camera_blocks_exchange(s);   // (a choice every rank makes alike: the verdict was agreed on)
     s->D_int_valid = false;
     const int rc_setup = op_cgnr_setup_bal(s, pre == CERES_HIP_JACOBI, s->cg_rhs, s->precond);
     s->merge_step_reduce = false;
@@ -1628,7 +1752,7 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     }
     s->precond_valid = true;
   }
-  HIP_TRY(s, hipEventRecord(s->ev[4], st));
+  TRY(rec(s, 4));
   CgSpec spec;
   spec.n = h.num_cols;
   spec.n_local = h.num_cols_e;  // sharded: first nelim column blocks are this rank's points
@@ -1662,16 +1786,23 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
     };
   }
   TRY(run_cg(s, spec, q_tol, r_tol, summary));
-  HIP_TRY(s, hipEventRecord(s->ev[5], st));
+  TRY(rec(s, 5));
   // LM step: the model-cost kernel reads the solution anyway and writes the negated step (no copy-out, no separate negation pass)
   if (s->lm_negate_in_solve) s->lm_cgnr_copy_pending = true;
   else TRY(copy_out_cgnr_solution(s, x));
-  HIP_TRY(s, hipEventRecord(s->ev[6], st));
+  TRY(rec(s, 6));
   return 0;
 }
 
 void collect_timing(ceres_hip_solver* s) {
   ceres_hip_solve_timing& t = s->timing;
+  if (!s->timing_enabled) {   // no events were recorded: the call's wall-clock time is all there is
+    const int apps = t.operator_applications;
+    t = ceres_hip_solve_timing{};
+    t.operator_applications = apps;
+    t.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->call_t0).count();
+    return;
+  }
   t.upload_ms = elapsed(s->ev[0], s->ev[1]);
   t.pack_ms = elapsed(s->ev[1], s->ev[2]);
   t.setup_ms = elapsed(s->ev[2], s->ev[3]);
@@ -1757,12 +1888,16 @@ ceres_hip_solver* ceres_hip_create(const ceres_hip_options* o) {
     return nullptr;
   }
   for (auto& e : s->ev) (void)hipEventCreate(&e);
-  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_pinned), sizeof(double) * (kReadbackDoubles + 8), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_pinned), sizeof(double) * (kReadbackDoubles + 8), hipHostMallocMapped) != hipSuccess) {
     fail(nullptr, CERES_HIP_E_HIP, "hipHostMalloc failed");
     return nullptr;
   }
   memset(s->h_pinned, 0, sizeof(double) * (kReadbackDoubles + 8));
   s->h_scalars = reinterpret_cast<CgScalars*>(s->h_pinned + kScalarsOffset);
+  s->h_stamp = reinterpret_cast<unsigned long long*>(s->h_pinned + kReadbackDoubles);
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_h_pinned), s->h_pinned, 0) == hipSuccess)
+    s->d_stamp = reinterpret_cast<unsigned long long*>(s->d_h_pinned + kReadbackDoubles);
+  else { s->d_h_pinned = nullptr; (void)hipGetLastError(); }   // (no mapping: read_back falls back to the copy + synchronise)
   return s.release();
 }
 
@@ -2140,6 +2275,31 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->tmp_e2, size_t(h.num_cols_e)));
   }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  // Sharded over the peer-to-peer communicator: do ALL ranks' camera-major passes exchange their blocks themselves (p2p.h)?  One
+  // all-reduce of the ranks' verdicts — set_structure is collective for such instances (the ranks plan for about as long as each other;
+  // this one exchange waits up to two minutes).
+  s->cam_exchange_agreed = false;
+  s->spec_agreed = false;
+  if (s->world > 1 && s->p2p && s->p2p_fuse) {
+    double* d_agree = nullptr;
+    TRY(dev_alloc(s, &d_agree, 2));
+    // [0]: the camera-major pass cannot exchange here; [1]: an LM step cannot run its tail speculatively here (lm_step_loaded)
+    const bool spec_local = s->speculate && is_schur(s) && !is_dense_schur(s) && s->path == CERES_HIP_PATH_BAL && !s->opt.use_explicit_schur_complement &&
+                            s->fused_grid < 2 * kMaxVecGrid && !has_remainder(s) && exchange_in_producer(s, 2, 1);
+    const double mine[2] = {camera_blocks_exchange_local(s) ? 0.0 : 1.0, spec_local ? 0.0 : 1.0};
+    double sum[2] = {1.0, 1.0};
+    HIP_TRY(s, hipMemcpyAsync(d_agree, mine, sizeof(mine), hipMemcpyHostToDevice, s->stream));
+    const double keep = s->p2p_timeout_s;
+    s->p2p_timeout_s = std::max(keep, 120.0);
+    const int rc = allreduce(s, d_agree, 2);
+    s->p2p_timeout_s = keep;
+    TRY(rc);
+    HIP_TRY(s, hipMemcpyAsync(sum, d_agree, sizeof(sum), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    TRY(check_comm_error(s));
+    s->cam_exchange_agreed = sum[0] == 0.0;
+    s->spec_agreed = sum[1] == 0.0;
+  }
   s->have_structure = true;
   return 0;
 }
@@ -2206,7 +2366,7 @@ int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world,
   HIP_TRY(s, hipSetDevice(s->opt.device));
   s->rank = rank; s->world = world;
   s->p2p_cap = ((max_elements + kP2pChunk - 1) / kP2pChunk) * kP2pChunk;
-  s->p2p_chunks_cap = int(s->p2p_cap / kP2pChunk);
+  s->p2p_chunks_cap = int(s->p2p_cap / kP2pFlagChunk) + 8;
   const size_t flag_bytes = ((size_t(2) * world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
   s->p2p_bytes = flag_bytes + size_t(2) * world * size_t(s->p2p_cap) * sizeof(double);
   // fine-grained: writes arriving from another device (or another XCD's L2) must be visible to this rank's loads.
@@ -2275,7 +2435,9 @@ int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
   if (!s || !s->p2p) return CERES_HIP_E_INVALID;
   HIP_TRY(s, hipSetDevice(s->opt.device));
   constexpr int kSelfTestRounds = 6;
-  const int n = int(std::min<int64_t>(s->p2p_cap, 2 * kP2pChunk + 3));
+  // (odd rounds: a vector long enough for the multi-chunk round trips of the long-vector kernel, where the slots allow)
+  const int n_short = int(std::min<int64_t>(s->p2p_cap, 2 * kP2pChunk + 3));
+  const int n = int(std::min<int64_t>(s->p2p_cap, 64 * 1024 + 2 * kP2pChunk + 3));
   std::vector<double> h(n);
   double* d = nullptr;
   HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(double)));
@@ -2284,13 +2446,14 @@ int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
   int rc = 0;
   const double w = double(s->world);
   for (int t = 0; t < kSelfTestRounds && !rc; ++t) {
-    for (int i = 0; i < n; ++i) h[i] = double(s->rank + 1) * (t + 1) + double(i % 7);
-    if (hipMemcpyAsync(d, h.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-    if (!rc) rc = allreduce(s, d, size_t(n));
-    if (!rc && hipMemcpyAsync(h.data(), d, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+    const int nt = (t & 1) ? n : n_short;
+    for (int i = 0; i < nt; ++i) h[i] = double(s->rank + 1) * (t + 1) + double(i % 7);
+    if (hipMemcpyAsync(d, h.data(), size_t(nt) * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
+    if (!rc) rc = allreduce(s, d, size_t(nt));
+    if (!rc && hipMemcpyAsync(h.data(), d, size_t(nt) * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
     if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
     if (!rc) rc = check_comm_error(s);
-    for (int i = 0; i < n && !rc; ++i) {
+    for (int i = 0; i < nt && !rc; ++i) {
       const double want = (t + 1) * w * (w + 1.0) / 2.0 + w * double(i % 7);
       if (h[i] != want) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: round %d element %d is %g, expected %g (world %d, %s receive buffer)",
                                   t, i, h[i], want, s->world, s->p2p_fine_grained ? "fine-grained" : "coarse-grained");
@@ -2326,6 +2489,8 @@ int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t ite
 int ceres_hip_comm_p2p_disable(ceres_hip_solver* s) {
   if (!s) return CERES_HIP_E_INVALID;
   s->p2p = false;
+  s->cam_exchange_agreed = false;
+  s->spec_agreed = false;
   if (s->h_comm_error) {
     HIP_TRY(s, hipSetDevice(s->opt.device));
     HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -2348,6 +2513,43 @@ int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world) {
   NCCL_TRY(s, ncclCommInitRank(&s->comm, 1, u, 0));
   s->rank = 0;
   s->world = logical_world;
+  return 0;
+}
+
+// Measurement: rank 0 of `logical_world` ranks whose peers are GHOSTS — the peer-to-peer all-reduce kernel does everything it does
+// between real ranks (push the chunk into every peer's slot, set every peer's flag, wait for the peers' flags, add the `world` slots
+// in rank order) but the peers' buffers are one local dummy allocation and their arrival flags in this rank's buffer are preset to
+// "arrived for every epoch", their slots to zero.  One rank's SHARD of a problem then runs the sharded code path alone on the device
+// at the cost a perfect interconnect would give (bench.py: extra.shard_ceiling); its sums are the shard's own (the ghosts add 0).
+int ceres_hip_debug_comm_ghost_peers(ceres_hip_solver* s, int32_t logical_world, int64_t max_elements) {
+  if (!s || logical_world < 2 || logical_world > kP2pMaxWorld || max_elements < 1) return CERES_HIP_E_INVALID;
+  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call before ceres_hip_set_structure");
+  if (s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "peer-to-peer buffer already prepared");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  s->rank = 0; s->world = logical_world;
+  s->p2p_cap = ((max_elements + kP2pChunk - 1) / kP2pChunk) * kP2pChunk;
+  s->p2p_chunks_cap = int(s->p2p_cap / kP2pFlagChunk) + 8;
+  const size_t flag_bytes = ((size_t(2) * s->world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
+  s->p2p_bytes = flag_bytes + size_t(2) * s->world * size_t(s->p2p_cap) * sizeof(double);
+  HIP_TRY(s, hipMalloc(&s->p2p_base, s->p2p_bytes));
+  void* ghost = nullptr;
+  HIP_TRY(s, hipMalloc(&ghost, s->p2p_bytes));
+  s->allocs.push_back(ghost);
+  HIP_TRY(s, hipMemset(s->p2p_base, 0, s->p2p_bytes));
+  HIP_TRY(s, hipMemset(s->p2p_base, 0xFF, flag_bytes));   // every peer has "arrived" at every epoch
+  HIP_TRY(s, hipMemset(ghost, 0, s->p2p_bytes));
+  HIP_TRY(s, hipHostMalloc(reinterpret_cast<void**>(&s->h_comm_error), sizeof(int), hipHostMallocMapped));
+  *s->h_comm_error = 0;
+  HIP_TRY(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_comm_error), s->h_comm_error, 0));
+  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error_seen), sizeof(int)));
+  HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
+  for (int q = 0; q < s->world; ++q) {
+    void* base = q == 0 ? s->p2p_base : ghost;
+    s->p2p_peers.flags[q] = reinterpret_cast<unsigned long long*>(base);
+    s->p2p_peers.slots[q] = reinterpret_cast<double*>(static_cast<char*>(base) + flag_bytes);
+  }
+  HIP_TRY(s, hipDeviceSynchronize());
+  s->p2p = true;
   return 0;
 }
 
@@ -2377,7 +2579,7 @@ int ceres_hip_solve(ceres_hip_solver* s, const double* hv, const double* hb, con
     return rc;
   };
   if (!s->have_structure) return fatal(fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called"));
-  (void)hipEventRecord(s->ev[0], s->stream);
+  (void)rec(s, 0);
   // upload (ev0..ev1), pack (ev1..ev2)
   const HostStructure& h = s->hs;
   if (!hv || !hb) return fatal(fail(s, CERES_HIP_E_INVALID, "values and b must not be NULL"));
@@ -2385,7 +2587,7 @@ int ceres_hip_solve(ceres_hip_solver* s, const double* hv, const double* hb, con
       hipMemcpyAsync(s->own_b, hb, sizeof(double) * h.num_rows, hipMemcpyHostToDevice, s->stream) != hipSuccess ||
       (hD && hipMemcpyAsync(s->own_D, hD, sizeof(double) * h.num_cols, hipMemcpyHostToDevice, s->stream) != hipSuccess))
     return fatal(fail(s, CERES_HIP_E_HIP, "host-to-device copy failed"));
-  (void)hipEventRecord(s->ev[1], s->stream);
+  (void)rec(s, 1);
   int rc = load_device(s, s->own_values, s->own_b, hD ? s->own_D : nullptr);
   if (rc) return fatal(rc);
   rc = solve_loaded(s, q_tol, r_tol, s->own_x, summary);
@@ -2394,7 +2596,7 @@ int ceres_hip_solve(ceres_hip_solver* s, const double* hv, const double* hb, con
     if (hipMemcpyAsync(hx, s->own_x, sizeof(double) * h.num_cols, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
       return fatal(fail(s, CERES_HIP_E_HIP, "device-to-host copy failed"));
   }
-  (void)hipEventRecord(s->ev[7], s->stream);
+  (void)rec(s, 7);
   if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
   collect_timing(s);
   return 0;
@@ -2411,11 +2613,11 @@ int ceres_hip_solve_unchanged_values(ceres_hip_solver* s, const double* hD, doub
   };
   if (!s->have_structure || !s->loaded || !s->have_b)
     return fatal(fail(s, CERES_HIP_E_INVALID, "ceres_hip_solve_unchanged_values needs the values and b of a previous ceres_hip_solve / ceres_hip_load"));
-  (void)hipEventRecord(s->ev[0], s->stream);
+  (void)rec(s, 0);
   const HostStructure& h = s->hs;
   if (hD && hipMemcpyAsync(s->own_D, hD, sizeof(double) * h.num_cols, hipMemcpyHostToDevice, s->stream) != hipSuccess)
     return fatal(fail(s, CERES_HIP_E_HIP, "host-to-device copy failed"));
-  (void)hipEventRecord(s->ev[1], s->stream);
+  (void)rec(s, 1);
   s->D = hD ? s->own_D : nullptr;
   s->have_D = hD != nullptr;
   keep_loaded_values(s);
@@ -2425,7 +2627,7 @@ int ceres_hip_solve_unchanged_values(ceres_hip_solver* s, const double* hD, doub
     if (hipMemcpyAsync(hx, s->own_x, sizeof(double) * h.num_cols, hipMemcpyDeviceToHost, s->stream) != hipSuccess)
       return fatal(fail(s, CERES_HIP_E_HIP, "device-to-host copy failed"));
   }
-  (void)hipEventRecord(s->ev[7], s->stream);
+  (void)rec(s, 7);
   if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
   collect_timing(s);
   return 0;
@@ -2441,13 +2643,13 @@ int ceres_hip_solve_device(ceres_hip_solver* s, const double* dv, const double* 
     snprintf(summary->message, sizeof(summary->message), "%s", s->err.c_str());
     return rc;
   };
-  (void)hipEventRecord(s->ev[0], s->stream);
-  (void)hipEventRecord(s->ev[1], s->stream);
+  (void)rec(s, 0);
+  (void)rec(s, 1);
   int rc = load_device(s, dv, db, dD);
   if (rc) return fatal(rc);
   rc = solve_loaded(s, q_tol, r_tol, dx, summary);
   if (rc) return fatal(rc);
-  (void)hipEventRecord(s->ev[7], s->stream);
+  (void)rec(s, 7);
   if (hipStreamSynchronize(s->stream) != hipSuccess) return fatal(fail(s, CERES_HIP_E_HIP, "stream synchronisation failed: %s", hipGetErrorString(hipGetLastError())));
   collect_timing(s);
   return 0;
@@ -2482,7 +2684,9 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   s->lm_negated = false;
   s->lm_cgnr_copy_pending = false;
   // (rows outside the tiles add ungated generic launches to the ITERATIVE_SCHUR tail: no speculation then)
-  s->lm_speculate = s->speculate && s->lm_negate_in_solve && s->world <= 1 && (!is_schur(s) || (s->lm_want_model_cost && !has_remainder(s)));
+  // (sharded: ITERATIVE_SCHUR where every rank can — the tail then holds one exchange per poll, which all ranks must issue alike)
+  s->lm_speculate = s->speculate && s->lm_negate_in_solve &&
+                    (s->world <= 1 ? (!is_schur(s) || (s->lm_want_model_cost && !has_remainder(s))) : (is_schur(s) && s->spec_agreed && s->p2p && s->lm_want_model_cost));
   s->spec_tail_done = false;
   const int rc = solve_loaded(s, o->eta, -1.0, dx, &res->linear_solver);
   const bool spec_done = s->spec_tail_done;
@@ -2537,11 +2741,21 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   double* hp = s->h_pinned;
   int* h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
   double v[2] = {0.0, 0.0};
-  if (s->world > 1) {
+  bool synced = false;   // the results are in h_pinned already (read_back waited for them)
+  if (s->world > 1 && spec_done) {
+    // the speculative tail summed them over ranks, and the poll that saw CG end brought them along
+    hp[0] = hp[kSumsOffset]; hp[1] = hp[kSumsOffset + 1];
+    synced = true;
+  } else if (s->world > 1) {
     // sharded: {flag, this rank's share of the cost} are summed over ranks ON THE DEVICE, then read back once
-    HIP_TRY(s, LaunchCollectScalars(s->d_nonfinite, parts_local, n_local, s->cg.comm, st));
-    TRY(allreduce(s, s->cg.comm, 2));
-    HIP_TRY(s, hipMemcpyAsync(hp, s->cg.comm, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    if (exchange_in_producer(s, 2, 1)) {
+      HIP_TRY(s, LaunchCollectScalarsExchange(s->d_nonfinite, parts_local, n_local, s->cg.comm, next_exchange(s), st));
+    } else {
+      HIP_TRY(s, LaunchCollectScalars(s->d_nonfinite, parts_local, n_local, s->cg.comm, st));
+      TRY(allreduce(s, s->cg.comm, 2));
+    }
+    if (n_shared == 0) { TRY(read_back(s, s->cg.comm, 2)); synced = true; }   // (nothing else to bring back: the mailbox, no synchronisation)
+    else HIP_TRY(s, hipMemcpyAsync(hp, s->cg.comm, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
   }
   // unsharded: the partial sums and the flag word live in one buffer (scalar_partials | flags): ONE copy brings them back
   const double* sp = s->scalar_partials;
@@ -2551,7 +2765,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   double* hsh = hp + kMaxVecGrid;
   if (one_copy) {
     // speculative tail: this copy was enqueued in front of the poll that saw CG end, and that poll synchronised
-    if (!spec_done) HIP_TRY(s, hipMemcpyAsync(hp, sp, sizeof(double) * (2 * kMaxVecGrid + 1), hipMemcpyDeviceToHost, st));
+    if (!spec_done) { TRY(read_back(s, sp, 2 * kMaxVecGrid + 1)); synced = true; }
     h_flag = reinterpret_cast<int*>(hp + 2 * kMaxVecGrid);
     if (n_local > 0) hl = hp + (parts_local - sp);
     if (n_shared > 0) hsh = hp + (parts_shared - sp);
@@ -2562,7 +2776,7 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
     }
     if (n_shared > 0) HIP_TRY(s, hipMemcpyAsync(hp + kMaxVecGrid, parts_shared, sizeof(double) * n_shared, hipMemcpyDeviceToHost, st));
   }
-  if (!(spec_done && one_copy)) {
+  if (!(spec_done && one_copy) && !synced) {
     HIP_TRY(s, hipStreamSynchronize(st));
     TRY(check_comm_error(s));
   }
@@ -2588,14 +2802,16 @@ int ceres_hip_lm_compute_step_device(ceres_hip_solver* s, const double* dv, cons
                                      const ceres_hip_lm_options* o, double* dx, ceres_hip_lm_result* res) {
   if (!s || !o || !dx || !res) return CERES_HIP_E_INVALID;
   HIP_TRY(s, hipSetDevice(s->opt.device));
-  (void)hipEventRecord(s->ev[0], s->stream);
-  (void)hipEventRecord(s->ev[1], s->stream);
+  (void)rec(s, 0);
+  (void)rec(s, 1);
   if (o->values_unchanged && s->loaded && s->have_b && s->values == dv && s->b == db) keep_loaded_values(s);
   else if (o->values_unchanged) return fail(s, CERES_HIP_E_INVALID, "values_unchanged = 1 but these are not the pointers of the previous load");
   else TRY(load_device(s, dv, db, nullptr));
   TRY(lm_step_loaded(s, o, dx, res));
-  (void)hipEventRecord(s->ev[7], s->stream);
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  (void)rec(s, 7);
+  // (the step's scalars came back through the mailbox, which the device stamps after everything else of the step: with nothing
+  // enqueued behind it — no phase event — the stream has drained, and a synchronisation would only cost the host its round trip)
+  if (s->timing_enabled || !s->mailbox || !s->final_sync_skippable) HIP_TRY(s, hipStreamSynchronize(s->stream));
   collect_timing(s);
   return 0;
 }
@@ -2604,7 +2820,7 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const doubl
                               double* hx, ceres_hip_lm_result* res) {
   if (!s || !o || !hx || !res) return CERES_HIP_E_INVALID;
   HIP_TRY(s, hipSetDevice(s->opt.device));
-  (void)hipEventRecord(s->ev[0], s->stream);
+  (void)rec(s, 0);
   if (o->values_unchanged) {   // the copies of the previous call are still in HBM: nothing crosses PCIe but the step
     if (!(s->loaded && s->have_b && s->values == s->own_values && s->b == s->own_b))
       return fail(s, CERES_HIP_E_INVALID, "values_unchanged = 1 needs a previous ceres_hip_lm_compute_step / ceres_hip_load with host values and residuals");
@@ -2612,12 +2828,12 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const doubl
   } else {
     TRY(load_host(s, hv, hb, nullptr));
   }
-  (void)hipEventRecord(s->ev[1], s->stream);
+  (void)rec(s, 1);
   TRY(lm_step_loaded(s, o, s->own_x, res));
   const int term = res->linear_solver.termination_type;
   if (term != CERES_HIP_FAILURE && term != CERES_HIP_FATAL_ERROR)
     HIP_TRY(s, hipMemcpyAsync(hx, s->own_x, sizeof(double) * s->hs.num_cols, hipMemcpyDeviceToHost, s->stream));
-  (void)hipEventRecord(s->ev[7], s->stream);
+  (void)rec(s, 7);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   collect_timing(s);
   return 0;
@@ -2644,6 +2860,12 @@ int ceres_hip_op_scale_columns(ceres_hip_solver* s, const double* host_scale, do
   if (host_values_out)
     HIP_TRY(s, hipMemcpyAsync(host_values_out, s->own_values, sizeof(double) * s->hs.values_extent, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int ceres_hip_set_phase_timing(ceres_hip_solver* s, int32_t enable) {
+  if (!s) return CERES_HIP_E_INVALID;
+  s->timing_enabled = enable != 0;
   return 0;
 }
 

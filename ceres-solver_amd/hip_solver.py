@@ -144,7 +144,9 @@ ABI = [
     ("ceres_hip_op_scale_columns", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_time_op", c_int32, [c_void_p, c_int32, c_int32, _DP]),
     ("ceres_hip_get_last_timing", c_int32, [c_void_p, POINTER(CTiming)]),
+    ("ceres_hip_set_phase_timing", c_int32, [c_void_p, c_int32]),
     ("ceres_hip_debug_comm_loopback", c_int32, [c_void_p, c_int32]),
+    ("ceres_hip_debug_comm_ghost_peers", c_int32, [c_void_p, c_int32, c_int64]),
     ("ceres_hip_debug_plan", c_int32, [POINTER(CBlockStructure), c_int32, POINTER(c_int32), POINTER(c_int64),
                                        POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_uint32),
                                        POINTER(c_int32), POINTER(c_int32), c_int64, c_char_p, c_int32]),
@@ -296,7 +298,7 @@ class HipLinearSolver:
     """
 
     def __init__(self, options: LinearSolverOptions, comm_id: Optional[bytes] = None, rank: int = 0,
-                 world_size: int = 1, loopback_world: int = 0, p2p_exchange=None, p2p_max_elements: int = 0):
+                 world_size: int = 1, loopback_world: int = 0, p2p_exchange=None, p2p_max_elements: int = 0, ghost_world: int = 0):
         """comm_id: RCCL unique id (ceres_hip_comm_init).  p2p_exchange: callable(bytes) -> list of every rank's bytes in
         rank order (e.g. a torch.distributed all_gather); connects the one-shot peer-to-peer all-reduce for vectors of
         up to p2p_max_elements doubles (99 * number of F blocks covers a step: blocks, rhs and column norms go through ONE all-reduce)."""
@@ -337,6 +339,9 @@ class HipLinearSolver:
                 raise HipError("peer-to-peer communicator failed and there is no RCCL communicator: " + self.p2p_error)
         if loopback_world > 1:  # debug: sharded code paths on one GPU (see include/ceres_hip.h)
             self._check(self._lib.ceres_hip_debug_comm_loopback(self._h, loopback_world))
+        if ghost_world > 1:  # measurement: rank 0 of ghost_world ranks, the peers are local dummy buffers (include/ceres_hip.h)
+            self._check(self._lib.ceres_hip_debug_comm_ghost_peers(self._h, ghost_world, int(p2p_max_elements)))
+            self.p2p_ok = True
 
     def p2p_selftest(self) -> bool:
         """Collective: all-reduces of known values through the peer-to-peer path.  ceres_hip_comm_p2p_connect has already run it once
@@ -478,6 +483,11 @@ class HipLinearSolver:
         out = np.full(self._values_extent, np.nan)
         self._check(self._lib.ceres_hip_op_scale_columns(self._h, _p(scale), _p(out)))
         return out
+
+    def set_phase_timing(self, enable: bool = True):
+        """Record the per-phase HIP events of the following solves / steps (last_timing); off by default: each event record between two
+        kernels idles the device for about 6 us."""
+        self._check(self._lib.ceres_hip_set_phase_timing(self._h, int(bool(enable))))
 
     def last_timing(self) -> CTiming:
         t = CTiming()

@@ -480,7 +480,11 @@ int ceres_hip_debug_bal_evaluate_tiles_timing(ceres_hip_bal* p, const double* st
 #define CERES_HIP_TIMED_CGNR_SETUP 10 /* CGNR per-step set-up on the <2,3,9> path (re-layout + J^T b + JACOBI blocks) */
 #define CERES_HIP_TIMED_READ_STREAM 9 /* read-only pass over the packed tiles, same loads as the fused kernels */
 int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms);
-/* Per-phase event timings (ms) of the most recent ceres_hip_solve*. */
+/* Per-phase event timings (ms) of the most recent ceres_hip_solve* / ceres_hip_lm_compute_step*.  The phases are bracketed by HIP events
+ * on the solver's stream, and an event record between two kernels idles the device for about 6 us (a barrier packet with a completion
+ * signal; seven of them in a step): they are recorded only after ceres_hip_set_phase_timing(s, 1) (or with CERES_HIP_TIMING=1 in the
+ * environment).  Without it only total_ms is filled, from the host's clock around the call, and operator_applications.               */
+int ceres_hip_set_phase_timing(ceres_hip_solver* s, int32_t enable);
 typedef struct ceres_hip_solve_timing {
   double upload_ms, pack_ms, setup_ms, preconditioner_ms, cg_ms, back_substitute_ms,
       download_ms, total_ms;
@@ -544,6 +548,13 @@ int ceres_hip_debug_staged_x_plan(const ceres_hip_block_structure* bs, int32_t n
 /* Debug: exercise the sharded (world > 1) code paths on one GPU through a 1-rank RCCL
  * communicator; the instance must then be given the WHOLE problem.  Call before set_structure. */
 int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world);
+/* Measurement (bench.py: extra.shard_ceiling): this instance becomes rank 0 of `logical_world` ranks whose PEERS ARE GHOSTS.  The
+ * peer-to-peer all-reduce kernel does all its work — pushes into every peer's slot, sets and awaits every peer's flags, adds the
+ * `world` slots in rank order — against local dummy buffers that read "arrived" with zero contributions.  Given ONE RANK'S SHARD of
+ * a problem the instance runs the sharded code path alone on the device: the time a perfect interconnect would give that rank
+ * (its sums are the shard's own, so its results are not the whole problem's).  Call before set_structure; max_elements as for
+ * ceres_hip_comm_p2p_prepare.                                                                                                  */
+int ceres_hip_debug_comm_ghost_peers(ceres_hip_solver* s, int32_t logical_world, int64_t max_elements);
 
 #ifdef __cplusplus
 }

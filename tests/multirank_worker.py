@@ -15,6 +15,8 @@ def run_rank(rank, world, conn, device, scenario):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ.setdefault("CERES_HIP_P2P_TIMEOUT", "20")
+    # the ranks of these tests SHARE one device: kernels that wait for their peers must fit on it beside each other (solver.hip: p2p_grid_cap)
+    os.environ.setdefault("CERES_HIP_P2P_SHARED_DEVICE", "1")
     try:
         import torch  # noqa: F401  (before the HIP library: see hip_solver.load_library)
         import __graft_entry__ as entry

@@ -8,7 +8,7 @@ for nc, npts, nobs in ((228, 50000, 250000), (456, 100000, 500000)):
     p = P.synthetic_bal(None, layout="schur", seed=3, skew=0.5, num_cameras=nc, num_points=npts, num_observations=nobs)
     o = hs.LinearSolverOptions(type=hs.DENSE_SCHUR, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=1)
     s = hs.HipLinearSolver(o)
-    t = time.time(); s.set_structure(p.bs); ts = time.time() - t
+    t = time.time(); s.set_structure(p.bs); ts = time.time() - t; s.set_phase_timing(True)
     for _ in range(2):
         x, summ = s.solve(p.values, p.b, hs.PerSolveOptions(D=p.D))
         tm = s.last_timing()

@@ -18,6 +18,7 @@ for name, typ, pre in (("cgnr", hs.CGNR, hs.JACOBI), ("schur", hs.ITERATIVE_SCHU
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=K, max_num_iterations=K,
                                                   elimination_groups=[prob.num_eliminate_blocks]))
     s.set_structure(prob.bs)
+    s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
     for _ in range(2):
         s.solve_device(tv.data_ptr(), tb.data_ptr(), tD.data_ptr(), tx.data_ptr(), -1.0, -1.0)
     torch.cuda.synchronize()

@@ -41,6 +41,7 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                   elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage, force_generic_path=force_generic))
     s.set_structure(prob.bs)
+    s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
     s.load(prob.values, prob.b, prob.D)
     for name, op, nbytes in ops:
         if nbytes == "tiles":

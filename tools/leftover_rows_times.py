@@ -20,6 +20,7 @@ for name, prob in (("pure", base), ("with_leftover_rows", withrows)):
         s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                       elimination_groups=[prob.num_eliminate_blocks]))
         s.set_structure(prob.bs)
+        s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
         assert s.info().kernel_path == hs.PATH_BAL
         best = None
         for _ in range(5):

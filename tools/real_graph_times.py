@@ -29,6 +29,7 @@ for problem, copies in cases:
         s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                       elimination_groups=[n_p]))
         s.set_structure(prob.bs)
+        s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
         info = s.info()
         s.load(prob.values, prob.b, prob.D)
         ms = min(s.time_op(op, 30) for _ in range(3))

@@ -27,6 +27,7 @@ def run(tag, prob, nf, ns, extra=None):
         s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                       elimination_groups=[n_p]))
         s.set_structure(prob.bs)
+        s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
         info = s.info()
         out["kernel_path"] = "fused" if info.kernel_path == hs.PATH_BAL else "generic"
         out["accumulators_in_lds"] = int(info.camera_accum_in_lds)
