@@ -147,6 +147,9 @@ def parse():
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=-1, help="also time the fp32-tile storage mode (extra.fp32_tiles; BASELINE.json configs[4] asks for a sweep over both "
                                                                "precisions): -1 = on the default Venice line, 1 = on, 0 = off")
+    ap.add_argument("--shard-ceiling", type=int, default=1,
+                    help="N = 1: also run rank 0's shard of the workload for N = 2, 4, 8 alone on the device with the sharded code path on "
+                         "(ghost peers) and report T_1 / (N T_shard) as extra.shard_ceiling (0: skip)")
     ap.add_argument("--oracle-check", type=int, default=-1,
                     help="(-1 = on where one oracle step takes about a second: the workloads whose camera sums fit in LDS) compare the step of the LAST timed solve with ONE oracle step on the same FULL-SIZE inputs (16 threads; N > 1: the ranks' "
                          "shards of the step are gathered and assembled first) and report it as oracle_check.  Independent of --no-cpu-baseline: "
@@ -241,36 +244,61 @@ def phase_timing(solver, ptrs, step_kind="lm_step", eta=0.1, radius=None):
         solver.set_phase_timing(False)
 
 
-def shard_ceiling(pkg, hs, prob, solver_kind, device, t1_ms, k_iters, eta, worlds=(2, 4, 8), steps=20, warmup=3, radius=None, dev=None):
+def shard_ceiling(pkg, hs, prob, solver_kind, device, t1_ms, k_iters, eta, worlds=(2, 4, 8), steps=20, warmup=3, radius=None, dev=None, many_cameras=None):
     """What ONE rank of an N-rank strong-scaling run costs, measured on one GPU: rank 0's shard of `prob`
-    (partition.shard_by_point) through ceres_hip_lm_compute_step_device with the SHARDED code path on — every all-reduce of the step
-    runs the peer-to-peer kernel against ghost peers (ceres_hip_debug_comm_ghost_peers: all pushes, flags, waits and sums, local
-    memory instead of xGMI) — and CG pinned to the iteration count of the whole problem's step (min = max = k_iters: the shard alone is
-    another linear system).  efficiency_ceiling = T_1 / (N T_shard): what a perfect interconnect would give; xGMI latency is NOT in it."""
+    (partition.shard_by_point) through ceres_hip_lm_compute_step_device with the SHARDED code path on — every sum over ranks of the
+    step runs its peer-to-peer exchange against ghost peers (ceres_hip_debug_comm_ghost_peers: all pushes, flags, waits and sums,
+    local memory instead of xGMI) — and CG pinned to the iteration count of the whole problem's step (min = max = k_iters: the shard
+    alone is another linear system).  efficiency_ceiling = T_1 / (N T_shard): what a perfect interconnect would give; xGMI latency is
+    NOT in it.  many_cameras = "synthetic10M" | "synthetic1M": the shard is generated like bench.py's rank 0 generates it (graph on the
+    host, N(0,1) values in HBM; worlds may contain 1 = the whole problem, unsharded)."""
     from ceres_solver_amd import partition
-    nelim = prob.num_eliminate_blocks
-    out = {"what": "rank 0's shard of the problem alone on the device, sharded code path on (peer-to-peer all-reduce kernel against ghost "
-                   "peers: local memory, no xGMI hop), CG iterations pinned to the whole problem's; efficiency_ceiling = T_1 / (N T_shard)",
+    out = {"what": "rank 0's shard of the problem alone on the device, sharded code path on (every sum over ranks runs its peer-to-peer exchange "
+                   "against ghost peers: local memory, no xGMI hop), CG iterations pinned to the whole problem's; efficiency_ceiling = T_1 / (N T_shard): "
+                   "what a perfect interconnect would give.  xGMI latency and link time are NOT measured (no box with two GPUs); "
+                   "efficiency_with_link_estimate adds the bytes one rank pushes to each peer at 76 GB/s, unoverlapped",
            "t1_ms": round(t1_ms, 4), "cg_iterations": int(k_iters), "cases": []}
     typ, pre = (hs.CGNR, hs.JACOBI) if solver_kind == "cgnr" else (hs.ITERATIVE_SCHUR, hs.SCHUR_JACOBI)
     for n in worlds:
-        sh = partition.shard_by_point(prob.bs, nelim, n, 0)
-        f = sh.bs.col_block_size[sh.num_eliminate_blocks:].astype(np.int64)
-        o = hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=int(k_iters), max_num_iterations=int(k_iters),
-                                   residual_reset_period=10, elimination_groups=[sh.num_eliminate_blocks], device=device)
-        sv = hs.HipLinearSolver(o, ghost_world=n, p2p_max_elements=int((f * f).sum() + 2 * f.sum() + 2))
-        sv.set_structure(sh.bs)
-        tvs, tbs = (torch.from_numpy(a).to(dev) for a in (sh.local_values(prob.values), sh.local_rows(prob.b)))
-        txs = torch.empty(sh.bs.num_cols, dtype=torch.float64, device=dev)
+        if many_cameras:
+            n_cams, n_points, n_obs = pkg.problems.BAL_SHAPES[many_cameras]
+            shp = pkg.problems.synthetic_bal(None, layout="schur", seed=38401, skew=0.6, num_cameras=n_cams, num_points=n_points // n,
+                                             num_observations=n_obs // n, with_values=False)
+            sbs, snelim = shp.bs, shp.num_eliminate_blocks
+            g = torch.Generator(device=dev)
+            g.manual_seed(38401)
+            tvs = torch.randn(24 * sbs.num_row_blocks, dtype=torch.float64, device=dev, generator=g)
+            tbs = torch.randn(2 * sbs.num_row_blocks, dtype=torch.float64, device=dev, generator=g)
+        else:
+            sh = partition.shard_by_point(prob.bs, prob.num_eliminate_blocks, n, 0)
+            sbs, snelim = sh.bs, sh.num_eliminate_blocks
+            tvs, tbs = (torch.from_numpy(a).to(dev) for a in (sh.local_values(prob.values), sh.local_rows(prob.b)))
+        f = sbs.col_block_size[snelim:].astype(np.int64)
+        pinned = n > 1 or many_cameras is None
+        o = hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=int(k_iters) if pinned else 0,
+                                   max_num_iterations=int(k_iters) if pinned else 500,
+                                   residual_reset_period=10, elimination_groups=[snelim], device=device)
+        sv = hs.HipLinearSolver(o, ghost_world=n, p2p_max_elements=int((f * f).sum() + 2 * f.sum() + 2)) if n > 1 else hs.HipLinearSolver(o)
+        sv.set_structure(sbs)
+        txs = torch.empty(sbs.num_cols, dtype=torch.float64, device=dev)
         el, its, last = timed_steps(sv, (tvs, tbs, None, txs), steps, warmup, torch.cuda.synchronize, "lm_step", eta, radius)
         ms = 1e3 * el / steps
         tm = phase_timing(sv, (tvs, tbs, None, txs), "lm_step", eta, radius)
-        out["cases"].append({"ranks": n, "shard_observations": int(sh.bs.num_row_blocks), "ms_per_step": round(ms, 4),
+        # what one rank pushes to EACH peer per step (doubles): rhs + the packed camera blocks (upper triangle + column norms) + one camera
+        # vector per CG iteration + the step's scalars — over xGMI that is link time the ghost peers do not charge (local HBM stands in for
+        # the links): 76 GB/s per direction and link (MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional), not overlapped with anything
+        nfv = int(f.sum())
+        per_cam = int((f * (f + 1) // 2 + f).sum())
+        pushed = (nfv + per_cam + int(k_iters) * nfv + 2) if solver_kind != "cgnr" else (nfv + per_cam + int(k_iters) * (nfv + 1) + 4 * (int(k_iters) + 1) + 2)
+        link_ms = 8.0 * pushed / 76e9 * 1e3 if n > 1 else 0.0
+        out["cases"].append({"ranks": n, "shard_observations": int(sbs.num_row_blocks), "ms_per_step": round(ms, 4),
                              "efficiency_ceiling": round(t1_ms / (n * ms), 4), "collectives_per_step": int(sv.info().collectives_last_step),
+                             "doubles_pushed_per_peer_per_step": pushed, "xgmi_link_ms_estimate_unoverlapped": round(link_ms, 4),
+                             "efficiency_with_link_estimate": round(t1_ms / (n * (ms + link_ms)), 4),
                              "cg_iterations": int(its[-1]), "cg_ms": round(tm.cg_ms, 4), "setup_ms": round(tm.setup_ms + tm.preconditioner_ms, 4),
                              "back_substitute_ms": round(tm.back_substitute_ms, 4)})
         sv.close()
-        del tvs, tbs, txs
+        del tvs, tbs, txs, sbs
     return out
 
 
@@ -487,6 +515,7 @@ def main():
         # nothing goes up, the step's first pass reads the resident tiles; radius halved as StepRejected does
         retry = []
         h_step = torch.empty(bs.num_cols, dtype=torch.float64).pin_memory()   # the caller's step vector (Ceres allocates it once per Solve())
+        h_stream_step = torch.empty(bs.num_cols, dtype=torch.float64).pin_memory()
         for k in range(nh):
             t0 = time.perf_counter()
             solver.lm_compute_step(None, None, RADIUS / 2.0, 0.1, reuse_diagonal=True, values_unchanged=True, out=h_step.numpy())
@@ -504,7 +533,57 @@ def main():
             torch.cuda.synchronize()
             dev_retry_ms = 1e3 * (time.perf_counter() - t0) / nh
             del tx_retry
+        # the upload HIDDEN behind the evaluator (ceres_hip_values_begin / _ready / _end): eight threads stand in for
+        # ProgramEvaluator::Evaluate's parallel loop — each "evaluates" runs of row blocks by copying them from a source Jacobian into the
+        # pinned arrays (the fastest evaluator there can be: a real one spends a microsecond per residual) and announces every run; what the
+        # minimizer then waits for is the time from the LAST announcement to the step on the host
+        streamed = None
+        try:
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+            src_v, src_b = prob.values, prob.b
+            n_rows_b = bs.num_row_blocks
+            e0 = bs.cell_value_pos[bs.row_cell_ptr[:-1]].astype(np.int64)           # first cell of every row (E|F split: the E stream)
+            f0 = bs.cell_value_pos[bs.row_cell_ptr[:-1] + 1].astype(np.int64)       # its second cell (the F stream)
+            n_chunks, n_thr = 256, 8
+            bounds = np.linspace(0, n_rows_b, n_chunks + 1).astype(np.int64)
+            runs_ms = []
+            for rep in range(3):
+                hv.zero_(); hb.zero_()
+                hvn, hbn = hv.numpy(), hb.numpy()
+                t_last = [0.0]
+                lock = threading.Lock()
+
+                def evaluate(k):
+                    r0, r1 = int(bounds[k]), int(bounds[k + 1])
+                    hvn[e0[r0]:e0[r1 - 1] + 6] = src_v[e0[r0]:e0[r1 - 1] + 6]
+                    hvn[f0[r0]:f0[r1 - 1] + 18] = src_v[f0[r0]:f0[r1 - 1] + 18]
+                    hbn[2 * r0:2 * r1] = src_b[2 * r0:2 * r1]
+                    solver.values_ready(r0, r1 - r0)
+                    t = time.perf_counter()
+                    with lock:
+                        t_last[0] = max(t_last[0], t)
+                t_begin = time.perf_counter()
+                solver.values_begin(hvn, hbn)
+                with ThreadPoolExecutor(n_thr) as ex:
+                    list(ex.map(evaluate, range(n_chunks)))
+                solver.values_end(None)
+                _, s_st, _ = solver.lm_compute_step(None, None, RADIUS, 0.1, values_unchanged=True, out=h_stream_step.numpy())
+                t_done = time.perf_counter()
+                runs_ms.append((1e3 * (t_done - t_last[0]), 1e3 * (t_last[0] - t_begin), 1e3 * (t_done - t_begin), int(s_st.num_iterations)))
+            best = min(runs_ms)
+            early_b, late_b, n_streams = solver.stream_stats()
+            ref_step, _, _ = solver.lm_compute_step(hv.numpy(), hb.numpy(), RADIUS, 0.1)
+            streamed = {"what": "ceres_hip_values_begin / _ready / _end: 8 threads copy 256 runs of row blocks from a source Jacobian into the pinned arrays ('evaluation' "
+                                "at memcpy speed) and announce each run; then ceres_hip_lm_compute_step with values_unchanged = 1 (D2H of the step included)",
+                        "ms_after_last_push": round(best[0], 3), "evaluator_ms": round(best[1], 3), "ms_begin_to_step": round(best[2], 3),
+                        "ms_after_last_push_each_run": [round(r[0], 3) for r in runs_ms], "cg_iterations": best[3],
+                        "value_streams": n_streams, "bytes_sent_before_end": early_b, "bytes_sent_in_end": late_b,
+                        "step_rel_diff_vs_plain_step": float(np.linalg.norm(h_stream_step.numpy() - ref_step) / np.linalg.norm(ref_step))}
+        except Exception as ex:  # the default line must not depend on it
+            streamed = {"error": repr(ex)[:400]}
         host_boundary = {"steps_per_s": round(1.0 / th, 3), "ms_per_step": round(1e3 * th, 3), "upload_ms": round(tm.upload_ms, 3),
+                         "streamed": streamed,
                          "download_ms": round(tm.download_ms, 3), "bytes_h2d": int(8 * (prob.values.shape[0] + prob.b.shape[0])),
                          "h2d_GBs": round(8 * (prob.values.shape[0] + prob.b.shape[0]) / max(tm.upload_ms, 1e-9) / 1e6, 1),
                          "what": "ceres_hip_lm_compute_step with pinned host values/residuals (PCIe H2D + step + D2H), median of " + str(nh) + " steps",
@@ -514,7 +593,7 @@ def main():
                                      "already holds is neither re-sent nor re-laid-out (D2H of the step included)",
                              "ms_per_step": round(1e3 * float(np.median(retry)), 3), "upload_ms": round(tr_.upload_ms, 3),
                              "device_pointer_retry_ms_per_step": None if dev_retry_ms is None else round(dev_retry_ms, 3)}}
-        del hv, hb, h_step
+        del hv, hb, h_step, h_stream_step
 
     # ---- the whole trust-region loop on the device, for the record (N = 1) ----------
     scene_tr = None
@@ -614,6 +693,18 @@ def main():
                     extra["conditioned_step"] = conditioned
                 except Exception as ex:  # the default line must not depend on it
                     extra["conditioned_step"] = {"error": repr(ex)[:400]}
+    # ---- strong-scaling ceiling measured on ONE GPU: rank 0's shard with the sharded code path on ----
+    if world == 1 and args.shard_ceiling and not storage and info.kernel_path == hs.PATH_BAL:
+        try:
+            t1_ms = 1e3 * elapsed / args.steps
+            if many_cameras:
+                extra["shard_ceiling"] = shard_ceiling(pkg, hs, None, args.solver, local_rank, t1_ms, int(iters[-1]), args.eta, worlds=(8,), steps=max(3, args.steps),
+                                                       warmup=1, dev=dev, many_cameras=args.workload)
+            else:
+                extra["shard_ceiling"] = shard_ceiling(pkg, hs, prob, args.solver, local_rank, t1_ms, int(iters[-1]), args.eta, worlds=(2, 4, 8), steps=args.steps,
+                                                       warmup=args.warmup, dev=dev)
+        except Exception as ex:  # the default line must not depend on it
+            extra["shard_ceiling"] = {"error": repr(ex)[:400]}
     extra["solve_phases_ms"] = {k: round(getattr(timing, k), 4) for k in
                                 ("pack_ms", "setup_ms", "preconditioner_ms", "cg_ms", "back_substitute_ms", "total_ms")}
     extra["operator_launches_enqueued_last_step"] = int(timing.operator_applications)
@@ -659,7 +750,7 @@ def main():
                     "cg_iterations_per_step": d["config"]["cg_iterations_per_step"], "solver": d["config"]["solver"],
                     ("sx" if kind == "sx" else "jtjx"): {"frac": ro["frac"], "GBs": ro["achieved"], "ms": ro["avg_launch_ms"], "kernel": ro["kernel"]},
                     ("jtjx" if kind == "sx" else "sx"): {"frac": rj.get("frac"), "GBs": rj.get("achieved"), "ms": rj.get("avg_launch_ms")},
-                    other: d["extra"].get(other), "fp32_tiles": d["extra"].get("fp32_tiles"),
+                    other: d["extra"].get(other), "fp32_tiles": d["extra"].get("fp32_tiles"), "shard_ceiling": d["extra"].get("shard_ceiling"),
                     "step_rel_diff_vs_oracle": (d.get("oracle_check") or {}).get("step_rel_diff_vs_oracle"), "oracle_check": d.get("oracle_check"),
                     "child_wall_s": round(time.perf_counter() - t10, 1)}
             except Exception as ex:  # the default line must not depend on the child

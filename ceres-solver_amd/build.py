@@ -70,7 +70,7 @@ def build_host_driver(force=False, verbose=False):
     deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), os.path.join(HERE, "host", "hip_bal_problem.h"), OUT]
     if force or _stale(HOST_DRIVER, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"), "-I", os.path.join(HERE, "host"),
-               HOST_DRIVER_SRC, "-o", HOST_DRIVER, "-L", CSRC, "-lceres_hip", "-Wl,-rpath," + CSRC,
+               HOST_DRIVER_SRC, "-o", HOST_DRIVER, "-pthread", "-L", CSRC, "-lceres_hip", "-Wl,-rpath," + CSRC,
                "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -185,6 +185,7 @@ struct CamGather {
   int want_sq = 0;                        // SCHUR items: the fused LM diagonal takes the camera columns' square sums from the items
   int few = 0;                            // every camera has a handful of items at most: seven cameras per wavefront gather their own
   const double* extra = nullptr;          // [nf nf c + nf a + b] raw sums added to the camera's block (rows outside the tiles: LaunchRemCameraBlocks)
+  const double* packed = nullptr;         // [cam_part c + e] the cameras' item sums already added up, and summed over ranks (camera_exchange); parts unused
 };
 // Camera-major pass of one chunk (cameras not in LDS): acc[nf c + k] += sum over the unit's entries of ring[nf slot + k].
 struct ZUnits {
@@ -234,9 +235,10 @@ struct BalOps {
   hipError_t (*pack)(const BalArgs& A, hipStream_t stream);   // A.src_values / src_b / slot_* / J_out (Jf_out) / b_out set
   hipError_t (*invert)(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm, const CamGather& gather,
                        hipStream_t stream);
-  // sharded: invert in gathering mode with the sum over ranks inside (p2p.h): slots kCamPart c + e, chunks ceil(kCamPart / 64) c + q
-  hipError_t (*invert_exchange)(double* blocks, const int64_t* cam_diag_off, int n_cameras, int* fail_flag, const LmFuse& lm, const CamGather& gather,
-                                const P2pComm& comm, int grid_cap, hipStream_t stream);
+  // sharded: every camera's items added up and summed over ranks (p2p.h: slots cam_part c + e, chunks ceil(cam_part / 64) c + q), left
+  // packed — cam_part doubles per camera — for invert (CamGather::packed)
+  hipError_t (*camera_exchange)(const double* parts, const int32_t* cam_item_ptr, int n_cameras, const double* extra, double* packed,
+                                const P2pComm& comm, int grid_cap, hipStream_t stream, bool few /* a handful of items per camera */);
   // Per-camera blocks in two steps: every item (<= kCamChunk observations of one camera) leaves its upper-triangle sums + nf column
   // square sums in parts[item][cam_part]; the items of a camera (cam_item_ptr) are then added in list order either by camera_finish
   // (raw sums to memory, + D_f^2 if given) or by the load phase of invert (CamGather).
@@ -508,6 +510,8 @@ hipError_t LaunchCgBegin(const CgBuffers& B, double q_tol, double r_tol, int min
 hipError_t LaunchCgFinalizeDirection(const CgBuffers& B, int it, hipStream_t stream);
 // comm[slot] = sum over the shard's workgroups of partials[slot] for slot in [first, first+count)
 hipError_t LaunchCgCollapse(const CgBuffers& B, int first_slot, int count, hipStream_t stream);
+// ... summed over ranks in the same launch (p2p.h)
+hipError_t LaunchCgCollapseExchange(const CgBuffers& B, int first_slot, int count, const P2pComm& comm, hipStream_t stream);
 
 // out[0] = (*flag != 0), out[1] = sum of parts[0 .. n) (one workgroup, fixed order)
 hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t stream);

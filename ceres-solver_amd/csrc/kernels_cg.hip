@@ -656,6 +656,24 @@ __global__ __launch_bounds__(kVecBlock) void cg_collapse_kernel(CgBuffers B, int
   }
 }
 
+// the same with the sum over ranks inside (p2p.h; slot index = k, one chunk: the numbering of the all-reduce of `count` doubles)
+__global__ __launch_bounds__(kVecBlock) void cg_collapse_exchange_kernel(CgBuffers B, int first_slot, int count, P2pComm C) {
+  __shared__ double sh[4];
+  __shared__ double tot[64];
+  for (int k = 0; k < count; ++k) {
+    const double* p = B.partials + (first_slot + k) * kMaxVecGrid;
+    double v = 0;
+    for (int b = threadIdx.x; b < B.grid_e; b += kVecBlock) v += p[b];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) tot[k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const double t = p2p_exchange_wave(C, 0, lane, lane < count, lane < count ? tot[lane] : 0.0);
+  if (lane < count) B.comm[first_slot + lane] = t;
+}
+
 inline int vec_grid(int64_t n) {
   int64_t g = (n + kVecBlock * 4 - 1) / (kVecBlock * 4);
   if (g < 1) g = 1;
@@ -831,6 +849,10 @@ hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, in
   hipLaunchKernelGGL(collect_scalars_exchange_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out, comm);
   return hipGetLastError();
 }
+hipError_t LaunchCgCollapseExchange(const CgBuffers& B, int first_slot, int count, const P2pComm& comm, hipStream_t s) {
+  hipLaunchKernelGGL(cg_collapse_exchange_kernel, dim3(1), dim3(kVecBlock), 0, s, B, first_slot, count, comm);
+  return hipGetLastError();
+}
 hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(collect_scalars_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out);
   return hipGetLastError();
@@ -855,7 +877,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(const double* __rest
     double v[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { const int64_t i = i0 + 64 * k + lane; v[k] = i < n ? in[i] : 0.0; }
-    p2p_exchange_wave_multi<K>(C, int(r * K), i0, n, v);
+    p2p_exchange_wave_multi<K>(C, int(r * K), i0, 64, 64, n, v);
 #pragma unroll
     for (int k = 0; k < K; ++k) { const int64_t i = i0 + 64 * k + lane; if (i < n) out[i] = v[k]; }
   }

@@ -75,19 +75,20 @@ __device__ __forceinline__ double p2p_exchange_wave(const P2pComm& C, int chunk,
   return timed_out ? __builtin_nan("") : s;
 }
 
-// K consecutive chunks by one wavefront in ONE round trip (the stand-alone all-reduce of a long vector): lane l holds slot indices
-// idx0 + 64 k + l, k < K (valid below n_end), chunk k has flag index chunk0 + k.  Same protocol per chunk as above.
+// K chunks by one wavefront in ONE round trip (the stand-alone all-reduce of a long vector; the camera-major pass of tens of thousands
+// of cameras): chunk k < K has flag index chunk0 + k and holds the slot indices idx0 + stride k + l for lanes l < lanes; indices at or
+// beyond n_end do not exist (the tail).  Same protocol per chunk as above.
 template <int K>
-__device__ __forceinline__ void p2p_exchange_wave_multi(const P2pComm& C, int chunk0, long long idx0, long long n_end, double (&v)[K]) {
+__device__ __forceinline__ void p2p_exchange_wave_multi(const P2pComm& C, int chunk0, long long idx0, int stride, int lanes, long long n_end, double (&v)[K]) {
   const int lane = threadIdx.x & 63;
   const int parity = int(C.epoch & 1ull);
   const long long base = (static_cast<long long>(parity) * C.world + C.rank) * C.cap;
   const bool broken = __hip_atomic_load(C.error_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  if (!broken) {
+  if (!broken && lane < lanes) {
     for (int q = 0; q < C.world; ++q) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const long long i = idx0 + 64 * k + lane;
+        const long long i = idx0 + static_cast<long long>(stride) * k + lane;
         if (i < n_end) __hip_atomic_store(C.peers.slots[q] + base + i, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -101,10 +102,10 @@ __device__ __forceinline__ void p2p_exchange_wave_multi(const P2pComm& C, int ch
     const unsigned long long* fi = C.peers.flags[C.rank] + (static_cast<long long>(parity) * C.world + q) * C.chunks_cap + chunk0;
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if (idx0 + 64 * k < n_end) __hip_atomic_store(fo + k, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (idx0 + static_cast<long long>(stride) * k < n_end) __hip_atomic_store(fo + k, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const long long t0 = wall_clock64();
     for (int k = 0; k < K && !timed_out; ++k) {
-      if (idx0 + 64 * k >= n_end) break;
+      if (idx0 + static_cast<long long>(stride) * k >= n_end) break;
       while (__hip_atomic_load(fi + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < C.epoch) {
         if (wall_clock64() - t0 > C.timeout_ticks) {
           __hip_atomic_store(C.error_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -122,9 +123,9 @@ __device__ __forceinline__ void p2p_exchange_wave_multi(const P2pComm& C, int ch
   const double* my = C.peers.slots[C.rank] + static_cast<long long>(parity) * C.world * C.cap;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const long long i = idx0 + 64 * k + lane;
+    const long long i = idx0 + static_cast<long long>(stride) * k + lane;
     double s = 0.0;
-    if (i < n_end)
+    if (i < n_end && lane < lanes)
       for (int q = 0; q < C.world; ++q) s += __hip_atomic_load(my + static_cast<long long>(q) * C.cap + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     v[k] = timed_out ? __builtin_nan("") : s;
   }

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -75,6 +76,7 @@ struct ceres_hip_solver {
   int32_t *d_tile_zbase = nullptr, *d_grp_tile_ptr = nullptr;  // cameras not in LDS: ring rows of the tiles; hybrid groups (plan.cc)
   unsigned int* d_cg_ticket = nullptr;   // CgTail: the S.x pass of a small camera space finishes the CG iteration (device.h)
   bool cg_tail_enabled = [] { const char* e = getenv("CERES_HIP_CG_TAIL"); return !e || atoi(e) != 0; }();   // (A/B switch)
+  bool cam_exchange_few = false;
   bool cam_items_few = false;   // no camera has more than a handful of items: bal_invert9_kernel gathers seven cameras per wavefront
   int32_t *d_long_ptr = nullptr, *d_round_ptr = nullptr, *d_seq_ptr = nullptr, *d_round_flag = nullptr;  // long points: where they begin, their rounds (plan.cc)
   uint32_t* d_round_word = nullptr;
@@ -82,6 +84,7 @@ struct ceres_hip_solver {
   CamItems cam_items;
   int32_t* d_cam_item_ptr = nullptr;
   double* d_cam_parts = nullptr;   // [items][kCamPart] partial sums of the camera-block pass
+  double* d_cam_packed = nullptr;  // [cameras][kCamPart] sharded: the cameras' sums over their items and over ranks (camera_exchange)
   ZUnits zunits;                   // chunked camera-major pass (cameras not in LDS): all chunks' units
   int chunk_grid = 0;              // workgroups of one chunk's tile pass
   // f1: LM step state
@@ -214,6 +217,20 @@ struct ceres_hip_solver {
   bool p2p_fuse = [] { const char* e = getenv("CERES_HIP_P2P_FUSE"); return !e || atoi(e) != 0; }();
   int p2p_grid_cap = [] { const char* e = getenv("CERES_HIP_P2P_SHARED_DEVICE"); return (e && atoi(e) != 0) ? 32 : (1 << 20); }();
   bool p2p_fine_grained = false;   // the receive buffer is a fine-grained allocation (false: the runtime could only export a coarse-grained one)
+  // Streamed upload (ceres_hip_values_begin / _ready / _end): while an evaluator is still writing later rows, the rows it has finished go
+  // up on a copy stream.  stream_lo / stream_hi[k][r]: the value range row block r owns in value stream k (k = 0: the rows' first cells
+  // — or whole rows where rows are contiguous —, k = 1: their other cells); n_value_streams = 0: the layout is not two monotone streams
+  // (everything goes up in _end).
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_done = nullptr;
+  std::mutex stream_mu;
+  bool streaming = false, stream_plan_ready = false;
+  int n_value_streams = 0;
+  std::vector<int64_t> stream_lo[2], stream_hi[2];
+  std::vector<uint8_t> stream_row_sent;
+  const double* stream_host_values = nullptr;
+  const double* stream_host_b = nullptr;
+  int64_t stream_rows_sent = 0, stream_bytes_early = 0, stream_bytes_late = 0;
   ceres_hip_solve_timing timing{};
   // per-phase HIP events of a solve (ceres_hip_get_last_timing): off unless asked for, see rec()
   bool timing_enabled = [] { const char* e = getenv("CERES_HIP_TIMING"); return e && atoi(e) != 0; }();
@@ -317,7 +334,7 @@ bool reduction_exchanges(const ceres_hip_solver* s) {
 bool camera_blocks_exchange_local(const ceres_hip_solver* s) {
   if (s->path != CERES_HIP_PATH_BAL || s->plan.ns != 0) return false;
   const int64_t per = s->ops->cam_part;
-  return exchange_in_producer(s, per * s->plan.n_cameras, ((per + 63) / 64) * s->plan.n_cameras);
+  return s->d_cam_packed != nullptr && exchange_in_producer(s, per * s->plan.n_cameras, ((per + 63) / 64) * s->plan.n_cameras);
 }
 bool camera_blocks_exchange(const ceres_hip_solver* s) { return s->cam_exchange_agreed && s->p2p; }
 
@@ -849,14 +866,14 @@ int op_preconditioner(ceres_hip_solver* s, int type, double* out, bool invert) {
       if (s->world > 1 && invert && camera_blocks_exchange(s) && !s->rhs_reduce_pending) {
         // sharded: the inversion kernel adds up this rank's items, sums the packed blocks (and column norms) over ranks (p2p.h), adds
         // D_f^2 — or forms the fused LM diagonal from the summed norms — and inverts: one launch, one exchange
+        HIP_TRY(s, s->ops->camera_exchange(s->d_cam_parts, s->d_cam_item_ptr, s->plan.n_cameras, rem_extra_blocks(s), s->d_cam_packed, next_exchange(s),
+                                           s->p2p_grid_cap, st, s->cam_exchange_few));
         CamGather g;
-        g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.want_sq = (fuse && schur) ? 1 : 0;
-        g.extra = rem_extra_blocks(s);
+        g.packed = s->d_cam_packed; g.want_sq = (fuse && schur) ? 1 : 0;
         g.D_f = fuse ? nullptr : D_f;
         g.cam_pos = s->plan.cameras_contiguous ? nullptr : s->d_cam_pos;
         g.cam_base = s->plan.cam_base;
-        HIP_TRY(s, s->ops->invert_exchange(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g,
-                                           next_exchange(s), s->p2p_grid_cap, st));
+        HIP_TRY(s, s->ops->invert(out, cam_f_offsets(s), s->plan.n_cameras, s->d_fail_flag, fuse ? lm_fuse_for_cameras(s, false) : LmFuse(), g, st));
       } else if (s->world <= 1 && invert) {
         // the inversion kernel adds up a camera's items itself (+ D_f^2, or the fused LM diagonal it forms from them)
         CamGather g;
@@ -982,13 +999,13 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
     return 0;
   }
   if (!merge && camera_blocks_exchange(s)) {   // sharded, the sums over ranks inside the inversion kernel (see op_preconditioner)
+    HIP_TRY(s, s->ops->camera_exchange(s->d_cam_parts, s->d_cam_item_ptr, s->plan.n_cameras, rem_extra_blocks(s), s->d_cam_packed, next_exchange(s),
+                                       s->p2p_grid_cap, st, s->cam_exchange_few));
     CamGather g;
-    g.parts = s->d_cam_parts; g.cam_item_ptr = s->d_cam_item_ptr; g.cam_pos = cam_pos;
+    g.packed = s->d_cam_packed; g.cam_pos = cam_pos;
     g.cam_base = s->plan.cam_base;
-    g.extra = rem_extra_blocks(s);
     g.D_f = s->lm_fuse_active ? nullptr : D_f;
-    HIP_TRY(s, s->ops->invert_exchange(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g,
-                                       next_exchange(s), s->p2p_grid_cap, st));
+    HIP_TRY(s, s->ops->invert(blocks, s->d_cam_diag_off, s->plan.n_cameras, s->d_fail_flag, lm_fuse_for_cameras(s, false), g, st));
     return 0;
   }
   // sharded: raw F^T F sums, all-reduce, then the diagonal (camera blocks are contiguous
@@ -1228,6 +1245,10 @@ int poll_scalars(ceres_hip_solver* s) { return read_back(s, s->scalar_partials, 
 
 int collapse_and_reduce(ceres_hip_solver* s, int first_slot, int count) {
   if (s->cg.grid_e == 0) return 0;
+  if (s->world > 1 && s->p2p && s->p2p_fuse && count <= 64) {   // collapse and sum over ranks in one launch (the slots of the all-reduce of `count` doubles)
+    HIP_TRY(s, LaunchCgCollapseExchange(s->cg, first_slot, count, next_exchange(s), s->stream));
+    return 0;
+  }
   HIP_TRY(s, LaunchCgCollapse(s->cg, first_slot, count, s->stream));
   return allreduce(s, s->cg.comm + first_slot, size_t(count));
 }
@@ -1911,6 +1932,8 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   if (s->h_comm_error) (void)hipHostFree(s->h_comm_error);
   if (s->d_comm_error_seen) (void)hipFree(s->d_comm_error_seen);
   free_all(s);
+  if (s->copy_done) (void)hipEventDestroy(s->copy_done);
+  if (s->copy_stream) { (void)hipStreamSynchronize(s->copy_stream); (void)hipStreamDestroy(s->copy_stream); }
   if (s->h_pinned) (void)hipHostFree(s->h_pinned);
   for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -2157,8 +2180,12 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
         int most = 0;
         for (int c = 0; c < P.n_cameras; ++c) most = std::max(most, P.cam_item_ptr[c + 1] - P.cam_item_ptr[c]);
         s->cam_items_few = most <= 4 && P.n_cameras >= 1024;
+        // the sharded exchange of the cameras' sums: four cameras per wavefront where the AVERAGE camera has a handful of items (a popular
+        // camera's hundred items are a hundred independent loads for its lane; one workgroup per camera is one exchange round trip per camera)
+        s->cam_exchange_few = int64_t(P.item_cam.size()) <= int64_t(4) * P.n_cameras && P.n_cameras >= 1024;
       }
       TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * s->ops->cam_part));
+      if (s->world > 1) TRY(dev_alloc(s, &s->d_cam_packed, size_t(std::max(1, P.n_cameras)) * s->ops->cam_part));
     }
     std::vector<int64_t> pdo(P.n_points), cdo(P.n_cameras);
     for (int p = 0; p < P.n_points; ++p) pdo[p] = h.diag_off_all[P.pt_block[p]];
@@ -2178,7 +2205,11 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(dev_alloc(s, &s->etei, size_t(P.n_points) * s->ops->etei_pitch));
     const size_t n9 = size_t(P.nf) * P.n_cameras + size_t(P.ns);   // accumulator entries: the cameras' scalars, then the strip
     s->lds_mode = P.cameras_in_lds;
-    s->fused_grid = s->lds_mode ? s->num_cus : s->num_cus * 4;
+    // (cameras beyond LDS: four workgroups per CU for the passes that scatter nothing, but fewer than the 2 kMaxVecGrid partial sums the
+    // LM step's read-back image holds — back-substitution leaves the model cost's partials there, one per workgroup (+ one for rows outside
+    // the tiles); at 1024 a separate pass over J formed it: 165 us of a 2.2 ms step on one rank's eighth of synthetic10M, profiles/r06e_*)
+    s->fused_grid = s->lds_mode ? s->num_cus : std::min(s->num_cus * 4, 2 * kMaxVecGrid - 2);
+    { const char* e = getenv("CERES_HIP_FUSED_GRID"); if (e && atoi(e) > 0 && s->lds_mode) s->fused_grid = std::min(s->fused_grid, atoi(e)); }   // (experiments)
     const int64_t tiles_per_wg = 512 / kTile;
     s->fused_grid = int(std::max<int64_t>(1, std::min<int64_t>(s->fused_grid, (P.n_tiles + tiles_per_wg - 1) / tiles_per_wg)));
     s->fused_grid = std::min(s->fused_grid, kMaxPqParts - kMaxVecGrid);  // one p.q partial per workgroup must fit cg_pq_parts (bal_scatter)
@@ -2836,6 +2867,147 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const doubl
   (void)rec(s, 7);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   collect_timing(s);
+  return 0;
+}
+
+// ---- streamed upload: the evaluator's finished rows go up while it is still writing the later ones ----------------------------
+namespace {
+// Which value ranges does a run of row blocks own?  Ceres' BlockJacobianWriter lays a Schur-ordered Jacobian out as all E cells (row
+// order) then all F cells (row order) (I/block_jacobian_writer.cc:68-167): two monotone streams; a row-sequential layout is one.
+void plan_value_streams(ceres_hip_solver* s) {
+  const HostStructure& h = s->hs;
+  s->stream_plan_ready = true;
+  s->n_value_streams = 0;
+  for (int k = 0; k < 2; ++k) { s->stream_lo[k].assign(size_t(h.nrb), 0); s->stream_hi[k].assign(size_t(h.nrb), 0); }
+  auto cell_range = [&](int r, int c, int64_t& lo, int64_t& hi) {
+    lo = h.cval[c];
+    hi = lo + int64_t(h.rsz[r]) * h.csz[h.ccol[c]];
+  };
+  // try ONE stream (rows contiguous one after the other), then TWO (first cell | other cells)
+  for (int streams = 1; streams <= 2 && s->n_value_streams == 0; ++streams) {
+    bool ok = true;
+    for (int k = 0; k < streams && ok; ++k) {
+      std::vector<int64_t>& L = s->stream_lo[k];
+      std::vector<int64_t>& H = s->stream_hi[k];
+      int64_t prev_hi = -1;
+      for (int r = 0; r < h.nrb && ok; ++r) {
+        int64_t lo = INT64_MAX, hi = -1, total = 0;
+        for (int c = h.rptr[r]; c < h.rptr[r + 1]; ++c) {
+          if (streams == 2 && ((c != h.rptr[r]) != (k == 1))) continue;   // class 0: the row's first cell; class 1: its other cells
+          int64_t a, b;
+          cell_range(r, c, a, b);
+          lo = std::min(lo, a); hi = std::max(hi, b); total += b - a;
+        }
+        if (hi < 0) { L[size_t(r)] = H[size_t(r)] = -1; continue; }               // no cell of this class in the row (filled in below)
+        if (hi - lo != total || (prev_hi >= 0 && lo != prev_hi)) { ok = false; break; }   // cells not back to back / not behind the previous row's
+        L[size_t(r)] = lo; H[size_t(r)] = hi; prev_hi = hi;
+      }
+      if (!ok) break;
+      // rows without a cell of the class own the empty range where the stream stands
+      int64_t at = -1;
+      for (int r = 0; r < h.nrb; ++r) { if (L[size_t(r)] >= 0) at = H[size_t(r)]; else if (at >= 0) L[size_t(r)] = H[size_t(r)] = at; }
+      at = -1;
+      for (int r = h.nrb - 1; r >= 0; --r) { if (L[size_t(r)] >= 0) at = L[size_t(r)]; else L[size_t(r)] = H[size_t(r)] = (at >= 0 ? at : 0); }
+    }
+    if (ok) s->n_value_streams = streams;
+  }
+}
+}  // namespace
+
+int ceres_hip_values_begin(ceres_hip_solver* s, const double* host_values, const double* host_residuals) {
+  if (!s || !host_values || !host_residuals) return CERES_HIP_E_INVALID;
+  if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  std::lock_guard<std::mutex> lock(s->stream_mu);
+  if (!s->copy_stream) {
+    HIP_TRY(s, hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(s, hipEventCreateWithFlags(&s->copy_done, hipEventDisableTiming));
+  }
+  if (!s->stream_plan_ready) plan_value_streams(s);
+  // the previous step may still be reading own_values / own_b on the solver's stream: the copies wait for it
+  HIP_TRY(s, hipEventRecord(s->copy_done, s->stream));
+  HIP_TRY(s, hipStreamWaitEvent(s->copy_stream, s->copy_done, 0));
+  s->stream_row_sent.assign(size_t(s->hs.nrb), 0);
+  s->stream_host_values = host_values;
+  s->stream_host_b = host_residuals;
+  s->stream_rows_sent = 0; s->stream_bytes_early = 0; s->stream_bytes_late = 0;
+  s->streaming = true;
+  return 0;
+}
+
+namespace {
+// (stream_mu held) enqueue the copies of row blocks [r0, r1) on the copy stream
+int send_rows(ceres_hip_solver* s, int r0, int r1, int64_t* bytes) {
+  const HostStructure& h = s->hs;
+  for (int k = 0; k < s->n_value_streams; ++k) {
+    const int64_t lo = s->stream_lo[k][size_t(r0)], hi = s->stream_hi[k][size_t(r1 - 1)];
+    if (hi > lo) {
+      HIP_TRY(s, hipMemcpyAsync(s->own_values + lo, s->stream_host_values + lo, sizeof(double) * size_t(hi - lo), hipMemcpyHostToDevice, s->copy_stream));
+      *bytes += 8 * (hi - lo);
+    }
+  }
+  const int64_t b0 = h.rpos[size_t(r0)], b1 = int64_t(h.rpos[size_t(r1 - 1)]) + h.rsz[size_t(r1 - 1)];
+  if (b1 > b0) {
+    HIP_TRY(s, hipMemcpyAsync(s->own_b + b0, s->stream_host_b + b0, sizeof(double) * size_t(b1 - b0), hipMemcpyHostToDevice, s->copy_stream));
+    *bytes += 8 * (b1 - b0);
+  }
+  return 0;
+}
+}  // namespace
+
+int ceres_hip_values_ready(ceres_hip_solver* s, int32_t first_row_block, int32_t num_row_blocks) {
+  if (!s) return CERES_HIP_E_INVALID;
+  if (num_row_blocks <= 0) return 0;
+  // (no s->err on this path before the lock: several evaluator threads call it at once)
+  if (hipSetDevice(s->opt.device) != hipSuccess) return CERES_HIP_E_HIP;
+  std::lock_guard<std::mutex> lock(s->stream_mu);
+  if (!s->streaming) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_values_ready outside ceres_hip_values_begin / _end");
+  const int r0 = first_row_block, r1 = first_row_block + num_row_blocks;
+  if (r0 < 0 || r1 > s->hs.nrb) return fail(s, CERES_HIP_E_INVALID, "row blocks [%d, %d) out of range", r0, r1);
+  for (int r = r0; r < r1; ++r) {
+    if (s->stream_row_sent[size_t(r)]) return fail(s, CERES_HIP_E_INVALID, "row block %d was announced twice", r);
+    s->stream_row_sent[size_t(r)] = 1;
+  }
+  s->stream_rows_sent += num_row_blocks;
+  if (s->n_value_streams == 0) return 0;   // a layout without monotone value streams: remembered, sent in _end
+  return send_rows(s, r0, r1, &s->stream_bytes_early);
+}
+
+int ceres_hip_values_end(ceres_hip_solver* s, const double* host_column_scale) {
+  if (!s) return CERES_HIP_E_INVALID;
+  HIP_TRY(s, hipSetDevice(s->opt.device));
+  std::lock_guard<std::mutex> lock(s->stream_mu);
+  if (!s->streaming) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_values_end without ceres_hip_values_begin");
+  s->streaming = false;
+  const HostStructure& h = s->hs;
+  if (s->n_value_streams == 0) {   // nothing went up early
+    HIP_TRY(s, hipMemcpyAsync(s->own_values, s->stream_host_values, sizeof(double) * size_t(h.values_extent), hipMemcpyHostToDevice, s->copy_stream));
+    HIP_TRY(s, hipMemcpyAsync(s->own_b, s->stream_host_b, sizeof(double) * size_t(h.num_rows), hipMemcpyHostToDevice, s->copy_stream));
+    s->stream_bytes_late += 8 * (h.values_extent + h.num_rows);
+  } else if (s->stream_rows_sent < h.nrb) {   // rows nobody announced: now, run by run
+    for (int r = 0; r < h.nrb;) {
+      if (s->stream_row_sent[size_t(r)]) { ++r; continue; }
+      int e = r;
+      while (e < h.nrb && !s->stream_row_sent[size_t(e)]) ++e;
+      TRY(send_rows(s, r, e, &s->stream_bytes_late));
+      r = e;
+    }
+  }
+  HIP_TRY(s, hipEventRecord(s->copy_done, s->copy_stream));
+  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->copy_done, 0));
+  TRY(load_device(s, s->own_values, s->own_b, nullptr));
+  if (host_column_scale) {   // BlockSparseMatrix::ScaleColumns on the copy in HBM (I/block_sparse_matrix.cc:403-450, I/trust_region_minimizer.cc:263-279)
+    HIP_TRY(s, hipMemcpyAsync(s->scratch_vec, host_column_scale, sizeof(double) * size_t(h.num_cols), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, LaunchGenScaleColumns(s->G, s->own_values, s->scratch_vec, s->stream));
+  }
+  return 0;
+}
+
+int ceres_hip_get_stream_stats(const ceres_hip_solver* s, int64_t* bytes_early, int64_t* bytes_late, int32_t* value_streams) {
+  if (!s) return CERES_HIP_E_INVALID;
+  if (bytes_early) *bytes_early = s->stream_bytes_early;
+  if (bytes_late) *bytes_late = s->stream_bytes_late;
+  if (value_streams) *value_streams = s->n_value_streams;
   return 0;
 }
 

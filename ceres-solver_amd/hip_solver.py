@@ -141,6 +141,10 @@ ABI = [
     ("ceres_hip_lm_compute_step", c_int32, [c_void_p, _DP, _DP, POINTER(CLmOptions), _DP, POINTER(CLmResult)]),
     ("ceres_hip_lm_compute_step_device", c_int32, [c_void_p, c_void_p, c_void_p, POINTER(CLmOptions), c_void_p, POINTER(CLmResult)]),
     ("ceres_hip_get_lm_diagonal", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_values_begin", c_int32, [c_void_p, _DP, _DP]),
+    ("ceres_hip_values_ready", c_int32, [c_void_p, c_int32, c_int32]),
+    ("ceres_hip_values_end", c_int32, [c_void_p, _DP]),
+    ("ceres_hip_get_stream_stats", c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32)]),
     ("ceres_hip_op_scale_columns", c_int32, [c_void_p, _DP, _DP]),
     ("ceres_hip_time_op", c_int32, [c_void_p, c_int32, c_int32, _DP]),
     ("ceres_hip_get_last_timing", c_int32, [c_void_p, POINTER(CTiming)]),
@@ -472,6 +476,30 @@ class HipLinearSolver:
         s = r.linear_solver
         return Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace")), \
             float(r.model_cost_change), bool(r.step_is_finite)
+
+    # -- the upload hidden behind the evaluator ---------------------------------
+    def values_begin(self, values, residuals):
+        """values / residuals: the (pinned) host arrays the evaluator is about to fill; kept alive until values_end."""
+        self._stream_keep = (_f64(values, self._values_extent, "values"), _f64(residuals, self._info.num_rows, "residuals"))
+        if self._stream_keep[0] is not values or self._stream_keep[1] is not residuals:
+            raise ValueError("values_begin needs contiguous float64 arrays (they are filled in place while rows go up)")
+        self._check(self._lib.ceres_hip_values_begin(self._h, _p(values), _p(residuals)))
+
+    def values_ready(self, first_row_block: int, num_row_blocks: int):
+        """Thread-safe: row blocks [first, first + n) are complete."""
+        rc = self._lib.ceres_hip_values_ready(self._h, int(first_row_block), int(num_row_blocks))
+        if rc != 0:
+            raise HipError(f"ceres_hip_values_ready: error {rc}")
+
+    def values_end(self, column_scale=None):
+        cs = _f64(column_scale, self._info.num_cols, "column_scale")
+        self._check(self._lib.ceres_hip_values_end(self._h, _p(cs)))
+        self._stream_keep = None
+
+    def stream_stats(self):
+        a, b, k = c_int64(0), c_int64(0), c_int32(0)
+        self._check(self._lib.ceres_hip_get_stream_stats(self._h, byref(a), byref(b), byref(k)))
+        return int(a.value), int(b.value), int(k.value)
 
     def lm_diagonal(self):
         out = np.full(self._info.num_cols, np.nan)

@@ -162,6 +162,33 @@ class HipLinearSolver final : public LinearSolver {
     return out;
   }
 
+  // The upload hidden behind the evaluator (include/ceres_hip.h: ceres_hip_values_begin / _ready / _end): BeginValues before
+  // ProgramEvaluator::Evaluate's parallel loop starts writing jacobian->values() and residuals; ValuesReady from any evaluator thread
+  // when a run of row blocks is complete; EndValues(jacobian_scaling) after the loop (the UNSCALED values went up: Jacobi scaling happens
+  // on the device); then ComputeLmStepOnStreamedValues.
+  bool BeginValues(BlockSparseMatrix* jacobian, const double* residuals, Summary* summary = nullptr) {
+    Summary local;
+    if (!EnsureStructure(jacobian, summary ? summary : &local)) return false;
+    return ceres_hip_values_begin(handle_, jacobian->values(), residuals) == CERES_HIP_OK;
+  }
+  bool ValuesReady(int first_row_block, int num_row_blocks) { return ceres_hip_values_ready(handle_, first_row_block, num_row_blocks) == CERES_HIP_OK; }
+  bool EndValues(const double* column_scale = nullptr) { return ceres_hip_values_end(handle_, column_scale) == CERES_HIP_OK; }
+  LmStep ComputeLmStepOnStreamedValues(double radius, double eta, double* step, bool reuse_diagonal = false, double min_diagonal = 1e-6,
+                                       double max_diagonal = 1e32) {
+    LmStep out;
+    ceres_hip_lm_options o{radius, min_diagonal, max_diagonal, eta, reuse_diagonal ? 1 : 0, 1};
+    ceres_hip_lm_result r{};
+    const int rc = ceres_hip_lm_compute_step(handle_, nullptr, nullptr, &o, step, &r);
+    out.summary.residual_norm = r.linear_solver.residual_norm;
+    out.summary.num_iterations = r.linear_solver.num_iterations;
+    out.summary.termination_type = rc == CERES_HIP_OK ? static_cast<LinearSolverTerminationType>(r.linear_solver.termination_type)
+                                                      : LinearSolverTerminationType::FATAL_ERROR;
+    out.summary.message = rc == CERES_HIP_OK ? r.linear_solver.message : ceres_hip_last_error(handle_);
+    out.model_cost_change = r.model_cost_change;
+    out.step_is_finite = r.step_is_finite != 0;
+    return out;
+  }
+
   Summary Solve(BlockSparseMatrix* A, const double* b, const PerSolveOptions& per_solve_options, double* x) override {
     Summary summary;
     if (!EnsureStructure(A, &summary)) return summary;

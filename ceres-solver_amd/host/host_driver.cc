@@ -5,10 +5,12 @@
 // internal/ceres/iterative_schur_complement_solver_test.cc:75-117).  Prints one line per
 // case and exits non-zero on any mismatch; then the whole Levenberg-Marquardt step (ComputeLmStep) on the BAL-shaped problem
 // against dense algebra.  Built by build.py with g++ against the C ABI.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "hip_linear_solver.h"
@@ -177,6 +179,85 @@ int RunLmStep(const char* name, BlockSparseMatrix* A, const std::vector<double>&
   return ok ? 0 : 1;
 }
 
+// The same step with the Jacobian STREAMED up by eight "evaluator" threads (ceres_hip_values_begin / _ready / _end): every thread
+// writes its runs of row blocks into the host arrays the solver was given — the E cells and the F cells of the rows, and their
+// residuals, as BlockJacobianWriter lays them out — and announces each run; the values go up UNSCALED and EndValues applies a column
+// scaling on the device.  Checked against ComputeLmStep on the host-scaled Jacobian (same solver type): the two must agree to rounding.
+int RunStreamedLmStep(const char* name, BlockSparseMatrix* A, const std::vector<double>& f, int nelim, LinearSolverType type,
+                      PreconditionerType pre, bool with_scale) {
+  LinearSolver::Options o;
+  o.type = type;
+  o.preconditioner_type = pre;
+  o.min_num_iterations = 0;
+  o.max_num_iterations = 4 * A->num_cols();
+  o.elimination_groups = {type == CGNR ? 0 : nelim};
+  const int n = A->num_cols();
+  const auto* bs = A->block_structure();
+  const int nrb = int(bs->rows.size());
+  std::vector<double> scale(n, 1.0);
+  if (with_scale) for (int j = 0; j < n; ++j) scale[j] = 1.0 / (1.0 + 0.01 * (j % 17));
+  // reference: the scaled Jacobian through the plain entry point
+  const std::vector<double> unscaled(A->values(), A->values() + A->num_nonzeros());
+  std::vector<double> scaled = unscaled;
+  for (const auto& r : bs->rows)
+    for (const auto& c : r.cells) {
+      const Block& cb = bs->cols[c.block_id];
+      for (int i = 0; i < r.block.size; ++i)
+        for (int j = 0; j < cb.size; ++j) scaled[c.position + i * cb.size + j] *= scale[cb.position + j];
+    }
+  std::vector<double> ref(n, std::nan("")), step(n, std::nan(""));
+  double ref_cost = 0;
+  {
+    for (int i = 0; i < A->num_nonzeros(); ++i) A->mutable_values()[i] = scaled[i];
+    HipLinearSolver solver(o);
+    const auto r = solver.ComputeLmStep(A, f.data(), 1e4, 1e-13, ref.data());
+    ref_cost = r.model_cost_change;
+    if (r.summary.termination_type != LinearSolverTerminationType::SUCCESS) { std::printf("FAIL %s: reference step: %s\n", name, r.summary.message.c_str()); return 1; }
+  }
+  // streamed: the host arrays start as garbage and are filled by the threads
+  for (int i = 0; i < A->num_nonzeros(); ++i) A->mutable_values()[i] = std::nan("");
+  std::vector<double> fh(f.size(), std::nan(""));
+  HipLinearSolver solver(o);
+  if (!solver.BeginValues(A, fh.data())) { std::printf("FAIL %s: BeginValues: %s\n", name, ceres_hip_last_error(solver.handle())); return 1; }
+  const int kThreads = 8, kRun = 5;
+  std::atomic<int> next{0}, failed{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < kThreads; ++t)
+    pool.emplace_back([&, t] {
+      for (;;) {
+        const int r0 = next.fetch_add(kRun);
+        if (r0 >= nrb) break;
+        const int r1 = std::min(nrb, r0 + kRun);
+        for (int r = r0; r < r1; ++r) {
+          const auto& row = bs->rows[r];
+          for (const auto& c : row.cells) {
+            const int len = row.block.size * bs->cols[c.block_id].size;
+            for (int i = 0; i < len; ++i) A->mutable_values()[c.position + i] = unscaled[c.position + i];
+          }
+          for (int i = 0; i < row.block.size; ++i) fh[row.block.position + i] = f[row.block.position + i];
+        }
+        if (t % 3 == 2 && r1 - r0 > 1) {   // some threads announce row by row, the last row first
+          for (int r = r1 - 1; r >= r0; --r) if (!solver.ValuesReady(r, 1)) failed = 1;
+        } else if (t % 3 == 1 && r0 % (2 * kRun) == 0) {
+          // ... and some runs are never announced: EndValues must send them
+        } else if (!solver.ValuesReady(r0, r1 - r0)) failed = 1;
+      }
+    });
+  for (auto& th : pool) th.join();
+  if (failed || !solver.EndValues(with_scale ? scale.data() : nullptr)) { std::printf("FAIL %s: streaming: %s\n", name, ceres_hip_last_error(solver.handle())); return 1; }
+  const auto r = solver.ComputeLmStepOnStreamedValues(1e4, 1e-13, step.data());
+  int64_t early = 0, late = 0; int32_t streams = 0;
+  ceres_hip_get_stream_stats(solver.handle(), &early, &late, &streams);
+  for (int i = 0; i < A->num_nonzeros(); ++i) A->mutable_values()[i] = unscaled[i];   // leave A as it was
+  double num = 0, den = 0;
+  for (int j = 0; j < n; ++j) { num += (step[j] - ref[j]) * (step[j] - ref[j]); den += ref[j] * ref[j]; }
+  const double err = std::sqrt(num / den), cost_err = std::fabs(r.model_cost_change - ref_cost) / std::fabs(ref_cost);
+  const bool ok = r.summary.termination_type == LinearSolverTerminationType::SUCCESS && r.step_is_finite && err <= 1e-12 && cost_err <= 1e-12 && streams > 0 && early > 0;
+  std::printf("%s %-28s type=%d scale=%d value_streams=%d bytes_early=%lld bytes_late=%lld step_rel_diff=%.2e model_cost_rel_diff=%.2e (%s)\n", ok ? "PASS" : "FAIL", name,
+              int(type), int(with_scale), int(streams), (long long)early, (long long)late, err, cost_err, r.summary.message.c_str());
+  return ok ? 0 : 1;
+}
+
 }  // namespace
 
 // host_driver <problem.txt> [max_num_iterations]: BALProblem + Evaluator + TrustRegionMinimizer through the C++ mirror
@@ -222,6 +303,11 @@ int main(int argc, char** argv) {
   // the step ends on the zeta test (q_tolerance = eta), not on a residual: 1e-6 on the step, the model cost is second order in it
   bad += RunLmStep("lm step bal<2,3,9>", bal.get(), b, nelim, ITERATIVE_SCHUR, SCHUR_JACOBI, 1e-6);
   bad += RunLmStep("lm step bal<2,3,9>", bal.get(), b, nelim, CGNR, JACOBI, 1e-6);
+  // the Jacobian streamed up by eight evaluator threads while "evaluation" is still going on, unscaled, Jacobi scaling on the device
+  auto big = SmallBal(23, 900, &b, &D, &nelim);
+  bad += RunStreamedLmStep("streamed lm step bal<2,3,9>", big.get(), b, nelim, ITERATIVE_SCHUR, SCHUR_JACOBI, false);
+  bad += RunStreamedLmStep("streamed lm step bal<2,3,9>", big.get(), b, nelim, ITERATIVE_SCHUR, SCHUR_JACOBI, true);
+  bad += RunStreamedLmStep("streamed lm step bal<2,3,9>", big.get(), b, nelim, CGNR, JACOBI, true);
   std::printf(bad ? "host_driver: %d case(s) FAILED\n" : "host_driver: all cases passed\n", bad);
   return bad ? 1 : 0;
 }

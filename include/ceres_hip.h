@@ -382,6 +382,29 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* host_values, co
 int ceres_hip_lm_compute_step_device(ceres_hip_solver* s, const double* dev_values, const double* dev_residuals,
                                      const ceres_hip_lm_options* options, double* dev_step,
                                      ceres_hip_lm_result* result);
+/* ---- the upload hidden behind the evaluator ---------------------------------------------------------------
+ * Through ceres_hip_lm_compute_step a step on a Venice-sized problem costs 21 ms, 18.4 of them the host-to-device copy of the
+ * Jacobian the CPU Evaluator has just written (1.04 GB at 56 GB/s).  The evaluator writes it row block by row block, over hundreds of
+ * milliseconds and from several threads (ProgramEvaluator::Evaluate's parallel loop, I/program_evaluator.h:168-300, into the pinned
+ * values_ of BlockSparseMatrix(use_page_locked_memory), I/block_jacobian_writer.cc:261-262): finished rows can go up while later
+ * rows are still being evaluated.
+ *   _begin(values, residuals)      before the evaluator starts: the host arrays it will fill (pinned for the copies to be asynchronous;
+ *                                  they must stay valid until _end returns)
+ *   _ready(first_row_block, n)     THREAD-SAFE; row blocks [first, first + n) are complete in both arrays: their value ranges and
+ *                                  residuals are enqueued on a copy stream.  Every row block at most once; any order; any granularity.
+ *                                  (Layouts whose rows are not one or two monotone value streams — Ceres' own are: all E cells then
+ *                                  all F cells in row order, or row-sequential — are remembered and sent by _end.)
+ *   _end(column_scale)             rows nobody announced go up now; the solver's stream waits for the copies; column_scale != NULL:
+ *                                  BlockSparseMatrix::ScaleColumns on the copy in HBM (I/block_sparse_matrix.cc:403-450) — the evaluator
+ *                                  hands over the UNSCALED Jacobian, Jacobi scaling (I/trust_region_minimizer.cc:263-279) happens here.
+ * The values then count as loaded by ceres_hip_load: ceres_hip_lm_compute_step(s, NULL, NULL, {.., values_unchanged = 1}, ..) computes the
+ * step without another copy (the first pass re-lays the tiles out as after any load).                                              */
+int ceres_hip_values_begin(ceres_hip_solver* s, const double* host_values, const double* host_residuals);
+int ceres_hip_values_ready(ceres_hip_solver* s, int32_t first_row_block, int32_t num_row_blocks);
+int ceres_hip_values_end(ceres_hip_solver* s, const double* host_column_scale);
+/* bytes that went up before / inside _end of the last streamed upload; value streams of the layout (0: not streamable, 1, 2) */
+int ceres_hip_get_stream_stats(const ceres_hip_solver* s, int64_t* bytes_early, int64_t* bytes_late, int32_t* value_streams);
+
 /* The D the last ceres_hip_lm_compute_step* used (num_cols doubles). */
 int ceres_hip_get_lm_diagonal(ceres_hip_solver* s, double* host_D);
 /* values[.., col] *= scale[col] on the loaded (device) copy; returns the scaled values if
