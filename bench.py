@@ -147,6 +147,8 @@ def parse():
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=-1, help="also time the fp32-tile storage mode (extra.fp32_tiles; BASELINE.json configs[4] asks for a sweep over both "
                                                                "precisions): -1 = on the default Venice line, 1 = on, 0 = off")
+    ap.add_argument("--extra-configs", type=int, default=1, help="default line: BASELINE.json configs[1] (Dubrovnik-16, CGNR + JACOBI) and configs[2] "
+                                                                 "(Ladybug-1723, ITERATIVE_SCHUR + SCHUR_JACOBI): steps/s, operator roofline, oracle check, CPU port (extra.configs)")
     ap.add_argument("--shard-ceiling", type=int, default=1,
                     help="N = 1: also run rank 0's shard of the workload for N = 2, 4, 8 alone on the device with the sharded code path on "
                          "(ghost peers) and report T_1 / (N T_shard) as extra.shard_ceiling (0: skip)")
@@ -231,6 +233,65 @@ def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta
         iters.append(s.num_iterations)
     sync()
     return time.perf_counter() - t0, iters, s
+
+
+def config_leg(pkg, hs, entry, workload, solver_kind, device, dev, args, no_cpu=False):
+    """One of BASELINE.json's smaller configurations on the line: steps/s of the LM step, the operator against the HBM roofline, the
+    step against the oracle at full size, and the oracle's own rate (the CPU port) on the same inputs."""
+    n_cams, n_points, n_obs = pkg.problems.BAL_SHAPES[workload]
+    p = pkg.problems.synthetic_bal(workload, layout="schur", seed=38401, skew=args.skew)
+    sv = make_solver(hs, p.bs, p.num_eliminate_blocks, solver_kind, device)
+    tvc, tbc = torch.from_numpy(p.values).to(dev), torch.from_numpy(p.b).to(dev)
+    txc = torch.full((p.bs.num_cols,), float("nan"), dtype=torch.float64, device=dev)
+    n_st = max(args.steps, 50)
+    el, its, last = timed_steps(sv, (tvc, tbc, None, txc), n_st, max(args.warmup, 5), torch.cuda.synchronize, "lm_step", args.eta)
+    kind = "jtjx" if solver_kind == "cgnr" else "sx"
+    # (the operator on the state the last step left loaded: the same values, D = the step's LM diagonal)
+    op_ms = min(sv.time_op(hs.TIMED_JTJX if kind == "jtjx" else hs.TIMED_SX, args.kernel_iters) for _ in range(3))
+    nb = algorithmic_bytes(kind, n_obs, n_points, n_cams)
+    mb = step_min_bytes(solver_kind, n_obs, n_points, n_cams, int(its[-1]))
+    ms = 1e3 * el / n_st
+    case = {"workload": f"{workload}-shaped synthetic BAL Jacobian <2,3,9>: {n_cams} cameras, {n_points} points, {n_obs} observations",
+            "solver": "CGNR + JACOBI" if solver_kind == "cgnr" else "ITERATIVE_SCHUR + SCHUR_JACOBI", "steps_per_s": round(n_st / el, 2), "ms_per_step": round(ms, 4),
+            "cg_iterations_per_step": int(its[-1]), "termination": hs.TERMINATION_NAMES[last.termination_type],
+            kind: {"ms": round(op_ms, 5), "GBs": round(nb / (op_ms * 1e-3) / 1e9, 1), "frac": round(nb / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "algorithmic_bytes_per_launch": nb},
+            "step_roofline_frac": round(mb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "cg_iteration_in_operator": int(sv.info().cg_iteration_in_operator)}
+    xg = txc.cpu().numpy()
+    sv.close()
+    del tvc, tbc, txc
+    if not no_cpu:
+        oracle = entry.load_oracle()
+        threads = min(os.cpu_count() or 1, 16)
+        oracle.set_num_threads(threads)
+        m = oracle.Matrix(p.bs, p.num_eliminate_blocks if solver_kind != "cgnr" else 0)
+        m_all = oracle.Matrix(p.bs, 0)
+        fn = m.iterative_schur_solve if solver_kind != "cgnr" else m.cgnr_solve
+        pre = 2 if solver_kind != "cgnr" else 1
+
+        def one(lo=0, hi=500, q=args.eta):
+            t = time.perf_counter()
+            Dc = np.sqrt(np.clip(m_all.squared_column_norm(p.values), 1e-6, 1e32) / RADIUS)
+            xo, so = fn(p.values, p.b, Dc, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=-1.0)
+            xo = -xo
+            model = m_all.right_multiply(p.values, xo)
+            _ = -model @ (p.b + model / 2.0)
+            return time.perf_counter() - t, xo, so
+        one()
+        n_done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0 and n_done < 200:
+            _, xo, so = one()
+            n_done += 1
+        cpu_t = time.perf_counter() - t0
+        if so.num_iterations != int(its[-1]):   # zeta crossed the threshold one index apart: the oracle's iterate of the product's index
+            k_ = int(its[-1])
+            _, xo, _ = one(k_, k_, -1.0)
+        oracle.set_num_threads(1)
+        case["cpu_port"] = {"steps_per_s": round(n_done / cpu_t, 3), "threads": threads, "cg_iterations": int(so.num_iterations), "sample": f"{n_done} steps in {cpu_t:.1f} s"}
+        case["step_rel_diff_vs_oracle"] = float(np.linalg.norm(xg - xo) / np.linalg.norm(xo))
+        case["speedup_vs_cpu_port"] = round((n_st / el) / (n_done / cpu_t), 1)
+    return case
 
 
 def phase_timing(solver, ptrs, step_kind="lm_step", eta=0.1, radius=None):
@@ -693,6 +754,17 @@ def main():
                     extra["conditioned_step"] = conditioned
                 except Exception as ex:  # the default line must not depend on it
                     extra["conditioned_step"] = {"error": repr(ex)[:400]}
+    # ---- BASELINE.json configs[1] and configs[2] on the driver line: the same step on the two smaller shapes ----
+    if world == 1 and args.extra_configs and args.workload == "venice1778" and not storage:
+        try:
+            extra["configs"] = {"what": "BASELINE.json configs[1] (BAL 16-22106, CGNR + JACOBI) and configs[2] (BAL Ladybug 1723-156502, ITERATIVE_SCHUR + "
+                                        "SCHUR_JACOBI) as synthetic Jacobians of those block counts: the same LM step through the same entry point, inputs "
+                                        "resident in HBM; operator = the step's dominant kernel(s) by HIP events; the oracle on the same inputs beside it",
+                                "cases": [config_leg(pkg, hs, entry, wl_c, sv_c, local_rank, dev, args, no_cpu=args.no_cpu_baseline)
+                                          for wl_c, sv_c in (("dubrovnik16", "cgnr"), ("ladybug1723", "iterative_schur"))]}
+        except Exception as ex:  # the default line must not depend on it
+            extra["configs"] = {"error": repr(ex)[:400]}
+
     # ---- strong-scaling ceiling measured on ONE GPU: rank 0's shard with the sharded code path on ----
     if world == 1 and args.shard_ceiling and not storage and info.kernel_path == hs.PATH_BAL:
         try:
