@@ -487,7 +487,10 @@ def main():
 
     def kernel_name(k):
         mode = "kJtJx" if k == "jtjx" else "kSx"
-        body = f"bal_stream_kernel<{mode}, fp32 tiles>" if storage else f"bal_stream_kernel<{mode}>"
+        # (the pipelined kernel runs unless an A/B switch says otherwise — kernels_bal.inc: UsePipeline, F32Pipelined)
+        pipelined = os.environ.get("CERES_HIP_PIPELINE", "1") != "0" and not (storage and os.environ.get("CERES_HIP_F32_PIPELINE", "1") == "0")
+        kern = "bal_stream_kernel" if pipelined else "bal_fused_kernel"
+        body = f"{kern}<{mode}, fp32 tiles>" if storage else f"{kern}<{mode}>"
         if info.camera_accum_in_lds:
             return body + " + bal_reduce_partials_kernel"
         return body + " (per-slot F'z, cameras do not fit in LDS) + bal_camera_chunk_kernel + bal_reduce_partials_kernel"
@@ -792,7 +795,7 @@ def main():
         ms32 = s32.time_op(hs.TIMED_JTJX if kind == "jtjx" else hs.TIMED_SX, args.kernel_iters)
         nb32 = algorithmic_bytes(kind, my_obs, my_points, n_cams, 4)
         extra["fp32_tiles"] = {"what": "Jacobian tiles rounded to fp32, fp64 arithmetic (BASELINE.json configs[4] asks for both precisions): an accuracy mode, never parity; "
-                                       "round 5: through the software-pipelined kernels like the fp64 tiles (CERES_HIP_F32_PIPELINE=0: the unpipelined ones)",
+                                       "through the software-pipelined kernels like the fp64 tiles (CERES_HIP_F32_PIPELINE=0: the unpipelined ones)",
                                "steps_per_s": round(n32 / e32, 3), "ms_per_step": round(1e3 * e32 / n32, 4), "cg_iterations": it32[-1],
                                f"{kind}_ms": round(ms32, 5), f"{kind}_frac_hbm_of_fp32_bytes": round(nb32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "step_rel_diff_vs_fp64": float((torch.linalg.norm(tx32 - tx) / torch.linalg.norm(tx)).item())}

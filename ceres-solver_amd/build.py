@@ -20,7 +20,7 @@ SOURCES = (["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal_com
            [f"kernels_bal_shape_e{ne}_f{nf}_s0.hip" for ne, nf in BAL_SHAPES_E] +
            [f"kernels_bal_shape_r{nr}_e{ne}_f{nf}_s0.hip" for nr, ne, nf in BAL_SHAPES_R] +
            ["kernels_schur.hip", "kernels_evaluator.hip", "solver.hip"])
-HEADERS = ["common.h", "device.h", "snavely.h", "bal_frontend.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
+HEADERS = ["common.h", "device.h", "p2p.h", "snavely.h", "bal_frontend.inc", "solver_comm.inc", "solver_stream.inc", "solver_ops.inc", "solver_debug.inc", "kernels_bal.inc", os.path.join("..", "..", "include", "ceres_hip.h")]
 HOST_DRIVER_SRC = os.path.join(HERE, "host", "host_driver.cc")
 HOST_DRIVER = os.path.join(HERE, "host", "host_driver")
 
@@ -67,7 +67,8 @@ def build_host_driver(force=False, verbose=False):
     """The C++ host-side mirror of ceres::internal::LinearSolver + a small driver (g++, links the C ABI)."""
     if not os.path.exists(HOST_DRIVER_SRC):
         return None
-    deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), os.path.join(HERE, "host", "hip_bal_problem.h"), OUT]
+    deps = [HOST_DRIVER_SRC, os.path.join(HERE, "host", "hip_linear_solver.h"), os.path.join(HERE, "host", "flatten_block_structure.h"),
+            os.path.join(HERE, "host", "hip_bal_problem.h"), OUT]
     if force or _stale(HOST_DRIVER, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"), "-I", os.path.join(HERE, "host"),
                HOST_DRIVER_SRC, "-o", HOST_DRIVER, "-pthread", "-L", CSRC, "-lceres_hip", "-Wl,-rpath," + CSRC,

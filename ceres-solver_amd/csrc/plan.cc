@@ -722,7 +722,10 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
 
   // The word the kernels read per slot: camera id | accumulator row << kSlotCamBits (kSlotSpill: no LDS row, the slot's F^T z is
-  // spilled).  With the accumulators of ALL cameras in LDS the row is the camera id itself and the upper bits stay 0.
+  // spilled).  With the accumulators of ALL cameras in LDS the accumulator row is the camera id itself; the word's row field then says
+  // whether the camera's part of x is STAGED in LDS (row + 1 of xhot_cam, 0: not) — set whenever the plan ranks cameras, also for a solver
+  // that ends up launching without the staged x (few tiles per workgroup, a kernel whose static LDS leaves no room): every LDS-mode
+  // consumer masks the field (finish_slot, kernels_bal.inc); nothing may read the word raw as a camera id.
   P.slot_word.assign(P.slot_cam.begin(), P.slot_cam.end());
   for (auto& w : P.slot_word) if (w == -2) w = 0;   // no camera cell: the tiles hold zeros for F, any camera's row takes the zero sums
   P.xhot_cam.clear();

@@ -378,10 +378,9 @@ BalArgs bal_args(ceres_hip_solver* s) {
   A.hyb_rows = s->plan.hybrid ? s->plan.hyb_rows : 0; A.z_flush_row0 = s->plan.z_flush_row0;
   A.mo_index = s->d_mo_index;
   A.n_acc = s->plan.nf * s->plan.n_cameras + s->plan.ns;
-  // (a workgroup stages its copy once per launch: that pays from about a hundred tiles per workgroup on — Ladybug-sized problems, 41
-  // tiles per workgroup, lose 3 us of a 42 us pass to it: profiles/r05n_*)
-  A.xhot_cam = s->d_xhot_cam; A.n_xhot = (s->d_xhot_cam && s->plan.n_tiles >= int64_t(100) * s->fused_grid) ? int(s->plan.xhot_cam.size()) : 0;
-  A.x_lds_scalars = (s->lds_mode && s->plan.n_tiles >= int64_t(100) * s->fused_grid) ? s->plan.nf * s->plan.n_cameras : 0;
+  // (the dispatcher drops both for launches of fewer than about a hundred tiles per workgroup: kernels_bal.inc, Fused)
+  A.xhot_cam = s->d_xhot_cam; A.n_xhot = s->d_xhot_cam ? int(s->plan.xhot_cam.size()) : 0;
+  A.x_lds_scalars = s->lds_mode ? s->plan.nf * s->plan.n_cameras : 0;
   A.cam_base = s->plan.cam_base;
   for (int j = 0; j < kMaxSharedScalars; ++j) A.sh_pos[j] = j < s->plan.ns_used ? s->plan.sh_pos[j] : -1;
   A.have_b = s->have_b ? 1 : 0;
@@ -2366,223 +2365,7 @@ int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info) {
   return 0;
 }
 
-int ceres_hip_comm_get_unique_id(uint8_t id[CERES_HIP_UNIQUE_ID_BYTES]) {
-  static_assert(sizeof(ncclUniqueId) == CERES_HIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
-  ncclUniqueId u;
-  if (ncclGetUniqueId(&u) != ncclSuccess) return CERES_HIP_E_COMM;
-  memcpy(id, &u, sizeof(u));
-  return 0;
-}
-
-int ceres_hip_comm_init(ceres_hip_solver* s, const uint8_t id[CERES_HIP_UNIQUE_ID_BYTES], int32_t rank, int32_t world) {
-  if (!s || !id || world < 1 || rank < 0 || rank >= world) return CERES_HIP_E_INVALID;
-  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_init before ceres_hip_set_structure");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  s->rank = rank; s->world = world;
-  if (world == 1) return 0;
-  ncclUniqueId u;
-  memcpy(&u, id, sizeof(u));
-  NCCL_TRY(s, ncclCommInitRank(&s->comm, world, u, rank));
-  return 0;
-}
-
-// ---- peer-to-peer communicator ---------------------------------------------------------------
-// Step 1 (every rank): allocate this rank's receive buffer and hand out its hipIpc handle.
-int ceres_hip_comm_p2p_prepare(ceres_hip_solver* s, int32_t rank, int32_t world, int64_t max_elements,
-                               uint8_t handle_out[CERES_HIP_IPC_HANDLE_BYTES]) {
-  static_assert(sizeof(hipIpcMemHandle_t) == CERES_HIP_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
-  if (!s || !handle_out || world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world || max_elements < 1) return CERES_HIP_E_INVALID;
-  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_p2p_prepare before ceres_hip_set_structure");
-  if (s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "peer-to-peer buffer already prepared");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  s->rank = rank; s->world = world;
-  s->p2p_cap = ((max_elements + kP2pChunk - 1) / kP2pChunk) * kP2pChunk;
-  s->p2p_chunks_cap = int(s->p2p_cap / kP2pFlagChunk) + 8;
-  const size_t flag_bytes = ((size_t(2) * world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
-  s->p2p_bytes = flag_bytes + size_t(2) * world * size_t(s->p2p_cap) * sizeof(double);
-  // fine-grained: writes arriving from another device (or another XCD's L2) must be visible to this rank's loads.
-  // CERES_HIP_P2P_COARSE=1 (or a runtime that cannot export a fine-grained allocation) falls back to hipMalloc; the
-  // kernel's system-scope release / acquire fences are what a same-device pair of ranks then relies on.
-  hipIpcMemHandle_t h;
-  const char* coarse = getenv("CERES_HIP_P2P_COARSE");
-  bool ok = false;
-  if (!(coarse && atoi(coarse) != 0)) {
-    if (hipExtMallocWithFlags(&s->p2p_base, s->p2p_bytes, hipDeviceMallocFinegrained) == hipSuccess) {
-      if (hipIpcGetMemHandle(&h, s->p2p_base) == hipSuccess) { ok = true; s->p2p_fine_grained = true; }
-      else { (void)hipFree(s->p2p_base); s->p2p_base = nullptr; }
-    }
-    (void)hipGetLastError();
-  }
-  if (!ok) {
-    HIP_TRY(s, hipMalloc(&s->p2p_base, s->p2p_bytes));
-    HIP_TRY(s, hipIpcGetMemHandle(&h, s->p2p_base));
-  }
-  HIP_TRY(s, hipMemset(s->p2p_base, 0, s->p2p_bytes));
-  HIP_TRY(s, hipHostMalloc(reinterpret_cast<void**>(&s->h_comm_error), sizeof(int), hipHostMallocMapped));
-  *s->h_comm_error = 0;
-  HIP_TRY(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_comm_error), s->h_comm_error, 0));
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error_seen), sizeof(int)));
-  HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
-  HIP_TRY(s, hipDeviceSynchronize());
-  { const char* e = getenv("CERES_HIP_P2P_TIMEOUT"); if (e && atof(e) > 0) s->p2p_timeout_s = atof(e); }
-  memcpy(handle_out, &h, sizeof(h));
-  return 0;
-}
-
-// Step 2 (every rank, after the host gathered all handles in rank order): map the peers' buffers.
-int ceres_hip_comm_p2p_connect(ceres_hip_solver* s, const uint8_t* all_handles) {
-  if (!s || !all_handles) return CERES_HIP_E_INVALID;
-  if (!s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "call ceres_hip_comm_p2p_prepare first");
-  if (s->p2p) return fail(s, CERES_HIP_E_INVALID, "peers already connected");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const size_t flag_bytes = ((size_t(2) * s->world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
-  for (int q = 0; q < s->world; ++q) {
-    void* base = s->p2p_base;
-    if (q != s->rank) {
-      hipIpcMemHandle_t h;
-      memcpy(&h, all_handles + size_t(q) * CERES_HIP_IPC_HANDLE_BYTES, sizeof(h));
-      HIP_TRY(s, hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
-      s->p2p_opened[q] = base;
-    }
-    s->p2p_peers.flags[q] = reinterpret_cast<unsigned long long*>(base);
-    s->p2p_peers.slots[q] = reinterpret_cast<double*>(static_cast<char*>(base) + flag_bytes);
-  }
-  s->p2p = true;
-  // The path is enabled only after it has carried known values: a coarse-grained receive buffer (the fallback of _prepare) written by
-  // ANOTHER device may keep stale lines in this device's L2 across slot re-use, which only shows in the data.  Every rank is inside
-  // _connect at this point (it is collective), so the self-test can run here; on failure the path stays disabled on this rank and
-  // the callers agree on the verdict out of band (ceres_hip_comm_p2p_disable everywhere, RCCL takes over).
-  return ceres_hip_comm_p2p_selftest(s);
-}
-
-// Self-test of the peer-to-peer all-reduce, a collective (every rank calls it): kSelfTestRounds all-reduces of a vector that spans
-// several chunks, with different values every round — round t sums (rank + 1)(t + 1) + i % 7 over ranks.  More than two rounds
-// matter: a slot is re-used every second epoch, so a receive buffer whose lines a cache keeps across epochs (a coarse-grained
-// allocation written by ANOTHER device) passes the first two rounds and fails the third.  Non-zero, with the communicator left
-// disabled, if a peer did not arrive in CERES_HIP_P2P_SELFTEST_TIMEOUT seconds (default 5) or a sum is wrong; callers then
-// agree (e.g. by an all-reduce of the verdict over their bootstrap transport) and fall back to RCCL with
-// ceres_hip_comm_p2p_disable on every rank.
-int ceres_hip_comm_p2p_selftest(ceres_hip_solver* s) {
-  if (!s || !s->p2p) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  constexpr int kSelfTestRounds = 6;
-  // (odd rounds: a vector long enough for the multi-chunk round trips of the long-vector kernel, where the slots allow)
-  const int n_short = int(std::min<int64_t>(s->p2p_cap, 2 * kP2pChunk + 3));
-  const int n = int(std::min<int64_t>(s->p2p_cap, 64 * 1024 + 2 * kP2pChunk + 3));
-  std::vector<double> h(n);
-  double* d = nullptr;
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(double)));
-  const double keep = s->p2p_timeout_s;
-  { const char* e = getenv("CERES_HIP_P2P_SELFTEST_TIMEOUT"); s->p2p_timeout_s = (e && atof(e) > 0) ? atof(e) : 5.0; }
-  int rc = 0;
-  const double w = double(s->world);
-  for (int t = 0; t < kSelfTestRounds && !rc; ++t) {
-    const int nt = (t & 1) ? n : n_short;
-    for (int i = 0; i < nt; ++i) h[i] = double(s->rank + 1) * (t + 1) + double(i % 7);
-    if (hipMemcpyAsync(d, h.data(), size_t(nt) * sizeof(double), hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-    if (!rc) rc = allreduce(s, d, size_t(nt));
-    if (!rc && hipMemcpyAsync(h.data(), d, size_t(nt) * sizeof(double), hipMemcpyDeviceToHost, s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-    if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-    if (!rc) rc = check_comm_error(s);
-    for (int i = 0; i < nt && !rc; ++i) {
-      const double want = (t + 1) * w * (w + 1.0) / 2.0 + w * double(i % 7);
-      if (h[i] != want) rc = fail(s, CERES_HIP_E_COMM, "peer-to-peer self-test: round %d element %d is %g, expected %g (world %d, %s receive buffer)",
-                                  t, i, h[i], want, s->world, s->p2p_fine_grained ? "fine-grained" : "coarse-grained");
-    }
-  }
-  s->p2p_timeout_s = keep;
-  (void)hipFree(d);
-  if (rc) s->p2p = false;
-  return rc;
-}
-
-// Collective timing probe: `iters` back-to-back all-reduces of n doubles on the solver's stream (whichever path allreduce()
-// takes for that size), HIP events around them; average microseconds per all-reduce.  For the latency budget of DESIGN.md §5.
-int ceres_hip_debug_allreduce_timing(ceres_hip_solver* s, int64_t n, int32_t iters, double* avg_us) {
-  if (!s || !avg_us || n < 1 || iters < 1 || s->world < 2) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  double* d = nullptr;
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d), size_t(n) * sizeof(double)));
-  HIP_TRY(s, hipMemsetAsync(d, 0, size_t(n) * sizeof(double), s->stream));
-  int rc = 0;
-  for (int w = 0; w < 3 && !rc; ++w) rc = allreduce(s, d, size_t(n));
-  if (!rc && hipEventRecord(s->ev[8], s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  for (int i = 0; i < iters && !rc; ++i) rc = allreduce(s, d, size_t(n));
-  if (!rc && hipEventRecord(s->ev[9], s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = CERES_HIP_E_HIP;
-  if (!rc) rc = check_comm_error(s);
-  if (!rc) *avg_us = 1e3 * double(elapsed(s->ev[8], s->ev[9])) / iters;
-  (void)hipFree(d);
-  return rc;
-}
-
-// Stop using the peer-to-peer path (all-reduces go to RCCL, which must then be connected).
-int ceres_hip_comm_p2p_disable(ceres_hip_solver* s) {
-  if (!s) return CERES_HIP_E_INVALID;
-  s->p2p = false;
-  s->cam_exchange_agreed = false;
-  s->spec_agreed = false;
-  if (s->h_comm_error) {
-    HIP_TRY(s, hipSetDevice(s->opt.device));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    *s->h_comm_error = 0;
-    HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
-  }
-  return 0;
-}
-
-// Debug: drive every `world > 1` branch on ONE GPU.  A 1-rank RCCL communicator is created
-// (so the all-reduces really go through ncclAllReduce on the solver's stream) while the
-// solver behaves as rank 0 of `logical_world` ranks.  With the whole problem given to this
-// instance the other ranks' contributions are zero, so results must equal the unsharded ones.
-int ceres_hip_debug_comm_loopback(ceres_hip_solver* s, int32_t logical_world) {
-  if (!s || logical_world < 2) return CERES_HIP_E_INVALID;
-  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call before ceres_hip_set_structure");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  ncclUniqueId u;
-  NCCL_TRY(s, ncclGetUniqueId(&u));
-  NCCL_TRY(s, ncclCommInitRank(&s->comm, 1, u, 0));
-  s->rank = 0;
-  s->world = logical_world;
-  return 0;
-}
-
-// Measurement: rank 0 of `logical_world` ranks whose peers are GHOSTS — the peer-to-peer all-reduce kernel does everything it does
-// between real ranks (push the chunk into every peer's slot, set every peer's flag, wait for the peers' flags, add the `world` slots
-// in rank order) but the peers' buffers are one local dummy allocation and their arrival flags in this rank's buffer are preset to
-// "arrived for every epoch", their slots to zero.  One rank's SHARD of a problem then runs the sharded code path alone on the device
-// at the cost a perfect interconnect would give (bench.py: extra.shard_ceiling); its sums are the shard's own (the ghosts add 0).
-int ceres_hip_debug_comm_ghost_peers(ceres_hip_solver* s, int32_t logical_world, int64_t max_elements) {
-  if (!s || logical_world < 2 || logical_world > kP2pMaxWorld || max_elements < 1) return CERES_HIP_E_INVALID;
-  if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "call before ceres_hip_set_structure");
-  if (s->p2p_base) return fail(s, CERES_HIP_E_INVALID, "peer-to-peer buffer already prepared");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  s->rank = 0; s->world = logical_world;
-  s->p2p_cap = ((max_elements + kP2pChunk - 1) / kP2pChunk) * kP2pChunk;
-  s->p2p_chunks_cap = int(s->p2p_cap / kP2pFlagChunk) + 8;
-  const size_t flag_bytes = ((size_t(2) * s->world * s->p2p_chunks_cap * sizeof(unsigned long long) + 4095) / 4096) * 4096;
-  s->p2p_bytes = flag_bytes + size_t(2) * s->world * size_t(s->p2p_cap) * sizeof(double);
-  HIP_TRY(s, hipMalloc(&s->p2p_base, s->p2p_bytes));
-  void* ghost = nullptr;
-  HIP_TRY(s, hipMalloc(&ghost, s->p2p_bytes));
-  s->allocs.push_back(ghost);
-  HIP_TRY(s, hipMemset(s->p2p_base, 0, s->p2p_bytes));
-  HIP_TRY(s, hipMemset(s->p2p_base, 0xFF, flag_bytes));   // every peer has "arrived" at every epoch
-  HIP_TRY(s, hipMemset(ghost, 0, s->p2p_bytes));
-  HIP_TRY(s, hipHostMalloc(reinterpret_cast<void**>(&s->h_comm_error), sizeof(int), hipHostMallocMapped));
-  *s->h_comm_error = 0;
-  HIP_TRY(s, hipHostGetDevicePointer(reinterpret_cast<void**>(&s->d_comm_error), s->h_comm_error, 0));
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&s->d_comm_error_seen), sizeof(int)));
-  HIP_TRY(s, hipMemset(s->d_comm_error_seen, 0, sizeof(int)));
-  for (int q = 0; q < s->world; ++q) {
-    void* base = q == 0 ? s->p2p_base : ghost;
-    s->p2p_peers.flags[q] = reinterpret_cast<unsigned long long*>(base);
-    s->p2p_peers.slots[q] = reinterpret_cast<double*>(static_cast<char*>(base) + flag_bytes);
-  }
-  HIP_TRY(s, hipDeviceSynchronize());
-  s->p2p = true;
-  return 0;
-}
+#include "solver_comm.inc"
 
 int ceres_hip_load(ceres_hip_solver* s, const double* hv, const double* hb, const double* hD) {
   if (!s) return CERES_HIP_E_INVALID;
@@ -2870,146 +2653,7 @@ int ceres_hip_lm_compute_step(ceres_hip_solver* s, const double* hv, const doubl
   return 0;
 }
 
-// ---- streamed upload: the evaluator's finished rows go up while it is still writing the later ones ----------------------------
-namespace {
-// Which value ranges does a run of row blocks own?  Ceres' BlockJacobianWriter lays a Schur-ordered Jacobian out as all E cells (row
-// order) then all F cells (row order) (I/block_jacobian_writer.cc:68-167): two monotone streams; a row-sequential layout is one.
-void plan_value_streams(ceres_hip_solver* s) {
-  const HostStructure& h = s->hs;
-  s->stream_plan_ready = true;
-  s->n_value_streams = 0;
-  for (int k = 0; k < 2; ++k) { s->stream_lo[k].assign(size_t(h.nrb), 0); s->stream_hi[k].assign(size_t(h.nrb), 0); }
-  auto cell_range = [&](int r, int c, int64_t& lo, int64_t& hi) {
-    lo = h.cval[c];
-    hi = lo + int64_t(h.rsz[r]) * h.csz[h.ccol[c]];
-  };
-  // try ONE stream (rows contiguous one after the other), then TWO (first cell | other cells)
-  for (int streams = 1; streams <= 2 && s->n_value_streams == 0; ++streams) {
-    bool ok = true;
-    for (int k = 0; k < streams && ok; ++k) {
-      std::vector<int64_t>& L = s->stream_lo[k];
-      std::vector<int64_t>& H = s->stream_hi[k];
-      int64_t prev_hi = -1;
-      for (int r = 0; r < h.nrb && ok; ++r) {
-        int64_t lo = INT64_MAX, hi = -1, total = 0;
-        for (int c = h.rptr[r]; c < h.rptr[r + 1]; ++c) {
-          if (streams == 2 && ((c != h.rptr[r]) != (k == 1))) continue;   // class 0: the row's first cell; class 1: its other cells
-          int64_t a, b;
-          cell_range(r, c, a, b);
-          lo = std::min(lo, a); hi = std::max(hi, b); total += b - a;
-        }
-        if (hi < 0) { L[size_t(r)] = H[size_t(r)] = -1; continue; }               // no cell of this class in the row (filled in below)
-        if (hi - lo != total || (prev_hi >= 0 && lo != prev_hi)) { ok = false; break; }   // cells not back to back / not behind the previous row's
-        L[size_t(r)] = lo; H[size_t(r)] = hi; prev_hi = hi;
-      }
-      if (!ok) break;
-      // rows without a cell of the class own the empty range where the stream stands
-      int64_t at = -1;
-      for (int r = 0; r < h.nrb; ++r) { if (L[size_t(r)] >= 0) at = H[size_t(r)]; else if (at >= 0) L[size_t(r)] = H[size_t(r)] = at; }
-      at = -1;
-      for (int r = h.nrb - 1; r >= 0; --r) { if (L[size_t(r)] >= 0) at = L[size_t(r)]; else L[size_t(r)] = H[size_t(r)] = (at >= 0 ? at : 0); }
-    }
-    if (ok) s->n_value_streams = streams;
-  }
-}
-}  // namespace
-
-int ceres_hip_values_begin(ceres_hip_solver* s, const double* host_values, const double* host_residuals) {
-  if (!s || !host_values || !host_residuals) return CERES_HIP_E_INVALID;
-  if (!s->have_structure) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_set_structure has not been called");
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  std::lock_guard<std::mutex> lock(s->stream_mu);
-  if (!s->copy_stream) {
-    HIP_TRY(s, hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(s, hipEventCreateWithFlags(&s->copy_done, hipEventDisableTiming));
-  }
-  if (!s->stream_plan_ready) plan_value_streams(s);
-  // the previous step may still be reading own_values / own_b on the solver's stream: the copies wait for it
-  HIP_TRY(s, hipEventRecord(s->copy_done, s->stream));
-  HIP_TRY(s, hipStreamWaitEvent(s->copy_stream, s->copy_done, 0));
-  s->stream_row_sent.assign(size_t(s->hs.nrb), 0);
-  s->stream_host_values = host_values;
-  s->stream_host_b = host_residuals;
-  s->stream_rows_sent = 0; s->stream_bytes_early = 0; s->stream_bytes_late = 0;
-  s->streaming = true;
-  return 0;
-}
-
-namespace {
-// (stream_mu held) enqueue the copies of row blocks [r0, r1) on the copy stream
-int send_rows(ceres_hip_solver* s, int r0, int r1, int64_t* bytes) {
-  const HostStructure& h = s->hs;
-  for (int k = 0; k < s->n_value_streams; ++k) {
-    const int64_t lo = s->stream_lo[k][size_t(r0)], hi = s->stream_hi[k][size_t(r1 - 1)];
-    if (hi > lo) {
-      HIP_TRY(s, hipMemcpyAsync(s->own_values + lo, s->stream_host_values + lo, sizeof(double) * size_t(hi - lo), hipMemcpyHostToDevice, s->copy_stream));
-      *bytes += 8 * (hi - lo);
-    }
-  }
-  const int64_t b0 = h.rpos[size_t(r0)], b1 = int64_t(h.rpos[size_t(r1 - 1)]) + h.rsz[size_t(r1 - 1)];
-  if (b1 > b0) {
-    HIP_TRY(s, hipMemcpyAsync(s->own_b + b0, s->stream_host_b + b0, sizeof(double) * size_t(b1 - b0), hipMemcpyHostToDevice, s->copy_stream));
-    *bytes += 8 * (b1 - b0);
-  }
-  return 0;
-}
-}  // namespace
-
-int ceres_hip_values_ready(ceres_hip_solver* s, int32_t first_row_block, int32_t num_row_blocks) {
-  if (!s) return CERES_HIP_E_INVALID;
-  if (num_row_blocks <= 0) return 0;
-  // (no s->err on this path before the lock: several evaluator threads call it at once)
-  if (hipSetDevice(s->opt.device) != hipSuccess) return CERES_HIP_E_HIP;
-  std::lock_guard<std::mutex> lock(s->stream_mu);
-  if (!s->streaming) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_values_ready outside ceres_hip_values_begin / _end");
-  const int r0 = first_row_block, r1 = first_row_block + num_row_blocks;
-  if (r0 < 0 || r1 > s->hs.nrb) return fail(s, CERES_HIP_E_INVALID, "row blocks [%d, %d) out of range", r0, r1);
-  for (int r = r0; r < r1; ++r) {
-    if (s->stream_row_sent[size_t(r)]) return fail(s, CERES_HIP_E_INVALID, "row block %d was announced twice", r);
-    s->stream_row_sent[size_t(r)] = 1;
-  }
-  s->stream_rows_sent += num_row_blocks;
-  if (s->n_value_streams == 0) return 0;   // a layout without monotone value streams: remembered, sent in _end
-  return send_rows(s, r0, r1, &s->stream_bytes_early);
-}
-
-int ceres_hip_values_end(ceres_hip_solver* s, const double* host_column_scale) {
-  if (!s) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  std::lock_guard<std::mutex> lock(s->stream_mu);
-  if (!s->streaming) return fail(s, CERES_HIP_E_INVALID, "ceres_hip_values_end without ceres_hip_values_begin");
-  s->streaming = false;
-  const HostStructure& h = s->hs;
-  if (s->n_value_streams == 0) {   // nothing went up early
-    HIP_TRY(s, hipMemcpyAsync(s->own_values, s->stream_host_values, sizeof(double) * size_t(h.values_extent), hipMemcpyHostToDevice, s->copy_stream));
-    HIP_TRY(s, hipMemcpyAsync(s->own_b, s->stream_host_b, sizeof(double) * size_t(h.num_rows), hipMemcpyHostToDevice, s->copy_stream));
-    s->stream_bytes_late += 8 * (h.values_extent + h.num_rows);
-  } else if (s->stream_rows_sent < h.nrb) {   // rows nobody announced: now, run by run
-    for (int r = 0; r < h.nrb;) {
-      if (s->stream_row_sent[size_t(r)]) { ++r; continue; }
-      int e = r;
-      while (e < h.nrb && !s->stream_row_sent[size_t(e)]) ++e;
-      TRY(send_rows(s, r, e, &s->stream_bytes_late));
-      r = e;
-    }
-  }
-  HIP_TRY(s, hipEventRecord(s->copy_done, s->copy_stream));
-  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->copy_done, 0));
-  TRY(load_device(s, s->own_values, s->own_b, nullptr));
-  if (host_column_scale) {   // BlockSparseMatrix::ScaleColumns on the copy in HBM (I/block_sparse_matrix.cc:403-450, I/trust_region_minimizer.cc:263-279)
-    HIP_TRY(s, hipMemcpyAsync(s->scratch_vec, host_column_scale, sizeof(double) * size_t(h.num_cols), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(s, LaunchGenScaleColumns(s->G, s->own_values, s->scratch_vec, s->stream));
-  }
-  return 0;
-}
-
-int ceres_hip_get_stream_stats(const ceres_hip_solver* s, int64_t* bytes_early, int64_t* bytes_late, int32_t* value_streams) {
-  if (!s) return CERES_HIP_E_INVALID;
-  if (bytes_early) *bytes_early = s->stream_bytes_early;
-  if (bytes_late) *bytes_late = s->stream_bytes_late;
-  if (value_streams) *value_streams = s->n_value_streams;
-  return 0;
-}
+#include "solver_stream.inc"
 
 int ceres_hip_get_lm_diagonal(ceres_hip_solver* s, double* host_D) {
   TRY(require_loaded(s));
@@ -3047,328 +2691,7 @@ int ceres_hip_get_last_timing(const ceres_hip_solver* s, ceres_hip_solve_timing*
   return 0;
 }
 
-// ---- operator-level entry points: host vectors in, host vectors out ----------
-namespace {
-int up(ceres_hip_solver* s, double* dev, const double* host, size_t n) {
-  if (n) HIP_TRY(s, hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  return 0;
-}
-int down(ceres_hip_solver* s, double* host, const double* dev, size_t n) {
-  if (n) HIP_TRY(s, hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
-}
-}  // namespace
-
-int ceres_hip_op_right_multiply(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  TRY(require_caller_values(s, "ceres_hip_op_right_multiply"));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  double *dx = s->scratch_vec, *dy = s->scratch_vec + h.num_cols;
-  TRY(up(s, dx, x, h.num_cols));
-  TRY(up(s, dy, y, h.num_rows));
-  HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, kAll, dx, dy, nullptr, s->stream));
-  return down(s, y, dy, h.num_rows);
-}
-
-int ceres_hip_op_left_multiply(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  TRY(require_caller_values(s, "ceres_hip_op_left_multiply"));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  double *dy = s->scratch_vec, *dx = s->scratch_vec + h.num_cols;
-  TRY(up(s, dx, x, h.num_rows));
-  TRY(up(s, dy, y, h.num_cols));
-  HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, kAll, dx, dy, nullptr, s->stream));
-  return down(s, y, dy, h.num_cols);
-}
-
-// ---- PartitionedMatrixView products (I/partitioned_matrix_view_impl.h:112-375) -----------------
-// E = the first cell of each of the first num_row_blocks_e rows, F = everything else; vectors are
-// indexed in the part's own column space (F: col_block_pos - num_cols_e), rows in the full row space.
-namespace {
-int pmv_product(ceres_hip_solver* s, int part, bool left, const double* x, double* y) {
-  TRY(require_loaded(s));
-  TRY(require_caller_values(s, "a PartitionedMatrixView product"));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  const size_t ncols = size_t(part == kE ? h.num_cols_e : h.num_cols_f);
-  const size_t nin = left ? size_t(h.num_rows) : ncols, nout = left ? ncols : size_t(h.num_rows);
-  // scratch_vec holds num_cols + num_rows doubles: column-space vector first, row-space vector behind it
-  double* dcol = s->scratch_vec;
-  double* drow = s->scratch_vec + h.num_cols;
-  double* dx = left ? drow : dcol;
-  double* dy = left ? dcol : drow;
-  TRY(up(s, dx, x, nin));
-  TRY(up(s, dy, y, nout));
-  if (left) HIP_TRY(s, LaunchGenLeftMultiply(s->G, s->values, part, dx, dy, nullptr, s->stream));
-  else HIP_TRY(s, LaunchGenRightMultiply(s->G, s->values, part, dx, dy, nullptr, s->stream));
-  return down(s, y, dy, nout);
-}
-int pmv_block_diagonal(ceres_hip_solver* s, int part, double* blocks, int64_t capacity) {
-  TRY(require_loaded(s));
-  TRY(require_caller_values(s, "a PartitionedMatrixView product"));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  const int64_t len = part == kE ? h.diag_off_e.back() : h.diag_off_f.back();
-  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
-  double* tmp = nullptr;
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * std::max<int64_t>(1, len)));
-  hipError_t e = LaunchGenBlockDiagonal(s->G, s->values, part, nullptr, tmp, len, s->stream);
-  int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "block diagonal kernel failed");
-  (void)hipFree(tmp);
-  return rc;
-}
-}  // namespace
-
-int ceres_hip_op_right_multiply_e(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kE, false, x, y); }
-int ceres_hip_op_right_multiply_f(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kF, false, x, y); }
-int ceres_hip_op_left_multiply_e(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kE, true, x, y); }
-int ceres_hip_op_left_multiply_f(ceres_hip_solver* s, const double* x, double* y) { return pmv_product(s, kF, true, x, y); }
-int ceres_hip_op_block_diagonal_ete(ceres_hip_solver* s, double* blocks, int64_t capacity) { return pmv_block_diagonal(s, kE, blocks, capacity); }
-int ceres_hip_op_block_diagonal_ftf(ceres_hip_solver* s, double* blocks, int64_t capacity) { return pmv_block_diagonal(s, kF, blocks, capacity); }
-
-int ceres_hip_op_squared_column_norm(ceres_hip_solver* s, double* x) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  TRY(op_squared_column_norm(s, s->scratch_vec));
-  return down(s, x, s->scratch_vec, s->hs.num_cols);
-}
-
-int ceres_hip_op_jtjx(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "jtjx is the CGNR operator; this instance is ITERATIVE_SCHUR");
-  TRY(up(s, s->cg.p, x, s->hs.num_cols));
-  TRY(op_jtjx(s, s->cg.p, s->cg.z, nullptr));
-  return down(s, y, s->cg.z, s->hs.num_cols);
-}
-
-int ceres_hip_op_jtb(ceres_hip_solver* s, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  TRY(op_jtb(s, s->scratch_vec));
-  return down(s, y, s->scratch_vec, s->hs.num_cols);
-}
-
-int ceres_hip_op_schur_init(ceres_hip_solver* s) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  TRY(op_schur_init(s, true));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
-}
-
-int ceres_hip_get_schur_rhs(ceres_hip_solver* s, double* rhs) {
-  TRY(require_loaded(s));
-  return down(s, rhs, s->rhs_f, s->hs.num_cols_f);
-}
-
-int ceres_hip_get_ete_inverse(ceres_hip_solver* s, double* blocks, int64_t capacity) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  const int64_t len = h.diag_off_e.back();
-  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
-  if (s->path == CERES_HIP_PATH_BAL) {
-    double* tmp = nullptr;
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * len));
-    hipError_t e = LaunchExpandSym(s->etei, s->ops->ne, s->ops->etei_pitch, tmp, s->d_pt_eoff, s->plan.n_points, s->stream);  // internal point order -> the caller's E blocks
-    int rc = e == hipSuccess ? down(s, blocks, tmp, size_t(len)) : fail(s, CERES_HIP_E_HIP, "expand failed");
-    (void)hipFree(tmp);
-    return rc;
-  }
-  return down(s, blocks, s->etei, size_t(len));
-}
-
-int ceres_hip_op_schur_sx(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  TRY(up(s, s->cg.p, x, s->hs.num_cols_f));
-  TRY(op_sx(s, s->cg.p, s->cg.z, nullptr));
-  return down(s, y, s->cg.z, s->hs.num_cols_f);
-}
-
-int ceres_hip_op_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  if (s->hs.num_cols_f > 0) TRY(up(s, s->cg.p, z, s->hs.num_cols_f));
-  TRY(op_back_substitute(s, s->hs.num_cols_f > 0 ? s->cg.p : nullptr, s->own_x));
-  return down(s, x, s->own_x, s->hs.num_cols);
-}
-
-int ceres_hip_op_power_series_operator(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  const int n = s->hs.num_cols_f;
-  TRY(up(s, s->cg.p, x, n));
-  TRY(up(s, s->cg.z, y, n));
-  TRY(op_power_series(s, s->cg.p, s->cg.z, nullptr));
-  return down(s, y, s->cg.z, n);
-}
-
-int ceres_hip_op_spse_apply(ceres_hip_solver* s, const double* x, double* y, int32_t max_iters, double tolerance) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  if (max_iters < 1) return fail(s, CERES_HIP_E_INVALID, "max_num_spse_iterations < 1");
-  const int n = s->hs.num_cols_f;
-  TRY(up(s, s->cg.p, x, n));
-  TRY(op_spse_apply(s, s->cg.p, s->cg.z, max_iters, tolerance, nullptr));
-  return down(s, y, s->cg.z, n);
-}
-
-int ceres_hip_op_block_jacobi_update(ceres_hip_solver* s) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (is_schur(s)) {
-    TRY(op_schur_init(s, false));
-    TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));
-  } else {
-    TRY(op_preconditioner(s, CERES_HIP_JACOBI, s->precond, true));
-  }
-  s->precond_valid = true;
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
-}
-
-int ceres_hip_op_schur_jacobi_update(ceres_hip_solver* s) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  TRY(op_schur_init(s, true));
-  TRY(op_preconditioner(s, CERES_HIP_SCHUR_JACOBI, s->precond, true));
-  s->precond_valid = true;
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return 0;
-}
-
-int ceres_hip_get_preconditioner_blocks(ceres_hip_solver* s, int32_t not_inverted, double* blocks, int64_t capacity) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  const HostStructure& h = s->hs;
-  const int64_t len = is_schur(s) ? h.diag_off_f.back() : h.diag_off_all.back();
-  if (capacity < len) return fail(s, CERES_HIP_E_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)len);
-  if (!not_inverted) {
-    if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
-    TRY(precond_to_caller_order(s));  // a CGNR solve left its point blocks in CG's order
-    return down(s, blocks, s->precond, size_t(len));
-  }
-  // re-assemble without inverting, into a temporary
-  double* tmp = nullptr;
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&tmp), sizeof(double) * std::max<int64_t>(1, len)));
-  int type = s->opt.preconditioner_type == CERES_HIP_IDENTITY ? CERES_HIP_JACOBI : s->opt.preconditioner_type;
-  int rc = 0;
-  if (is_schur(s)) rc = op_schur_init(s, true);
-  if (!rc) rc = op_preconditioner(s, type, tmp, false);
-  if (!rc) rc = down(s, blocks, tmp, size_t(len));
-  (void)hipFree(tmp);
-  return rc;
-}
-
-int ceres_hip_op_precond_apply(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!s->precond_valid) return fail(s, CERES_HIP_E_INVALID, "no preconditioner has been computed");
-  TRY(precond_to_caller_order(s));  // a CGNR solve left its point blocks in CG's order
-  const HostStructure& h = s->hs;
-  const int n = is_schur(s) ? h.num_cols_f : h.num_cols;
-  TRY(up(s, s->cg.p, x, n));
-  TRY(up(s, s->cg.z, y, n));
-  if (is_schur(s))
-    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, h.nelim, h.ncb - h.nelim, s->G.diag_off_f, s->precond, s->cg.p, s->cg.z, nullptr, s->stream));
-  else
-    HIP_TRY(s, LaunchGenBlockDiagonalApply(s->G, 0, h.ncb, s->G.diag_off_all, s->precond, s->cg.p, s->cg.z, nullptr, s->stream));
-  return down(s, y, s->cg.z, n);
-}
-
-int ceres_hip_op_schur_eliminate_dense(ceres_hip_solver* s, double* lhs, double* rhs) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  if (s->path != CERES_HIP_PATH_GENERIC) return fail(s, CERES_HIP_E_UNSUPPORTED, "dense elimination runs on the generic path: create the solver with force_generic_path = 1");
-  const HostStructure& h = s->hs;
-  TRY(op_schur_init(s, false));
-  const int64_t n = h.num_cols_f;
-  double* d_lhs = nullptr;
-  HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&d_lhs), sizeof(double) * std::max<int64_t>(1, n * n)));
-  hipError_t e = LaunchGenSchurDense(s->G, s->values, s->etei, s->D, d_lhs, s->stream);
-  int rc = e == hipSuccess ? down(s, lhs, d_lhs, size_t(n * n)) : fail(s, CERES_HIP_E_HIP, "dense Schur kernel failed");
-  (void)hipFree(d_lhs);
-  if (rc) return rc;
-  if (rhs && s->have_b) return down(s, rhs, s->rhs_f, size_t(n));
-  return 0;
-}
-
-// ---- explicit Schur complement in BlockRandomAccessSparseMatrix storage (use_explicit_schur_complement, one rank) ----
-int ceres_hip_schur_storage_info(const ceres_hip_solver* s, int64_t* num_block_pairs, int64_t* num_values) {
-  if (!s || !s->have_structure || !s->sparse_S) return CERES_HIP_E_INVALID;
-  if (num_block_pairs) *num_block_pairs = int64_t(s->schur_storage.pair_i.size());
-  if (num_values) *num_values = s->schur_storage.num_values();
-  return 0;
-}
-
-int ceres_hip_op_schur_eliminate_sparse(ceres_hip_solver* s, int32_t* pair_i, int32_t* pair_j, int64_t* pair_offset, double* values,
-                                        int64_t pair_capacity, int64_t value_capacity) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!s->sparse_S) return fail(s, CERES_HIP_E_INVALID, "create the solver with use_explicit_schur_complement = 1 (one rank)");
-  const SchurStorage& Q = s->schur_storage;
-  const int64_t np = int64_t(Q.pair_i.size());
-  if (pair_capacity < np || value_capacity < Q.num_values()) return fail(s, CERES_HIP_E_INVALID, "capacity too small");
-  TRY(op_schur_init(s, false));
-  HIP_TRY(s, LaunchSchurSparseEliminate(s->G, s->schur_pairs, s->values, s->etei, s->D, s->d_S, s->stream));
-  for (int64_t p = 0; p < np; ++p) { pair_i[p] = Q.pair_i[p]; pair_j[p] = Q.pair_j[p]; pair_offset[p] = Q.pair_off[p]; }
-  return down(s, values, s->d_S, size_t(Q.num_values()));
-}
-
-int ceres_hip_op_schur_symmetric_multiply(ceres_hip_solver* s, const double* x, double* y) {
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!s->sparse_S) return fail(s, CERES_HIP_E_INVALID, "create the solver with use_explicit_schur_complement = 1 (one rank)");
-  const int n = s->hs.num_cols_f;
-  TRY(up(s, s->cg.p, x, n));
-  TRY(up(s, s->cg.z, y, n));
-  HIP_TRY(s, LaunchSchurSparseSymv(s->G, s->schur_pairs, s->d_S, s->cg.p, s->cg.z, nullptr, 1, s->stream));
-  return down(s, y, s->cg.z, n);
-}
-
-int ceres_hip_op_eliminator_back_substitute(ceres_hip_solver* s, const double* z, double* x) {
-  // SchurEliminator::BackSubstitute recomputes (E^T E + D^2)^-1 per chunk and applies it to
-  // E^T (b - F z): the same result as ImplicitSchurComplement::BackSubstitute after Init.
-  TRY(require_loaded(s));
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (!is_schur(s)) return fail(s, CERES_HIP_E_INVALID, "not an ITERATIVE_SCHUR instance");
-  TRY(op_schur_init(s, false));
-  return ceres_hip_op_back_substitute(s, z, x);
-}
-
-int ceres_hip_op_dot(ceres_hip_solver* s, const double* x, const double* y, int64_t n, double* result) {
-  if (!s || !s->have_structure) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (n > s->hs.num_cols) return fail(s, CERES_HIP_E_INVALID, "n exceeds num_cols");
-  double *dx = s->scratch_vec, *dy = s->own_x;
-  TRY(up(s, dx, x, size_t(n)));
-  TRY(up(s, dy, y, size_t(n)));
-  HIP_TRY(s, LaunchDot(dx, dy, n, s->cg.partials, s->cg.comm, s->stream));
-  return down(s, result, s->cg.comm, 1);
-}
-
-int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b, const double* y, int64_t n, double* z) {
-  if (!s || !s->have_structure) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  if (n > s->hs.num_cols) return fail(s, CERES_HIP_E_INVALID, "n exceeds num_cols");
-  double *dx = s->scratch_vec, *dy = s->own_x;
-  TRY(up(s, dx, x, size_t(n)));
-  TRY(up(s, dy, y, size_t(n)));
-  HIP_TRY(s, LaunchAxpby(a, dx, b, dy, dy, n, s->stream));  // z may alias y (CG does both, I/conjugate_gradients_solver.h:190,220-226)
-  return down(s, z, dy, size_t(n));
-}
+#include "solver_ops.inc"
 
 int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* avg_ms) {
   TRY(require_loaded(s));
@@ -3444,154 +2767,6 @@ int ceres_hip_time_op(ceres_hip_solver* s, int32_t op, int32_t iters, double* av
   return 0;
 }
 
-// ---- debug exports: the host-side packing plan, testable without a GPU -------
-int ceres_hip_debug_staged_x_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int64_t counts[4], int32_t* staged_cam,
-                                  int32_t* slot_word, int64_t staged_capacity, int64_t slot_capacity) {
-  HostStructure h;
-  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
-  BalPlan P;
-  BuildBalPlan(h, num_eliminate_blocks > 0 ? kReorderIfContiguous : kReorderNever, HybridRequest(), &P);
-  if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
-  counts[0] = P.n_tiles; counts[1] = P.n_cameras; counts[2] = int64_t(P.xhot_cam.size());
-  counts[3] = int64_t((size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double));
-  if (staged_capacity >= int64_t(P.xhot_cam.size()) && staged_cam)
-    for (size_t r = 0; r < P.xhot_cam.size(); ++r) staged_cam[r] = P.xhot_cam[r];
-  const int64_t n_slots = P.n_tiles * kTile;
-  if (slot_capacity >= n_slots && slot_word)
-    for (int64_t i = 0; i < n_slots; ++i) slot_word[i] = P.slot_cam[i] < 0 ? -1 : P.slot_word[i];
-  return 0;
-}
-
-int ceres_hip_debug_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t* eligible,
-                         int64_t* n_tiles, int32_t* slot_row_out, int32_t* slot_cam_out, int32_t* slot_pt_out,
-                         uint32_t* slot_seg_out, int32_t* tile_kind_out, int32_t* tile_aux_out, int64_t slot_capacity,
-                         char* why_not, int32_t why_capacity) {
-  HostStructure h;
-  std::string e = AnalyzeStructure(*bs, num_eliminate_blocks, &h);
-  if (!e.empty()) { if (why_not) snprintf(why_not, why_capacity, "%s", e.c_str()); *eligible = 0; return CERES_HIP_E_INVALID; }
-  BalPlan P;
-  // CERES_HIP_DEBUG_PLAN_REORDER=1: the plan a Schur solver builds (points renumbered so that the tiles fill up)
-  { const char* e = getenv("CERES_HIP_DEBUG_PLAN_REORDER"); BuildBalPlan(h, (e && atoi(e) != 0 && num_eliminate_blocks > 0) ? kReorderAlways : kReorderNever, HybridRequest(), &P); }
-  *eligible = P.eligible ? 1 : 0;
-  if (why_not) snprintf(why_not, why_capacity, "%s", P.why_not.c_str());
-  *n_tiles = P.n_tiles;
-  if (!P.eligible) return 0;
-  const int64_t n_slots = P.n_tiles * kTile;
-  if (slot_capacity < n_slots) return 0;  // caller only wanted the counts
-  for (int64_t i = 0; i < n_slots; ++i) {
-    slot_row_out[i] = P.slot_row[i];
-    slot_cam_out[i] = P.slot_cam[i];
-    slot_pt_out[i] = P.slot_pt[i];
-    slot_seg_out[i] = P.slot_seg[i];
-  }
-  for (int64_t t = 0; t < P.n_tiles; ++t) { tile_kind_out[t] = P.tile_kind[t]; tile_aux_out[t] = P.tile_aux[t]; }
-  return 0;
-}
-
-int ceres_hip_op_dense_cholesky_solve(ceres_hip_solver* s, int32_t n, const double* A, const double* b, double* x, int32_t repeats,
-                                      double* factor_ms, int32_t* failed) {
-  if (!s || !A || !b || !x || n < 1 || repeats < 1) return CERES_HIP_E_INVALID;
-  HIP_TRY(s, hipSetDevice(s->opt.device));
-  hipStream_t st = s->stream;
-  const size_t nn = size_t(n) * size_t(n);
-  double *dA0 = nullptr, *dA = nullptr, *dx = nullptr;
-  int* dflag = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  auto cleanup = [&] {
-    if (dA0) (void)hipFree(dA0); if (dA) (void)hipFree(dA); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
-    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-  };
-  auto run = [&]() -> int {
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dA0), nn * sizeof(double)));
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dA), nn * sizeof(double)));
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dx), size_t(n) * sizeof(double)));
-    HIP_TRY(s, hipMalloc(reinterpret_cast<void**>(&dflag), sizeof(int)));
-    HIP_TRY(s, hipEventCreate(&e0)); HIP_TRY(s, hipEventCreate(&e1));
-    HIP_TRY(s, hipMemcpyAsync(dA0, A, nn * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(dx, b, size_t(n) * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemsetAsync(dflag, 0, sizeof(int), st));
-    double total = 0.0;
-    for (int r = 0; r < repeats; ++r) {   // the factorisation is in place: every repeat starts from a fresh copy, only the factorisation is timed
-      HIP_TRY(s, hipMemcpyAsync(dA, dA0, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
-      HIP_TRY(s, hipEventRecord(e0, st));
-      HIP_TRY(s, LaunchDenseCholesky(dA, n, dflag, st));
-      HIP_TRY(s, hipEventRecord(e1, st));
-      HIP_TRY(s, hipEventSynchronize(e1));
-      float ms = 0;
-      HIP_TRY(s, hipEventElapsedTime(&ms, e0, e1));
-      total += ms;
-    }
-    if (factor_ms) *factor_ms = total / repeats;
-    int flag = 0;
-    HIP_TRY(s, hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(s, hipStreamSynchronize(st));
-    if (failed) *failed = flag;
-    if (!flag) HIP_TRY(s, LaunchDenseCholeskySolve(dA, n, dx, st));
-    HIP_TRY(s, hipMemcpyAsync(x, dx, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(s, hipStreamSynchronize(st));
-    return 0;
-  };
-  const int rc = run();
-  cleanup();
-  return rc;
-}
-
-int ceres_hip_debug_hybrid_plan(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t groups, int32_t rows,
-                                int64_t counts[8], int32_t* slot_word, int32_t* slot_row, int32_t* tile_zbase, int32_t* grp_tile_ptr,
-                                int32_t* entry_row, int32_t* unit_cam, int32_t* unit_begin, int32_t* unit_end,
-                                int64_t slot_capacity, int64_t entry_capacity, int64_t unit_capacity) {
-  if (!bs || !counts) return CERES_HIP_E_INVALID;
-  HostStructure h;
-  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
-  BalPlan P;
-  HybridRequest hyb;
-  hyb.groups = groups; hyb.rows = rows;
-  BuildBalPlan(h, num_eliminate_blocks > 0 ? kReorderAlways : kReorderNever, hyb, &P);
-  if (!P.eligible || P.cameras_in_lds) return CERES_HIP_E_UNSUPPORTED;
-  const int64_t n_slots = P.n_tiles * kTile, n_entries = int64_t(P.zc_slot.size()), n_units = int64_t(P.zu_cam.size());
-  counts[0] = P.n_tiles; counts[1] = P.hybrid ? 1 : 0; counts[2] = P.hyb_rows; counts[3] = P.hyb_hot;
-  counts[4] = P.z_flush_row0; counts[5] = P.z_ring_rows; counts[6] = n_entries; counts[7] = n_units;
-  if (slot_capacity < n_slots || entry_capacity < n_entries || unit_capacity < n_units) return 0;  // the caller only wanted the counts
-  for (int64_t i = 0; i < n_slots; ++i) {
-    slot_word[i] = P.slot_cam[i] < 0 ? -1 : P.slot_word[i];
-    slot_row[i] = P.slot_row[i];
-  }
-  std::copy(P.tile_zbase.begin(), P.tile_zbase.end(), tile_zbase);
-  if (P.hybrid) std::copy(P.grp_tile_ptr.begin(), P.grp_tile_ptr.end(), grp_tile_ptr);
-  std::copy(P.zc_slot.begin(), P.zc_slot.end(), entry_row);
-  std::copy(P.zu_cam.begin(), P.zu_cam.end(), unit_cam);
-  std::copy(P.zu_begin.begin(), P.zu_begin.end(), unit_begin);
-  std::copy(P.zu_end.begin(), P.zu_end.end(), unit_end);
-  return 0;
-}
-
-int ceres_hip_debug_long_rounds(const ceres_hip_block_structure* bs, int32_t num_eliminate_blocks, int32_t renumber, int32_t groups,
-                                int32_t rows, int64_t counts[5], int32_t* tile_kind, int32_t* tile_aux, int32_t* range_tile_ptr,
-                                int32_t* long_ptr, int32_t* round_ptr, int32_t* seq_ptr, int32_t* round_flag, uint32_t* round_word,
-                                int64_t tile_capacity, int64_t range_capacity, int64_t round_capacity) {
-  if (!bs || !counts) return CERES_HIP_E_INVALID;
-  HostStructure h;
-  if (!AnalyzeStructure(*bs, num_eliminate_blocks, &h).empty()) return CERES_HIP_E_INVALID;
-  BalPlan P;
-  HybridRequest hyb;
-  hyb.groups = groups; hyb.rows = rows;
-  BuildBalPlan(h, renumber ? kReorderAlways : kReorderNever, hyb, &P);
-  if (!P.eligible) return CERES_HIP_E_UNSUPPORTED;
-  const int64_t n_ranges = int64_t(P.long_ptr.size()), n_rounds = int64_t(P.round_word.size()) / kRoundWaves;
-  counts[0] = P.n_tiles; counts[1] = n_ranges; counts[2] = n_rounds; counts[3] = P.long_behind ? 1 : 0; counts[4] = int64_t(P.seq_ptr.size()) - 1;
-  if (tile_capacity < P.n_tiles || range_capacity < n_ranges || round_capacity < n_rounds) return 0;  // the caller only wanted the counts
-  std::copy(P.tile_kind.begin(), P.tile_kind.end(), tile_kind);
-  std::copy(P.tile_aux.begin(), P.tile_aux.end(), tile_aux);
-  if (P.grp_tile_ptr.empty()) { range_tile_ptr[0] = 0; range_tile_ptr[1] = int32_t(P.n_tiles); }
-  else std::copy(P.grp_tile_ptr.begin(), P.grp_tile_ptr.end(), range_tile_ptr);
-  std::copy(P.long_ptr.begin(), P.long_ptr.end(), long_ptr);
-  std::copy(P.round_ptr.begin(), P.round_ptr.end(), round_ptr);
-  std::copy(P.round_word.begin(), P.round_word.end(), round_word);
-  std::copy(P.seq_ptr.begin(), P.seq_ptr.end(), seq_ptr);
-  std::copy(P.round_flag.begin(), P.round_flag.end(), round_flag);
-  return 0;
-}
-
-}  // extern "C"
+#include "solver_debug.inc"
 
 #include "bal_frontend.inc"

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "ceres_hip.h"
+#include "flatten_block_structure.h"
 
 namespace ceres_hip {
 
@@ -209,17 +210,8 @@ class HipLinearSolver final : public LinearSolver {
   // Flattens the structure on first use: one instance sees one sparsity (internal/ceres/linear_solver.h:137-142).
   bool EnsureStructure(BlockSparseMatrix* A, Summary* summary) {
     if (!structure_set_) {
-      const CompressedRowBlockStructure* bs = A->block_structure();
-      std::vector<int32_t> rsz, rpos, csz, cpos, ptr{0}, ccol, cval;
-      for (const auto& c : bs->cols) { csz.push_back(c.size); cpos.push_back(c.position); }
-      for (const auto& r : bs->rows) {
-        rsz.push_back(r.block.size);
-        rpos.push_back(r.block.position);
-        for (const auto& cell : r.cells) { ccol.push_back(cell.block_id); cval.push_back(cell.position); }
-        ptr.push_back(int32_t(ccol.size()));
-      }
-      ceres_hip_block_structure flat{int32_t(rsz.size()), int32_t(csz.size()), rsz.data(), rpos.data(), csz.data(),
-                                     cpos.data(), ptr.data(), ccol.data(), cval.data()};
+      const FlatBlockStructure flat_arrays = FlattenBlockStructure(*A->block_structure());   // (flatten_block_structure.h: the code INTEGRATION.md's adapter runs)
+      const ceres_hip_block_structure flat = flat_arrays.view();
       if (ceres_hip_set_structure(handle_, &flat) != CERES_HIP_OK) {
         summary->termination_type = LinearSolverTerminationType::FATAL_ERROR;
         summary->message = ceres_hip_last_error(handle_);

@@ -22,9 +22,18 @@ def oracle():
     return entry.load_oracle()
 
 
+class _Problems:
+    """The package's problem generators plus the reference-held test vectors (tests/reference_fixtures.py) under one name."""
+    def __getattr__(self, name):
+        import reference_fixtures
+        if hasattr(reference_fixtures, name) and not name.startswith("_"):
+            return getattr(reference_fixtures, name)
+        return getattr(pkg.problems, name)
+
+
 @pytest.fixture(scope="session")
 def problems():
-    return pkg.problems
+    return _Problems()
 
 
 @pytest.fixture(scope="session")

@@ -30,6 +30,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))   # tests/: reference_fixtures.py (the reference-held known-answer problems)
 
 import __graft_entry__ as entry  # noqa: E402
 
@@ -108,7 +109,8 @@ def main():
     print("bal_evaluator_small", {k: np.asarray(v).shape for k, v in ev.items()})
     ka = {}
     for pid in (0, 2, 3, 4, 5, 6):
-        p = pkg.problems.linear_least_squares_problem(pid)
+        import reference_fixtures
+        p = reference_fixtures.linear_least_squares_problem(pid)
         ka[str(pid)] = {k: (None if v is None else np.asarray(v).tolist()) for k, v in p.known.items()}
         ka[str(pid)]["num_cols"] = int(p.num_cols)
         ka[str(pid)]["num_eliminate_blocks"] = int(p.num_eliminate_blocks)
