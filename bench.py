@@ -147,6 +147,7 @@ def parse():
     ap.add_argument("--extra-dense-cholesky", type=int, default=1, help="default line: DENSE_SCHUR's factorisation at n = 8190 (extra.dense_schur_cholesky)")
     ap.add_argument("--also-fp32", type=int, default=-1, help="also time the fp32-tile storage mode (extra.fp32_tiles; BASELINE.json configs[4] asks for a sweep over both "
                                                                "precisions): -1 = on the default Venice line, 1 = on, 0 = off")
+    ap.add_argument("--extra-banded", type=int, default=1, help="default line: S.x / JtJx on a 50 000-camera sequence-like (banded) graph (extra.banded50k)")
     ap.add_argument("--extra-configs", type=int, default=1, help="default line: BASELINE.json configs[1] (Dubrovnik-16, CGNR + JACOBI) and configs[2] "
                                                                  "(Ladybug-1723, ITERATIVE_SCHUR + SCHUR_JACOBI): steps/s, operator roofline, oracle check, CPU port (extra.configs)")
     ap.add_argument("--shard-ceiling", type=int, default=1,
@@ -856,6 +857,34 @@ def main():
         except Exception as ex:  # the default line must not depend on it
             extra["real_graph"] = {"error": repr(ex)[:300]}
 
+    # ---- the many-camera regime on a graph that HAS locality: 50 000 cameras, every point seen by consecutive cameras ----
+    if world == 1 and args.extra_banded and args.workload == "venice1778" and not storage:
+        try:
+            bc, bp, bo = pkg.problems.BAL_SHAPES["synthetic1M"]
+            pb = pkg.problems.banded_bal(None, seed=38401, num_cameras=bc, num_points=bp, num_observations=bo, with_values=False)
+            gb = torch.Generator(device=dev)
+            gb.manual_seed(38401)
+            vb = torch.randn(24 * bo, dtype=torch.float64, device=dev, generator=gb)
+            bb = torch.randn(2 * bo, dtype=torch.float64, device=dev, generator=gb)
+            Db = torch.rand(pb.bs.num_cols, dtype=torch.float64, device=dev, generator=gb) * 0.1 + 0.05
+            case = {"what": "S.x / JtJx (HIP events, as roofline) on a SEQUENCE-like graph with synthetic1M's block counts: 50 000 cameras, 1 M points, 3 M observations, "
+                            "every point seen by consecutive cameras (problems.banded_bal), N(0,1) values generated in HBM: the camera accumulators do not fit in LDS, "
+                            "but a workgroup's tiles touch few cameras once the plan has grouped the points by camera window",
+                    "cameras": bc, "points": bp, "observations": bo}
+            for sv_, kd_ in (("iterative_schur", "sx"), ("cgnr", "jtjx")):
+                sb_ = make_solver(hs, pb.bs, pb.num_eliminate_blocks, sv_, local_rank, None, 0)
+                ib_ = sb_.info()
+                sb_.load_device(vb.data_ptr(), bb.data_ptr(), Db.data_ptr())
+                ms_ = min(sb_.time_op(hs.TIMED_SX if kd_ == "sx" else hs.TIMED_JTJX, 20) for _ in range(3))
+                case[kd_] = {"ms": round(ms_, 5), "frac": round(algorithmic_bytes(kd_, bo, bp, bc, 8) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                case.update({"accumulators_in_lds": int(ib_.camera_accum_in_lds), "hybrid": int(ib_.camera_accum_hybrid),
+                             "observations_summed_in_lds": round(ib_.num_observations_in_lds / float(bo), 4)})
+                sb_.close()
+            extra["banded50k"] = case
+            del vb, bb, Db
+        except Exception as ex:  # the default line must not depend on it
+            extra["banded50k"] = {"error": repr(ex)[:300]}
+
     # ---- the fused path beyond <2,3,9> and the generic path, on the default line ----
     if world == 1 and args.extra_other_shapes and args.workload == "venice1778" and not storage:
         try:
@@ -867,6 +896,8 @@ def main():
                 oracle_s.set_num_threads(min(os.cpu_count() or 1, 16))
             cases = [("<2,3,10> quaternion cameras (bundle_adjuster --use_quaternions)", dict(camera_width=10), False),
                      ("<2,3,6>", dict(camera_width=6), False),
+                     ("<2,3,7> (a width the reference reaches through its dynamic (2,3,d) specialisation; round 6: every camera width 2 .. 10 is compiled)", dict(camera_width=7), False),
+                     ("<2,3,5>", dict(camera_width=5), False),
                      ("<2,3,9> on the GENERIC kernels (force_generic_path)", dict(camera_width=9), True),
                      ("libmv structure <2, 8 | 6, 3>: shared intrinsics + 6-wide pose + point, first camera constant", dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)), False),
                      ("<2,4,9> homogeneous points (the reference's (2,4,9) specialisation; round 5: point blocks 2 and 4 wide on the fused path)", dict(camera_width=9, point_width=4), False),

@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libceres_hip.so")
 # the fused kernels are compiled once per SHAPE (camera width, shared strip): kernels_bal.inc through kernels_bal_shape_*.hip (common.h)
-BAL_SHAPES = [(3, 0), (4, 0), (6, 0), (8, 0), (9, 0), (10, 0), (6, 4), (6, 8), (9, 4), (9, 8)]
+# (round 6: every camera width 2 .. 10 — the widths the reference reaches through its (2,3,d) / (2,4,d) / (2,2,d) dynamic specialisations)
+BAL_SHAPES = [(2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0), (9, 0), (10, 0), (6, 4), (6, 8), (9, 4), (9, 8)]
 # point blocks other than 3 wide (round 5): (ne, nf), no strip
-BAL_SHAPES_E = [(2, 2), (2, 3), (2, 4), (4, 3), (4, 4), (4, 6), (4, 8), (4, 9)]
+BAL_SHAPES_E = [(2, 2), (2, 3), (2, 4), (2, 6), (2, 9), (4, 2), (4, 3), (4, 4), (4, 5), (4, 6), (4, 7), (4, 8), (4, 9), (4, 10)]
 # row blocks other than 2 high (round 5): (nr, ne, nf), no strip — the reference's (3,3,3), (4,4,2), (4,4,3), (4,4,4)
 BAL_SHAPES_R = [(3, 3, 3), (4, 4, 2), (4, 4, 3), (4, 4, 4)]
 SOURCES = (["plan.cc", "kernels_generic.hip", "kernels_cg.hip", "kernels_bal_common.hip"] + [f"kernels_bal_shape_f{nf}_s{ns}.hip" for nf, ns in BAL_SHAPES] +

@@ -83,10 +83,12 @@ inline bool BalShapeCompiled(int nr, int ne, int nf, int ns) {
   if (nr == 3) return ne == 3 && nf == 3 && ns == 0;
   if (nr == 4) return ne == 4 && ns == 0 && (nf == 2 || nf == 3 || nf == 4);
   if (nr != 2) return false;
-  if (ne == 2) return ns == 0 && (nf == 2 || nf == 3 || nf == 4);
-  if (ne == 4) return ns == 0 && (nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9);
+  // (round 6: every camera width 2 .. 10 next to 3- and 4-wide points — what the reference's dynamic-size specialisations (2,3,d),
+  // (2,4,d) cover in practice: 5-wide cameras without distortion, 7-wide quaternion poses — and 6 / 9 next to 2-wide points)
+  if (ne == 2) return ns == 0 && (nf == 2 || nf == 3 || nf == 4 || nf == 6 || nf == 9);
+  if (ne == 4) return ns == 0 && nf >= 2 && nf <= 10;
   if (ne != 3) return false;
-  if (ns == 0) return nf == 3 || nf == 4 || nf == 6 || nf == 8 || nf == 9 || nf == 10;
+  if (ns == 0) return nf >= 2 && nf <= 10;
   return (nf == 6 || nf == 9) && (ns == 4 || ns == 8);
 }
 inline int BalStripWidthFor(int ns_used) { return ns_used <= 0 ? 0 : (ns_used <= 4 ? 4 : (ns_used <= 8 ? 8 : -1)); }

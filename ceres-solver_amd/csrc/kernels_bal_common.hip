@@ -41,9 +41,12 @@ int BalBlockFor(int mode) {
 }
 
 // one per kernels_bal_shape_*.hip; the list is common.h's BalShapeCompiled
+const BalOps* BalOps_bal_f2_s0();
 const BalOps* BalOps_bal_f3_s0();
 const BalOps* BalOps_bal_f4_s0();
+const BalOps* BalOps_bal_f5_s0();
 const BalOps* BalOps_bal_f6_s0();
+const BalOps* BalOps_bal_f7_s0();
 const BalOps* BalOps_bal_f8_s0();
 const BalOps* BalOps_bal_f9_s0();
 const BalOps* BalOps_bal_f10_s0();
@@ -54,7 +57,13 @@ const BalOps* BalOps_bal_f9_s8();
 const BalOps* BalOps_bal_e2_f2_s0();
 const BalOps* BalOps_bal_e2_f3_s0();
 const BalOps* BalOps_bal_e2_f4_s0();
+const BalOps* BalOps_bal_e2_f6_s0();
+const BalOps* BalOps_bal_e2_f9_s0();
+const BalOps* BalOps_bal_e4_f2_s0();
 const BalOps* BalOps_bal_e4_f3_s0();
+const BalOps* BalOps_bal_e4_f5_s0();
+const BalOps* BalOps_bal_e4_f7_s0();
+const BalOps* BalOps_bal_e4_f10_s0();
 const BalOps* BalOps_bal_e4_f4_s0();
 const BalOps* BalOps_bal_e4_f6_s0();
 const BalOps* BalOps_bal_e4_f8_s0();
@@ -80,23 +89,32 @@ const BalOps* GetBalOps(int nr, int ne, int nf, int ns) {
       case 2: return BalOps_bal_e2_f2_s0();
       case 3: return BalOps_bal_e2_f3_s0();
       case 4: return BalOps_bal_e2_f4_s0();
+      case 6: return BalOps_bal_e2_f6_s0();
+      case 9: return BalOps_bal_e2_f9_s0();
     }
     return nullptr;
   }
   if (ne == 4) {
     switch (nf) {
+      case 2: return BalOps_bal_e4_f2_s0();
       case 3: return BalOps_bal_e4_f3_s0();
       case 4: return BalOps_bal_e4_f4_s0();
+      case 5: return BalOps_bal_e4_f5_s0();
       case 6: return BalOps_bal_e4_f6_s0();
+      case 7: return BalOps_bal_e4_f7_s0();
       case 8: return BalOps_bal_e4_f8_s0();
       case 9: return BalOps_bal_e4_f9_s0();
+      case 10: return BalOps_bal_e4_f10_s0();
     }
     return nullptr;
   }
   switch (nf * 100 + ns) {
+    case 200: return BalOps_bal_f2_s0();
     case 300: return BalOps_bal_f3_s0();
     case 400: return BalOps_bal_f4_s0();
+    case 500: return BalOps_bal_f5_s0();
     case 600: return BalOps_bal_f6_s0();
+    case 700: return BalOps_bal_f7_s0();
     case 800: return BalOps_bal_f8_s0();
     case 900: return BalOps_bal_f9_s0();
     case 1000: return BalOps_bal_f10_s0();

@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = {
     "f3": dict(camera_width=3), "f4": dict(camera_width=4), "f6": dict(camera_width=6), "f8": dict(camera_width=8),
+    # round 6: the widths the reference reaches through (2,3,d) — 2, 5 (a camera without distortion terms), 7 (quaternion + translation)
+    "f2": dict(camera_width=2), "f5": dict(camera_width=5), "f7": dict(camera_width=7),
     "f10_quaternion_cameras": dict(camera_width=10),
     "f6_s8_libmv_like": dict(camera_width=6, shared_widths=(8,), locked_cameras=(0,)),
     "f6_s3_subset_manifold": dict(camera_width=6, shared_widths=(3,), locked_cameras=(0, 5)),
@@ -133,13 +135,15 @@ def test_strip_and_locked_cameras_beyond_lds(hip, oracle, problems):
 
 
 def test_unsupported_widths_fall_back_to_the_generic_path(hip, oracle, problems):
-    p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)
+    p = problems.synthetic_structured(12, 200, 900, camera_width=11, seed=9)
     assert_errs(check_schur_operators(hip, oracle, p, False, hip.PATH_GENERIC))
 
 
 # ---- point blocks that are not 3 wide (round 5): the reference's (2,2,*) and (2,4,*) specialisations
 # (internal/ceres/generate_template_specializations.py:55-75) on the fused path — every (E, F) pair of that list
-POINT_SHAPES = {f"e{ne}_f{nf}": dict(point_width=ne, camera_width=nf) for ne, nf in ((2, 2), (2, 3), (2, 4), (4, 3), (4, 4), (4, 6), (4, 8), (4, 9))}
+# (round 6: + the camera widths of (2,2,d) / (2,4,d) that are compiled statically: 6 and 9 next to 2-wide points, 2, 5, 7, 10 next to 4-wide ones)
+POINT_SHAPES = {f"e{ne}_f{nf}": dict(point_width=ne, camera_width=nf) for ne, nf in ((2, 2), (2, 3), (2, 4), (4, 3), (4, 4), (4, 6), (4, 8), (4, 9),
+                                                                                   (2, 6), (2, 9), (4, 2), (4, 5), (4, 7), (4, 10))}
 
 
 @pytest.mark.parametrize("name", list(POINT_SHAPES))
@@ -153,9 +157,10 @@ def test_operators_with_point_blocks_of_2_and_4(hip, oracle, problems, name):
     info = s.info()
     assert (info.row_block_size, info.e_block_size, info.f_block_size) == (2, kw["point_width"], kw["camera_width"])
     s.close()
-    # CGNR knows no elimination order: "points" are whatever is 3 wide.  (2,4,3): the 3-wide cameras take the points' role and the 4-wide
-    # points the cameras' — a <2,3,4> plan, fused; everything else here has no such reading and runs on the generic kernels.
-    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL if name == "e4_f3" else hip.PATH_GENERIC))
+    # CGNR knows no elimination order: "points" are whatever is 3 wide.  (2,4,3) / (2,2,3): the 3-wide cameras take the points' role and the
+    # 4- / 2-wide points the cameras' — a <2,3,4> / <2,3,2> plan, fused (<2,3,2> since round 6); everything else here has no such reading
+    # and runs on the generic kernels.
+    assert_errs(check_cgnr_operators(hip, oracle, p, False, hip.PATH_BAL if kw["camera_width"] == 3 else hip.PATH_GENERIC))
 
 
 @pytest.mark.parametrize("name", ["e4_f9", "e4_f6", "e2_f3", "e2_f2", "e4_f3"])

@@ -260,7 +260,7 @@ def test_plan_rejections(problems):
     p = problems.random_schur_problem(static_sizes=(2, 3, 6), seed=1)   # rows with several 6-wide F cells on many blocks: no camera / shared split
     r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
     assert not r["eligible"] and "shared strip" in r["why"]
-    p = problems.synthetic_structured(12, 200, 900, camera_width=5, seed=9)   # a camera width no kernels are compiled for
+    p = problems.synthetic_structured(12, 200, 900, camera_width=11, seed=9)   # a camera width no kernels are compiled for (round 6: 2 .. 10 all are)
     r = hs.debug_plan(p.bs, p.num_eliminate_blocks)
     assert not r["eligible"] and "no fused kernels" in r["why"]
     # a point that sees the same camera twice cannot use the fused SCHUR_JACOBI kernel

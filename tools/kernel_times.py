@@ -14,7 +14,16 @@ args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 wl = args_[0] if args_ else "venice1778"
 cache = f"/tmp/{wl}.npz"
 P = pkg.problems
-if os.path.exists(cache):
+many = wl in ("synthetic1M", "synthetic10M") and os.environ.get("KERNEL_TIMES_HOST_VALUES", "0") != "1"
+dev_vals = None
+if many:   # values generated in HBM, like bench.py's many-camera workloads (5.76 GB of Jacobian for synthetic10M)
+    prob = P.synthetic_bal(wl, layout="schur", seed=38401, skew=0.6, with_values=False)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(38401)
+    nrb = prob.bs.num_row_blocks
+    dev_vals = (torch.randn(24 * nrb, dtype=torch.float64, device="cuda", generator=g), torch.randn(2 * nrb, dtype=torch.float64, device="cuda", generator=g),
+                torch.rand(prob.bs.num_cols, dtype=torch.float64, device="cuda", generator=g) * 0.1 + 0.05)
+elif os.path.exists(cache):
     z = np.load(cache)
     bs = pkg.BlockStructure(*(z[k] for k in ("rsz", "rpos", "csz", "cpos", "rptr", "ccol", "cval")))
     prob = P.LinearProblem(bs, z["values"], z["b"], z["D"], int(z["nelim"]))
@@ -42,7 +51,10 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
                                                   elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage, force_generic_path=force_generic))
     s.set_structure(prob.bs)
     s.set_phase_timing(True)   # (last_timing below: the phase events are opt-in)
-    s.load(prob.values, prob.b, prob.D)
+    if dev_vals is not None:
+        s.load_device(*(t.data_ptr() for t in dev_vals))
+    else:
+        s.load(prob.values, prob.b, prob.D)
     for name, op, nbytes in ops:
         if nbytes == "tiles":
             nbytes = int(s.info().num_tiles) * 12288
@@ -51,6 +63,9 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
         if nbytes:
             out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
             out[name + "_frac"] = round(nbytes / ms / 1e6 / 8000, 4)
+    if dev_vals is not None:
+        s.close()
+        continue
     x, summ = s.solve(prob.values, prob.b, hs.PerSolveOptions(D=prob.D, q_tolerance=0.1, r_tolerance=-1.0))
     t = s.last_timing()
     out[solver + "_solve"] = {"its": summ.num_iterations, "total_ms": round(t.total_ms, 3), "upload_ms": round(t.upload_ms, 3), "pack_ms": round(t.pack_ms, 3),
