@@ -14,10 +14,16 @@ args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 wl = args_[0] if args_ else "venice1778"
 cache = f"/tmp/{wl}.npz"
 P = pkg.problems
-many = wl in ("synthetic1M", "synthetic10M") and os.environ.get("KERNEL_TIMES_HOST_VALUES", "0") != "1"
+many = wl in ("synthetic1M", "synthetic10M", "banded50k") and os.environ.get("KERNEL_TIMES_HOST_VALUES", "0") != "1"
 dev_vals = None
+if wl == "banded50k":   # bench.py's extra.banded50k: synthetic1M's block counts, every point seen by consecutive cameras
+    P.BAL_SHAPES["banded50k"] = P.BAL_SHAPES["synthetic1M"]
 if many:   # values generated in HBM, like bench.py's many-camera workloads (5.76 GB of Jacobian for synthetic10M)
-    prob = P.synthetic_bal(wl, layout="schur", seed=38401, skew=0.6, with_values=False)
+    if wl == "banded50k":
+        bc, bp, bo = P.BAL_SHAPES[wl]
+        prob = P.banded_bal(None, seed=38401, num_cameras=bc, num_points=bp, num_observations=bo, with_values=False)
+    else:
+        prob = P.synthetic_bal(wl, layout="schur", seed=38401, skew=0.6, with_values=False)
     g = torch.Generator(device="cuda")
     g.manual_seed(38401)
     nrb = prob.bs.num_row_blocks
