@@ -876,7 +876,15 @@ def main():
                 ib_ = sb_.info()
                 sb_.load_device(vb.data_ptr(), bb.data_ptr(), Db.data_ptr())
                 ms_ = min(sb_.time_op(hs.TIMED_SX if kd_ == "sx" else hs.TIMED_JTJX, 20) for _ in range(3))
-                case[kd_] = {"ms": round(ms_, 5), "frac": round(algorithmic_bytes(kd_, bo, bp, bc, 8) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                nb_ = algorithmic_bytes(kd_, bo, bp, bc, 8)
+                case[kd_] = {"ms": round(ms_, 5), "frac": round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": nb_}
+                try:   # HBM bytes by PMC of an EARLIER run of tools/kernel_times.py banded50k (profiles/pmc_traffic.json), like roofline.traffic
+                    rec_ = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                    if rec_.get(f"banded50k:{kd_}"):
+                        case[kd_].update({"traffic": rec_[f"banded50k:{kd_}"], "traffic_over_algorithmic": round(rec_[f"banded50k:{kd_}"] / nb_, 3),
+                                          "traffic_source": rec_.get("source", {}).get(f"banded50k:{kd_}")})
+                except Exception:
+                    pass
                 case.update({"accumulators_in_lds": int(ib_.camera_accum_in_lds), "hybrid": int(ib_.camera_accum_hybrid),
                              "observations_summed_in_lds": round(ib_.num_observations_in_lds / float(bo), 4)})
                 sb_.close()

@@ -15,7 +15,9 @@ LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01f_bench_*.json")) + 
                                                           "r04a_bench_default_iterative_schur.json", "r04l_bench_default_iterative_schur.json",
                                                           "r04_final_bench_default_iterative_schur.json", "r05_final_bench_default_iterative_schur.json",
                                                           "r05_final_bench_under_rocprof_iterative_schur.json", "r05_final_bench_under_rocprof_cgnr.json",
-                                                          "r05x_bench_default_iterative_schur_second_box.json")])
+                                                          "r05x_bench_default_iterative_schur_second_box.json",
+                                                          "r06_final_bench_default_iterative_schur.json", "r06_final_bench_under_rocprof_iterative_schur.json",
+                                                          "r06_final_bench_under_rocprof_cgnr.json")])
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -42,7 +44,7 @@ def test_committed_bench_lines_follow_the_contract(path):
     if "under_rocprof" not in path and "fp32" not in path and not two_ranks:   # profiled / fp32-storage / validation runs skip the CPU leg
         assert cpu and cpu["kind"] == "port" and cpu["unit"] == "steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0
         assert "sample" in cpu
-    if os.path.basename(path).startswith(("r02", "r03", "r04", "r05")):   # since round 2: what the traffic figure is, and the probe for real Ceres
+    if os.path.basename(path).startswith(("r02", "r03", "r04", "r05", "r06")):   # since round 2: what the traffic figure is, and the probe for real Ceres
         assert r["traffic"] is None or "profiles/" in r["traffic_source"]
         if cpu:
             assert "tools/probe.sh" in cpu["sample"]
@@ -155,3 +157,23 @@ def test_round5_two_rank_lines_at_the_headline_size(solver, collectives):
     assert d["n_gpus"] == 2 and d["config"]["collectives_per_step"] == collectives
     oc = d["oracle_check"]
     assert oc["ranks"] == 2 and oc["observations"] == 5001946 and oc["step_rel_diff_vs_oracle"] < 1e-9 and oc["cg_iterations_gpu"] == oc["cg_iterations_oracle"]
+
+
+def test_round6_default_line_carries_what_the_review_asked_for():
+    """VERDICT r05 "next" 1 / 2 / 4 / 5: the strong-scaling ceiling measured on one GPU, the streamed upload at the plugin boundary, the
+    banded many-camera workload and BASELINE.json configs[1] / configs[2] are fields of the N = 1 line."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_final_bench_default_iterative_schur.json")).read())
+    sc = d["extra"]["shard_ceiling"]
+    assert [c["ranks"] for c in sc["cases"]] == [2, 4, 8] and "NOT measured" in sc["what"]
+    for c in sc["cases"]:
+        assert c["efficiency_ceiling"] == pytest.approx(sc["t1_ms"] / (c["ranks"] * c["ms_per_step"]), rel=2e-3)
+        assert c["efficiency_with_link_estimate"] < c["efficiency_ceiling"] and c["collectives_per_step"] >= 4
+    st = d["host_boundary"]["streamed"]
+    assert st["ms_after_last_push"] < d["host_boundary"]["ms_per_step"] / 3 and st["bytes_sent_in_end"] == 0 and st["step_rel_diff_vs_plain_step"] < 1e-12
+    b = d["extra"]["banded50k"]
+    assert b["cameras"] == 50000 and b["observations_summed_in_lds"] > 0.9 and 0 < b["sx"]["frac"] < 1
+    cases = d["extra"]["configs"]["cases"]
+    assert cases[0]["solver"].startswith("CGNR") and "dubrovnik16" in cases[0]["workload"] and cases[1]["solver"].startswith("ITERATIVE_SCHUR") and "ladybug1723" in cases[1]["workload"]
+    for c in cases:
+        assert c["step_rel_diff_vs_oracle"] < 1e-9 and c["cpu_port"]["steps_per_s"] > 0 and c["steps_per_s"] == pytest.approx(1e3 / c["ms_per_step"], rel=1e-2)
+    assert d["extra"]["synthetic10M"]["shard_ceiling"]["cases"][0]["ranks"] == 8

@@ -212,6 +212,38 @@ def test_lm_step_sharded_code_paths_in_loopback(hip, problems, solver_type, pre)
 
 
 @pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("nc", [25, 1500])
+def test_lm_step_with_ghost_peers_equals_the_unsharded_step(hip, problems, monkeypatch, solver_type, pre, fuse, nc):
+    """ceres_hip_debug_comm_ghost_peers (bench.py: extra.shard_ceiling): rank 0 of eight ranks whose peers are local dummy buffers that
+    contribute zeros — every exchange of the sharded step runs (inside the producing kernels, or with CERES_HIP_P2P_FUSE=0 as stand-alone
+    all-reduces), so with the WHOLE problem on this rank the step must be the unsharded one.  1500 cameras: the four-cameras-per-wavefront
+    exchange of the per-camera sums."""
+    monkeypatch.setenv("CERES_HIP_P2P_FUSE", fuse)
+    p = problems.synthetic_bal(None, num_cameras=nc, num_points=1500 if nc == 25 else 4000, num_observations=7000 if nc == 25 else 14000, seed=46)
+    o = hip.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=300,
+                                elimination_groups=[p.num_eliminate_blocks])
+    ref = hip.HipLinearSolver(o)
+    ghost = hip.HipLinearSolver(o, ghost_world=8, p2p_max_elements=99 * nc + 2)
+    ref.set_structure(p.bs)
+    ghost.set_structure(p.bs)
+    assert ghost.info().world_size == 8 and ghost.info().p2p_enabled
+    a = ref.lm_compute_step(p.values, p.b, 1e4, 0.1)
+    b = ghost.lm_compute_step(p.values, p.b, 1e4, 0.1)
+    assert rel(ghost.lm_diagonal(), ref.lm_diagonal()) <= 1e-13
+    assert a[1].termination_type == b[1].termination_type == hip.SUCCESS and a[1].num_iterations == b[1].num_iterations
+    assert rel(b[0], a[0]) <= 1e-10 and abs(a[2] - b[2]) <= 1e-10 * abs(a[2])
+    assert ghost.info().collectives_last_step >= 4
+    for radius, reuse in ((5e3, True), (2e4, False)):   # a rejected step, then a fresh one
+        a = ref.lm_compute_step(p.values * 1.25, p.b, radius, 0.1, reuse_diagonal=reuse)
+        b = ghost.lm_compute_step(p.values * 1.25, p.b, radius, 0.1, reuse_diagonal=reuse)
+        assert a[1].num_iterations == b[1].num_iterations
+        assert rel(b[0], a[0]) <= 1e-10 and abs(a[2] - b[2]) <= 1e-10 * abs(a[2])
+    ref.close()
+    ghost.close()
+
+
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
 def test_speculative_tail_equals_the_two_synchronisation_sequence(hip, oracle, problems, monkeypatch, solver_type, pre):
     """The LM step's tail (back-substitution / model cost, negation, finite check, read-back) is enqueued in front of every poll
     of the CG status word and gated by it on the device.  Every class of CG ending must give what the plain
