@@ -152,3 +152,19 @@ def test_misuse_is_an_error(hip, problems):
     s.values_end()
     step, summ, mcc = s.lm_compute_step(None, None, 1e4, 0.1, values_unchanged=True)
     assert np.isfinite(step).all() and mcc > 0
+
+
+@pytest.mark.parametrize("shuffle,streams", [(False, 1), (True, 0)])
+def test_streaming_on_the_generic_kernels(hip, oracle, problems, shuffle, streams):
+    """Any block sizes, rows with several F cells and rows without an E block (the generic path): a row-sequential value layout is one
+    stream, a shuffled one goes up at the end; the solve on the streamed values equals the plain solve and the oracle's."""
+    p = problems.random_schur_problem(num_e_blocks=40, num_f_blocks=9, seed=8, shuffle_values=shuffle)
+    ref = make(hip, p, 5, 2)
+    assert ref.info().kernel_path == hip.PATH_GENERIC
+    step0, summ0, mcc0 = ref.lm_compute_step(p.values, p.b, 1e4, 1e-12)
+    s = make(hip, p, 5, 2)
+    early, late, k = stream_up(s, p, p.values, p.b, run=3)
+    assert k == streams and (early > 0) == (streams > 0)
+    step, summ, mcc = s.lm_compute_step(None, None, 1e4, 1e-12, values_unchanged=True)
+    assert summ.termination_type == hip.SUCCESS and same(step, step0, 1e-9) and same(mcc, mcc0, 1e-9)
+    check_step(oracle, hip, p, 5, 2, s.lm_diagonal(), step, summ, mcc, 1e-12, tol=1e-8)
