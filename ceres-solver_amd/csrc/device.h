@@ -152,6 +152,9 @@ struct BalArgs {
   const int* run_after_cg = nullptr;
   double* pq_out = nullptr;      // kJtJx: partial x_e . y_e of the point part, one per workgroup (CG's p.q without a pass of its own)
   const int* status = nullptr;   // CG status word; non-zero => kernel returns immediately
+  // first pass of a solve (kInit / kCgnrInit; neither raises them): the step's finite-step and factorization flags, two adjacent ints,
+  // are cleared here instead of by a memset command in front of the pass (a fill kernel and its launch per step)
+  int* clear_flags = nullptr;
   CgTail tail;                   // kSx, pipelined kernel, every camera's accumulator in LDS: finish the CG iteration (see CgTail)
 };
 
@@ -516,7 +519,10 @@ hipError_t LaunchCgCollapseExchange(const CgBuffers& B, int first_slot, int coun
 // out[0] = (*flag != 0), out[1] = sum of parts[0 .. n) (one workgroup, fixed order)
 hipError_t LaunchCollectScalars(const int* flag, const double* parts, int n, double* out, hipStream_t stream);
 // ... summed over ranks in the same launch (p2p.h)
-hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t stream);
+// image != nullptr: also the mailbox read-back of image[0 .. n_image) (out must lie inside it), stamped with `stamp`
+hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t stream,
+                                        const double* image = nullptr, int n_image = 0, double* host_dst = nullptr,
+                                        unsigned long long* host_stamp = nullptr, unsigned long long stamp = 0);
 
 // ---- one-shot peer-to-peer all-reduce (kernels_cg.hip) ----
 // out = sum over ranks of in (n <= cap; in may alias out); comm.epoch counts this communicator's exchanges from 1 (solver.hip: next_exchange).

@@ -833,20 +833,32 @@ __global__ __launch_bounds__(kVecBlock) void collect_scalars_kernel(const int* f
 }  // namespace
 namespace {
 // The same with the sum over ranks inside (p2p.h): out = sum over ranks of {flag != 0, sum(parts)}.
-__global__ __launch_bounds__(kVecBlock) void collect_scalars_exchange_kernel(const int* flag, const double* parts, int n, double* out, P2pComm C) {
+// image != nullptr: the kernel is also the read-back of the poll that follows (mailbox_kernel's job: image[0 .. n_image) to mapped host
+// memory, then the stamp) — the sharded speculative tail ends in ONE launch instead of two.
+__global__ __launch_bounds__(kVecBlock) void collect_scalars_exchange_kernel(const int* flag, const double* parts, int n, double* out, P2pComm C,
+                                                                             const double* image, int n_image, double* host_dst,
+                                                                             unsigned long long* host_stamp, unsigned long long stamp) {
   __shared__ double sh[4];
   double v = 0;
   for (int k = threadIdx.x; k < n; k += kVecBlock) v += parts[k];
   v = block_sum(v, sh);
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  const double mine = lane == 0 ? ((*flag != 0) ? 1.0 : 0.0) : v;
-  const double t = p2p_exchange_wave(C, 0, lane, lane < 2, mine);
-  if (lane < 2) out[lane] = t;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const double mine = lane == 0 ? ((*flag != 0) ? 1.0 : 0.0) : v;
+    const double t = p2p_exchange_wave(C, 0, lane, lane < 2, mine);
+    if (lane < 2) out[lane] = t;
+  }
+  if (image == nullptr) return;
+  __syncthreads();   // the sums are in the image
+  for (int i = threadIdx.x; i < n_image; i += kVecBlock) host_dst[i] = image[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_stamp, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
-hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t s) {
-  hipLaunchKernelGGL(collect_scalars_exchange_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out, comm);
+hipError_t LaunchCollectScalarsExchange(const int* flag, const double* parts, int n, double* out, const P2pComm& comm, hipStream_t s,
+                                        const double* image, int n_image, double* host_dst, unsigned long long* host_stamp, unsigned long long stamp) {
+  hipLaunchKernelGGL(collect_scalars_exchange_kernel, dim3(1), dim3(kVecBlock), 0, s, flag, parts, n, out, comm, image, n_image, host_dst, host_stamp, stamp);
   return hipGetLastError();
 }
 hipError_t LaunchCgCollapseExchange(const CgBuffers& B, int first_slot, int count, const P2pComm& comm, hipStream_t s) {

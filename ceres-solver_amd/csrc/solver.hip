@@ -90,6 +90,7 @@ struct ceres_hip_solver {
   // f1: LM step state
   double *lm_diag = nullptr, *lm_D = nullptr, *scalar_partials = nullptr;
   int* d_nonfinite = nullptr;
+  bool clear_flags_pending = false;   // the solve's first fused pass still has to clear the two flags (solve_loaded_impl)
   bool fail_flag_clean = false, nonfinite_clean = false;  // cleared together at the start of a solve: the per-operator memsets are skipped once
   bool have_lm_diag = false;
   bool lm_want_model_cost = false;  // op_back_substitute also accumulates the model cost change (fused <2,3,9> path)
@@ -188,6 +189,7 @@ struct ceres_hip_solver {
   unsigned long long* h_stamp = nullptr;        // = h_pinned + kReadbackDoubles (host view), d_stamp its device view
   unsigned long long* d_stamp = nullptr;
   unsigned long long mailbox_seq = 0;
+  unsigned long long tail_mailbox_seq = 0;      // != 0: the image of the next poll is already on its way (collect_scalars_exchange_kernel)
   bool final_sync_skippable = [] { const char* e = getenv("CERES_HIP_FINAL_SYNC"); return e && atoi(e) == 0; }();   // (A/B: default keeps the synchronisation)
   bool mailbox = [] { const char* e = getenv("CERES_HIP_MAILBOX"); return !e || atoi(e) != 0; }();
   double* scratch_vec = nullptr;   // num_cols + num_rows doubles for op-level entry points
@@ -722,6 +724,7 @@ int op_schur_init(ceres_hip_solver* s, bool want_Mo) {
     BalArgs A = bal_args(s);
     A.D_e = s->D;
     A.Mo = want_Mo ? s->d_Mo : nullptr;
+    if (s->clear_flags_pending) { A.clear_flags = s->d_nonfinite; s->clear_flags_pending = false; }
     PackGuard g = use_gather_if_unpacked(s, A);  // the step's first pass over J also writes the tiles
     if (s->have_b) {
       const bool defer = s->world > 1 && s->merge_step_reduce && s->merged_layout;
@@ -966,6 +969,7 @@ int op_cgnr_setup_bal(ceres_hip_solver* s, bool jacobi, double* rhs, double* blo
   if (!s->fail_flag_clean) HIP_TRY(s, hipMemsetAsync(s->d_fail_flag, 0, sizeof(int), st));
   s->fail_flag_clean = false;
   BalArgs A = bal_args(s);
+  if (s->clear_flags_pending) { A.clear_flags = s->d_nonfinite; s->clear_flags_pending = false; }
   A.etei = nullptr;
   A.D_e = s->D;
   A.y_e = rhs;
@@ -1240,7 +1244,14 @@ int read_back(ceres_hip_solver* s, const double* src, int n) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return check_comm_error(s);
 }
-int poll_scalars(ceres_hip_solver* s) { return read_back(s, s->scalar_partials, kReadbackDoubles); }
+int poll_scalars(ceres_hip_solver* s) {
+  if (s->tail_mailbox_seq != 0) {   // the speculative tail's last kernel was this poll's read-back already
+    const unsigned long long seq = s->tail_mailbox_seq;
+    s->tail_mailbox_seq = 0;
+    return wait_mailbox(s, seq);
+  }
+  return read_back(s, s->scalar_partials, kReadbackDoubles);
+}
 
 int collapse_and_reduce(ceres_hip_solver* s, int first_slot, int count) {
   if (s->cg.grid_e == 0) return 0;
@@ -1474,6 +1485,10 @@ int solve_loaded(ceres_hip_solver* s, double q_tol, double r_tol, double* x, cer
   // explicit S, IDENTITY, early returns) clear and raise d_fail_flag themselves, and a later op-level call must not skip its memset
   s->fail_flag_clean = false;
   s->nonfinite_clean = false;
+  if (s->clear_flags_pending) {   // no fused first pass took the clearing along: cannot happen on the paths that set it — an error, not a silent skip
+    s->clear_flags_pending = false;
+    if (rc == 0) rc = fail(s, CERES_HIP_E_INVALID, "internal: the solve's flags were never cleared (no first pass ran)");
+  }
   return rc;
 }
 int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x, ceres_hip_summary* summary) {
@@ -1487,7 +1502,10 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
   // ImplicitSchurComplement::Init / Preconditioner::Update do on every Solve.
   s->ftf_inv_valid = false;
   s->precond_valid = false;
-  HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), st));  // finite-step flag + factorization flag, adjacent
+  // finite-step flag + factorization flag, adjacent.  Fused path: the solve's first pass clears them itself (BalArgs::clear_flags:
+  // op_schur_init / op_cgnr_setup_bal, which every fused solve starts with) — no fill command in front of it
+  s->clear_flags_pending = s->path == CERES_HIP_PATH_BAL && s->ops != nullptr;
+  if (!s->clear_flags_pending) HIP_TRY(s, hipMemsetAsync(s->d_nonfinite, 0, 2 * sizeof(int), st));
   s->fail_flag_clean = true;
   s->nonfinite_clean = true;
   TRY(rec(s, 2));
@@ -1731,9 +1749,17 @@ int solve_loaded_impl(ceres_hip_solver* s, double q_tol, double r_tol, double* x
         if (rc) return rc;
         // sharded: {finite-step flag, this rank's share of the model cost} summed over ranks into the read-back image, in the same tail
         // (the exchange runs whether CG has ended or not — a handshake per epoch on every rank, p2p.h; its sums only mean something once it has)
-        if (s->world > 1)
-          HIP_TRY(s, LaunchCollectScalarsExchange(s->d_nonfinite, s->scalar_partials, s->backsub_cost_parts, s->scalar_partials + kSumsOffset,
-                                                  next_exchange(s), s->stream));
+        if (s->world > 1) {
+          if (s->mailbox && s->d_h_pinned) {   // ... and the poll's read-back (the whole image, stamped): one launch for the two
+            s->tail_mailbox_seq = ++s->mailbox_seq;
+            HIP_TRY(s, LaunchCollectScalarsExchange(s->d_nonfinite, s->scalar_partials, s->backsub_cost_parts, s->scalar_partials + kSumsOffset,
+                                                    next_exchange(s), s->stream, s->scalar_partials, kReadbackDoubles, s->d_h_pinned, s->d_stamp,
+                                                    s->tail_mailbox_seq));
+          } else {
+            HIP_TRY(s, LaunchCollectScalarsExchange(s->d_nonfinite, s->scalar_partials, s->backsub_cost_parts, s->scalar_partials + kSumsOffset,
+                                                    next_exchange(s), s->stream));
+          }
+        }
         s->spec_tail_done = true;   // (the poll that follows copies the partial sums and flags together with the CG scalars)
         return 0;
       };
