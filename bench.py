@@ -228,6 +228,20 @@ def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta
         s = one()
         assert s.termination_type in (0, 1), s
     sync()
+    if step_kind == "lm_step":
+        # the timed loop calls the C ABI with its argument structs built once, like a C++ caller (hip_solver.lm_stepper); every step's
+        # result is checked after the loop
+        step = solver.lm_stepper(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), radius, eta)
+        res = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = step()
+            res.append((r.linear_solver.num_iterations, r.linear_solver.termination_type, r.model_cost_change, r.step_is_finite))
+        sync()
+        el = time.perf_counter() - t0
+        for it, term, mcc, finite in res:
+            assert finite and mcc > 0 and term in (0, 1), (it, term, mcc, finite)
+        return el, [int(r[0]) for r in res], s
     t0 = time.perf_counter()
     for _ in range(steps):
         s = one()

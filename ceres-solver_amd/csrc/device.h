@@ -112,7 +112,7 @@ struct BalArgs {
   // vectors: *_e indexed by pt_pos, *_f by cam_pos
   const double* x_e = nullptr;
   const double* x_f = nullptr;
-  int flags = 0;                    // reserved
+  int flags = 0;                    // 1: per-lane point-space accesses in JtJx, 2: blocked tile walk (experiments); 4: plain (not non-temporal) tile stores
   double* y_e = nullptr;
   const double* D_e = nullptr;  // nullptr => no regularisation on the point part
   // fused LM diagonal (lm_radius > 0): D_e is formed in the kernel from the point block's own diagonal

@@ -2207,7 +2207,9 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
         s->cam_items_few = most <= 4 && P.n_cameras >= 1024;
         // the sharded exchange of the cameras' sums: four cameras per wavefront where the AVERAGE camera has a handful of items (a popular
         // camera's hundred items are a hundred independent loads for its lane; one workgroup per camera is one exchange round trip per camera)
-        s->cam_exchange_few = int64_t(P.item_cam.size()) <= int64_t(4) * P.n_cameras && P.n_cameras >= 1024;
+        // (measured cross-over: 1778 cameras 37 us against 14 us for a workgroup per camera, 50 000 cameras 111 against 267: profiles/r06t_*)
+        s->cam_exchange_few = int64_t(P.item_cam.size()) <= int64_t(4) * P.n_cameras && P.n_cameras >= 8192;
+        { const char* e = getenv("CERES_HIP_CAM_EXCHANGE_FEW"); if (e) s->cam_exchange_few = atoi(e) != 0; }   // (A/B switch)
       }
       TRY(dev_alloc(s, &s->d_cam_parts, size_t(P.item_cam.size()) * s->ops->cam_part));
       if (s->world > 1) TRY(dev_alloc(s, &s->d_cam_packed, size_t(std::max(1, P.n_cameras)) * s->ops->cam_part));
@@ -2323,6 +2325,12 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
       s->bal_flags = (e && atoi(e) == 0) ? 1 : 0;
       const char* w = getenv("CERES_HIP_TILE_WALK");  // "blocked": a workgroup of the pipelined kernels takes one contiguous run of tiles (experiment)
       if (w && strcmp(w, "blocked") == 0) s->bal_flags |= 2;
+      // tiles that fit the Infinity Cache (the bound launch_stream uses for plain LOADS): the first pass writes them with plain stores
+      // — opt-in (CERES_HIP_PLAIN_TILE_STORES=1): measured level or behind non-temporal stores on every shape tried (one rank's eighth of
+      // Venice 0.352 against 0.346 ms per step, Ladybug and Dubrovnik level; profiles/r06u_prefetch_ab.jsonl)
+      const char* ps = getenv("CERES_HIP_PLAIN_TILE_STORES");
+      const int64_t tile_bytes = s->opt.jacobian_storage == 1 ? int64_t(P.n_tiles) * kTile * 96 : int64_t(P.n_tiles) * s->ops->tile_pitch * 16;   // (what launch_stream counts)
+      if (ps && atoi(ps) != 0 && tile_bytes <= (int64_t(200) << 20)) s->bal_flags |= 4;
     }
   } else {
     TRY(dev_alloc(s, &s->etei, size_t(h.diag_off_e.back())));

@@ -477,6 +477,23 @@ class HipLinearSolver:
         return Summary(s.residual_norm, s.num_iterations, s.termination_type, s.message.decode(errors="replace")), \
             float(r.model_cost_change), bool(r.step_is_finite)
 
+    def lm_stepper(self, d_values: int, d_residuals: int, d_step: int, radius, eta=0.1, min_diagonal=1e-6, max_diagonal=1e32):
+        """A callable that runs lm_compute_step_device on fixed device arrays with the argument structs built ONCE (what a C++ caller
+        does: the structs live across trust-region iterations); returns the raw CLmResult, which the next call overwrites.  A timed
+        loop through it pays one ctypes call per step and none of this wrapper's per-call Python work (three struct constructions,
+        a message decode), during which the device idles between two steps."""
+        o = CLmOptions(radius, min_diagonal, max_diagonal, eta, 0, 0)
+        r = CLmResult()
+        fn, h, po, pr, check = self._lib.ceres_hip_lm_compute_step_device, self._h, byref(o), byref(r), self._check
+        keep = (o, r)
+
+        def step():
+            rc = fn(h, d_values, d_residuals, po, d_step, pr)
+            if rc != 0:
+                check(rc)
+            return keep[1]
+        return step
+
     # -- the upload hidden behind the evaluator ---------------------------------
     def values_begin(self, values, residuals):
         """values / residuals: the (pinned) host arrays the evaluator is about to fill; kept alive until values_end."""
