@@ -150,6 +150,9 @@ def parse():
     ap.add_argument("--extra-banded", type=int, default=1, help="default line: S.x / JtJx on a 50 000-camera sequence-like (banded) graph (extra.banded50k)")
     ap.add_argument("--extra-configs", type=int, default=1, help="default line: BASELINE.json configs[1] (Dubrovnik-16, CGNR + JACOBI) and configs[2] "
                                                                  "(Ladybug-1723, ITERATIVE_SCHUR + SCHUR_JACOBI): steps/s, operator roofline, oracle check, CPU port (extra.configs)")
+    ap.add_argument("--pmc-live", type=int, default=1, help="N = 1: measure roofline.traffic now with two rocprofv3 --pmc passes in child processes "
+                                                            "(tools/pmc_live.py; 0: the committed constant of profiles/pmc_traffic.json)")
+    ap.add_argument("--pmc-live-timeout", type=float, default=300.0, help="seconds per counter pass")
     ap.add_argument("--shard-ceiling", type=int, default=1,
                     help="N = 1: also run rank 0's shard of the workload for N = 2, 4, 8 alone on the device with the sharded code path on "
                          "(ghost peers) and report T_1 / (N T_shard) as extra.shard_ceiling (0: skip)")
@@ -241,7 +244,10 @@ def timed_steps(solver, ptrs, steps, warmup, sync, step_kind="linear_solve", eta
         el = time.perf_counter() - t0
         for it, term, mcc, finite in res:
             assert finite and mcc > 0 and term in (0, 1), (it, term, mcc, finite)
-        return el, [int(r[0]) for r in res], s
+        ls = r.linear_solver   # (the last step's summary; `r` is the stepper's result struct, which the next call would overwrite)
+        last = sys.modules[type(solver).__module__].Summary(ls.residual_norm, ls.num_iterations, ls.termination_type,
+                                                            ls.message.decode(errors="replace"))
+        return el, [int(x[0]) for x in res], last
     t0 = time.perf_counter()
     for _ in range(steps):
         s = one()
@@ -516,17 +522,38 @@ def main():
         nbytes = algorithmic_bytes(k, my_obs, my_points, n_cams, scalar_bytes)
         return ms, nbytes, nbytes / (ms * 1e-3) / 1e9
 
+    pmc_live = {}   # filled once (both operators come out of the same two counter passes)
+
     def pmc_traffic(k):
-        # HBM bytes per application from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, collected and corrected as
-        # MI355X_MICROARCH.md prescribes) of an EARLIER run of this same command on this workload: profiles/pmc_traffic.json
-        # names the files.  Not a measurement of this run (the counters need their own rocprofv3 passes).
+        # HBM bytes per application from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, collected and corrected as
+        # MI355X_MICROARCH.md prescribes).  LIVE (default at N = 1 on the fp64 tiles): tools/pmc_live.py runs the two passes now, in
+        # child processes, around tools/kernel_times.py <workload> --operators-only — the same operators on the same generated
+        # problem.  Otherwise, and whenever the live passes fail (no rocprofv3, this process itself under a profiler, a time-out), the
+        # constant of an EARLIER run of the same passes: profiles/pmc_traffic.json names its files.
         f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        key = f"{args.workload}:{k}" + (":fp32" if storage else "")
         try:
             rec = json.load(open(f))
-            key = f"{args.workload}:{k}" + (":fp32" if storage else "")
-            return rec.get(key), rec.get("source", {}).get(key, rec.get("_source"))
+            committed, committed_src = rec.get(key), rec.get("source", {}).get(key, rec.get("_source"))
         except Exception:
-            return None, None
+            committed, committed_src = None, None
+        if args.pmc_live and world == 1 and not storage:
+            if not pmc_live:
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import pmc_live as pl
+                    if pl.under_a_profiler():
+                        raise RuntimeError("this process already runs under a profiler")
+                    pmc_live.update(pl.measure(args.workload, timeout=args.pmc_live_timeout,
+                                               env_extra={"CERES_HIP_PROBLEM_CACHE": os.environ.get("CERES_HIP_PROBLEM_CACHE", "/tmp/ceres_problem_cache")}))
+                except Exception as ex:
+                    pmc_live["error"] = repr(ex)[:300]
+            if k in pmc_live:
+                return pmc_live[k], (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes run by this invocation (tools/pmc_live.py, "
+                                     f"{pmc_live.get('seconds')} s; 1024 (2 FETCH_SIZE + WRITE_SIZE) over {sorted(pmc_live['breakdown_KiB'][k])}); "
+                                     f"the committed constant of an earlier run (profiles/pmc_traffic.json): {committed}")
+            committed_src = f"{committed_src}; live passes failed: {pmc_live.get('error')}"
+        return committed, committed_src
 
     op_ms, alg_bytes, achieved = measure_operator(solver, kind)
     extra = {"pack_ms": solver.time_op(hs.TIMED_PACK, 10)}
@@ -826,7 +853,7 @@ def main():
             extra["synthetic10M"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, the child wants 60"}
         else:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", "synthetic10M", "--steps", "5", "--warmup", "1", "--kernel-iters", "20",
-                   "--no-cpu-baseline", "--oracle-check", "1", "--host-boundary-steps", "0", "--minimizer-iterations", "0", "--extra-synthetic10m", "0", "--also-fp32", "1",
+                   "--no-cpu-baseline", "--oracle-check", "1", "--host-boundary-steps", "0", "--minimizer-iterations", "0", "--extra-synthetic10m", "0", "--pmc-live", "0", "--also-fp32", "1",
                    "--solver", args.solver, "--eta", str(args.eta)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)

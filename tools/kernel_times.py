@@ -10,6 +10,7 @@ import __graft_entry__ as entry
 pkg = entry.load_package()
 hs = pkg.hip_solver
 force_generic = "--force-generic" in sys.argv
+operators_only = "--operators-only" in sys.argv   # tools/pmc_live.py: S.x and JtJx only, a dozen applications each, no solve
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 wl = args_[0] if args_ else "venice1778"
 cache = f"/tmp/{wl}.npz"
@@ -53,6 +54,8 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
         ops = [o for o in ops if o[0] not in ("read_stream",)]
     if force_generic:
         ops = [o for o in ops if o[0] in ("jtjx", "block_jacobi", "sx", "schur_init", "schur_jacobi", "back_substitute")]
+    if operators_only:
+        ops = [o for o in ops if o[0] in ("jtjx", "sx")]
     s = hs.HipLinearSolver(hs.LinearSolverOptions(type=typ, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=500,
                                                   elimination_groups=[prob.num_eliminate_blocks], jacobian_storage=storage, force_generic_path=force_generic))
     s.set_structure(prob.bs)
@@ -64,12 +67,12 @@ for solver, typ, pre, ops in (("cgnr", hs.CGNR, hs.JACOBI, [("jtjx", hs.TIMED_JT
     for name, op, nbytes in ops:
         if nbytes == "tiles":
             nbytes = int(s.info().num_tiles) * 12288
-        ms = min(s.time_op(op, 5 if force_generic else 30) for _ in range(2 if force_generic else 3))
+        ms = min(s.time_op(op, 5 if force_generic else (12 if operators_only else 30)) for _ in range(1 if operators_only else (2 if force_generic else 3)))
         out[name + "_ms"] = round(ms, 4)
         if nbytes:
             out[name + "_GBs"] = round(nbytes / ms / 1e6, 1)
             out[name + "_frac"] = round(nbytes / ms / 1e6 / 8000, 4)
-    if dev_vals is not None:
+    if dev_vals is not None or operators_only:
         s.close()
         continue
     x, summ = s.solve(prob.values, prob.b, hs.PerSolveOptions(D=prob.D, q_tolerance=0.1, r_tolerance=-1.0))
