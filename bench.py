@@ -152,7 +152,7 @@ def parse():
                                                                  "(Ladybug-1723, ITERATIVE_SCHUR + SCHUR_JACOBI): steps/s, operator roofline, oracle check, CPU port (extra.configs)")
     ap.add_argument("--pmc-live", type=int, default=1, help="N = 1: measure roofline.traffic now with two rocprofv3 --pmc passes in child processes "
                                                             "(tools/pmc_live.py; 0: the committed constant of profiles/pmc_traffic.json)")
-    ap.add_argument("--pmc-live-timeout", type=float, default=300.0, help="seconds per counter pass")
+    ap.add_argument("--pmc-live-timeout", type=float, default=120.0, help="seconds per counter pass")
     ap.add_argument("--shard-ceiling", type=int, default=1,
                     help="N = 1: also run rank 0's shard of the workload for N = 2, 4, 8 alone on the device with the sharded code path on "
                          "(ghost peers) and report T_1 / (N T_shard) as extra.shard_ceiling (0: skip)")
