@@ -838,7 +838,9 @@ __global__ __launch_bounds__(kB) void rem_model_cost_kernel(const double* __rest
 }  // namespace
 
 // one instantiation per camera width kernels_bal.inc is compiled for (common.h: BalShapeCompiled)
-#define CERES_HIP_REM_WIDTHS(X) X(2) X(3) X(4) X(6) X(8) X(9) X(10)
+// (every camera width the fused path is compiled for: build.py BAL_SHAPES — a width missing here made every pass over rows without a point cell fail
+// with hipErrorInvalidValue for cameras 5 and 7 wide, found by tools/fuzz_parity.py)
+#define CERES_HIP_REM_WIDTHS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 hipError_t LaunchRemCameraBlocks(const GenStructure& R, const double* values, const int32_t* cam_block, int n_cameras, int nf, double* out, hipStream_t s) {
   if (n_cameras <= 0) return hipSuccess;
   const dim3 grid((n_cameras + kB / 64 - 1) / (kB / 64));

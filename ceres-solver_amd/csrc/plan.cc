@@ -11,12 +11,29 @@
 // 64 observations, which is what lets the fused kernels do every per-point
 // reduction with wavefront shuffles and no inter-workgroup traffic.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
 #include "common.h"
 
 namespace chip {
+
+// CERES_HIP_PLAN_TIMING=1: seconds since the previous mark, to stderr (where set_structure's host time goes)
+namespace {
+struct PlanClock {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PlanClock() : on(getenv("CERES_HIP_PLAN_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plan] %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
 
 std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, HostStructure* hs) {
   HostStructure& h = *hs;
@@ -134,6 +151,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   P = BalPlan();
   auto no = [&](const char* why) { P.eligible = false; P.why_not = why; };
   if (h.nrb == 0) return no("empty matrix");
+  PlanClock clk;
   // Classify column blocks: POINTS (the eliminated blocks; without an elimination order: the 3-wide ones), and among the others the
   // CAMERAS (at most one cell per row, all of one width nf) and a few SHARED blocks (common.h: the strip).
   // The eliminated blocks are all of ONE width: 3, or — with an elimination order — 2 or 4 (common.h: BalShapeCompiled; the reference's
@@ -216,6 +234,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   for (size_t q = 0; q < P.sh_block.size(); ++q)
     for (int k = 0; k < h.csz[P.sh_block[q]]; ++k) P.sh_pos.push_back(h.cpos[P.sh_block[q]] - h.num_cols_e + k);
 
+  clk.mark("classify, shared blocks");
   // Every conforming row: 2 scalar rows, exactly one point cell, at most one camera cell, at most kMaxSharedCellsPerRow shared cells.
   std::vector<int32_t> row_pt(n_conf), row_cam(n_conf, -1), row_epos(n_conf), row_fpos(n_conf, -1);
   std::vector<int32_t> row_hpos[kMaxSharedCellsPerRow], row_hdesc[kMaxSharedCellsPerRow];
@@ -247,6 +266,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   }
   if (h.nelim > 0 && !h.chunks_contiguous) return no("rows of one E block are not contiguous");
 
+  clk.mark("rows");
   // Observations grouped by point (stable: keeps the caller's order inside a point).
   std::vector<int32_t> order(n_conf);
   std::iota(order.begin(), order.end(), 0);
@@ -285,6 +305,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   const bool reorder_points = reorder_mode == kReorderAlways || (reorder_mode == kReorderIfContiguous && P.caller_contiguous);
   P.renumbered = reorder_points;
 
+  clk.mark("group by point, distinct cameras");
   // Cameras whose 9-double accumulators do not fit in LDS (decided here: the point order below depends on it).
   // (1 KiB of the 160 stays free for the kernels' static LDS: workgroup reductions, the exchange area of the long points' rounds)
   P.cameras_in_lds = (size_t(P.nf) * P.n_cameras + size_t(P.ns)) * sizeof(double) <= kLdsBytesPerCu - 1024;
@@ -399,6 +420,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     }
   }
 
+  clk.mark("hybrid assignment");
   // INTERNAL point order.  A tile holds whole points, so the greedy packing in the caller's order wastes the slots behind the last
   // point that fits: about half a track per tile, 5 % of the slots on the Venice shape — 5 % of the bytes of EVERY pass over the
   // tiles.  With reorder_points (no CG vector walks the caller's point order in tile order: the Schur solvers, and CGNR on internal
@@ -462,6 +484,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     track.swap(trk);
   }
 
+  clk.mark("point order");
   // Vector offsets.
   P.pt_pos.resize(P.n_points);
   P.cam_pos.resize(P.n_cameras);
@@ -594,6 +617,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   for (int64_t s = 0; s < P.n_tiles * kTile; ++s)
     if (!(P.slot_seg[s] & (1u << 16))) { const uint32_t l = uint32_t(s % kTile); P.slot_seg[s] |= l | (l << 8); }
 
+  clk.mark("tiles");
   // ROUNDS of long points.  A streaming kernel's workgroup has kRoundWaves waves; in a round each of them takes ONE tile, the waves
   // of a point exchange their tile sums through LDS, and every wave finishes its tile from registers: a long point is read once,
   // with a tile per wave in flight, instead of one wave walking all its tiles twice.  A round holds whole points (tightest fit,
@@ -654,6 +678,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
     P.round_ptr.resize(long_ptr.size() + 1, 0);
   }
 
+  clk.mark("rounds");
   // Camera-major lists (counting sort over slots keeps point order inside a camera).
   P.cam_ptr.assign(P.n_cameras + 1, 0);
   for (int64_t s = 0; s < P.n_tiles * kTile; ++s) if (P.slot_cam[s] >= 0) ++P.cam_ptr[P.slot_cam[s] + 1];
@@ -721,6 +746,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
   }
   if (P.n_tiles * kTile >= (int64_t(1) << 31)) return no("more than 2^31 slots");
 
+  clk.mark("camera-major lists, items");
   // The word the kernels read per slot: camera id | accumulator row << kSlotCamBits (kSlotSpill: no LDS row, the slot's F^T z is
   // spilled).  With the accumulators of ALL cameras in LDS the accumulator row is the camera id itself; the word's row field then says
   // whether the camera's part of x is STAGED in LDS (row + 1 of xhot_cam, 0: not) — set whenever the plan ranks cameras, also for a solver
@@ -852,6 +878,7 @@ void BuildBalPlan(const HostStructure& h, int reorder_mode, const HybridRequest&
       P.zc_unit_ptr.push_back(int32_t(P.zu_cam.size()));
     }
   }
+  clk.mark("slot words, ring");
   P.eligible = true;
 }
 

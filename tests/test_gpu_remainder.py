@@ -128,6 +128,9 @@ OTHER_SHAPES = {
     "f9": dict(camera_width=9),   # (the BAL shape too: CGNR WITHOUT elimination groups on Schur-ordered columns — cameras back to back behind the points)
     "f10_quaternion_cameras": dict(camera_width=10), "f6": dict(camera_width=6), "f3": dict(camera_width=3), "f4": dict(camera_width=4),
     "f8": dict(camera_width=8), "e4_f9": dict(point_width=4, camera_width=9), "e2_f2": dict(point_width=2, camera_width=2),
+    # round 6: the widths added to the fused path this round had no remainder kernels (hipErrorInvalidValue from every pass over the
+    # leftover rows; found by tools/fuzz_parity.py)
+    "f5": dict(camera_width=5), "f7": dict(camera_width=7), "f2": dict(camera_width=2), "e4_f7": dict(point_width=4, camera_width=7),
     "r3_e3_f3": dict(row_height=3, point_width=3, camera_width=3), "r4_e4_f4": dict(row_height=4, point_width=4, camera_width=4),
 }
 
