@@ -7,7 +7,8 @@ fixed-count solves and one LM step, against the oracle (the checks of tests/test
 Fixed-count solves run with r_tolerance = -1 (as LevenbergMarquardtStrategy calls them): with r_tolerance = 0 a six-unknown system whose
 residual becomes EXACTLY zero in one implementation and 1e-17 in the other ends "converged" here and "maximum iterations" there.
 
-usage: fuzz_parity.py [first_seed] [count] [--stop]     one JSON line per case; exit code 1 if any case failed
+usage: fuzz_parity.py [first_seed] [count] [--stop] [--generic]     one JSON line per case; exit code 1 if any case failed
+(--generic: random E|F-partitioned structures with blocks 1 .. 4 wide instead of bundle-adjustment ones)
 """
 import json
 import os
@@ -85,6 +86,16 @@ def build(case, k, rng, layout):
     return p
 
 
+def rel_x(x, xo):
+    """rel(), for solves that may END IN FAILURE: CG forced on past exact convergence (a reduced system with two distinct eigenvalues) fails
+    with rho = r'z = 0 and leaves NaN in x — in the reference's algorithm as here; the two must then fail alike (same NaN positions)."""
+    nx, no = np.isnan(x), np.isnan(xo)
+    if nx.any() or no.any():
+        assert np.array_equal(nx, no), "NaN in different places"
+        return float(rel(x[~nx], xo[~no])) if (~nx).any() else 0.0
+    return float(rel(x, xo))
+
+
 def path_of(p, typ, pre):
     s = make_solver(hip, p, typ, pre)
     path = s.info().kernel_path
@@ -104,13 +115,13 @@ def run_case(seed):
     errs = check_schur_operators(hip, oracle, p, False, path)
     worst.update({"schur:" + a: float(b) for a, b in errs.items()})
     m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
-    for kk in (1, 4):
+    for kk in sorted({min(kk, max(1, m.num_cols_f // 2)) for kk in (1, 4)}):   # (CG forced on past exact convergence of a two-unknown system is 0 / 0)
         s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, min_it=kk, max_it=kk)
         x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=-1.0))
         s.close()
         xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=hip.SCHUR_JACOBI, min_it=kk, max_it=kk, q_tol=-1.0, r_tol=-1.0)
         assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
-        worst[f"schur:solve_k{kk}"] = float(rel(x, xo))
+        worst[f"schur:solve_k{kk}"] = rel_x(x, xo)
     # ---- CGNR side (no elimination order: a 3-wide camera or shared block cannot be told from a point -> generic kernels, still checked)
     q = type(p)(p.bs, p.values, p.b, p.D, 0)
     cpath = path_of(q, hip.CGNR, hip.JACOBI)
@@ -124,7 +135,7 @@ def run_case(seed):
         s.close()
         xo, so = m0.cgnr_solve(p.values, p.b, p.D, preconditioner=hip.JACOBI, min_it=kk, max_it=kk, q_tol=-1.0, r_tol=-1.0)
         assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
-        worst[f"cgnr:solve_k{kk}"] = float(rel(x, xo))
+        worst[f"cgnr:solve_k{kk}"] = rel_x(x, xo)
     # ---- one LM step on the device, both solvers
     radius = 1.0   # (D = sqrt(diag(J'J)): well conditioned, see build())
     diag = np.clip(m0.squared_column_norm(p.values), 1e-6, 1e32)
@@ -142,9 +153,107 @@ def run_case(seed):
             worst[f"lm_step_other_termination:{typ}"] = float(np.linalg.norm(-step - xo) / max(np.linalg.norm(xo), 1e-300)) if np.linalg.norm(xo) > 0 else float(np.linalg.norm(step))
             continue
         check_step(oracle, hip, pp, typ, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1, STEP_TOL)
-    bad = {a: b for a, b in worst.items() if not (b <= (STEP_TOL if "solve" in a else OP_TOL))}
+    extras(case, p, q, m, m0, diag, worst)
+    bad = {a: b for a, b in worst.items() if not (b <= (STEP_TOL if ("solve" in a or "retry" in a or "dense" in a) else OP_TOL))}
     out.update(ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 2))
     return out
+
+
+def extras(case, p, q, m, m0, diag, worst):
+    """Second round of the campaign: the retry after a rejected step, CGNR on the same rows in another order, the power-series operator
+    and preconditioner, and — where the reduced system is small — the explicit Schur complement and DENSE_SCHUR."""
+    rng = np.random.default_rng(case["seed"] + 77)
+    # ---- LM step, then the retry at half the radius without re-sending the values (TrustRegionMinimizer after a rejected step)
+    for typ, pre, pp in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, p), (hip.CGNR, hip.JACOBI, q)):
+        s = make_solver(hip, pp, typ, pre, max_it=500)
+        s.lm_compute_step(p.values, p.b, 1.0, 0.1)
+        step, summ, mcc = s.lm_compute_step(None, None, 0.5, 0.1, reuse_diagonal=True, values_unchanged=True)
+        s.close()
+        if "zeta" in summ.message:
+            check_step(oracle, hip, pp, typ, pre, np.sqrt(diag / 0.5), step, summ, mcc, 0.1, STEP_TOL)
+            worst[f"retry:{typ}"] = 0.0
+    # ---- CGNR with the row blocks in a random order (no elimination order: rows are in residual-block order)
+    nrb = p.bs.num_row_blocks
+    if nrb <= 60000:
+        qp = P.permute_rows(q, rng.permutation(nrb))
+        cpath = path_of(qp, hip.CGNR, hip.JACOBI)
+        errs = check_cgnr_operators(hip, oracle, qp, False, cpath)
+        worst.update({"cgnr_permuted:" + a: float(b) for a, b in errs.items()})
+        s = make_solver(hip, qp, hip.CGNR, hip.JACOBI, min_it=3, max_it=3)
+        x, summ = s.solve(qp.values, qp.b, hip.PerSolveOptions(D=qp.D, q_tolerance=-1.0, r_tolerance=-1.0))
+        s.close()
+        xo, so = oracle.Matrix(qp.bs, 0).cgnr_solve(qp.values, qp.b, qp.D, preconditioner=hip.JACOBI, min_it=3, max_it=3, q_tol=-1.0, r_tol=-1.0)
+        assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
+        worst["cgnr_permuted:solve_k3"] = float(rel(x, xo))
+    # ---- SCHUR_POWER_SERIES_EXPANSION: the operator and the preconditioner's apply
+    isc = oracle.ImplicitSchurComplement(m)
+    isc.init(p.values, p.D, p.b)
+    isc.compute_ftf_inverse()
+    s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_POWER_SERIES_EXPANSION, min_num_iterations=0,
+                                                    max_num_iterations=100, elimination_groups=[p.num_eliminate_blocks]))
+    s.set_structure(p.bs)
+    s.load(p.values, p.b, p.D)
+    s.schur_init()
+    xf, y0 = rng.standard_normal(m.num_cols_f), rng.standard_normal(m.num_cols_f)
+    worst["spse:operator"] = float(rel(s.power_series_operator(xf, y0), isc.power_series_operator(xf, y0)))
+    worst["spse:apply_5"] = float(rel(s.spse_apply(xf, 5, 0.0), isc.spse_apply(xf, 5, 0.0)))
+    s.close()
+    # ---- explicit Schur complement (block-sparse lhs) and DENSE_SCHUR where the reduced system is small
+    if m.num_cols_f <= 1200 and nrb <= 20000:
+        lhs, rhs = m.schur_eliminate(p.values, p.b, p.D)
+        nf = rhs.shape[0]
+        S = np.triu(lhs.reshape(nf, nf))
+        S = S + np.triu(S, 1).T
+        sizes = p.bs.col_block_size[p.num_eliminate_blocks:]
+        Minv = np.zeros_like(S)
+        o = 0
+        for n in sizes:
+            Minv[o:o + n, o:o + n] = np.linalg.inv(S[o:o + n, o:o + n])
+            o += n
+        K = 3
+        z, so = oracle.cg_dense(S, rhs, Minv=Minv, min_it=K, max_it=K, q_tol=-1.0, r_tol=-1.0)
+        s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, elimination_groups=[p.num_eliminate_blocks],
+                                                        use_explicit_schur_complement=True, min_num_iterations=K, max_num_iterations=K))
+        s.set_structure(p.bs)
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=-1.0))
+        s.close()
+        assert summ.num_iterations == so.num_iterations == K, (summ, so)
+        ne = p.bs.col_block_pos[p.num_eliminate_blocks]
+        worst["explicit:solve_k3"] = float(rel(x[ne:], z))   # NO_CONVERGENCE at the cap: no back-substitution (schur_complement_solver.cc:150-154)
+        s = hip.HipLinearSolver(hip.LinearSolverOptions(type=hip.DENSE_SCHUR, elimination_groups=[p.num_eliminate_blocks], max_num_iterations=1))
+        s.set_structure(p.bs)
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D))
+        s.close()
+        assert summ.termination_type == hip.SUCCESS, summ
+        zd = np.linalg.solve(S, rhs)
+        xd = m.schur_back_substitute(p.values, p.b, p.D, zd)
+        worst["dense_schur"] = float(rel(x, xd))
+
+
+def run_generic(seed):
+    """A structure that is NOT bundle adjustment: random E|F-partitioned blocks of sizes 1 .. 4 (the generic kernels)."""
+    rng = np.random.default_rng(7000003 * seed + 3)
+    static = [None, None, (2, 3, 6), (1, 1, 1), (3, 2, 4)][int(rng.integers(5))]
+    kw = dict(num_e_blocks=int(rng.choice([1, 3, 40, 300])), num_f_blocks=int(rng.choice([1, 2, 9, 40])), max_rows_per_e=int(rng.choice([1, 4, 9])),
+              num_no_e_rows=int(rng.choice([0, 3, 20])), static_sizes=static, seed=seed)
+    p = P.random_schur_problem(**kw)
+    t0 = time.time()
+    worst = {}
+    errs = check_schur_operators(hip, oracle, p, False, path_of(p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI))
+    worst.update({"schur:" + a: float(b) for a, b in errs.items()})
+    errs = check_cgnr_operators(hip, oracle, p, False, path_of(type(p)(p.bs, p.values, p.b, p.D, 0), hip.CGNR, hip.JACOBI))
+    worst.update({"cgnr:" + a: float(b) for a, b in errs.items()})
+    m = oracle.Matrix(p.bs, p.num_eliminate_blocks)
+    for kk in sorted({min(kk, max(1, m.num_cols_f // 2)) for kk in (1, 4)}):   # (CG forced on past exact convergence of a two-unknown system is 0 / 0)
+        s = make_solver(hip, p, hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, min_it=kk, max_it=kk)
+        x, summ = s.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=-1.0, r_tolerance=-1.0))
+        s.close()
+        xo, so = m.iterative_schur_solve(p.values, p.b, p.D, preconditioner=hip.SCHUR_JACOBI, min_it=kk, max_it=kk, q_tol=-1.0, r_tol=-1.0)
+        assert (summ.termination_type, summ.num_iterations) == (so.termination_type, so.num_iterations), (summ, so)
+        worst[f"schur:solve_k{kk}"] = rel_x(x, xo)
+    bad = {a: b for a, b in worst.items() if not (b <= (STEP_TOL if "solve" in a else OP_TOL))}
+    return dict(generic=True, **{k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}, ok=not bad, worst=max(worst.values()),
+                worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 2))
 
 
 def main():
@@ -153,12 +262,17 @@ def main():
     count = int(args[1]) if len(args) > 1 else 50
     stop = "--stop" in sys.argv
     failed = 0
+    generic = "--generic" in sys.argv
     for seed in range(first, first + count):
         try:
-            r = run_case(seed)
+            r = run_generic(seed) if generic else run_case(seed)
         except Exception as ex:   # an assertion of the shared checkers, or an error code of the library
-            case = draw_case(seed)[0]
+            case = dict(seed=seed, generic=True) if generic else draw_case(seed)[0]
             r = dict(case, ok=False, error=repr(ex)[:600], trace=traceback.format_exc()[-900:])
+            if isinstance(ex, AssertionError) and "rho = r'z = 0.000000e+00" in repr(ex) and "Maximum number of iterations" in repr(ex):
+                # CG forced on past EXACT convergence: r'z is exactly 0 in one implementation (FAILURE, as the reference would report) and
+                # 1e-33 in the other (which iterates on): a tie on a rounding, in systems of a handful of distinct eigenvalues
+                r.update(ok=True, tie_at_exact_convergence=True)
         failed += 0 if r["ok"] else 1
         print(json.dumps(r), flush=True)
         if failed and stop:
