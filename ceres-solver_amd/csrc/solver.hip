@@ -215,6 +215,7 @@ struct ceres_hip_solver {
   // their peers are launched with few workgroups, so that all ranks' waiting workgroups fit on the device beside each other.
   bool spec_agreed = false;           // sharded ITERATIVE_SCHUR: every rank can run the LM step's tail speculatively (agreed likewise)
   bool cam_exchange_agreed = false;   // every rank's camera-major pass exchanges its blocks itself (agreed at the end of set_structure)
+  bool rx_agreed = false;             // every rank's camera-space reduction exchanges itself (agreed likewise: reduction_exchanges)
   bool p2p_fences = [] { const char* e = getenv("CERES_HIP_P2P_FENCES"); return e && atoi(e) != 0; }();   // p2p.h: system-scope fences on top (A/B, fall-back)
   bool p2p_fuse = [] { const char* e = getenv("CERES_HIP_P2P_FUSE"); return !e || atoi(e) != 0; }();
   int p2p_grid_cap = [] { const char* e = getenv("CERES_HIP_P2P_SHARED_DEVICE"); return (e && atoi(e) != 0) ? 32 : (1 << 20); }();
@@ -323,14 +324,18 @@ int allreduce(ceres_hip_solver* s, double* dev, size_t n) {
 bool exchange_in_producer(const ceres_hip_solver* s, int64_t slots, int64_t chunks) {
   return s->world > 1 && s->p2p && s->p2p_fuse && s->path == CERES_HIP_PATH_BAL && slots <= s->p2p_cap && chunks <= s->p2p_chunks_cap;
 }
-// ... the camera-space reduction of a tile pass: a LOCAL choice — the kernel speaks the protocol of the stand-alone all-reduce of the
-// F-space vector, so a rank that cannot take it (rows outside its tiles join the raw sums first; cameras scattered over F space) meets
-// the others in the same slots
-bool reduction_exchanges(const ceres_hip_solver* s) {
+// ... the camera-space reduction of a tile pass.  The kernel speaks the protocol of the stand-alone all-reduce of the F-space vector, so
+// a rank that cannot take it (rows outside its tiles join the raw sums first; cameras scattered over F space) WOULD meet the others in
+// the same slots — but the two forms sum the replicated p . q in different groupings, and a rank whose CG scalars differ from its
+// peers' in the last bit can leave CG an iteration before them (the peers then wait for an exchange that never comes).  Found by
+// tools/fuzz_multirank.py: with camera priors on the last rank the "replicated" camera part was not bit-identical across ranks.
+// So all ranks take it or none: reduction_exchanges_local is this rank's view, the ranks agree at the end of set_structure.
+bool reduction_exchanges_local(const ceres_hip_solver* s) {
   if (s->path != CERES_HIP_PATH_BAL) return false;
   const int64_t nfv = s->hs.num_cols_f;
   return exchange_in_producer(s, nfv + 1, (nfv + 64) / 64) && s->plan.n_rem_rows == 0 && s->plan.cameras_contiguous;
 }
+bool reduction_exchanges(const ceres_hip_solver* s) { return s->rx_agreed && s->p2p && reduction_exchanges_local(s); }
 // ... the camera-major pass (cam_part packed sums per camera): its exchange has a numbering of its own (a chunk per camera), so ALL
 // ranks must take it or none: camera_blocks_exchange_local is this rank's view, the ranks agree at the end of set_structure
 bool camera_blocks_exchange_local(const ceres_hip_solver* s) {
@@ -2344,18 +2349,20 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
   // this one exchange waits up to two minutes).
   s->cam_exchange_agreed = false;
   s->spec_agreed = false;
+  s->rx_agreed = false;
   if (s->world > 1 && s->p2p && s->p2p_fuse) {
     double* d_agree = nullptr;
-    TRY(dev_alloc(s, &d_agree, 2));
+    TRY(dev_alloc(s, &d_agree, 3));
     // [0]: the camera-major pass cannot exchange here; [1]: an LM step cannot run its tail speculatively here (lm_step_loaded)
     const bool spec_local = s->speculate && is_schur(s) && !is_dense_schur(s) && s->path == CERES_HIP_PATH_BAL && !s->opt.use_explicit_schur_complement &&
                             s->fused_grid < 2 * kMaxVecGrid && !has_remainder(s) && exchange_in_producer(s, 2, 1);
-    const double mine[2] = {camera_blocks_exchange_local(s) ? 0.0 : 1.0, spec_local ? 0.0 : 1.0};
-    double sum[2] = {1.0, 1.0};
+    // [2]: the camera-space reduction of a tile pass cannot exchange itself here
+    const double mine[3] = {camera_blocks_exchange_local(s) ? 0.0 : 1.0, spec_local ? 0.0 : 1.0, reduction_exchanges_local(s) ? 0.0 : 1.0};
+    double sum[3] = {1.0, 1.0, 1.0};
     HIP_TRY(s, hipMemcpyAsync(d_agree, mine, sizeof(mine), hipMemcpyHostToDevice, s->stream));
     const double keep = s->p2p_timeout_s;
     s->p2p_timeout_s = std::max(keep, 120.0);
-    const int rc = allreduce(s, d_agree, 2);
+    const int rc = allreduce(s, d_agree, 3);
     s->p2p_timeout_s = keep;
     TRY(rc);
     HIP_TRY(s, hipMemcpyAsync(sum, d_agree, sizeof(sum), hipMemcpyDeviceToHost, s->stream));
@@ -2363,6 +2370,7 @@ int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure
     TRY(check_comm_error(s));
     s->cam_exchange_agreed = sum[0] == 0.0;
     s->spec_agreed = sum[1] == 0.0;
+    s->rx_agreed = sum[2] == 0.0;
   }
   s->have_structure = true;
   return 0;

@@ -56,8 +56,17 @@ def split_points(bs: BlockStructure, num_eliminate_blocks: int, world_size: int)
     cum = np.concatenate([[0.0], np.cumsum(work)])
     targets = cum[-1] * np.arange(1, world_size) / world_size
     cuts = np.searchsorted(cum, targets, side="left")
-    bounds = np.concatenate([[0], cuts, [nelim]]).astype(np.int64)
-    return np.maximum.accumulate(bounds)
+    bounds = np.maximum.accumulate(np.concatenate([[0], cuts, [nelim]]).astype(np.int64))
+    # every rank gets at least one E block (a handful of points of very different track lengths would otherwise leave a rank without
+    # eliminated blocks — ITERATIVE_SCHUR refuses such a shard and its peers wait for it until their exchange times out; found by
+    # tools/fuzz_multirank.py).  Fewer E blocks than ranks cannot be sharded by point at all.
+    if nelim < world_size:
+        raise ValueError(f"{nelim} eliminated blocks cannot be sharded over {world_size} ranks (one point block per rank at least)")
+    for r in range(1, world_size):          # forward: strictly increasing
+        bounds[r] = max(bounds[r], bounds[r - 1] + 1)
+    for r in range(world_size - 1, 0, -1):  # backward: room for the ranks behind
+        bounds[r] = min(bounds[r], bounds[r + 1] - 1)
+    return bounds
 
 
 def shard_by_point(bs: BlockStructure, num_eliminate_blocks: int, world_size: int, rank: int) -> Shard:

@@ -34,7 +34,11 @@ def run_rank(rank, world, conn, device, scenario):
             os.environ["CERES_HIP_CG_FUSED"] = kw.get("cg_fused", "1")  # read when a solver is created
             os.environ["CERES_HIP_P2P_TIMEOUT"] = str(kw.get("p2p_timeout", 20))
             kind = kw["kind"]
-            if kind == "bal" and kw.get("structured"):   # camera widths other than 9, shared blocks, locked cameras (problems.synthetic_structured)
+            if kind == "fuzz":   # a random structure of the parity campaign (tests/fuzz_cases.py), built alike on every rank
+                import fuzz_cases
+                case, k, _ = fuzz_cases.draw_case(kw["seed"])
+                prob = fuzz_cases.build(pkg.problems, case, k)
+            elif kind == "bal" and kw.get("structured"):   # camera widths other than 9, shared blocks, locked cameras (problems.synthetic_structured)
                 prob = pkg.problems.synthetic_structured(kw["nc"], kw["np"], kw["no"], seed=kw["seed"], skew=kw.get("skew", 0.5), **kw["structured"])
             elif kind == "bal":
                 prob = pkg.problems.synthetic_bal(None, layout="schur", seed=kw["seed"], skew=kw.get("skew", 0.5),
@@ -82,7 +86,7 @@ def run_rank(rank, world, conn, device, scenario):
                 x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=0.1, r_tolerance=-1.0))
                 rec["lm_style"] = (x, summ.termination_type, summ.num_iterations, None, summ.message)
                 # (3) the whole LM step on the device (f1), incl. the all-reduced {finite flag, model cost}
-                step, summ, mcc = s.lm_compute_step(v, b, 1e4, 0.1)
+                step, summ, mcc = s.lm_compute_step(v, b, kw.get("radius", 1e4), 0.1)
                 rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
                 rec["collectives"] = int(s.info().collectives_last_step)
                 # (4) operators that sum over ranks

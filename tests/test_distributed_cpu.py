@@ -31,6 +31,22 @@ def test_partition_covers_everything_once(problems):
                 np.testing.assert_array_equal(s.bs.to_dense(s.local_values(p.values)), A)
 
 
+def test_partition_gives_every_rank_a_point(problems):
+    """A handful of points of very different track lengths: balancing by values alone left a rank without eliminated blocks (an
+    ITERATIVE_SCHUR shard of no E blocks is refused, its peers then wait for it; tools/fuzz_multirank.py).  Fewer points than ranks
+    cannot be sharded by point."""
+    from ceres_solver_amd import partition
+    p = problems.bal_from_tracks([36, 3, 3, 3, 3], 64, seed=1)
+    for world in (2, 3, 4, 5):
+        bounds = partition.split_points(p.bs, p.num_eliminate_blocks, world)
+        assert bounds[0] == 0 and bounds[-1] == p.num_eliminate_blocks and (np.diff(bounds) >= 1).all(), bounds
+        shards = [partition.shard_by_point(p.bs, p.num_eliminate_blocks, world, r) for r in range(world)]
+        assert all(s.num_eliminate_blocks >= 1 for s in shards)
+        assert np.array_equal(np.concatenate([np.arange(*s.row_block_range) for s in shards]), np.arange(p.bs.num_row_blocks))
+    with pytest.raises(ValueError):
+        partition.split_points(p.bs, p.num_eliminate_blocks, 6)
+
+
 def test_partition_keeps_e_free_rows(problems):
     from ceres_solver_amd import partition
     p = problems.random_schur_problem(num_e_blocks=10, num_f_blocks=4, num_no_e_rows=3, seed=3)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""The randomised parity campaign on SHARDED instances (GPU box; the ranks share device 0 like tests/test_gpu_multirank.py): a random
+structure of tests/fuzz_cases.py sharded by point over 2 .. 4 ranks — ITERATIVE_SCHUR + SCHUR_JACOBI, and CGNR + JACOBI where the columns
+are points-then-cameras — converged solve, the LM-style solve and the LM step on the device assembled over ranks against the oracle on the
+whole problem; the replicated camera part must be bit-identical on every rank.
+
+usage: fuzz_multirank.py [first_seed] [count]      one JSON line per case; exit code 1 if any case failed"""
+import json
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402,F401
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+oracle = entry.load_oracle()
+hip = pkg.hip_solver
+import fuzz_cases  # noqa: E402
+from step_check import assert_lm_style_step  # noqa: E402
+from test_gpu_multirank import assemble, run_ranks  # noqa: E402
+from test_gpu_operators import rel  # noqa: E402
+
+
+def run_case(seed):
+    case, k, _ = fuzz_cases.draw_case(seed)
+    rng = np.random.default_rng(seed + 123)
+    world = int(rng.choice([2, 3, 4, 8]))
+    out = dict(case, world=world)
+    if case["n_points"] < world or case["n_obs"] > 60000:
+        return dict(out, ok=True, skipped="fewer points than ranks, or a large case (kept short: every case starts its own processes)")
+    p = fuzz_cases.build(pkg.problems, case, k)
+    nr, ne, nf = case["shape"]
+    solvers = [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)]
+    if not case["shared"] and nf != ne:   # sharded CGNR tells points from cameras by their width, in points-then-cameras columns
+        solvers.append((hip.CGNR, hip.JACOBI))
+    kw = dict(kind="fuzz", seed=seed, solvers=solvers, radius=1.0, max_it=600, p2p_timeout=8)
+    t0 = time.time()
+    res = run_ranks([("fuzz", kw)], world)
+    m, m0 = oracle.Matrix(p.bs, p.num_eliminate_blocks), oracle.Matrix(p.bs, 0)
+    diag = np.clip(m0.squared_column_norm(p.values), 1e-6, 1e32)
+    worst = {}
+    for solver_type, pre in solvers:
+        recs = [res[r][("fuzz", solver_type, pre)] for r in range(world)]
+        tag = "schur" if solver_type == hip.ITERATIVE_SCHUR else "cgnr"
+        out[tag + "_path"] = [int(rec["path"]) for rec in recs]
+        fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m0.cgnr_solve
+        solve = lambda lo, hi, q, r, D=p.D: fn(p.values, p.b, D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r)
+        xo, so = solve(0, 600, -1.0, 1e-12)
+        assert all(rec["converged"][1] == so.termination_type for rec in recs), ([rec["converged"][1:] for rec in recs], so)
+        worst[tag + ":converged"] = float(rel(assemble(None, recs, p.bs.num_cols, "converged"), xo))
+        for key in ("converged", "lm_style", "lm_step"):   # the camera part is replicated: identical bits on every rank
+            a = recs[0][key][0][recs[0]["n_e"]:]
+            for rec in recs[1:]:
+                assert np.array_equal(a, rec[key][0][rec["n_e"]:]), (key, "replicated part differs between ranks")
+                assert recs[0][key][2] == rec[key][2] and recs[0][key][4] == rec[key][4], (key, recs[0][key][1:], rec[key][1:])
+
+        class S:
+            termination_type, num_iterations, message = recs[0]["lm_style"][1], recs[0]["lm_style"][2], recs[0]["lm_style"][4]
+        if "zeta" in S.message:
+            assert_lm_style_step(assemble(None, recs, p.bs.num_cols, "lm_style"), S, solve, 0.1, hip.SUCCESS)
+        step = assemble(None, recs, p.bs.num_cols, "lm_step")
+        S.termination_type, S.num_iterations, S.message = recs[0]["lm_step"][1], recs[0]["lm_step"][2], recs[0]["lm_step"][4]
+        if "zeta" in S.message:
+            Dlm = np.sqrt(diag / 1.0)
+            assert_lm_style_step(-step, S, lambda lo, hi, q, r: solve(lo, hi, q, r, Dlm), 0.1, hip.SUCCESS)
+            Jx = m0.right_multiply(p.values, step)
+            want = -(Jx @ (p.b + Jx / 2))
+            worst[tag + ":model_cost"] = float(abs(recs[0]["lm_step"][3] - want) / max(abs(want), 1e-300))
+    bad = {a: b for a, b in worst.items() if not (b <= 1e-8)}
+    return dict(out, ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 1))
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if args else 0
+    count = int(args[1]) if len(args) > 1 else 20
+    failed = 0
+    for seed in range(first, first + count):
+        try:
+            r = run_case(seed)
+        except Exception as ex:
+            r = dict(fuzz_cases.draw_case(seed)[0], ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
+        failed += 0 if r["ok"] else 1
+        print(json.dumps(r), flush=True)
+    print(json.dumps({"cases": count, "failed": failed}), flush=True)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
