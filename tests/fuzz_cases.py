@@ -6,11 +6,17 @@ SHAPES = [(2, 3, w) for w in range(2, 11)] + [(2, 2, w) for w in (2, 3, 4, 6, 9)
          [(3, 3, 3), (4, 4, 2), (4, 4, 3), (4, 4, 4)]
 
 
-def draw_case(seed):
+def draw_case(seed, big=False):
+    """big: half a million to three million observations — enough tiles per workgroup (40, 100) for the software-pipelined kernels and the
+    staged x; the small cases (the default) never reach them."""
     rng = np.random.default_rng(1000003 * seed + 17)
     n_cams = int(rng.choice([2, 3, 7, 16, 63, 64, 65, 130, 500, 1800, 2261, 2262, 2300, 2600, 5000, 30000]))
     n_points = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 1500, 6000, 25000]))
     mean = float(rng.choice([1.2, 2.5, 4.0, 7.0]))
+    if big:
+        n_cams = int(rng.choice([16, 130, 500, 1800, 2262, 5000, 30000]))
+        n_points = int(rng.choice([150000, 400000]))
+        mean = float(rng.choice([2.5, 4.0, 7.0]))
     k = np.clip(rng.geometric(1.0 / mean, size=n_points), 1, n_cams)
     if rng.random() < 0.35:   # some long tracks: whole tiles, rounds, more than eight tiles
         longs = [v for v in (63, 64, 65, 127, 128, 129, 200, 511, 512, 513, 700) if v <= n_cams]

@@ -7,7 +7,7 @@ fixed-count solves and one LM step, against the oracle (the checks of tests/test
 Fixed-count solves run with r_tolerance = -1 (as LevenbergMarquardtStrategy calls them): with r_tolerance = 0 a six-unknown system whose
 residual becomes EXACTLY zero in one implementation and 1e-17 in the other ends "converged" here and "maximum iterations" there.
 
-usage: fuzz_parity.py [first_seed] [count] [--stop] [--generic]     one JSON line per case; exit code 1 if any case failed
+usage: fuzz_parity.py [first_seed] [count] [--stop] [--generic] [--big]     one JSON line per case; exit code 1 if any case failed
 (--generic: random E|F-partitioned structures with blocks 1 .. 4 wide instead of bundle-adjustment ones)
 """
 import json
@@ -59,8 +59,11 @@ def path_of(p, typ, pre):
     return path
 
 
+BIG = "--big" in sys.argv
+
+
 def run_case(seed):
-    case, k, rng = draw_case(seed)
+    case, k, rng = draw_case(seed, BIG)
     out = dict(case)
     t0 = time.time()
     worst = {}
@@ -109,7 +112,8 @@ def run_case(seed):
             worst[f"lm_step_other_termination:{typ}"] = float(np.linalg.norm(-step - xo) / max(np.linalg.norm(xo), 1e-300)) if np.linalg.norm(xo) > 0 else float(np.linalg.norm(step))
             continue
         check_step(oracle, hip, pp, typ, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1, STEP_TOL)
-    extras(case, p, q, m, m0, diag, worst)
+    if not BIG:
+        extras(case, p, q, m, m0, diag, worst)
     if case["n_obs"] <= 40000:
         extras_boundary(case, p, q, worst)
         extras_variants(case, p, q, m, m0, worst)
@@ -347,7 +351,7 @@ def main():
         try:
             r = run_generic(seed) if generic else run_case(seed)
         except Exception as ex:   # an assertion of the shared checkers, or an error code of the library
-            case = dict(seed=seed, generic=True) if generic else draw_case(seed)[0]
+            case = dict(seed=seed, generic=True) if generic else draw_case(seed, BIG)[0]
             r = dict(case, ok=False, error=repr(ex)[:600], trace=traceback.format_exc()[-900:])
             if isinstance(ex, AssertionError) and "rho = r'z = 0.000000e+00" in repr(ex) and ("Maximum number of iterations" in repr(ex) or "zeta = -0.0" in repr(ex) or "zeta = 0.0" in repr(ex)):
                 # CG forced on past EXACT convergence: r'z is exactly 0 in one implementation (FAILURE, as the reference would report) and
