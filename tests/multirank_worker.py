@@ -36,7 +36,7 @@ def run_rank(rank, world, conn, device, scenario):
             kind = kw["kind"]
             if kind == "fuzz":   # a random structure of the parity campaign (tests/fuzz_cases.py), built alike on every rank
                 import fuzz_cases
-                case, k, _ = fuzz_cases.draw_case(kw["seed"])
+                case, k, _ = fuzz_cases.draw_case(kw["seed"], kw.get("big", False))
                 prob = fuzz_cases.build(pkg.problems, case, k)
             elif kind == "bal" and kw.get("structured"):   # camera widths other than 9, shared blocks, locked cameras (problems.synthetic_structured)
                 prob = pkg.problems.synthetic_structured(kw["nc"], kw["np"], kw["no"], seed=kw["seed"], skew=kw.get("skew", 0.5), **kw["structured"])

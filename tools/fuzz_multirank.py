@@ -28,19 +28,22 @@ from test_gpu_multirank import assemble, run_ranks  # noqa: E402
 from test_gpu_operators import rel  # noqa: E402
 
 
+BIG = "--big" in sys.argv   # half a million to three million observations (every rank builds the whole problem: a minute per case)
+
+
 def run_case(seed):
-    case, k, _ = fuzz_cases.draw_case(seed)
+    case, k, _ = fuzz_cases.draw_case(seed, BIG)
     rng = np.random.default_rng(seed + 123)
     world = int(rng.choice([2, 3, 4, 8]))
     out = dict(case, world=world)
-    if case["n_points"] < world or case["n_obs"] > 60000:
+    if case["n_points"] < world or (case["n_obs"] > 60000 and not BIG):
         return dict(out, ok=True, skipped="fewer points than ranks, or a large case (kept short: every case starts its own processes)")
     p = fuzz_cases.build(pkg.problems, case, k)
     nr, ne, nf = case["shape"]
     solvers = [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI)]
     if not case["shared"] and nf != ne:   # sharded CGNR tells points from cameras by their width, in points-then-cameras columns
         solvers.append((hip.CGNR, hip.JACOBI))
-    kw = dict(kind="fuzz", seed=seed, solvers=solvers, radius=1.0, max_it=600, p2p_timeout=8)
+    kw = dict(kind="fuzz", seed=seed, big=BIG, solvers=solvers, radius=1.0, max_it=600, p2p_timeout=60 if BIG else 8)
     t0 = time.time()
     res = run_ranks([("fuzz", kw)], world)
     m, m0 = oracle.Matrix(p.bs, p.num_eliminate_blocks), oracle.Matrix(p.bs, 0)
@@ -86,7 +89,7 @@ def main():
         try:
             r = run_case(seed)
         except Exception as ex:
-            r = dict(fuzz_cases.draw_case(seed)[0], ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
+            r = dict(fuzz_cases.draw_case(seed, BIG)[0], ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
         failed += 0 if r["ok"] else 1
         print(json.dumps(r), flush=True)
     print(json.dumps({"cases": count, "failed": failed}), flush=True)
