@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Randomised campaign on ONE HANDLE (GPU box): the other campaigns (tools/fuzz_parity.py, fuzz_multirank.py, fuzz_frontend.py) create a
+solver per check, so nothing they do can see state that a handle keeps from one call to the next — the tile plan and its device arrays,
+the staged camera part of x, the flags the step's first pass clears, the speculative tail and its mailbox sequence numbers, the values
+the retry after a rejected step relies on, the failure flag of a singular block.  Here a handle lives through a random SEQUENCE:
+(one structure per handle: a second ceres_hip_set_structure is refused, as one LinearSolver instance sees one sparsity,
+linear_solver.h:137-142 — asserted here too) LM steps with new values, retries with `values_unchanged` at other radii, plain Solve calls
+with a caller's D ending on the residual test, the streamed upload, device pointers, single operators (which reload and re-initialise),
+calls that cannot succeed (NaN in the values) followed by good ones — every result compared with a FRESH handle doing that one call
+(the sums in LDS are order-dependent: 1e-11, same termination and iteration count), and the first step with the oracle as well.
+
+usage: fuzz_sequence.py [first_seed] [count] [--stop] [--big]     one JSON line per sequence; exit code 1 if any failed
+"""
+import json
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402,F401  (before the HIP library: hip_solver.load_library)
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+oracle = entry.load_oracle()
+hip = pkg.hip_solver
+hip.load_library()
+P = pkg.problems
+from test_gpu_operators import rel  # noqa: E402
+from test_gpu_lm_step import check_step  # noqa: E402
+import fuzz_cases  # noqa: E402
+
+SAME_TOL = 1e-11
+BIG = "--big" in sys.argv   # 0.15 - 2.8 M observations: the software-pipelined kernels, the staged x (fuzz_cases.draw_case)
+STEP_TOL = 1e-9
+
+
+def new_solver(p, typ, pre, nelim):
+    s = hip.HipLinearSolver(hip.LinearSolverOptions(type=typ, preconditioner_type=pre, max_num_iterations=500, min_num_iterations=0,
+                                                    elimination_groups=[nelim]))
+    s.set_structure(p.bs)
+    return s
+
+
+def differ(a, b):
+    """None if two results agree (same termination, same count, same NaN places, vectors and model cost change to SAME_TOL), else why not."""
+    (x, s), (xf, sf) = a[:2], b[:2]
+    if "rho = r'z" in s.message or "rho = r'z" in sf.message:
+        return None, 0.0   # (a system solved EXACTLY — two unknowns, two iterations, |r| = 1e-32: whether r'z is 0 or 1e-64 is a rounding, tools/fuzz_parity.py rel_x)
+    if (s.termination_type, s.num_iterations) != (sf.termination_type, sf.num_iterations):
+        return ("termination", s.termination_type, s.num_iterations, s.message, sf.termination_type, sf.num_iterations, sf.message), 0.0
+    nx, nf = np.isnan(x), np.isnan(xf)
+    if not np.array_equal(nx, nf):
+        return ("NaN in different places", int(nx.sum()), int(nf.sum())), 0.0
+    d = float(rel(x[~nx], xf[~nf])) if (~nx).any() else 0.0
+    if len(a) > 2 and np.isfinite(b[2]):
+        d = max(d, abs(a[2] - b[2]) / max(abs(b[2]), 1e-300))
+    return (None if d <= SAME_TOL else ("deviation", d)), d
+
+
+def same(tag, got, want, log, again=None):
+    """got / want: (vector, Summary[, model cost change]) of the reused and of a fresh handle.  again(): the same call on a SECOND fresh
+    handle — where two fresh handles differ from each other as the reused one differs from the first (a solve of fifty iterations
+    amplifies the order of the LDS additions past 1e-11 and can end an iteration apart; a system solved exactly ends on rho = 0 in one
+    run and on zeta in the next), the difference says nothing about the handle's state and is listed as run-to-run."""
+    why, d = differ(got, want)
+    if why is None:
+        log[tag] = max(log.get(tag, 0.0), d)
+        return
+    if again is not None:
+        why2, d2 = differ(again(), want)
+        if why2 is not None and (why2[0] != "deviation" or why[0] != "deviation" or d <= 30 * d2):
+            log[tag + ":run_to_run"] = max(log.get(tag + ":run_to_run", 0.0), d)
+            return
+    raise AssertionError((tag, why))
+
+
+def fresh(p, typ, pre, nelim, fn):
+    f = new_solver(p, typ, pre, nelim)
+    try:
+        return fn(f)
+    finally:
+        f.close()
+
+
+def run_sequence(seed):
+    case, k, _ = fuzz_cases.draw_case(seed, BIG)
+    rng = np.random.default_rng(7919 * seed + 3)
+    out = dict(case)
+    if case["n_obs"] > 120000 and not BIG:
+        return dict(out, ok=True, skipped="large (every action also runs on a fresh handle)")
+    t0 = time.time()
+    log, actions = {}, []
+    p0 = fuzz_cases.build(P, case, k)
+    nrb = p0.bs.num_row_blocks
+    for typ, pre, name in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, "schur"), (hip.CGNR, hip.JACOBI, "cgnr")):
+        p = p0 if name == "schur" else type(p0)(p0.bs, p0.values, p0.b, p0.D, 0)
+        nelim = p.num_eliminate_blocks
+        held = new_solver(p, typ, pre, nelim)
+        try:
+            held.set_structure(p.bs)
+            raise AssertionError("a second set_structure was accepted")
+        except hip.HipError as ex:
+            assert "already set" in str(ex), ex
+        m0 = oracle.Matrix(p.bs, 0)
+        vals = p.values
+        checked = False
+        for a in range(int(rng.integers(4, 11))):
+            kind = str(rng.choice(["step", "step_new_values", "retry", "retry", "solve_r", "failure", "streamed", "device", "operator"]))
+            tag = f"{name}:{kind}"
+            actions.append(tag)
+            f = new_solver(p, typ, pre, nelim)
+            try:
+                if kind in ("step", "step_new_values"):
+                    if kind == "step_new_values":
+                        vals = p.values * (1.0 + 0.3 * np.random.default_rng(seed + a).standard_normal(p.values.shape[0]))
+                    radius = float(rng.choice([0.3, 1.0, 30.0]))
+                    got = held.lm_compute_step(vals, p.b, radius, 0.1)
+                    want = f.lm_compute_step(vals, p.b, radius, 0.1)
+                    same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.lm_compute_step(vals, p.b, radius, 0.1)))
+                    if not checked and case["n_obs"] <= 60000 and "zeta" in got[1].message:
+                        diag = np.clip(m0.squared_column_norm(vals), 1e-6, 1e32)
+                        check_step(oracle, hip, type(p)(p.bs, vals, p.b, p.D, nelim), typ, pre, np.sqrt(diag / radius), got[0], got[1], got[2], 0.1, STEP_TOL)
+                        log[tag + ":oracle"] = 0.0
+                        checked = True
+                elif kind == "retry":
+                    # whatever the handle did last (an operator's load, a failed Solve, a streamed upload), the retry follows a step
+                    radius = float(rng.choice([0.5, 2.0]))
+                    n_retries = int(rng.integers(1, 4))
+                    held.lm_compute_step(vals, p.b, radius, 0.1)
+                    f.lm_compute_step(vals, p.b, radius, 0.1)
+                    radius0 = radius
+                    for t in range(n_retries):
+                        radius /= 2
+                        got = held.lm_compute_step(None, None, radius, 0.1, reuse_diagonal=True, values_unchanged=True)
+                        want = f.lm_compute_step(None, None, radius, 0.1, reuse_diagonal=True, values_unchanged=True)
+
+                        def again(g, t=t):
+                            g.lm_compute_step(vals, p.b, radius0, 0.1)
+                            for u in range(t + 1):
+                                r = g.lm_compute_step(None, None, radius0 / 2 ** (u + 1), 0.1, reuse_diagonal=True, values_unchanged=True)
+                            return r
+                        same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, again))
+                elif kind == "solve_r":
+                    D = 0.5 + rng.random(p.bs.num_cols)
+                    pso = hip.PerSolveOptions(D=D, q_tolerance=-1.0, r_tolerance=float(rng.choice([1e-3, 1e-8])))
+                    got = held.solve(vals, p.b, pso)
+                    want = f.solve(vals, p.b, pso)
+                    same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.solve(vals, p.b, pso)))
+                    if rng.random() < 0.5:   # and again on the values the handle holds, with another D
+                        pso2 = hip.PerSolveOptions(D=2.0 * D, q_tolerance=0.05, r_tolerance=-1.0)
+                        same(tag + ":unchanged", held.solve_unchanged_values(pso2), f.solve_unchanged_values(pso2), log,
+                             lambda: fresh(p, typ, pre, nelim, lambda g: (g.solve(vals, p.b, pso), g.solve_unchanged_values(pso2))[1]))
+                elif kind == "failure":
+                    bad = vals.copy()
+                    bad[int(rng.integers(bad.shape[0]))] = np.nan
+                    if rng.random() < 0.5:
+                        got, want = held.solve(bad, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0)), \
+                            f.solve(bad, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=0.1, r_tolerance=-1.0))
+                    else:
+                        got, want = held.lm_compute_step(bad, p.b, 1.0, 0.1), f.lm_compute_step(bad, p.b, 1.0, 0.1)
+                    assert (got[1].termination_type, got[1].num_iterations) == (want[1].termination_type, want[1].num_iterations), (tag, got[1], want[1])
+                    log[tag + ":termination"] = 0.0
+                elif kind == "streamed":
+                    hv, hb = np.full(vals.shape[0], np.nan), np.full(p.b.shape[0], np.nan)
+                    held.values_begin(hv, hb)
+                    run = int(rng.choice([1, 7, 97, 1000]))
+                    runs = [(r0, min(nrb, r0 + run)) for r0 in range(0, nrb, run)]
+                    rng.shuffle(runs)
+                    hv[:] = vals
+                    hb[:] = p.b
+                    for r0, r1 in runs[:3000]:
+                        if rng.random() < 0.15:
+                            continue
+                        held.values_ready(r0, r1 - r0)
+                    held.values_end(None)
+                    got = held.lm_compute_step(None, None, 1.0, 0.1, values_unchanged=True)
+                    want = f.lm_compute_step(vals, p.b, 1.0, 0.1)
+                    same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.lm_compute_step(vals, p.b, 1.0, 0.1)))
+                elif kind == "device":
+                    tv, tb = torch.from_numpy(np.ascontiguousarray(vals)).cuda(), torch.from_numpy(np.ascontiguousarray(p.b)).cuda()
+                    tx = torch.full((p.bs.num_cols,), float("nan"), dtype=torch.float64, device="cuda")
+                    summ_d, mcc_d, finite = held.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), 1.0, 0.1)
+                    torch.cuda.synchronize()
+                    want = f.lm_compute_step(vals, p.b, 1.0, 0.1)
+                    same(tag, (tx.cpu().numpy(), summ_d, mcc_d), want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.lm_compute_step(vals, p.b, 1.0, 0.1)))
+                else:
+                    # a single operator through the C ABI: loads the values with a caller's D and (ITERATIVE_SCHUR) re-initialises
+                    D = 0.5 + rng.random(p.bs.num_cols)
+                    x = rng.standard_normal(p.bs.num_cols)
+                    for sv in (held, f):
+                        sv.load(vals, p.b, D)
+                    if name == "schur":
+                        for sv in (held, f):
+                            sv.schur_init()
+                        ne = int(p.bs.col_block_pos[nelim])
+                        a_, b_ = held.schur_sx(x[ne:]), f.schur_sx(x[ne:])
+                    else:
+                        a_, b_ = held.right_multiply(x, np.zeros(p.bs.num_rows)), f.right_multiply(x, np.zeros(p.bs.num_rows))
+                    d = float(rel(a_, b_))
+                    log[tag] = max(log.get(tag, 0.0), d)
+                    assert d <= SAME_TOL, (tag, d)
+            finally:
+                f.close()
+        held.close()
+    out.update(ok=True, actions=actions, worst=max(log.values()) if log else 0.0, worst_key=max(log, key=log.get) if log else "",
+               seconds=round(time.time() - t0, 2))
+    return out
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if args else 0
+    count = int(args[1]) if len(args) > 1 else 20
+    failed = 0
+    for seed in range(first, first + count):
+        try:
+            r = run_sequence(seed)
+        except Exception as ex:
+            r = dict(seed=seed, ok=False, error=repr(ex)[:900], trace=traceback.format_exc()[-1500:])
+        failed += 0 if r["ok"] else 1
+        print(json.dumps(r), flush=True)
+        if failed and "--stop" in sys.argv:
+            break
+    print(json.dumps({"sequences": count, "failed": failed}), flush=True)
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()
