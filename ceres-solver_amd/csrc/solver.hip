@@ -171,6 +171,7 @@ struct ceres_hip_solver {
   double *ftf_inv = nullptr, *spse_a = nullptr, *spse_b = nullptr;
   bool ftf_inv_valid = false;
   int* d_fail_flag = nullptr;
+  double* d_verdict = nullptr;   // sharded: the factorization verdict summed over ranks (check_factorization)
   // CG
   CgBuffers cg;
   double* cg_rhs = nullptr;
@@ -1410,6 +1411,20 @@ int check_factorization(ceres_hip_solver* s, bool* failed) {
   int flag = 0;
   HIP_TRY(s, hipMemcpyAsync(&flag, s->d_fail_flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (s->world > 1) {
+    // A verdict the ranks SHARE: the flag is raised by this rank's blocks (a point block of its shard), and a rank that left the solve
+    // here on its own would leave its peers waiting in the next all-reduce — and with another answer (tools/probes/poison_ranks.py:
+    // one rank "E^T E + D^2 is not positive definite", the other a time-out, and the exchange epochs of the two apart for good).
+    // Every rank reaches these checks in the same order (they depend on the options and the kernel path only).
+    double v = flag != 0 ? 1.0 : 0.0;
+    if (!s->d_verdict) TRY(dev_alloc(s, &s->d_verdict, 1));
+    HIP_TRY(s, hipMemcpyAsync(s->d_verdict, &v, sizeof(double), hipMemcpyHostToDevice, s->stream));
+    TRY(allreduce(s, s->d_verdict, 1));
+    HIP_TRY(s, hipMemcpyAsync(&v, s->d_verdict, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    TRY(check_comm_error(s));
+    flag = !(v == 0.0);   // (NaN: an exchange that timed out)
+  }
   *failed = flag != 0;
   return 0;
 }
@@ -2517,7 +2532,8 @@ int lm_step_loaded(ceres_hip_solver* s, const ceres_hip_lm_options* o, double* d
   hipStream_t st = s->stream;
   memset(res, 0, sizeof(*res));
   s->collectives = 0;
-  if (!(o->radius > 0) || !(o->min_diagonal > 0) || o->min_diagonal > o->max_diagonal)
+  // (Solver::Options::IsValid, I/solver.cc:414-416: min_lm_diagonal >= 0, max_lm_diagonal >= 0, min <= max; a NaN fails every test)
+  if (!(o->radius > 0) || !(o->min_diagonal >= 0) || !(o->max_diagonal >= 0) || !(o->min_diagonal <= o->max_diagonal))
     return fail(s, CERES_HIP_E_INVALID, "bad LM options");
   // A fresh diagonal is diag(J^T J), which the set-up kernels of the <2,3,9> path have in hand anyway
   // (the point block's own diagonal; the camera columns' norms in the camera-major pass): then D

@@ -359,7 +359,7 @@ int ceres_hip_op_axpby(ceres_hip_solver* s, double a, const double* x, double b,
  * J is read in place; nothing but the step and a few scalars returns to the host.            */
 typedef struct ceres_hip_lm_options {
   double radius;          /* trust-region radius                                   */
-  double min_diagonal;    /* Solver::Options::min_lm_diagonal (1e-6)               */
+  double min_diagonal;    /* Solver::Options::min_lm_diagonal (1e-6; >= 0, I/solver.cc:414) */
   double max_diagonal;    /* Solver::Options::max_lm_diagonal (1e32)               */
   double eta;             /* q_tolerance of the linear solve                       */
   int32_t reuse_diagonal; /* 1 after a rejected step: keep the previous diag(J'J)  */

@@ -77,6 +77,38 @@ def run_rank(rank, world, conn, device, scenario):
                                                      "p2p_enabled": int(info.p2p_enabled), "fine_grained": int(info.p2p_fine_grained)}
                     s.close()
                     continue
+                if "poison" in kw:
+                    # ONE rank's shard cannot be solved (a NaN in a Jacobian cell, or a point block that is singular: a zeroed E cell and
+                    # no D): every rank must end the call the same way — the ranks of a step that disagree about its verdict would
+                    # part ways in the caller's loop — and the instances stay usable for a good call afterwards
+                    pr, what = kw["poison"]
+                    vb, Db = v.copy(), D.copy()
+                    if rank == pr:
+                        if what == "nan":
+                            vb[int(sh.bs.cell_value_pos[0]) + 1] = np.nan
+                        else:   # the first row's point: all its E cells zero (its rows are the first of this shard), D = 0 on its columns
+                            c0 = int(sh.bs.cell_col_block[0])
+                            rows = [r for r in range(min(sh.bs.num_row_blocks, 4096)) if int(sh.bs.cell_col_block[sh.bs.row_cell_ptr[r]]) == c0]
+                            for r in rows:
+                                q = int(sh.bs.row_cell_ptr[r])
+                                n = int(sh.bs.row_block_size[r]) * int(sh.bs.col_block_size[c0])
+                                vb[int(sh.bs.cell_value_pos[q]): int(sh.bs.cell_value_pos[q]) + n] = 0.0
+                            p0 = int(sh.bs.col_block_pos[c0])
+                            Db[p0: p0 + int(sh.bs.col_block_size[c0])] = 0.0
+                    rec = {"rank": rank}
+                    x, summ = s.solve(vb, b, hs.PerSolveOptions(D=Db, q_tolerance=0.1, r_tolerance=-1.0))
+                    rec["bad_solve"] = (summ.termination_type, summ.num_iterations, summ.message, bool(np.isfinite(x).all()))
+                    try:
+                        step, summ, mcc = s.lm_compute_step(vb, b, 1e4, 0.1, min_diagonal=0.0 if what != "nan" else 1e-6)
+                        rec["bad_step"] = (summ.termination_type, summ.num_iterations, summ.message, bool(np.isfinite(step).all()))
+                    except hs.HipError as ex:
+                        rec["bad_step"] = ("error", str(ex))
+                    x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=0.1, r_tolerance=-1.0))
+                    rec["good_solve"] = (x, summ.termination_type, summ.num_iterations, None, summ.message)
+                    rec["col_index"], rec["n_e"] = sh.col_index, int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum())
+                    s.close()
+                    out[(name, solver_type, pre)] = rec
+                    continue
                 rec = {"path": int(info.kernel_path), "world": int(info.world_size), "rank": int(info.rank),
                        "col_index": sh.col_index, "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum())}
                 # (1) converged solve

@@ -286,3 +286,21 @@ def test_speculative_tail_equals_the_two_synchronisation_sequence(hip, oracle, p
     fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m.cgnr_solve
     xk, sk = fn(hard.values, hard.b, ref_D, preconditioner=pre, min_it=a[1][2], max_it=a[1][2], q_tol=-1.0, r_tol=-1.0)
     assert sk.num_iterations == a[1][2] and rel(a[1][0], -xk) <= 1e-8, (sk, rel(a[1][0], -xk))
+
+
+@pytest.mark.parametrize("solver_type,pre", [(5, 2), (6, 1)])
+def test_min_lm_diagonal_zero_is_a_valid_option(hip, oracle, problems, solver_type, pre):
+    """Solver::Options::IsValid accepts min_lm_diagonal = 0 (internal/ceres/solver.cc:414: OPTION_GE): the LM diagonal is then the
+    unclipped column norm.  (The boundary used to refuse it: found by the sharded failure-path probe, tools/probes/poison_ranks.py.)"""
+    p = problems.synthetic_bal(None, layout="schur", num_cameras=30, num_points=2000, num_observations=9000, seed=41, skew=0.5)
+    if solver_type == hip.CGNR:
+        p.num_eliminate_blocks = 0
+    s = make_solver(hip, p, solver_type, pre, max_it=500)
+    radius = 3.0
+    step, summ, mcc = s.lm_compute_step(p.values, p.b, radius, 0.1, min_diagonal=0.0, max_diagonal=1e32)
+    diag = oracle.Matrix(p.bs, 0).squared_column_norm(p.values)
+    check_step(oracle, hip, p, solver_type, pre, np.sqrt(diag / radius), step, summ, mcc, 0.1)
+    for bad in (dict(min_diagonal=-1.0), dict(min_diagonal=2.0, max_diagonal=1.0), dict(min_diagonal=float("nan")), dict(max_diagonal=-1.0, min_diagonal=0.0)):
+        with pytest.raises(hip.HipError, match="bad LM options"):
+            s.lm_compute_step(p.values, p.b, radius, 0.1, **bad)
+    s.close()

@@ -296,3 +296,36 @@ def test_a_rank_that_leaves_mid_run_is_an_error_not_a_hang(hip):
             assert rec["p2p_enabled"] == 1
             assert rec["error"] is not None and "timed out" in rec["error"] and f"error {hip.E_COMM}" in rec["error"], rec
             assert rec["seconds"] < 30.0, rec
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("what", ["nan", "singular_point"])
+@pytest.mark.parametrize("WORLD", [2, 4])
+def test_a_shard_that_cannot_be_solved_ends_the_call_alike_on_every_rank(hip, oracle, problems, WORLD, what, generic):
+    """One rank's shard holds a NaN (or a point whose block is singular: zeroed E cells, no D).  The ranks of one call must agree about
+    how it ended — one rank reporting FAILURE while its peers return a "successful" step computed without that rank's sums would send
+    the ranks of the caller's loop different ways — and nobody may wait for a peer that has already left the solve.  Afterwards the same
+    instances solve the unpoisoned problem, against the oracle.  (On the generic kernels the verdict on the point blocks was a read-back
+    of the rank's own flag: the rank with the singular block left with "E^T E + D^2 is not positive definite", its peer waited out an
+    all-reduce, and the exchange epochs of the two stayed apart — every later call failed.  tools/probes/poison_ranks.py.)"""
+    kw = dict(kind="bal", seed=31, nc=20, np=1500, no=7000, skew=0.5, solvers=[(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)],
+              poison=(WORLD - 1 if what == "nan" else 0, what), p2p_timeout=5, force_generic=generic)
+    res = run_ranks([("poison", kw)], WORLD, timeout=180)
+    p = problems.synthetic_bal(None, layout="schur", seed=31, skew=0.5, num_cameras=20, num_points=1500, num_observations=7000)
+    for solver in kw["solvers"]:
+        recs = [res[r][("poison",) + solver] for r in range(WORLD)]
+        for key in ("bad_solve", "bad_step"):
+            kinds = {rec[key][0] for rec in recs}
+            assert len(kinds) == 1, (solver, key, [rec[key][:3] for rec in recs])
+            assert kinds != {"error"}, (solver, key, recs[0][key])
+            assert len({rec[key][1] for rec in recs}) == 1, (solver, key, [rec[key][:3] for rec in recs])
+            if generic:   # the early returns of the generic path: every rank leaves at the same check
+                assert len({rec[key][2] for rec in recs}) == 1, (solver, key, [rec[key][:3] for rec in recs])
+            if what == "nan":   # a NaN cannot end in a finite "successful" step anywhere
+                assert not any(rec[key][0] == hip.SUCCESS and rec[key][3] for rec in recs), (solver, key, [rec[key][:3] for rec in recs])
+        m = oracle.Matrix(p.bs, p.num_eliminate_blocks if solver[0] == hip.ITERATIVE_SCHUR else 0)
+        fn = m.iterative_schur_solve if solver[0] == hip.ITERATIVE_SCHUR else m.cgnr_solve
+        solve = lambda lo, hi, q, r: fn(p.values, p.b, p.D, preconditioner=solver[1], min_it=lo, max_it=hi, q_tol=q, r_tol=r)
+        x = assemble(None, recs, p.bs.num_cols, "good_solve")
+        summ = type("S", (), dict(termination_type=recs[0]["good_solve"][1], num_iterations=recs[0]["good_solve"][2], message=recs[0]["good_solve"][4]))
+        assert_lm_style_step(x, summ, solve, 0.1, hip.SUCCESS, 1e-9)
