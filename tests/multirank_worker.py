@@ -121,6 +121,9 @@ def run_rank(rank, world, conn, device, scenario):
                 step, summ, mcc = s.lm_compute_step(v, b, kw.get("radius", 1e4), 0.1)
                 rec["lm_step"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
                 rec["collectives"] = int(s.info().collectives_last_step)
+                # (3b) the retry after a rejected step: the shard keeps its tiles, the diagonal is reused at half the radius
+                step, summ, mcc = s.lm_compute_step(None, None, kw.get("radius", 1e4) / 2, 0.1, reuse_diagonal=True, values_unchanged=True)
+                rec["retry"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
                 # (4) operators that sum over ranks
                 if solver_type == hs.ITERATIVE_SCHUR:
                     s.load(v, b, D)

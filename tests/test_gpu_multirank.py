@@ -164,7 +164,7 @@ def check_sharded_case(hip, case, world):
         assert all(rec["converged"][1] == hip.SUCCESS for rec in recs)
         assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-8
         # the camera part is REPLICATED: identical bits on every rank (the all-reduce sums in rank order everywhere)
-        for key in ("converged", "lm_style", "lm_step"):
+        for key in ("converged", "lm_style", "lm_step", "retry"):
             a = recs[0][key][0][recs[0]["n_e"]:]
             for rec in recs[1:]:
                 assert np.array_equal(a, rec[key][0][rec["n_e"]:]), key

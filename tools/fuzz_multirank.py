@@ -58,7 +58,7 @@ def run_case(seed):
         xo, so = solve(0, 600, -1.0, 1e-12)
         assert all(rec["converged"][1] == so.termination_type for rec in recs), ([rec["converged"][1:] for rec in recs], so)
         worst[tag + ":converged"] = float(rel(assemble(None, recs, p.bs.num_cols, "converged"), xo))
-        for key in ("converged", "lm_style", "lm_step"):   # the camera part is replicated: identical bits on every rank
+        for key in ("converged", "lm_style", "lm_step", "retry"):   # the camera part is replicated: identical bits on every rank
             a = recs[0][key][0][recs[0]["n_e"]:]
             for rec in recs[1:]:
                 assert np.array_equal(a, rec[key][0][rec["n_e"]:]), (key, "replicated part differs between ranks")
@@ -76,6 +76,14 @@ def run_case(seed):
             Jx = m0.right_multiply(p.values, step)
             want = -(Jx @ (p.b + Jx / 2))
             worst[tag + ":model_cost"] = float(abs(recs[0]["lm_step"][3] - want) / max(abs(want), 1e-300))
+        step = assemble(None, recs, p.bs.num_cols, "retry")   # values_unchanged at half the radius (TrustRegionMinimizer after a rejected step)
+        S.termination_type, S.num_iterations, S.message = recs[0]["retry"][1], recs[0]["retry"][2], recs[0]["retry"][4]
+        if "zeta" in S.message:
+            Dlm = np.sqrt(diag / 0.5)
+            assert_lm_style_step(-step, S, lambda lo, hi, q, r: solve(lo, hi, q, r, Dlm), 0.1, hip.SUCCESS)
+            Jx = m0.right_multiply(p.values, step)
+            want = -(Jx @ (p.b + Jx / 2))
+            worst[tag + ":retry_model_cost"] = float(abs(recs[0]["retry"][3] - want) / max(abs(want), 1e-300))
     bad = {a: b for a, b in worst.items() if not (b <= 1e-8)}
     return dict(out, ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 1))
 
