@@ -52,6 +52,21 @@ def run_rank(rank, world, conn, device, scenario):
             n_f_blocks = sh.bs.num_col_blocks - sh.num_eliminate_blocks
             fsz = sh.bs.col_block_size[sh.num_eliminate_blocks:].astype(np.int64)
             max_elems = int((fsz ** 2).sum() + 2 * fsz.sum() + 2)   # a step sums [blocks | rhs | column norms] in one all-reduce
+            for vi, var in enumerate(kw.get("variants", ())):
+                # the solver OPTIONS sharded (DENSE_SCHUR, the explicit Schur complement, the power-series preconditioner and initialisation,
+                # JACOBI / IDENTITY): one Solve each, compared by the parent with a single-rank instance on the whole problem
+                var = dict(var)
+                q_tol, r_tol = var.pop("q_tolerance", -1.0), var.pop("r_tolerance", -1.0)
+                o = hs.LinearSolverOptions(elimination_groups=[sh.num_eliminate_blocks], device=device, **var)
+                s = hs.HipLinearSolver(o, rank=rank, world_size=world, p2p_exchange=exchange, p2p_max_elements=max_elems)
+                try:
+                    s.set_structure(sh.bs)
+                    x, summ = s.solve(v, b, hs.PerSolveOptions(D=D, q_tolerance=q_tol, r_tolerance=r_tol))
+                    out[(name, "variant", vi)] = {"x": (x, summ.termination_type, summ.num_iterations, None, summ.message), "col_index": sh.col_index,
+                                                  "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum()), "path": int(s.info().kernel_path)}
+                except hs.HipError as ex:
+                    out[(name, "variant", vi)] = {"error": str(ex)}
+                s.close()
             for solver_type, pre in kw["solvers"]:
                 o = hs.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=kw.get("max_it", 400),
                                            elimination_groups=[sh.num_eliminate_blocks], device=device,

@@ -329,3 +329,50 @@ def test_a_shard_that_cannot_be_solved_ends_the_call_alike_on_every_rank(hip, or
         x = assemble(None, recs, p.bs.num_cols, "good_solve")
         summ = type("S", (), dict(termination_type=recs[0]["good_solve"][1], num_iterations=recs[0]["good_solve"][2], message=recs[0]["good_solve"][4]))
         assert_lm_style_step(x, summ, solve, 0.1, hip.SUCCESS, 1e-9)
+
+
+def _variants(hip):
+    K = dict(min_num_iterations=3, max_num_iterations=3)
+    out = []
+    for generic in (False, True):
+        g = dict(force_generic_path=generic)
+        out += [dict(type=hip.DENSE_SCHUR, max_num_iterations=1, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, use_explicit_schur_complement=True, **K, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_POWER_SERIES_EXPANSION, max_num_spse_iterations=5, spse_tolerance=0.1, **K, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, use_spse_initialization=True, max_num_spse_iterations=5, spse_tolerance=0.1, **K, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.JACOBI, **K, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.IDENTITY, **K, **g),
+                dict(type=hip.CGNR, preconditioner_type=hip.IDENTITY, **K, **g),
+                dict(type=hip.ITERATIVE_SCHUR, preconditioner_type=hip.SCHUR_JACOBI, residual_reset_period=1, min_num_iterations=0, max_num_iterations=50, r_tolerance=1e-6, **g)]
+    return out
+
+
+@pytest.mark.parametrize("WORLD", [2, 3])
+def test_sharded_solver_options_equal_the_single_rank_instance(hip, problems, WORLD):
+    """DENSE_SCHUR, the explicit Schur complement, SCHUR_POWER_SERIES_EXPANSION as preconditioner and as initialisation, JACOBI and
+    IDENTITY, a residual reset every iteration — sharded by point, each against ONE instance on the whole problem with the same options
+    (which tests/test_gpu_explicit_schur.py, test_gpu_spse.py and the option campaign of tools/fuzz_parity.py hold against the oracle)."""
+    variants = _variants(hip)
+    kw = dict(kind="bal", seed=33, nc=20, np=1500, no=7000, skew=0.5, solvers=[], variants=variants, p2p_timeout=10)
+    res = run_ranks([("opts", kw)], WORLD, timeout=240)
+    p = problems.synthetic_bal(None, layout="schur", seed=33, skew=0.5, num_cameras=20, num_points=1500, num_observations=7000)
+    for vi, var in enumerate(variants):
+        var = dict(var)
+        q_tol, r_tol = var.pop("q_tolerance", -1.0), var.pop("r_tolerance", -1.0)
+        recs = [res[r][("opts", "variant", vi)] for r in range(WORLD)]
+        one = hip.HipLinearSolver(hip.LinearSolverOptions(elimination_groups=[p.num_eliminate_blocks], **var))
+        one.set_structure(p.bs)
+        xo, so = one.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=q_tol, r_tolerance=r_tol))
+        one.close()
+        errors = [rec.get("error") for rec in recs]
+        assert not any(errors), (var, errors)
+        assert all((rec["x"][1], rec["x"][2]) == (so.termination_type, so.num_iterations) for rec in recs), (var, [rec["x"][1:] for rec in recs], so)
+        x = np.full(p.bs.num_cols, np.nan)
+        for rec in recs:
+            x[rec["col_index"][: rec["n_e"]]] = rec["x"][0][: rec["n_e"]]
+        x[recs[0]["col_index"][recs[0]["n_e"]:]] = recs[0]["x"][0][recs[0]["n_e"]:]
+        for rec in recs[1:]:   # the camera part is replicated
+            assert np.array_equal(recs[0]["x"][0][recs[0]["n_e"]:], rec["x"][0][rec["n_e"]:]), var
+        nx, no = np.isnan(x), np.isnan(xo)
+        assert np.array_equal(nx, no), (var, int(nx.sum()), int(no.sum()))   # (NO_CONVERGENCE at the cap: no back-substitution, the point part stays NaN)
+        assert rel(x[~nx], xo[~no]) <= 1e-9, (var, rel(x[~nx], xo[~no]))
