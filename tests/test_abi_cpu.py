@@ -97,3 +97,31 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert got[0] == cname
         want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(v) for v in got[1:]] == want, cname
+
+
+def test_null_arguments_are_errors_not_crashes():
+    """Every exported function called with NULL for every pointer (the handle included) and zero for every number returns — an error
+    code, or for the handful without a handle a harmless value — instead of dereferencing: what a binding in another language gets wrong
+    first.  One child process; a crash is reported with the name of the function that was running."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import pkg
+hs = pkg.hip_solver
+lib = hs.load_library()
+harmless = {"ceres_hip_abi_version", "ceres_hip_device_count", "ceres_hip_last_error", "ceres_hip_destroy"}
+for n, res, args in hs.ABI:
+    print("CALL", n, flush=True)
+    vals = [0 if a in (ctypes.c_int32, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32) else 0.0 if a is ctypes.c_double else None for a in args]
+    r = getattr(lib, n)(*vals)
+    if n not in harmless and res is ctypes.c_int32 and r == 0:
+        print("ACCEPTED", n, flush=True)
+print("DONE", flush=True)
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    lines = p.stdout.strip().splitlines()
+    assert p.returncode == 0 and lines and lines[-1] == "DONE", (p.returncode, lines[-3:], p.stderr[-500:])
+    accepted = [l.split()[1] for l in lines if l.startswith("ACCEPTED")]
+    assert not accepted, accepted
