@@ -12,6 +12,7 @@
 // reduction with wavefront shuffles and no inter-workgroup traffic.
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -57,23 +58,26 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
 
   // Rows and columns must tile [0, num_rows) / [0, num_cols) in order, as every
   // BlockSparseMatrix does (I/block_sparse_matrix.cc:178-216).
-  int pos = 0;
+  // (positions are `int` in the reference's CompressedRowBlockStructure: sums that leave that range are refused, not wrapped)
+  int64_t pos = 0;
   for (int i = 0; i < h.nrb; ++i) {
     if (h.rsz[i] <= 0) return "row block with non-positive size";
     if (h.rpos[i] != pos) return "row block positions are not the running sum of sizes";
     pos += h.rsz[i];
+    if (pos > INT32_MAX) return "more than 2^31 - 1 rows";
     h.max_block = std::max(h.max_block, h.rsz[i]);
   }
-  h.num_rows = pos;
+  h.num_rows = int(pos);
   pos = 0;
   for (int j = 0; j < h.ncb; ++j) {
     if (h.csz[j] <= 0) return "column block with non-positive size";
     if (h.cpos[j] != pos) return "column block positions are not the running sum of sizes";
     pos += h.csz[j];
+    if (pos > INT32_MAX) return "more than 2^31 - 1 columns";
     h.max_block = std::max(h.max_block, h.csz[j]);
     (j < nelim ? h.num_cols_e : h.num_cols_f) += h.csz[j];
   }
-  h.num_cols = pos;
+  h.num_cols = int(pos);
   h.row_block_of.resize(h.num_rows);
   for (int i = 0; i < h.nrb; ++i) std::fill_n(h.row_block_of.begin() + h.rpos[i], h.rsz[i], i);
   h.col_block_of.resize(h.num_cols);
@@ -85,6 +89,7 @@ std::string AnalyzeStructure(const ceres_hip_block_structure& bs, int nelim, Hos
       if (j < 0 || j >= h.ncb) return "cell with column block id out of range";
       if (h.cval[k] < 0) return "cell with negative value position";
       const int64_t n = int64_t(h.rsz[i]) * h.csz[j];
+      if (int64_t(h.cval[k]) + n - 1 > INT32_MAX) return "cell beyond the range of int value positions";
       h.nnz += n;
       h.values_extent = std::max(h.values_extent, int64_t(h.cval[k]) + n);
     }

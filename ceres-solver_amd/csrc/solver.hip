@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <exception>
+#include <new>
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -1985,8 +1987,19 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   delete s;
 }
 
+static int set_structure_impl(ceres_hip_solver* s, const ceres_hip_block_structure* bs);
+// (the host-side analysis and the tile plan allocate with the structure's sizes: no C++ exception may cross the C boundary)
 int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure* bs) {
   if (!s || !bs) return CERES_HIP_E_INVALID;
+  try {
+    return set_structure_impl(s, bs);
+  } catch (const std::bad_alloc&) {
+    return fail(s, CERES_HIP_E_INVALID, "out of host memory while analysing the block structure");
+  } catch (const std::exception& ex) {
+    return fail(s, CERES_HIP_E_INVALID, "block structure analysis failed: %s", ex.what());
+  }
+}
+static int set_structure_impl(ceres_hip_solver* s, const ceres_hip_block_structure* bs) {
   HIP_TRY(s, hipSetDevice(s->opt.device));
   if (s->have_structure) return fail(s, CERES_HIP_E_INVALID, "structure already set: one instance sees one sparsity (I/linear_solver.h:137-142)");
   const int nelim = s->opt.num_eliminate_blocks;

@@ -4,7 +4,9 @@ emulated in numpy against the oracle."""
 import numpy as np
 import pytest
 
-from conftest import pkg
+import os
+
+from conftest import ROOT, pkg
 
 
 def plan_of(p):
@@ -625,3 +627,52 @@ def test_no_staged_x_where_the_accumulators_do_not_fit(problems):
     # row or "spilled" (0xFFF), never a staged-x row — there is no staged x in this regime
     rows = w[real] >> 20
     assert (rows == 0xFFF).any() and (rows < 0xFFF).any()
+
+
+def test_malformed_structures_are_refused_or_planned_never_a_crash():
+    """The boundary hands over raw int arrays (ceres_hip_block_structure): 400 random single-entry corruptions of a valid structure —
+    negative, zero, huge, INT32_MAX, off by one, swapped — with elimination counts in and out of range go through the host-side analysis
+    and the tile plan in a child process; each is refused with a reason or planned, none crashes (sums that leave `int` used to wrap:
+    a last row block of INT32_MAX rows sized a vector with a negative number).  Three overflow cases must be refused by name."""
+    import subprocess
+    import sys
+    code = r'''
+import copy, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import os
+
+from conftest import ROOT, pkg
+hs, P = pkg.hip_solver, pkg.problems
+base = P.synthetic_bal(None, layout="schur", num_cameras=7, num_points=40, num_observations=150, seed=3)
+rng = np.random.default_rng(5)
+fields = ["row_block_size", "row_block_pos", "col_block_size", "col_block_pos", "row_cell_ptr", "cell_col_block", "cell_value_pos"]
+for trial in range(400):
+    bs = copy.deepcopy(base.bs)
+    field = fields[int(rng.integers(len(fields)))]
+    a = getattr(bs, field).copy()
+    k = int(rng.integers(a.shape[0]))
+    how = int(rng.integers(6))
+    if how == 0: a[k] = -int(rng.integers(1, 5))
+    elif how == 1: a[k] = 0
+    elif how == 2: a[k] = int(rng.integers(10**6, 10**8))
+    elif how == 3: a[k] = 2**31 - 1
+    elif how == 4: a[k] += 1
+    else:
+        j = int(rng.integers(a.shape[0])); a[k], a[j] = a[j], a[k]
+    setattr(bs, field, a)
+    nelim = int(rng.choice([0, base.num_eliminate_blocks, base.num_eliminate_blocks + 1, -1, 10**6]))
+    print("TRY", trial, field, k, how, nelim, flush=True)
+    hs.debug_plan(bs, nelim)
+    hs.debug_staged_x_plan(bs, nelim)
+for field, k, want in (("row_block_size", -1, "rows"), ("col_block_size", -1, "columns"), ("cell_value_pos", 3, "value positions")):
+    bs = copy.deepcopy(base.bs)
+    a = getattr(bs, field).copy(); a[k] = 2**31 - 1; setattr(bs, field, a)
+    r = hs.debug_plan(bs, base.num_eliminate_blocks)
+    print("OVERFLOW", field, r["eligible"], r.get("why", ""), flush=True)
+    assert not r["eligible"] and want in r["why"], r
+print("DONE", flush=True)
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    lines = p.stdout.strip().splitlines()
+    assert p.returncode == 0 and lines and lines[-1] == "DONE", (p.returncode, lines[-3:], p.stderr[-800:])
