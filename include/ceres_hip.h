@@ -244,7 +244,12 @@ int ceres_hip_solve(ceres_hip_solver* s, const double* host_values, const double
 int ceres_hip_solve_unchanged_values(ceres_hip_solver* s, const double* host_D, double q_tolerance, double r_tolerance,
                                      double* host_x, ceres_hip_summary* summary);
 /* Same, all four arrays already resident in HBM (used by bench.py so that the
- * timed region holds no PCIe traffic; also the form a device evaluator uses). */
+ * timed region holds no PCIe traffic; also the form a device evaluator uses).
+ * STREAM ORDER of every *_device entry point: the work runs on the handle's own stream, created hipStreamNonBlocking — it does NOT
+ * wait for the legacy default stream or for any stream of the caller.  Whatever produced dev_values / dev_b / dev_D, and whatever
+ * last wrote the output array (a fill, say), must have COMPLETED before the call (hipStreamSynchronize or an event the host waited
+ * for); when the call returns, its device work has completed and the output may be read from any stream.  (Found by
+ * tools/fuzz_sequence.py --threads: a NaN fill of the output queued on a busy default stream landed after the step.)           */
 int ceres_hip_solve_device(ceres_hip_solver* s, const double* dev_values, const double* dev_b,
                            const double* dev_D, double q_tolerance, double r_tolerance,
                            double* dev_x, ceres_hip_summary* summary);

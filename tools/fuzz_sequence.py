@@ -9,7 +9,7 @@ with a caller's D ending on the residual test, the streamed upload, device point
 calls that cannot succeed (NaN in the values) followed by good ones — every result compared with a FRESH handle doing that one call
 (the sums in LDS are order-dependent: 1e-11, same termination and iteration count), and the first step with the oracle as well.
 
-usage: fuzz_sequence.py [first_seed] [count] [--stop] [--big]     one JSON line per sequence; exit code 1 if any failed
+usage: fuzz_sequence.py [first_seed] [count] [--stop] [--big] [--threads=N]     one JSON line per sequence; exit code 1 if any failed
 """
 import json
 import os
@@ -35,6 +35,7 @@ from test_gpu_lm_step import check_step  # noqa: E402
 import fuzz_cases  # noqa: E402
 
 SAME_TOL = 1e-11
+ORACLE_CHECK = True
 BIG = "--big" in sys.argv   # 0.15 - 2.8 M observations: the software-pipelined kernels, the staged x (fuzz_cases.draw_case)
 STEP_TOL = 1e-9
 
@@ -122,7 +123,7 @@ def run_sequence(seed):
                     got = held.lm_compute_step(vals, p.b, radius, 0.1)
                     want = f.lm_compute_step(vals, p.b, radius, 0.1)
                     same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.lm_compute_step(vals, p.b, radius, 0.1)))
-                    if not checked and case["n_obs"] <= 60000 and "zeta" in got[1].message:
+                    if ORACLE_CHECK and not checked and case["n_obs"] <= 60000 and "zeta" in got[1].message:
                         diag = np.clip(m0.squared_column_norm(vals), 1e-6, 1e32)
                         check_step(oracle, hip, type(p)(p.bs, vals, p.b, p.D, nelim), typ, pre, np.sqrt(diag / radius), got[0], got[1], got[2], 0.1, STEP_TOL)
                         log[tag + ":oracle"] = 0.0
@@ -184,6 +185,7 @@ def run_sequence(seed):
                 elif kind == "device":
                     tv, tb = torch.from_numpy(np.ascontiguousarray(vals)).cuda(), torch.from_numpy(np.ascontiguousarray(p.b)).cuda()
                     tx = torch.full((p.bs.num_cols,), float("nan"), dtype=torch.float64, device="cuda")
+                    torch.cuda.synchronize()   # the handle's stream does not wait for torch's: inputs and the NaN fill must have landed (include/ceres_hip.h, STREAM ORDER)
                     summ_d, mcc_d, finite = held.lm_compute_step_device(tv.data_ptr(), tb.data_ptr(), tx.data_ptr(), 1.0, 0.1)
                     torch.cuda.synchronize()
                     want = f.lm_compute_step(vals, p.b, 1.0, 0.1)
@@ -217,6 +219,26 @@ def main():
     first = int(args[0]) if args else 0
     count = int(args[1]) if len(args) > 1 else 20
     failed = 0
+    threads = max([int(a.split("=")[1]) for a in sys.argv if a.startswith("--threads=")] or [0])
+    if threads > 1:
+        # N sequences AT ONCE, each on handles of its own, from N host threads (ctypes releases the GIL in every call): separate
+        # instances are independent (one stream, one set of buffers per handle) — whatever they share by accident (a static
+        # cache, the default stream, the current device) shows as a difference between a handle and its fresh twin
+        global ORACLE_CHECK
+        ORACLE_CHECK = False   # (the oracle's OpenMP loops from several host threads at once measure nothing about the product)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def guarded(seed):
+            try:
+                return run_sequence(seed)
+            except Exception as ex:
+                return dict(seed=seed, ok=False, error=repr(ex)[:900], trace=traceback.format_exc()[-1500:])
+        with ThreadPoolExecutor(threads) as pool:
+            for r in pool.map(guarded, range(first, first + count)):
+                failed += 0 if r["ok"] else 1
+                print(json.dumps(r), flush=True)
+        print(json.dumps({"sequences": count, "failed": failed, "threads": threads}), flush=True)
+        sys.exit(1 if failed else 0)
     for seed in range(first, first + count):
         try:
             r = run_sequence(seed)
