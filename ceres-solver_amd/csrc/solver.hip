@@ -1987,6 +1987,22 @@ void ceres_hip_destroy(ceres_hip_solver* s) {
   delete s;
 }
 
+// A few doubles summed over ranks from the host (agreements at set-up time: ranks reach them at different moments — host-side planning
+// takes tenths of a second —, so the exchange's time-out is raised for the call).
+static int allreduce_host_doubles(ceres_hip_solver* s, double* v, int n) {
+  double* d = nullptr;
+  TRY(dev_alloc(s, &d, size_t(n)));
+  HIP_TRY(s, hipMemcpyAsync(d, v, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+  const double keep = s->p2p_timeout_s;
+  s->p2p_timeout_s = std::max(keep, 120.0);
+  const int rc = allreduce(s, d, size_t(n));
+  s->p2p_timeout_s = keep;
+  TRY(rc);
+  HIP_TRY(s, hipMemcpyAsync(v, d, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return check_comm_error(s);
+}
+
 static int set_structure_impl(ceres_hip_solver* s, const ceres_hip_block_structure* bs);
 // (the host-side analysis and the tile plan allocate with the structure's sizes: no C++ exception may cross the C boundary)
 int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure* bs) {
@@ -2039,6 +2055,20 @@ static int set_structure_impl(ceres_hip_solver* s, const ceres_hip_block_structu
     s->plan.why_not = "point blocks that are not 3 wide or rows that are not 2 high: the fused path takes the Schur solvers";
   }
   s->path = (s->plan.eligible && !s->opt.force_generic_path && !s->opt.use_explicit_schur_complement && !(is_dense_schur(s) && s->world > 1)) ? CERES_HIP_PATH_BAL : CERES_HIP_PATH_GENERIC;
+  if (s->world > 1) {
+    // The kernel path is a property of THIS rank's shard — a shard of a general structure can look like bundle adjustment (every row of
+    // it one point cell and one camera cell) while its neighbour's does not — and the two paths issue different sequences of exchanges:
+    // ranks that disagreed waited for each other until the time-out (tools/fuzz_multirank.py --generic).  All ranks take the fused
+    // path, with the same shape, or none does; a shard whose columns are not points-then-cameras votes against it too.
+    const bool fused_ok = s->path == CERES_HIP_PATH_BAL && (is_schur(s) ? s->plan.cameras_contiguous : s->plan.caller_contiguous);
+    const double dims[4] = {double(s->plan.nr), double(s->plan.ne), double(s->plan.nf), double(s->plan.ns)};
+    double v[9] = {fused_ok ? 0.0 : 1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) { v[1 + i] = fused_ok ? dims[i] : 0.0; v[5 + i] = fused_ok ? dims[i] * dims[i] : 0.0; }
+    TRY(allreduce_host_doubles(s, v, 9));
+    bool same = v[0] == 0.0;
+    for (int i = 0; i < 4 && same; ++i) same = v[1 + i] * v[1 + i] == double(s->world) * v[5 + i];   // (equal iff every rank holds the same number)
+    if (!same) s->path = CERES_HIP_PATH_GENERIC;   // (as with force_generic_path: the plan stays, nothing uses it)
+  }
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
   if (s->path == CERES_HIP_PATH_GENERIC && h.max_block > kMaxGenericBlock)
     return fail(s, CERES_HIP_E_UNSUPPORTED, "block size %d exceeds the generic kernels' limit of %d", h.max_block, kMaxGenericBlock);

@@ -45,6 +45,8 @@ def run_rank(rank, world, conn, device, scenario):
                                                   num_cameras=kw["nc"], num_points=kw["np"], num_observations=kw["no"])
                 if kw.get("camera_rows", 0):  # rows without a point cell: partition.py hands them to the last rank
                     prob = pkg.problems.add_camera_rows(prob, kw["camera_rows"], seed=kw["seed"], pair_fraction=0.3)
+            elif kind == "general_fuzz":   # tools/fuzz_multirank.py --generic: random E|F-partitioned structures, blocks 1 .. 4 wide
+                prob = pkg.problems.random_schur_problem(**kw["problem"])
             else:
                 prob = pkg.problems.random_schur_problem(num_e_blocks=kw["ne"], num_f_blocks=kw["nf"], num_no_e_rows=2, seed=kw["seed"])
             sh = partition.shard_by_point(prob.bs, prob.num_eliminate_blocks, world, rank)

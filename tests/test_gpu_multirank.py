@@ -376,3 +376,25 @@ def test_sharded_solver_options_equal_the_single_rank_instance(hip, problems, WO
         nx, no = np.isnan(x), np.isnan(xo)
         assert np.array_equal(nx, no), (var, int(nx.sum()), int(no.sum()))   # (NO_CONVERGENCE at the cap: no back-substitution, the point part stays NaN)
         assert rel(x[~nx], xo[~no]) <= 1e-9, (var, rel(x[~nx], xo[~no]))
+
+
+@pytest.mark.parametrize("seed,WORLD,pk", [
+    (52, 3, dict(num_e_blocks=40, num_f_blocks=2, max_rows_per_e=1, num_no_e_rows=3, static_sizes=(2, 3, 6), seed=52)),
+    (83, 8, dict(num_e_blocks=8, num_f_blocks=2, max_rows_per_e=1, num_no_e_rows=0, static_sizes=None, seed=83))])
+def test_ranks_agree_on_the_kernel_path(hip, oracle, problems, seed, WORLD, pk):
+    """A shard of a GENERAL structure can look like bundle adjustment — each of its rows one point cell and one camera cell — while its
+    neighbour's does not; the two kernel paths issue different sequences of exchanges, and ranks that chose for themselves waited for
+    each other until the time-out (tools/fuzz_multirank.py --generic, seeds 52 and 83 among nine of 149).  ceres_hip_set_structure now
+    agrees on the path (and on the fused shape) over the ranks."""
+    solvers = [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)]
+    kw = dict(kind="general_fuzz", problem=pk, solvers=solvers, radius=1.0, max_it=3000, p2p_timeout=8)
+    res = run_ranks([("g", kw)], WORLD, timeout=120)
+    p = problems.random_schur_problem(**pk)
+    m, m0 = oracle.Matrix(p.bs, p.num_eliminate_blocks), oracle.Matrix(p.bs, 0)
+    for solver_type, pre in solvers:
+        recs = [res[r][("g", solver_type, pre)] for r in range(WORLD)]
+        assert len({rec["path"] for rec in recs}) == 1, [rec["path"] for rec in recs]
+        fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m0.cgnr_solve
+        xo, so = fn(p.values, p.b, p.D, preconditioner=pre, min_it=0, max_it=3000, q_tol=-1.0, r_tol=1e-12)
+        assert all(rec["converged"][1] == so.termination_type for rec in recs), [rec["converged"][1:] for rec in recs]
+        assert rel(assemble(None, recs, p.bs.num_cols, "converged"), xo) <= 1e-7

@@ -22,6 +22,7 @@ import __graft_entry__ as entry  # noqa: E402
 pkg = entry.load_package()
 oracle = entry.load_oracle()
 hip = pkg.hip_solver
+P = pkg.problems
 import fuzz_cases  # noqa: E402
 from step_check import assert_lm_style_step  # noqa: E402
 from test_gpu_multirank import assemble, run_ranks  # noqa: E402
@@ -88,6 +89,72 @@ def run_case(seed):
     return dict(out, ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 1))
 
 
+def run_generic(seed):
+    """--generic: a structure that is NOT bundle adjustment (random E|F-partitioned blocks 1 .. 4 wide: the generic kernels), sharded by
+    E block: converged solves, the LM-style call, the LM step and its retry, the operators that sum over ranks — against the oracle."""
+    rng = np.random.default_rng(7000003 * seed + 11)
+    static = [None, None, (2, 3, 6), (1, 1, 1), (3, 2, 4)][int(rng.integers(5))]
+    world = int(rng.choice([2, 3, 4, 8]))
+    pk = dict(num_e_blocks=int(rng.choice([8, 40, 300])), num_f_blocks=int(rng.choice([1, 2, 9, 40])), max_rows_per_e=int(rng.choice([1, 4, 9])),
+              num_no_e_rows=int(rng.choice([0, 3, 20])), static_sizes=static, seed=seed)
+    p = P.random_schur_problem(**pk)
+    out = dict(generic=True, world=world, **{k: (list(v) if isinstance(v, tuple) else v) for k, v in pk.items()})
+    solvers = [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI), (hip.CGNR, hip.JACOBI)]
+    kw = dict(kind="general_fuzz", problem=pk, solvers=solvers, radius=1.0, max_it=3000, p2p_timeout=8)
+    t0 = time.time()
+    res = run_ranks([("gfuzz", kw)], world)
+    m, m0 = oracle.Matrix(p.bs, p.num_eliminate_blocks), oracle.Matrix(p.bs, 0)
+    diag = np.clip(m0.squared_column_norm(p.values), 1e-6, 1e32)
+    worst = {}
+    for solver_type, pre in solvers:
+        recs = [res[r][("gfuzz", solver_type, pre)] for r in range(world)]
+        tag = "schur" if solver_type == hip.ITERATIVE_SCHUR else "cgnr"
+        out[tag + "_path"] = [int(rec["path"]) for rec in recs]
+        fn = m.iterative_schur_solve if solver_type == hip.ITERATIVE_SCHUR else m0.cgnr_solve
+        solve = lambda lo, hi, q, r, D=p.D: fn(p.values, p.b, D, preconditioner=pre, min_it=lo, max_it=hi, q_tol=q, r_tol=r)
+        xo, so = solve(0, 3000, -1.0, 1e-12)
+        assert all(rec["converged"][1] == so.termination_type for rec in recs), ([rec["converged"][1:] for rec in recs], so)
+        worst[tag + ":converged"] = float(rel(assemble(None, recs, p.bs.num_cols, "converged"), xo)) * 1e-2   # (1e-12 on |r|: 1e-6 on x at these condition numbers; scaled to the 1e-8 bar)
+        for key in ("converged", "lm_style", "lm_step", "retry"):
+            for rec in recs[1:]:
+                assert (recs[0][key][1], recs[0][key][2]) == (rec[key][1], rec[key][2]), (key, recs[0][key][1:], rec[key][1:])
+
+        class S:
+            termination_type, num_iterations, message = recs[0]["lm_style"][1], recs[0]["lm_style"][2], recs[0]["lm_style"][4]
+        # (a reduced system of one or two unknowns is solved EXACTLY: rho = r'z = 0 in one implementation, 1e-64 and "zeta" in the other — a tie)
+        exact = lambda D: "rho = r'z" in solve(0, 500, 0.1, -1.0, D)[1].message
+        if "zeta" in S.message and not exact(p.D):
+            assert_lm_style_step(assemble(None, recs, p.bs.num_cols, "lm_style"), S, solve, 0.1, hip.SUCCESS)
+        for key, radius in (("lm_step", 1.0), ("retry", 0.5)):
+            step = assemble(None, recs, p.bs.num_cols, key)
+            S.termination_type, S.num_iterations, S.message = recs[0][key][1], recs[0][key][2], recs[0][key][4]
+            Dlm = np.sqrt(diag / radius)
+            if "zeta" in S.message and not exact(Dlm):
+                assert_lm_style_step(-step, S, lambda lo, hi, q, r: solve(lo, hi, q, r, Dlm), 0.1, hip.SUCCESS)
+                Jx = m0.right_multiply(p.values, step)
+                want = -(Jx @ (p.b + Jx / 2))
+                worst[f"{tag}:{key}_model_cost"] = float(abs(recs[0][key][3] - want) / max(abs(want), 1e-300))
+        if solver_type == hip.ITERATIVE_SCHUR:
+            isc = oracle.ImplicitSchurComplement(m)
+            isc.init(p.values, p.D, p.b)
+            xf = np.random.default_rng(5).standard_normal(m.num_cols_f)
+            inv = m.schur_jacobi(p.values, p.D)[0]
+            for rec in recs:
+                worst["schur:rhs"] = max(worst.get("schur:rhs", 0.0), float(rel(rec["rhs"], isc.rhs())))
+                worst["schur:sx"] = max(worst.get("schur:sx", 0.0), float(rel(rec["sx"], isc.sx(xf))))
+                worst["schur:precond"] = max(worst.get("schur:precond", 0.0), float(rel(rec["precond"], inv)))
+        else:
+            xx = np.random.default_rng(6).standard_normal(p.bs.num_cols)
+            want = m0.left_multiply(p.values, m0.right_multiply(p.values, xx)) + p.D ** 2 * xx
+            g = m0.left_multiply(p.values, p.b)
+            for rec in recs:
+                ci = rec["col_index"]
+                worst["cgnr:jtjx"] = max(worst.get("cgnr:jtjx", 0.0), float(rel(rec["jtjx"], want[ci])))
+                worst["cgnr:jtb"] = max(worst.get("cgnr:jtb", 0.0), float(rel(rec["jtb"], g[ci])))
+    bad = {a: b for a, b in worst.items() if not (b <= 1e-8)}
+    return dict(out, ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 1))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     first = int(args[0]) if args else 0
@@ -95,9 +162,9 @@ def main():
     failed = 0
     for seed in range(first, first + count):
         try:
-            r = run_case(seed)
+            r = run_generic(seed) if "--generic" in sys.argv else run_case(seed)
         except Exception as ex:
-            r = dict(fuzz_cases.draw_case(seed, BIG)[0], ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
+            r = dict(fuzz_cases.draw_case(seed, BIG)[0] if "--generic" not in sys.argv else dict(seed=seed, generic=True), ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
         failed += 0 if r["ok"] else 1
         print(json.dumps(r), flush=True)
     print(json.dumps({"cases": count, "failed": failed}), flush=True)
