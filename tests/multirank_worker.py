@@ -141,6 +141,19 @@ def run_rank(rank, world, conn, device, scenario):
                 # (3b) the retry after a rejected step: the shard keeps its tiles, the diagonal is reused at half the radius
                 step, summ, mcc = s.lm_compute_step(None, None, kw.get("radius", 1e4) / 2, 0.1, reuse_diagonal=True, values_unchanged=True)
                 rec["retry"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
+                # (3c) the same step with the values streamed up behind an "evaluator" (ceres_hip_values_begin / _ready / _end): a shard's upload
+                if not kw.get("no_streamed"):
+                    hv, hb = np.full(v.shape[0], np.nan), np.full(b.shape[0], np.nan)
+                    s.values_begin(hv, hb)
+                    hv[:] = v
+                    hb[:] = b
+                    nrb = sh.bs.num_row_blocks
+                    for r0 in range(0, nrb, max(1, nrb // 5)):
+                        if (r0 // max(1, nrb // 5)) % 3 != 2:   # (some runs of row blocks never announced: _end sends them)
+                            s.values_ready(r0, min(max(1, nrb // 5), nrb - r0))
+                    s.values_end(None)
+                    step, summ, mcc = s.lm_compute_step(None, None, kw.get("radius", 1e4), 0.1, values_unchanged=True)
+                    rec["streamed"] = (step, summ.termination_type, summ.num_iterations, mcc, summ.message)
                 # (4) operators that sum over ranks
                 if solver_type == hs.ITERATIVE_SCHUR:
                     s.load(v, b, D)

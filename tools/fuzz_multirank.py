@@ -77,6 +77,10 @@ def run_case(seed):
             Jx = m0.right_multiply(p.values, step)
             want = -(Jx @ (p.b + Jx / 2))
             worst[tag + ":model_cost"] = float(abs(recs[0]["lm_step"][3] - want) / max(abs(want), 1e-300))
+        for rec in recs:   # the streamed upload of a shard: the step it leads to is the plain call's
+            assert (rec["streamed"][1], rec["streamed"][2]) == (rec["lm_step"][1], rec["lm_step"][2]), (rec["streamed"][1:], rec["lm_step"][1:])
+            if np.isfinite(rec["lm_step"][0]).all():
+                worst[tag + ":streamed"] = max(worst.get(tag + ":streamed", 0.0), float(rel(rec["streamed"][0], rec["lm_step"][0])) * 1e3)   # (1e-11 counts as the 1e-8 bar)
         step = assemble(None, recs, p.bs.num_cols, "retry")   # values_unchanged at half the radius (TrustRegionMinimizer after a rejected step)
         S.termination_type, S.num_iterations, S.message = recs[0]["retry"][1], recs[0]["retry"][2], recs[0]["retry"][4]
         if "zeta" in S.message:
