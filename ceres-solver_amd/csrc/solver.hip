@@ -2062,11 +2062,11 @@ static int set_structure_impl(ceres_hip_solver* s, const ceres_hip_block_structu
     // path, with the same shape, or none does; a shard whose columns are not points-then-cameras votes against it too.
     const bool fused_ok = s->path == CERES_HIP_PATH_BAL && (is_schur(s) ? s->plan.cameras_contiguous : s->plan.caller_contiguous);
     const double dims[4] = {double(s->plan.nr), double(s->plan.ne), double(s->plan.nf), double(s->plan.ns)};
-    double v[9] = {fused_ok ? 0.0 : 1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double v[10] = {fused_ok ? 0.0 : 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0};   // [9]: the ranks that take part (a loop-back communicator: one)
     for (int i = 0; i < 4; ++i) { v[1 + i] = fused_ok ? dims[i] : 0.0; v[5 + i] = fused_ok ? dims[i] * dims[i] : 0.0; }
-    TRY(allreduce_host_doubles(s, v, 9));
+    TRY(allreduce_host_doubles(s, v, 10));
     bool same = v[0] == 0.0;
-    for (int i = 0; i < 4 && same; ++i) same = v[1 + i] * v[1 + i] == double(s->world) * v[5 + i];   // (equal iff every rank holds the same number)
+    for (int i = 0; i < 4 && same; ++i) same = v[1 + i] * v[1 + i] == v[9] * v[5 + i];   // (equal iff every rank holds the same number)
     if (!same) s->path = CERES_HIP_PATH_GENERIC;   // (as with force_generic_path: the plan stays, nothing uses it)
   }
   s->dense_from_blocks = is_dense_schur(s) && s->world <= 1;
