@@ -9,7 +9,7 @@ with a caller's D ending on the residual test, the streamed upload, device point
 calls that cannot succeed (NaN in the values) followed by good ones — every result compared with a FRESH handle doing that one call
 (the sums in LDS are order-dependent: 1e-11, same termination and iteration count), and the first step with the oracle as well.
 
-usage: fuzz_sequence.py [first_seed] [count] [--stop] [--big] [--threads=N]     one JSON line per sequence; exit code 1 if any failed
+usage: fuzz_sequence.py [first_seed] [count] [--stop] [--big] [--threads=N] [--variants]     one JSON line per sequence; exit code 1 if any failed
 """
 import json
 import os
@@ -41,8 +41,11 @@ STEP_TOL = 1e-9
 
 
 def new_solver(p, typ, pre, nelim):
+    extras = {}
+    if isinstance(pre, tuple):   # (--variants) a preconditioner with further options of the handle
+        pre, extras = pre
     s = hip.HipLinearSolver(hip.LinearSolverOptions(type=typ, preconditioner_type=pre, max_num_iterations=500, min_num_iterations=0,
-                                                    elimination_groups=[nelim]))
+                                                    elimination_groups=[nelim], **extras))
     s.set_structure(p.bs)
     return s
 
@@ -73,10 +76,14 @@ def same(tag, got, want, log, again=None):
         log[tag] = max(log.get(tag, 0.0), d)
         return
     if again is not None:
-        why2, d2 = differ(again(), want)
-        if why2 is not None and (why2[0] != "deviation" or why[0] != "deviation" or d <= 30 * d2):
-            log[tag + ":run_to_run"] = max(log.get(tag + ":run_to_run", 0.0), d)
-            return
+        # (up to five more fresh samples: on a small structure the LDS additions often happen in the SAME order twice — two runs then
+        # agree to the last bit — and in another order the third time, which an ill-conditioned unpreconditioned solve amplifies to 1e-6:
+        # seed 3137 of the --variants campaign, IDENTITY on 64 points seen by 2600 cameras, passes and fails by turns)
+        for _ in range(5):
+            why2, d2 = differ(again(), want)
+            if why2 is not None and (why2[0] != "deviation" or why[0] != "deviation" or d <= 30 * d2):
+                log[tag + ":run_to_run"] = max(log.get(tag + ":run_to_run", 0.0), d)
+                return
     raise AssertionError((tag, why))
 
 
@@ -98,8 +105,21 @@ def run_sequence(seed):
     log, actions = {}, []
     p0 = fuzz_cases.build(P, case, k)
     nrb = p0.bs.num_row_blocks
-    for typ, pre, name in ((hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, "schur"), (hip.CGNR, hip.JACOBI, "cgnr")):
-        p = p0 if name == "schur" else type(p0)(p0.bs, p0.values, p0.b, p0.D, 0)
+    handles = [(hip.ITERATIVE_SCHUR, hip.SCHUR_JACOBI, "schur"), (hip.CGNR, hip.JACOBI, "cgnr")]
+    if "--variants" in sys.argv:
+        # the other OPTIONS a handle can be created with: each keeps state of its own between calls (the F^T F inverse of the power series,
+        # the explicit Schur complement's storage, which preconditioner blocks are valid)
+        spse = dict(max_num_spse_iterations=5, spse_tolerance=0.1)
+        pool = [(hip.ITERATIVE_SCHUR, (hip.SCHUR_POWER_SERIES_EXPANSION, spse), "schur_spse"),
+                (hip.ITERATIVE_SCHUR, (hip.SCHUR_JACOBI, dict(use_spse_initialization=True, **spse)), "schur_spse_init"),
+                (hip.ITERATIVE_SCHUR, hip.JACOBI, "schur_jacobi"), (hip.ITERATIVE_SCHUR, hip.IDENTITY, "schur_identity"),
+                (hip.CGNR, hip.IDENTITY, "cgnr_identity")]
+        nf_cols = int(p0.bs.col_block_size[p0.num_eliminate_blocks:].sum())
+        if nf_cols <= 1200 and nrb <= 20000:
+            pool.append((hip.ITERATIVE_SCHUR, (hip.SCHUR_JACOBI, dict(use_explicit_schur_complement=True)), "schur_explicit"))
+        handles = [pool[i] for i in rng.choice(len(pool), size=2, replace=False)]
+    for typ, pre, name in handles:
+        p = p0 if name.startswith("schur") else type(p0)(p0.bs, p0.values, p0.b, p0.D, 0)
         nelim = p.num_eliminate_blocks
         held = new_solver(p, typ, pre, nelim)
         try:
@@ -123,7 +143,7 @@ def run_sequence(seed):
                     got = held.lm_compute_step(vals, p.b, radius, 0.1)
                     want = f.lm_compute_step(vals, p.b, radius, 0.1)
                     same(tag, got, want, log, lambda: fresh(p, typ, pre, nelim, lambda g: g.lm_compute_step(vals, p.b, radius, 0.1)))
-                    if ORACLE_CHECK and not checked and case["n_obs"] <= 60000 and "zeta" in got[1].message:
+                    if ORACLE_CHECK and name in ("schur", "cgnr") and not checked and case["n_obs"] <= 60000 and "zeta" in got[1].message:
                         diag = np.clip(m0.squared_column_norm(vals), 1e-6, 1e32)
                         check_step(oracle, hip, type(p)(p.bs, vals, p.b, p.D, nelim), typ, pre, np.sqrt(diag / radius), got[0], got[1], got[2], 0.1, STEP_TOL)
                         log[tag + ":oracle"] = 0.0
@@ -196,7 +216,7 @@ def run_sequence(seed):
                     x = rng.standard_normal(p.bs.num_cols)
                     for sv in (held, f):
                         sv.load(vals, p.b, D)
-                    if name == "schur":
+                    if name.startswith("schur"):
                         for sv in (held, f):
                             sv.schur_init()
                         ne = int(p.bs.col_block_pos[nelim])
