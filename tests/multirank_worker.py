@@ -68,6 +68,7 @@ def run_rank(rank, world, conn, device, scenario):
                                                   "n_e": int(sh.bs.col_block_size[: sh.num_eliminate_blocks].sum()), "path": int(s.info().kernel_path)}
                 except hs.HipError as ex:
                     out[(name, "variant", vi)] = {"error": str(ex)}
+                    print(f"rank {rank} variant {vi} {var}: {ex}", file=sys.stderr, flush=True)
                 s.close()
             for solver_type, pre in kw["solvers"]:
                 o = hs.LinearSolverOptions(type=solver_type, preconditioner_type=pre, min_num_iterations=0, max_num_iterations=kw.get("max_it", 400),

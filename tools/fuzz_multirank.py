@@ -159,6 +159,56 @@ def run_generic(seed):
     return dict(out, ok=not bad, worst=max(worst.values()), worst_key=max(worst, key=worst.get), bad=bad, seconds=round(time.time() - t0, 1))
 
 
+def run_variants(seed):
+    """--variants: the solver OPTIONS sharded on a random structure (DENSE_SCHUR and the explicit Schur complement where the reduced
+    system is small, the power series as preconditioner and as initialisation, JACOBI, IDENTITY, reset period 1; fused and generic
+    kernels) — three iterations each, against ONE instance on the whole problem with the same options."""
+    from test_gpu_multirank import _variants
+    case, k, _ = fuzz_cases.draw_case(seed)
+    rng = np.random.default_rng(seed + 977)
+    world = int(rng.choice([2, 3, 4, 8]))
+    out = dict(case, world=world)
+    if case["n_points"] < world or case["n_obs"] > 30000:
+        return dict(out, ok=True, skipped="fewer points than ranks, or a large case")
+    p = fuzz_cases.build(pkg.problems, case, k)
+    nf_cols = int(p.bs.col_block_size[p.num_eliminate_blocks:].sum())
+    nr, ne, nf = case["shape"]
+    variants = [v for v in _variants(hip)
+                if (nf_cols <= 1200 or not (v["type"] == hip.DENSE_SCHUR or v.get("use_explicit_schur_complement")))
+                and (v["type"] != hip.CGNR or (not case["shared"] and nf != ne))]
+    variants = [variants[i] for i in sorted(rng.choice(len(variants), size=min(6, len(variants)), replace=False))]
+    kw = dict(kind="fuzz", seed=seed, solvers=[], variants=variants, p2p_timeout=30)   # (eight ranks load their code objects on the two host cores of the test box: seconds apart)
+    t0 = time.time()
+    res = run_ranks([("v", kw)], world)
+    worst = {}
+    for vi, var in enumerate(variants):
+        var = dict(var)
+        q_tol, r_tol = var.pop("q_tolerance", -1.0), var.pop("r_tolerance", -1.0)
+        tag = f"{var['type']}:{var.get('preconditioner_type', 1)}:{'explicit:' if var.get('use_explicit_schur_complement') else ''}{'spse_init:' if var.get('use_spse_initialization') else ''}{'generic' if var.get('force_generic_path') else 'fused'}"
+        recs = [res[r][("v", "variant", vi)] for r in range(world)]
+        one = hip.HipLinearSolver(hip.LinearSolverOptions(elimination_groups=[p.num_eliminate_blocks], **var))
+        one.set_structure(p.bs)
+        xo, so = one.solve(p.values, p.b, hip.PerSolveOptions(D=p.D, q_tolerance=q_tol, r_tolerance=r_tol))
+        one.close()
+        errors = [rec.get("error") for rec in recs]
+        assert not any(errors), (tag, errors)
+        if "rho = r'z" in so.message or any("rho = r'z" in rec["x"][4] for rec in recs):
+            continue   # (a system solved exactly: a tie)
+        assert all((rec["x"][1], rec["x"][2]) == (so.termination_type, so.num_iterations) for rec in recs), (tag, [rec["x"][1:] for rec in recs], so)
+        x = np.full(p.bs.num_cols, np.nan)
+        for rec in recs:
+            x[rec["col_index"][: rec["n_e"]]] = rec["x"][0][: rec["n_e"]]
+        x[recs[0]["col_index"][recs[0]["n_e"]:]] = recs[0]["x"][0][recs[0]["n_e"]:]
+        for rec in recs[1:]:
+            assert np.array_equal(recs[0]["x"][0][recs[0]["n_e"]:], rec["x"][0][rec["n_e"]:], equal_nan=True), (tag, "replicated part differs between ranks")
+        nx, no = np.isnan(x), np.isnan(xo)
+        assert np.array_equal(nx, no), (tag, int(nx.sum()), int(no.sum()))
+        worst[tag] = max(worst.get(tag, 0.0), float(rel(x[~nx], xo[~no])) if (~nx).any() else 0.0)
+    bad = {a: b for a, b in worst.items() if not (b <= 1e-8)}
+    return dict(out, ok=not bad, variants=len(variants), worst=max(worst.values()) if worst else 0.0, worst_key=max(worst, key=worst.get) if worst else "",
+                bad=bad, seconds=round(time.time() - t0, 1))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     first = int(args[0]) if args else 0
@@ -166,7 +216,7 @@ def main():
     failed = 0
     for seed in range(first, first + count):
         try:
-            r = run_generic(seed) if "--generic" in sys.argv else run_case(seed)
+            r = run_generic(seed) if "--generic" in sys.argv else run_variants(seed) if "--variants" in sys.argv else run_case(seed)
         except Exception as ex:
             r = dict(fuzz_cases.draw_case(seed, BIG)[0] if "--generic" not in sys.argv else dict(seed=seed, generic=True), ok=False, error=repr(ex)[:700], trace=traceback.format_exc()[-1200:])
         failed += 0 if r["ok"] else 1
