@@ -191,7 +191,10 @@ const char* ceres_hip_last_error(const ceres_hip_solver* s);
 /* Upload the (constant) sparsity once per solver instance.  For a sharded run
  * each rank passes the structure of ITS rows only: E (point) column blocks are
  * disjoint across ranks, F (camera) column blocks are the same on every rank
- * (SURVEY.md §8e).                                                           */
+ * (SURVEY.md §8e).  On a sharded instance (a communicator is connected) the call
+ * is COLLECTIVE: the ranks agree on the kernel path and the fused shape — a shard
+ * can look like bundle adjustment to one rank alone — and on where the exchanges
+ * run; every rank must make it, in the same order among its collective calls.  */
 int ceres_hip_set_structure(ceres_hip_solver* s, const ceres_hip_block_structure* bs);
 int ceres_hip_get_info(const ceres_hip_solver* s, ceres_hip_info* info);
 
